@@ -1,0 +1,73 @@
+"""Denoiser / sampler dimension sets for the DiffuseStyleGesture hot path.
+
+Each `DSGConfig` names the dimensions the reference hard-codes:
+
+* ZEGGS (DiffuseStyleGesture): `main/mydiffusion_zeggs/sample.py:51-56`
+  (njoints=1141, latent_dim=256, n_seed=8, cond_mode cross_local_attention3_style1),
+  `main/mydiffusion_zeggs/configs/DiffuseStyleGesture.yml:10` (n_poses=88),
+  `main/model/mdm.py:51` (audio latent 64), `:131-140` (window 11, 8 local heads).
+* BEAT / TWH (DiffuseStyleGesture+): `BEAT-TWH-main/mydiffusion_beat_twh/configs/DiffuseStyleGesture.yml`
+  and `BEAT-TWH-main/model/mdm.py:83-118` (cross_local_attention4, window 15).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, asdict
+
+VARIANT_DSG = 3       # cross_local_attention3_style1 (ZEGGS)
+VARIANT_DSGPLUS = 4   # cross_local_attention4_style1 (BEAT / TWH)
+
+
+@dataclass(frozen=True)
+class DSGConfig:
+    name: str
+    variant: int          # 3 or 4
+    njoints: int          # J: pose feature dim
+    n_poses: int          # T: frames per denoised window
+    n_seed: int           # S: seed frames
+    latent_dim: int       # D
+    audio_src_dim: int    # A_src
+    audio_dim: int        # A: audio latent
+    style_dim_in: int     # one-hot style/speaker width
+    window: int           # local attention window
+    num_layers: int = 8
+    num_heads: int = 4        # self-attention heads
+    ff_size: int = 1024
+    local_heads: int = 8      # mdm.py:58 self.num_head = 8
+    pe_max_len: int = 5000    # mdm.py:373
+
+    @property
+    def audio_frames(self) -> int:
+        # DSG: audio covers all T frames; DSG+ (attention4): T - S audio frames, the
+        # first S "audio" rows are the per-frame seed embedding (BEAT-TWH mdm.py:188-190)
+        return self.n_poses if self.variant == VARIANT_DSG else self.n_poses - self.n_seed
+
+    @property
+    def stride(self) -> int:
+        return self.n_poses - self.n_seed
+
+    @property
+    def tok_style_dim(self) -> int:
+        # width of embed_style output
+        return 64 if self.variant == VARIANT_DSG else self.latent_dim
+
+    def as_dict(self):
+        return asdict(self)
+
+
+ZEGGS = DSGConfig("zeggs", VARIANT_DSG, njoints=1141, n_poses=88, n_seed=8, latent_dim=256,
+                  audio_src_dim=1024, audio_dim=64, style_dim_in=6, window=11)
+BEAT = DSGConfig("beat", VARIANT_DSGPLUS, njoints=2052, n_poses=150, n_seed=30, latent_dim=384,
+                 audio_src_dim=1434, audio_dim=96, style_dim_in=2, window=15)
+TWH = DSGConfig("twh", VARIANT_DSGPLUS, njoints=2232, n_poses=150, n_seed=30, latent_dim=512,
+                audio_src_dim=1435, audio_dim=128, style_dim_in=17, window=15)
+# tiny dims for fast CPU tests (same structure, small sizes; J deliberately odd)
+# (the reference MDM classes hard-code 8 local heads, the window, and -- for ZEGGS -- the
+#  1024->64 audio map and the 6->64 style map, so the tiny sets keep those)
+TINY = DSGConfig("tiny", VARIANT_DSG, njoints=37, n_poses=22, n_seed=4, latent_dim=128,
+                 audio_src_dim=1024, audio_dim=64, style_dim_in=6, window=11,
+                 num_layers=2, num_heads=4, ff_size=128)
+TINY4 = DSGConfig("tiny4", VARIANT_DSGPLUS, njoints=37, n_poses=30, n_seed=6, latent_dim=64,
+                  audio_src_dim=40, audio_dim=16, style_dim_in=3, window=15,
+                  num_layers=2, num_heads=2, ff_size=128)
+
+CONFIGS = {c.name: c for c in (ZEGGS, BEAT, TWH, TINY, TINY4)}

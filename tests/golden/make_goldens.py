@@ -1,0 +1,300 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by IMPORTING the reference (dev container only).
+
+    python tests/golden/make_goldens.py zeggs      # main/ (DiffuseStyleGesture, ZEGGS dims + tiny dims)
+    python tests/golden/make_goldens.py dsgplus    # BEAT-TWH-main/ (DiffuseStyleGesture+)
+    python tests/golden/make_goldens.py clip       # main/mydiffusion_zeggs/sample.py inference() (G6)
+
+The two reference trees use the same module names, hence one process per tree.  Nothing from
+/root/reference is copied: the script imports it, feeds it seeded synthetic weights / inputs
+(diffusestylegesture_amd.synth) and the framework's counter-based noise (oracle.philox, injected by
+patching torch.randn / torch.randn_like as seen by the reference sampler), and stores only inputs'
+seeds and the reference's outputs.  /root/reference does not exist on the GPU box; tests read the
+committed .npz files only.
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from diffusestylegesture_amd import config as C
+from diffusestylegesture_amd.synth import synth_state_dict, synth_window_inputs
+from oracle import philox
+
+REF = "/root/reference"
+WSEED = 20240                 # synthetic-weight seed used by every fixture
+torch.set_grad_enabled(False)
+torch.set_num_threads(8)
+
+
+def _to_torch_sd(sd):
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+
+
+def _y_torch(y):
+    return {"style": torch.from_numpy(y["style"]), "seed": torch.from_numpy(y["seed"]),
+            "audio": torch.from_numpy(y["audio"]), "mask_local": torch.from_numpy(y["mask_local"])}
+
+
+class NoiseInjector:
+    """Replaces torch.randn / torch.randn_like with the framework's Philox stream (draw counter)."""
+
+    def __init__(self, seed, stream=0):
+        self.seed, self.stream, self.draw = seed, stream, 0
+
+    def _next(self, shape):
+        z = philox.normal_bj1t(tuple(shape), self.seed, self.draw, self.stream)
+        self.draw += 1
+        return torch.from_numpy(z)
+
+    def __enter__(self):
+        self._r, self._rl = torch.randn, torch.randn_like
+        torch.randn = lambda *shape, **kw: self._next(shape[0] if isinstance(shape[0], (tuple, list)) else shape)
+        torch.randn_like = lambda x, **kw: self._next(x.shape)
+        return self
+
+    def __exit__(self, *a):
+        torch.randn, torch.randn_like = self._r, self._rl
+
+
+def _build_ref_zeggs(cfg):
+    from model.mdm import MDM
+    m = MDM(modeltype='', njoints=cfg.njoints, nfeats=1, cond_mode='cross_local_attention3_style1',
+            audio_feat='wavlm', arch='trans_enc', latent_dim=cfg.latent_dim, n_seed=cfg.n_seed,
+            ff_size=cfg.ff_size, num_layers=cfg.num_layers, num_heads=cfg.num_heads)
+    if cfg.pe_max_len != 5000:
+        raise SystemExit("reference PositionalEncoding max_len is 5000")
+    sd = synth_state_dict(cfg, WSEED)
+    missing, unexpected = m.load_state_dict(_to_torch_sd(sd), strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    return m.eval(), sd
+
+
+def _capture_layers(model, store):
+    hooks = []
+    for i, layer in enumerate(model.seqTransEncoder.layers):
+        hooks.append(layer.register_forward_hook(
+            lambda mod, inp, out, i=i: store.__setitem__(f"after_layer{i}", out.permute(1, 0, 2).numpy().copy())))
+    return hooks
+
+
+def gen_zeggs():
+    sys.path[:0] = [REF + "/main", REF + "/main/model"]
+    np.float = float          # shim: data_loaders/humanml/common/quaternion.py uses np.float
+    from utils.model_util import create_gaussian_diffusion
+    from diffusion import gaussian_diffusion as gd
+    from diffusion.respace import SpacedDiffusion, space_timesteps
+
+    # ---- G1 schedule tables -------------------------------------------------------------------
+    diff = create_gaussian_diffusion()
+    names = ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
+             "sqrt_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+             "posterior_variance", "posterior_log_variance_clipped", "posterior_mean_coef1",
+             "posterior_mean_coef2"]
+    g1 = {"full_" + n: np.asarray(getattr(diff, n)) for n in names}
+    g1["full_timestep_map"] = np.asarray(diff.timestep_map)
+
+    def spaced_diff(resp):
+        betas = gd.get_named_beta_schedule('cosine', 1000, 1.)
+        return SpacedDiffusion(use_timesteps=space_timesteps(1000, resp), betas=betas,
+                               model_mean_type=gd.ModelMeanType.START_X,
+                               model_var_type=gd.ModelVarType.FIXED_SMALL,
+                               loss_type=gd.LossType.MSE, rescale_timesteps=False)
+    d50 = spaced_diff("ddim50")
+    for n in names:
+        g1["ddim50_" + n] = np.asarray(getattr(d50, n))
+    g1["ddim50_timestep_map"] = np.asarray(d50.timestep_map)
+    d3 = spaced_diff("10,15,20")
+    g1["sect_timestep_map"] = np.asarray(d3.timestep_map)
+    g1["sect_betas"] = np.asarray(d3.betas)
+    np.savez_compressed(os.path.join(HERE, "g1_schedule.npz"), **g1)
+    print("G1 ok")
+
+    # ---- G2 forward, ZEGGS dims ---------------------------------------------------------------
+    cfg = C.ZEGGS
+    model, _ = _build_ref_zeggs(cfg)
+    g2 = {"wseed": WSEED}
+    cases = [("b1_t0", 1, [0], 0.0), ("b1_t999", 1, [999], 0.5), ("b2_t999_3", 2, [999, 3], 0.5)]
+    for name, B, ts, sps in cases:
+        y = synth_window_inputs(cfg, B, window=1, seed_pose_scale=sps)
+        x = np.random.RandomState(4242 + B).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+        store = {}
+        hooks = _capture_layers(model, store) if name == "b1_t999" else []
+        out = model(torch.from_numpy(x), torch.tensor(ts, dtype=torch.long), y=_y_torch(y)).numpy()
+        for h in hooks:
+            h.remove()
+        g2[name + "_out"] = out.astype(np.float32)
+        g2[name + "_meta"] = np.array([B, sps, 4242 + B] + ts, dtype=np.float64)
+        if store:
+            g2[name + "_after_layer0"] = store["after_layer0"]
+            g2[name + f"_after_layer{cfg.num_layers - 1}"] = store[f"after_layer{cfg.num_layers - 1}"]
+        print("G2", name, float(np.abs(out).mean()), float(np.abs(out).max()))
+    np.savez_compressed(os.path.join(HERE, "g2_forward_zeggs.npz"), **g2)
+
+    # ---- G3 / G4 / G8 sampling chains, ZEGGS dims, B=1 ------------------------------------------
+    y = synth_window_inputs(cfg, 1, window=0)
+    shape = (1, cfg.njoints, 1, cfg.n_poses)
+    g3 = {"wseed": WSEED, "noise_seed": 123456}
+    for tag, skip in (("ddpm5", 995), ("ddpm25", 975), ("ddpm1000", 0)):
+        with NoiseInjector(123456, stream=0):
+            s = diff.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": _y_torch(y)},
+                                   skip_timesteps=skip, init_image=None, progress=False,
+                                   dump_steps=None, noise=None, const_noise=False)
+        g3[tag] = s.numpy().astype(np.float32)
+        print("G3", tag, float(np.abs(g3[tag]).mean()))
+    for tag, skip, eta in (("ddim50", 0, 0.0), ("ddim5_eta05", 45, 0.5)):
+        with NoiseInjector(123456, stream=7):
+            s = d50.ddim_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": _y_torch(y)},
+                                     skip_timesteps=skip, init_image=None, progress=False, eta=eta)
+        g3[tag] = s.numpy().astype(np.float32)
+        print("G4", tag, float(np.abs(g3[tag]).mean()))
+    np.savez_compressed(os.path.join(HERE, "g3_chains_zeggs.npz"), **g3)
+
+    # ---- tiny dims: masks, batch 2, init_image, const_noise, dump_steps -------------------------
+    cfg = C.TINY
+    # PositionalEncoding max_len is fixed to 5000 in the reference; the tiny config mirrors that
+    model, _ = _build_ref_zeggs(cfg)
+    gt = {"wseed": WSEED}
+    B = 2
+    y = synth_window_inputs(cfg, B, window=2, seed_pose_scale=0.3)
+    x = np.random.RandomState(99).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+    ts = [998, 17]
+    gt["fwd_allones"] = model(torch.from_numpy(x), torch.tensor(ts), y=_y_torch(y)).numpy()
+    m1 = np.ones((1, cfg.n_poses), bool); m1[0, [3, 12, 13]] = False
+    y1 = dict(y, mask_local=m1)
+    gt["mask1"] = m1
+    gt["fwd_mask1"] = model(torch.from_numpy(x), torch.tensor(ts), y=_y_torch(y1)).numpy()
+    m2 = np.ones((2, cfg.n_poses), bool); m2[0, 0:11] = False; m2[1, [5, 21]] = False
+    y2 = dict(y, mask_local=m2)
+    gt["mask2"] = m2
+    gt["fwd_mask2"] = model(torch.from_numpy(x), torch.tensor(ts), y=_y_torch(y2)).numpy()
+    gt["fwd_uncond"] = model(torch.from_numpy(x), torch.tensor(ts), y=_y_torch(y), uncond_info=True).numpy()
+    shape = (B, cfg.njoints, 1, cfg.n_poses)
+    with NoiseInjector(77, stream=3):
+        gt["ddpm_skip990"] = diff.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": _y_torch(y)},
+                                                skip_timesteps=990, progress=False).numpy()
+    init = np.random.RandomState(5).randn(*shape).astype(np.float32)
+    with NoiseInjector(77, stream=4):
+        gt["ddpm_init_skip992"] = diff.p_sample_loop(model, shape, clip_denoised=False,
+                                                     model_kwargs={"y": _y_torch(y)}, skip_timesteps=992,
+                                                     init_image=torch.from_numpy(init), progress=False).numpy()
+    with NoiseInjector(77, stream=5):
+        gt["ddpm_const_noise"] = diff.p_sample_loop(model, shape, clip_denoised=False,
+                                                    model_kwargs={"y": _y_torch(y)}, skip_timesteps=994,
+                                                    const_noise=True, progress=False).numpy()
+    with NoiseInjector(77, stream=6):
+        dump = diff.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": _y_torch(y)},
+                                  skip_timesteps=994, dump_steps=[0, 3, 5], progress=False)
+    gt["ddpm_dump035"] = np.stack([d.numpy() for d in dump])
+    with NoiseInjector(77, stream=8):
+        gt["ddim50_full"] = d50.ddim_sample_loop(model, shape, clip_denoised=False,
+                                                 model_kwargs={"y": _y_torch(y)}, progress=False, eta=0.0).numpy()
+    with NoiseInjector(77, stream=9):
+        gt["ddim50_eta1_skip40"] = d50.ddim_sample_loop(model, shape, clip_denoised=False,
+                                                        model_kwargs={"y": _y_torch(y)}, progress=False,
+                                                        eta=1.0, skip_timesteps=40).numpy()
+    with NoiseInjector(77, stream=10):
+        gt["ddpm200_tiny"] = diff.p_sample_loop(model, shape, clip_denoised=False,
+                                                model_kwargs={"y": _y_torch(y)}, skip_timesteps=800,
+                                                progress=False).numpy()
+    np.savez_compressed(os.path.join(HERE, "gt_tiny_zeggs.npz"), **gt)
+    print("tiny ok", {k: float(np.abs(v).mean()) for k, v in gt.items() if k.startswith(("fwd", "dd"))})
+
+
+def gen_dsgplus():
+    sys.path[:0] = [REF + "/BEAT-TWH-main", REF + "/BEAT-TWH-main/model"]
+    from model.mdm import MDM
+    g5 = {"wseed": WSEED}
+    for cfg, ts in ((C.BEAT, 999), (C.TWH, 0), (C.TINY4, 500)):
+        m = MDM(modeltype='', njoints=cfg.njoints, nfeats=1, cond_mode='cross_local_attention4_style1_sample',
+                arch='trans_enc', latent_dim=cfg.latent_dim, n_seed=cfg.n_seed, ff_size=cfg.ff_size,
+                num_layers=cfg.num_layers, num_heads=cfg.num_heads, style_dim=cfg.style_dim_in,
+                source_audio_dim=cfg.audio_src_dim, audio_feat_dim_latent=cfg.audio_dim)
+        sd = synth_state_dict(cfg, WSEED)
+        if cfg.pe_max_len != 5000:
+            raise SystemExit("pe_max_len")
+        missing, unexpected = m.load_state_dict(_to_torch_sd(sd), strict=False)
+        assert not missing and not unexpected, (missing, unexpected)
+        m.eval()
+        B = 1 if cfg.name != "tiny4" else 2
+        y = synth_window_inputs(cfg, B, window=3, seed_pose_scale=0.1)
+        x = np.random.RandomState(31 + B).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+        out = m(torch.from_numpy(x), torch.tensor([ts] * B), y=_y_torch(y)).numpy()
+        g5[cfg.name + "_out"] = out.astype(np.float32)
+        g5[cfg.name + "_meta"] = np.array([B, 0.1, 31 + B, ts], dtype=np.float64)
+        print("G5", cfg.name, out.shape, float(np.abs(out).mean()))
+        if cfg.name == "tiny4":
+            yu = _y_torch(y); yu["uncond"] = True
+            g5["tiny4_uncond"] = m(torch.from_numpy(x), torch.tensor([ts] * B), y=yu).numpy()
+    np.savez_compressed(os.path.join(HERE, "g5_forward_dsgplus.npz"), **g5)
+
+
+def gen_clip():
+    """G6: the reference's own `inference()` (window loop + stitching + de-normalisation) with a fake WavLM
+    and 3 DDPM steps per window; pose2bvh is replaced by a capture so no file is written."""
+    zdir = REF + "/main/mydiffusion_zeggs"
+    os.chdir(zdir)
+    for name in ("librosa", "omegaconf", "easydict"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["omegaconf"].DictConfig = dict
+
+    class _ED(dict):
+        __getattr__ = dict.__getitem__
+    sys.modules["easydict"].EasyDict = _ED
+    np.float = float
+    sys.path[:0] = [zdir]
+    import sample as S
+    cfg = C.ZEGGS
+    S.mydevice = torch.device("cpu")
+    S.batch_size = 1
+    S.save_dir = "/tmp"
+    captured = {}
+    S.pose2bvh = lambda poses, path, length, smoothing: captured.__setitem__("poses", np.array(poses))
+
+    n_win = 4
+    feats = [synth_window_inputs(cfg, 1, window=w)["audio"] for w in range(n_win)]
+
+    class FakeWavLM:
+        def __init__(self):
+            self.calls = 0
+
+        def extract_features(self, wav):
+            # 219 frames like WavLM on 70400 samples; content chosen so that the reference's
+            # align_corners linear interpolation to 88 frames returns feats[w] exactly is not
+            # possible -> instead bypass interpolation by patching wav2wavlm below.
+            raise RuntimeError
+    calls = {"n": 0}
+
+    def fake_wav2wavlm(model, wav, device):
+        w = calls["n"]; calls["n"] += 1
+        return torch.from_numpy(feats[w])
+    S.wav2wavlm = fake_wav2wavlm
+    model, _ = _build_ref_zeggs(cfg)
+    from utils.model_util import create_gaussian_diffusion
+    diff = create_gaussian_diffusion()
+    args = _ED(n_poses=88)
+    audio = np.zeros(320 * 800, dtype=np.float32)
+    style = [1, 0, 0, 0, 0, 0]
+    with NoiseInjector(123456, stream=0) as inj:
+        # one Philox stream runs through all windows like torch's global generator does (sample.py:212)
+        S.inference(args, None, audio, diff.p_sample_loop, model, n_frames=320, smoothing=True,
+                    SG_filter=True, minibatch=True, skip_timesteps=997, style=style, seed=123456)
+        draws = inj.draw
+    mean = np.load(REF + "/ubisoft-laforge-ZeroEGGS-main/data/processed_v1/processed/mean.npz")["mean"].squeeze()
+    std = np.load(REF + "/ubisoft-laforge-ZeroEGGS-main/data/processed_v1/processed/std.npz")["std"].squeeze()
+    np.savez_compressed(os.path.join(HERE, "g6_clip_zeggs.npz"), poses_denorm=captured["poses"].astype(np.float64),
+                        draws=draws, wseed=WSEED, noise_seed=123456, skip_timesteps=997)
+    np.savez_compressed(os.path.join(HERE, "zeggs_mean_std.npz"), mean=mean, std=std)
+    print("G6", captured["poses"].shape, draws)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1]
+    {"zeggs": gen_zeggs, "dsgplus": gen_dsgplus, "clip": gen_clip}[which]()
