@@ -1,0 +1,22 @@
+# Build the MI355X (gfx950) C-ABI library in-tree; `make emu` builds the CPU SIMT emulation of the same sources
+# (test infrastructure only, see tests/emu/README.md).
+HIPCC ?= /opt/rocm/bin/hipcc
+HOSTCXX ?= /opt/rocm/lib/llvm/bin/clang++
+CSRC := diffusestylegesture_amd/csrc
+LIB := $(CSRC)/libdsg_hip.so
+EMU := tests/emu/_build/libdsg_emu.so
+
+all: $(LIB)
+
+$(LIB): $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h include/dsg.h
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed $(CSRC)/dsg_hip.cpp -o $@
+
+emu: $(EMU)
+$(EMU): $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h include/dsg.h tests/emu/shim/hip/hip_runtime.h tests/emu/emu_rt.cpp
+	mkdir -p tests/emu/_build
+	$(HOSTCXX) -O2 -g -std=c++17 -fPIC -shared -pthread -Itests/emu/shim -DDSG_EMU=1 \
+	    $(CSRC)/dsg_hip.cpp tests/emu/emu_rt.cpp -o $@
+
+clean:
+	rm -f $(LIB) $(EMU)
+.PHONY: all emu clean

@@ -1,0 +1,918 @@
+// dsg_hip.cpp -- host side of libdsg_hip.so (C ABI in include/dsg.h): weight ingestion / repacking, per-window
+// conditioning, the per-step launch sequence, hipGraph capture of the step loop, and the sampler entry points.
+// See dsg_kernels.h for the kernels and the reference file:line each one replaces.
+#include "dsg_kernels.h"
+#include "../../include/dsg.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+using namespace dsg;
+
+// ---------------------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(expr)                                                                                     \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return fail(DSG_E_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(e_) + " @" +        \
+                                           std::to_string(__LINE__));                                    \
+    } while (0)
+#define CHK(expr)                  \
+    do {                           \
+        int r_ = (expr);           \
+        if (r_ != 0) return r_;    \
+    } while (0)
+
+extern "C" const char* dsg_last_error(void) { return g_err.c_str(); }
+extern "C" int dsg_version(void) { return DSG_VERSION; }
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int rup(int a, int b) { return cdiv(a, b) * b; }
+
+static bool is_device_ptr(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t at;
+    hipError_t e = hipPointerGetAttributes(&at, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// schedule tables (float64), GaussianDiffusion.__init__ (main/diffusion/gaussian_diffusion.py:161-198)
+// ---------------------------------------------------------------------------------------------------------
+struct Sched {
+    int n = 0;
+    std::vector<double> betas, ac, acp, sqrt_ac, sqrt_1mac, sqrt_recip, sqrt_recipm1, pvar, plogvar, coef1, coef2;
+    std::vector<int> tmap;
+};
+static int build_sched(const double* betas, int n, Sched& s) {
+    if (n <= 0) return fail(DSG_E_INVALID, "schedule: n <= 0");
+    s.n = n;
+    s.betas.assign(betas, betas + n);
+    for (int i = 0; i < n; ++i)
+        if (!(betas[i] > 0.0 && betas[i] <= 1.0)) return fail(DSG_E_INVALID, "schedule: betas must be in (0, 1]");
+    auto rs = [&](std::vector<double>& v) { v.resize(n); };
+    rs(s.ac); rs(s.acp); rs(s.sqrt_ac); rs(s.sqrt_1mac); rs(s.sqrt_recip); rs(s.sqrt_recipm1); rs(s.pvar);
+    rs(s.plogvar); rs(s.coef1); rs(s.coef2);
+    double c = 1.0;
+    for (int i = 0; i < n; ++i) { c *= (1.0 - betas[i]); s.ac[i] = c; }
+    for (int i = 0; i < n; ++i) s.acp[i] = i == 0 ? 1.0 : s.ac[i - 1];
+    for (int i = 0; i < n; ++i) {
+        s.sqrt_ac[i] = std::sqrt(s.ac[i]);
+        s.sqrt_1mac[i] = std::sqrt(1.0 - s.ac[i]);
+        s.sqrt_recip[i] = std::sqrt(1.0 / s.ac[i]);
+        s.sqrt_recipm1[i] = std::sqrt(1.0 / s.ac[i] - 1);
+        s.pvar[i] = betas[i] * (1.0 - s.acp[i]) / (1.0 - s.ac[i]);
+        s.coef1[i] = betas[i] * std::sqrt(s.acp[i]) / (1.0 - s.ac[i]);
+        s.coef2[i] = (1.0 - s.acp[i]) * std::sqrt(1.0 - betas[i]) / (1.0 - s.ac[i]);
+    }
+    for (int i = 0; i < n; ++i) s.plogvar[i] = std::log(n > 1 ? s.pvar[i == 0 ? 1 : i] : s.pvar[0]);
+    return 0;
+}
+extern "C" int dsg_schedule_tables(const double* betas, int n, double* out) {
+    Sched s;
+    CHK(build_sched(betas, n, s));
+    const std::vector<double>* t[11] = {&s.betas, &s.ac, &s.acp, &s.sqrt_ac, &s.sqrt_1mac, &s.sqrt_recip,
+                                        &s.sqrt_recipm1, &s.pvar, &s.plogvar, &s.coef1, &s.coef2};
+    for (int k = 0; k < 11; ++k) memcpy(out + (size_t)k * n, t[k]->data(), sizeof(double) * n);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------------------------------------
+struct RawT { float* d = nullptr; std::vector<int64_t> shape; size_t n = 0; };
+struct Layer {
+    void *Wqkv = nullptr, *Wo = nullptr, *W1 = nullptr, *W2 = nullptr;
+    float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr, *g1 = nullptr, *be1 = nullptr, *g2 = nullptr,
+          *be2 = nullptr;
+};
+
+struct dsg_handle {
+    dsg_config cfg;
+    int prec = 0, es = 4, kbk = 16;      // element size / k-block of the precision policy
+    int J, T, S, D, As, A, W, L, H, hd, ff, Hl, hdl, ntok, Tp, Jp, Jq, Bmax, Ta, n_te;
+    int KSin = 4;                        // split-K of the pose-embedding GEMM: one split per 256 pose features
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+    std::vector<void*> allocs;
+    std::map<std::string, RawT> raw;
+    bool finalized = false, cond_set = false;
+    int condB = 0;
+    // weights
+    void* Wp_in = nullptr; void* Wp_out = nullptr; float* b_out = nullptr;
+    std::vector<Layer> layers;
+    float *TE = nullptr, *TE2 = nullptr, *rcos = nullptr, *rsin = nullptr, *cbase = nullptr, *zero_bias = nullptr;
+    // window conditioning
+    float *emb1 = nullptr, *Cf = nullptr, *enc = nullptr, *cvec = nullptr;
+    float *c_style = nullptr, *c_seed = nullptr, *c_audio = nullptr;
+    unsigned char* mask = nullptr; int mb = 1;
+    // state / activations
+    float *xs32 = nullptr, *partial = nullptr, *X0 = nullptr, *pre1 = nullptr, *pre2 = nullptr, *Xn = nullptr,
+          *X1 = nullptr, *fwd_out = nullptr, *io_tmp = nullptr, *io_tmp2 = nullptr, *ext_noise = nullptr;
+    size_t ext_noise_cap = 0;
+    void *xsA = nullptr, *X0a = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *attn = nullptr, *hidden = nullptr;
+    int* ctr = nullptr; int* t_arr = nullptr; unsigned* dyn = nullptr;
+    int* st_tmodel = nullptr; float* st_c[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int st_cap = 0;
+    Sched sched;
+    // graphs: key = (B, out_mode, ext_noise?, const_noise) -> exec
+    struct GKey { int B, mode, mb, cn; bool operator<(const GKey& o) const {
+        return std::tie(B, mode, mb, cn) < std::tie(o.B, o.mode, o.mb, o.cn); } };
+    struct GVal { hipGraphExec_t exec; hipGraph_t graph; int steps; };
+    std::map<GKey, GVal> graphs;
+    float last_ms = -1.f; int last_steps = 0; bool timing_valid = false;
+};
+
+template <class T>
+static int dalloc(dsg_handle* h, T** p, size_t n_elems, bool zero = true) {
+    void* d = nullptr;
+    size_t bytes = n_elems * sizeof(T);
+    if (bytes == 0) bytes = 16;
+    HIPCHK(hipMalloc(&d, bytes));
+    if (zero) HIPCHK(hipMemset(d, 0, bytes));
+    h->allocs.push_back(d);
+    *p = (T*)d;
+    return 0;
+}
+static int dalloc_bytes(dsg_handle* h, void** p, size_t bytes) {
+    unsigned char* d = nullptr;
+    CHK(dalloc(h, &d, bytes));
+    *p = d;
+    return 0;
+}
+
+// expected checkpoint tensors (name -> shape); the reference's state_dict contract
+static std::map<std::string, std::vector<int64_t>> expected_tensors(const dsg_handle* h) {
+    std::map<std::string, std::vector<int64_t>> m;
+    const int64_t D = h->D, J = h->J, S = h->S, A = h->A, As = h->As, ff = h->ff;
+    m["WavEncoder.audio_feature_map.weight"] = {A, As};
+    m["WavEncoder.audio_feature_map.bias"] = {A};
+    m["sequence_pos_encoder.pe"] = {h->cfg.pe_max_len, 1, D};
+    m["input_process.poseEmbedding.weight"] = {D, J};
+    m["input_process.poseEmbedding.bias"] = {D};
+    for (int i = 0; i < h->L; ++i) {
+        const std::string p = "seqTransEncoder.layers." + std::to_string(i) + ".";
+        m[p + "self_attn.in_proj_weight"] = {3 * D, D};
+        m[p + "self_attn.in_proj_bias"] = {3 * D};
+        m[p + "self_attn.out_proj.weight"] = {D, D};
+        m[p + "self_attn.out_proj.bias"] = {D};
+        m[p + "linear1.weight"] = {ff, D};
+        m[p + "linear1.bias"] = {ff};
+        m[p + "linear2.weight"] = {D, ff};
+        m[p + "linear2.bias"] = {D};
+        m[p + "norm1.weight"] = {D}; m[p + "norm1.bias"] = {D};
+        m[p + "norm2.weight"] = {D}; m[p + "norm2.bias"] = {D};
+    }
+    m["embed_timestep.time_embed.0.weight"] = {D, D};
+    m["embed_timestep.time_embed.0.bias"] = {D};
+    m["embed_timestep.time_embed.2.weight"] = {D, D};
+    m["embed_timestep.time_embed.2.bias"] = {D};
+    if (h->cfg.variant == 3) {
+        m["embed_style.weight"] = {64, h->cfg.style_dim_in};
+        m["embed_style.bias"] = {64};
+        m["embed_text.weight"] = {D - 64, J * S};
+        m["embed_text.bias"] = {D - 64};
+    } else {
+        m["embed_style.weight"] = {D, h->cfg.style_dim_in};
+        m["embed_style.bias"] = {D};
+        m["embed_text.weight"] = {A, J};
+        m["embed_text.bias"] = {A};
+    }
+    m["output_process.poseFinal.weight"] = {J, D};
+    m["output_process.poseFinal.bias"] = {J};
+    m["rel_pos.inv_freq"] = {h->hdl / 2};
+    m["input_process2.weight"] = {D, 2 * D + A};
+    m["input_process2.bias"] = {D};
+    return m;
+}
+
+extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
+    if (!c || !out) return fail(DSG_E_INVALID, "dsg_create: null argument");
+    if (c->variant != 3 && c->variant != 4) return fail(DSG_E_NOT_IMPLEMENTED, "variant must be 3 or 4");
+    if (c->latent_dim % 64 || c->latent_dim > 512 || c->latent_dim <= 0)
+        return fail(DSG_E_INVALID, "latent_dim must be a multiple of 64, <= 512");
+    if (c->variant == 3 && c->latent_dim <= 64) return fail(DSG_E_INVALID, "variant 3 needs latent_dim > 64");
+    if (c->window <= 0 || c->window > 16 || c->n_poses % c->window)
+        return fail(DSG_E_INVALID, "n_poses must be a multiple of window (<= 16)");
+    if (c->num_heads <= 0 || c->latent_dim % c->num_heads) return fail(DSG_E_INVALID, "num_heads");
+    const int hd = c->latent_dim / c->num_heads;
+    if (!(hd == 32 || hd == 64 || hd == 96 || hd == 128)) return fail(DSG_E_INVALID, "self-attention head dim must be 32/64/96/128");
+    if (c->local_heads <= 0 || c->latent_dim % c->local_heads) return fail(DSG_E_INVALID, "local_heads");
+    const int hdl = c->latent_dim / c->local_heads;
+    if (hdl > 64 || (hdl & 1)) return fail(DSG_E_INVALID, "local head dim must be even and <= 64");
+    if (c->ff_size % 128 || c->ff_size <= 0) return fail(DSG_E_INVALID, "ff_size must be a multiple of 128");
+    if (c->audio_dim % 4) return fail(DSG_E_INVALID, "audio_dim must be a multiple of 4");
+    if (c->max_batch <= 0 || c->njoints <= 0 || c->n_seed < 0 || c->n_seed >= c->n_poses)
+        return fail(DSG_E_INVALID, "bad dims");
+    if (c->precision != DSG_PREC_FP32 && c->precision != DSG_PREC_BF16) return fail(DSG_E_INVALID, "precision");
+    const int ntok = c->n_poses + 1, Tp = rup(ntok, 32);
+    if (!(Tp == 32 || Tp == 96 || Tp == 160))
+        return fail(DSG_E_NOT_IMPLEMENTED, "attention kernel is instantiated for n_poses+1 padded to 32, 96 or 160 tokens");
+    HIPCHK(hipSetDevice(c->device));
+
+    dsg_handle* h = new dsg_handle();
+    h->cfg = *c;
+    h->prec = c->precision;
+    h->es = h->prec == DSG_PREC_BF16 ? 2 : 4;
+    h->kbk = h->prec == DSG_PREC_BF16 ? 32 : 16;
+    h->J = c->njoints; h->T = c->n_poses; h->S = c->n_seed; h->D = c->latent_dim; h->As = c->audio_src_dim;
+    h->A = c->audio_dim; h->W = c->window; h->L = c->num_layers; h->H = c->num_heads; h->hd = hd; h->ff = c->ff_size;
+    h->Hl = c->local_heads; h->hdl = hdl; h->ntok = ntok; h->Tp = Tp;
+    h->Jp = rup(h->J, 128); h->Jq = rup(h->J, 4); h->Bmax = c->max_batch;
+    h->KSin = cdiv(h->Jp, 256);
+    h->Ta = c->variant == 3 ? h->T : h->T - h->S;
+    h->n_te = c->train_steps > 0 ? c->train_steps : 1000;
+    if (h->n_te > c->pe_max_len) { delete h; return fail(DSG_E_INVALID, "train_steps > pe_max_len"); }
+    h->layers.resize(h->L);
+    *out = h;
+
+    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming));
+    HIPCHK(hipEventCreate(&h->ev_t0));
+    HIPCHK(hipEventCreate(&h->ev_t1));
+
+    const int B = h->Bmax, D = h->D;
+    const size_t Min_pad = rup(B * h->T, 16), M_pad = rup(B * ntok, 16);
+    CHK(dalloc(h, &h->xs32, (size_t)B * h->T * h->Jp + 16 * h->Jp));
+    if (h->prec == DSG_PREC_BF16) CHK(dalloc_bytes(h, &h->xsA, ((size_t)Min_pad * h->Jp) * h->es));
+    CHK(dalloc(h, &h->partial, (size_t)h->KSin * Min_pad * D));
+    CHK(dalloc(h, &h->X0, M_pad * D));
+    CHK(dalloc_bytes(h, &h->X0a, M_pad * D * h->es));
+    CHK(dalloc(h, &h->pre1, M_pad * D));
+    CHK(dalloc(h, &h->pre2, M_pad * D));
+    CHK(dalloc(h, &h->Xn, M_pad * D));
+    CHK(dalloc(h, &h->X1, M_pad * D));
+    CHK(dalloc_bytes(h, &h->attn, M_pad * D * h->es));
+    CHK(dalloc_bytes(h, &h->hidden, M_pad * (size_t)h->ff * h->es));
+    const size_t qkv_elems = (size_t)B * h->H * Tp * hd;
+    CHK(dalloc_bytes(h, &h->q, qkv_elems * h->es));
+    CHK(dalloc_bytes(h, &h->k, qkv_elems * h->es));
+    CHK(dalloc_bytes(h, &h->vt, qkv_elems * h->es));
+    CHK(dalloc(h, &h->fwd_out, (size_t)B * h->J * h->T));
+    CHK(dalloc(h, &h->io_tmp, (size_t)B * h->J * h->T));
+    CHK(dalloc(h, &h->io_tmp2, (size_t)B * h->J * h->T));
+    CHK(dalloc(h, &h->emb1, (size_t)B * D));
+    CHK(dalloc(h, &h->cvec, (size_t)B * D));
+    CHK(dalloc(h, &h->Cf, (size_t)B * h->T * D));
+    CHK(dalloc(h, &h->enc, (size_t)B * h->T * h->A));
+    CHK(dalloc(h, &h->c_style, (size_t)B * c->style_dim_in));
+    CHK(dalloc(h, &h->c_seed, (size_t)B * h->J * (h->S > 0 ? h->S : 1)));
+    CHK(dalloc(h, &h->c_audio, (size_t)B * h->Ta * h->As));
+    CHK(dalloc(h, &h->mask, (size_t)B * h->T));
+    CHK(dalloc(h, &h->ctr, 4));
+    CHK(dalloc(h, &h->dyn, 8));
+    CHK(dalloc(h, &h->t_arr, (size_t)B));
+    // the xs32 master is read as a GEMM operand in fp32 mode: rows padded to a 16-row tile exist (allocated above)
+    return 0;
+}
+
+extern "C" int dsg_destroy(dsg_handle* h) {
+    if (!h) return 0;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto& kv : h->graphs) { (void)hipGraphExecDestroy(kv.second.exec); (void)hipGraphDestroy(kv.second.graph); }
+    for (void* p : h->allocs) (void)hipFree(p);
+    if (h->ev_in) (void)hipEventDestroy(h->ev_in);
+    if (h->ev_out) (void)hipEventDestroy(h->ev_out);
+    if (h->ev_t0) (void)hipEventDestroy(h->ev_t0);
+    if (h->ev_t1) (void)hipEventDestroy(h->ev_t1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+extern "C" int dsg_load_tensor(dsg_handle* h, const char* name, const void* data, const int64_t* shape, int ndim,
+                               int dtype) {
+    if (!h || !name || !data || !shape) return fail(DSG_E_INVALID, "dsg_load_tensor: null argument");
+    if (dtype != 0) return fail(DSG_E_NOT_IMPLEMENTED, "dsg_load_tensor: only float32 (dtype 0)");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    std::string nm(name);
+    if (nm == "embed_timestep.sequence_pos_encoder.pe") nm = "sequence_pos_encoder.pe";   // aliased buffer
+    auto exp = expected_tensors(h);
+    auto it = exp.find(nm);
+    if (it == exp.end()) return fail(DSG_E_UNEXPECTED_KEY, "unexpected key in state_dict: " + nm);
+    size_t n = 1, ne = 1;
+    for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+    for (auto v : it->second) ne *= (size_t)v;
+    bool same = (int)it->second.size() == ndim;
+    for (int i = 0; same && i < ndim; ++i) same = it->second[i] == shape[i];
+    if (!same || n != ne) return fail(DSG_E_INVALID, "size mismatch for " + nm);
+    RawT& r = h->raw[nm];
+    if (!r.d) CHK(dalloc(h, &r.d, n, false));
+    r.n = n; r.shape.assign(shape, shape + ndim);
+    HIPCHK(hipMemcpy(r.d, data, n * sizeof(float), is_device_ptr(data) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    h->finalized = false;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// launch helpers
+// ---------------------------------------------------------------------------------------------------------
+static int launch_mm(dsg_handle* h, float* C, int ldc, const float* A, long long sam, long long sak, const float* Bm,
+                     long long sbn, long long sbk, const float* bias, const float* add, long long sadd, int add_div,
+                     int M, int N, int K, int act = 0) {
+    MMArgs a;
+    a.C = C; a.ldc = ldc; a.A = A; a.sam = sam; a.sak = sak; a.Bm = Bm; a.sbn = sbn; a.sbk = sbk; a.bias = bias;
+    a.add = add; a.sadd = sadd; a.add_div = add_div < 1 ? 1 : add_div; a.M = M; a.N = N; a.K = K; a.act = act;
+    const size_t n = (size_t)M * N;
+    if (n == 0) return 0;
+    const int grid = (int)std::min<size_t>((n + 127) / 128, 4096);
+    hipLaunchKernelGGL(k_mm_naive, dim3(grid), dim3(128), 0, h->stream, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+template <class P>
+static int launch_pack(dsg_handle* h, void** dst, const float* W, long long ldw, int N, int K, int NT, int KBtot) {
+    const size_t n = (size_t)NT * KBtot * 64 * P::E;
+    CHK(dalloc_bytes(h, dst, n * sizeof(typename P::elem)));
+    const int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
+    hipLaunchKernelGGL((k_pack_w<P>), dim3(grid), dim3(256), 0, h->stream, *dst, W, ldw, N, K, NT, KBtot);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+static int pack(dsg_handle* h, void** dst, const float* W, long long ldw, int N, int K, int Npad, int Kpad) {
+    if (h->prec == DSG_PREC_BF16) return launch_pack<PBF16>(h, dst, W, ldw, N, K, Npad / 16, Kpad / 32);
+    return launch_pack<PF32>(h, dst, W, ldw, N, K, Npad / 16, Kpad / 16);
+}
+static int padded_vec(dsg_handle* h, float** dst, const float* src, int n, int npad) {
+    CHK(dalloc(h, dst, (size_t)npad));
+    hipLaunchKernelGGL(k_copy_pad, dim3(cdiv(npad, 256)), dim3(256), 0, h->stream, *dst, src, n, npad);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int dsg_finalize_weights(dsg_handle* h) {
+    if (!h) return fail(DSG_E_INVALID, "null handle");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    auto exp = expected_tensors(h);
+    for (auto& kv : exp)
+        if (!h->raw.count(kv.first)) return fail(DSG_E_MISSING_KEY, "missing key in state_dict: " + kv.first);
+    auto R = [&](const std::string& n) { return h->raw[n].d; };
+    const int D = h->D, J = h->J, A = h->A, ff = h->ff, L = h->L;
+    const int W2ld = 2 * D + A;
+    const float* W2 = R("input_process2.weight");
+
+    // time-embedding tables  (TimestepEmbedder, main/model/mdm.py:434-448)
+    float* H1 = nullptr;
+    CHK(dalloc(h, &H1, (size_t)h->n_te * D));
+    CHK(dalloc(h, &h->TE, (size_t)h->n_te * D));
+    CHK(dalloc(h, &h->TE2, (size_t)h->n_te * D));
+    CHK(launch_mm(h, H1, D, R("sequence_pos_encoder.pe"), D, 1, R("embed_timestep.time_embed.0.weight"), D, 1,
+                  R("embed_timestep.time_embed.0.bias"), nullptr, 0, 1, h->n_te, D, D, 1));
+    CHK(launch_mm(h, h->TE, D, H1, D, 1, R("embed_timestep.time_embed.2.weight"), D, 1,
+                  R("embed_timestep.time_embed.2.bias"), nullptr, 0, 1, h->n_te, D, D, 0));
+    CHK(launch_mm(h, h->TE2, D, h->TE, D, 1, W2, W2ld, 1, nullptr, nullptr, 0, 1, h->n_te, D, D, 0));
+    // fold input_process2[:, D:2D] . poseEmbedding   (mdm.py:198, :202-206) -> [D][J]
+    float* Wfold = nullptr;
+    CHK(dalloc(h, &Wfold, (size_t)D * J));
+    CHK(launch_mm(h, Wfold, J, W2 + D, W2ld, 1, R("input_process.poseEmbedding.weight"), 1, J, nullptr, nullptr, 0, 1,
+                  D, J, D, 0));
+    CHK(dalloc(h, &h->cbase, (size_t)D));
+    CHK(launch_mm(h, h->cbase, D, R("input_process.poseEmbedding.bias"), 0, 1, W2 + D, W2ld, 1,
+                  R("input_process2.bias"), nullptr, 0, 1, 1, D, D, 0));
+    CHK(pack(h, &h->Wp_in, Wfold, J, D, J, D, h->Jp));
+    CHK(dalloc(h, &h->zero_bias, (size_t)std::max(D, h->Jp)));
+    for (int i = 0; i < L; ++i) {
+        const std::string p = "seqTransEncoder.layers." + std::to_string(i) + ".";
+        Layer& l = h->layers[i];
+        CHK(pack(h, &l.Wqkv, R(p + "self_attn.in_proj_weight"), D, 3 * D, D, 3 * D, D));
+        CHK(pack(h, &l.Wo, R(p + "self_attn.out_proj.weight"), D, D, D, D, D));
+        CHK(pack(h, &l.W1, R(p + "linear1.weight"), D, ff, D, ff, D));
+        CHK(pack(h, &l.W2, R(p + "linear2.weight"), ff, D, ff, D, ff));
+        l.bqkv = R(p + "self_attn.in_proj_bias"); l.bo = R(p + "self_attn.out_proj.bias");
+        l.b1 = R(p + "linear1.bias"); l.b2 = R(p + "linear2.bias");
+        l.g1 = R(p + "norm1.weight"); l.be1 = R(p + "norm1.bias");
+        l.g2 = R(p + "norm2.weight"); l.be2 = R(p + "norm2.bias");
+    }
+    CHK(pack(h, &h->Wp_out, R("output_process.poseFinal.weight"), D, J, D, h->Jp, D));
+    CHK(padded_vec(h, &h->b_out, R("output_process.poseFinal.bias"), J, h->Jp));
+
+    // rotary tables (rotary.py:12-16): freqs = pos * inv_freq in fp32, cos/sin of that fp32 value
+    {
+        const int half = h->hdl / 2, npos = h->T + 1;
+        std::vector<float> inv(half), c((size_t)npos * half), s((size_t)npos * half);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(inv.data(), R("rel_pos.inv_freq"), half * sizeof(float), hipMemcpyDeviceToHost));
+        for (int p = 0; p < npos; ++p)
+            for (int k = 0; k < half; ++k) {
+                const float fr = (float)p * inv[k];
+                c[(size_t)p * half + k] = (float)std::cos((double)fr);
+                s[(size_t)p * half + k] = (float)std::sin((double)fr);
+            }
+        CHK(dalloc(h, &h->rcos, c.size()));
+        CHK(dalloc(h, &h->rsin, s.size()));
+        HIPCHK(hipMemcpy(h->rcos, c.data(), c.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->rsin, s.data(), s.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->finalized = true;
+    return 0;
+}
+
+extern "C" int dsg_set_schedule(dsg_handle* h, const double* betas, const int64_t* tmap, int n) {
+    if (!h || !betas || !tmap) return fail(DSG_E_INVALID, "dsg_set_schedule: null argument");
+    Sched s;
+    CHK(build_sched(betas, n, s));
+    s.tmap.resize(n);
+    for (int i = 0; i < n; ++i) {
+        if (tmap[i] < 0 || tmap[i] >= h->n_te) return fail(DSG_E_INVALID, "timestep_map entry out of range");
+        s.tmap[i] = (int)tmap[i];
+    }
+    h->sched = s;
+    if (n > h->st_cap) {
+        HIPCHK(hipSetDevice(h->cfg.device));
+        CHK(dalloc(h, &h->st_tmodel, (size_t)n));
+        for (int k = 0; k < 5; ++k) CHK(dalloc(h, &h->st_c[k], (size_t)n));
+        h->st_cap = n;
+        // graphs hold the old table pointers
+        for (auto& kv : h->graphs) { (void)hipGraphExecDestroy(kv.second.exec); (void)hipGraphDestroy(kv.second.graph); }
+        h->graphs.clear();
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// per-window conditioning (mdm.py:180-190; BEAT-TWH mdm.py:145, :188-190): everything that does not depend on x_t or t
+// ---------------------------------------------------------------------------------------------------------
+static int upload(dsg_handle* h, void* dst, const void* src, size_t bytes) {
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, is_device_ptr(src) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    return 0;
+}
+
+extern "C" int dsg_set_window_cond(dsg_handle* h, const float* style, const float* seed, const float* audio,
+                                   const uint8_t* mask_local, int mask_batch, int B, int uncond) {
+    if (!h) return fail(DSG_E_INVALID, "null handle");
+    if (!h->finalized) return fail(DSG_E_STATE, "dsg_set_window_cond before dsg_finalize_weights");
+    if (B <= 0 || B > h->Bmax) return fail(DSG_E_INVALID, "batch exceeds max_batch");
+    if (!style || !audio || (h->S > 0 && !seed)) return fail(DSG_E_INVALID, "style/seed/audio required");
+    if (mask_local && !(mask_batch >= 1 && (B * h->Hl) % mask_batch == 0))
+        return fail(DSG_E_INVALID, "mask_local batch must divide B*heads");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    auto R = [&](const std::string& n) { return h->raw[n].d; };
+    const int D = h->D, J = h->J, S = h->S, A = h->A, As = h->As, T = h->T, sdi = h->cfg.style_dim_in;
+    const int W2ld = 2 * D + A;
+    const float* W2 = R("input_process2.weight");
+    CHK(upload(h, h->c_style, style, (size_t)B * sdi * sizeof(float)));
+    if (S > 0) CHK(upload(h, h->c_seed, seed, (size_t)B * J * S * sizeof(float)));
+    CHK(upload(h, h->c_audio, audio, (size_t)B * h->Ta * As * sizeof(float)));
+    if (mask_local) {
+        CHK(upload(h, h->mask, mask_local, (size_t)mask_batch * T));
+        h->mb = mask_batch;
+    } else {
+        HIPCHK(hipMemsetAsync(h->mask, 1, (size_t)T, h->stream));
+        h->mb = 1;
+    }
+    const int sdo = h->cfg.variant == 3 ? 64 : D;
+    if (uncond) {       // mask_cond(force_mask=True): zeros AFTER the style linear (mdm.py:156-159, :180)
+        hipLaunchKernelGGL(k_fill_f32, dim3(cdiv(B * D, 256)), dim3(256), 0, h->stream, h->emb1, 0.f, (size_t)B * D);
+        HIPCHK(hipGetLastError());
+    } else {
+        CHK(launch_mm(h, h->emb1, D, h->c_style, sdi, 1, R("embed_style.weight"), sdi, 1, R("embed_style.bias"),
+                      nullptr, 0, 1, B, sdo, sdi));
+    }
+    if (h->cfg.variant == 3) {
+        // embed_text(flattened seed) -> emb1[:, 64:]; with force_mask the seed is zeroed BEFORE the linear (bias only)
+        CHK(launch_mm(h, h->emb1 + 64, D, h->c_seed, (long long)J * S, 1, R("embed_text.weight"), (long long)J * S, 1,
+                      R("embed_text.bias"), nullptr, 0, 1, B, D - 64, uncond ? 0 : J * S));
+        CHK(launch_mm(h, h->enc, A, h->c_audio, As, 1, R("WavEncoder.audio_feature_map.weight"), As, 1,
+                      R("WavEncoder.audio_feature_map.bias"), nullptr, 0, 1, B * T, A, As));
+    } else {
+        for (int b = 0; b < B; ++b) {
+            // per-frame seed embedding: rows 0..S-1 of the "audio" block  (BEAT-TWH mdm.py:188)
+            CHK(launch_mm(h, h->enc + (size_t)b * T * A, A, h->c_seed + (size_t)b * J * S, 1, S, R("embed_text.weight"),
+                          J, 1, R("embed_text.bias"), nullptr, 0, 1, S, A, J));
+            CHK(launch_mm(h, h->enc + ((size_t)b * T + S) * A, A, h->c_audio + (size_t)b * h->Ta * As, As, 1,
+                          R("WavEncoder.audio_feature_map.weight"), As, 1, R("WavEncoder.audio_feature_map.bias"),
+                          nullptr, 0, 1, h->Ta, A, As));
+        }
+    }
+    // cvec[b] = b2 + W2b.bp + W2a.emb1[b];  Cf[b,f] = W2c.enc[b,f] + cvec[b]
+    CHK(launch_mm(h, h->cvec, D, h->emb1, D, 1, W2, W2ld, 1, nullptr, h->cbase, 0, 1, B, D, D));
+    CHK(launch_mm(h, h->Cf, D, h->enc, A, 1, W2 + 2 * D, W2ld, 1, nullptr, h->cvec, D, T, B * T, D, A));
+    h->cond_set = true;
+    h->condB = B;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// one denoising step = 3 + 5*L launches
+// ---------------------------------------------------------------------------------------------------------
+struct StepCtx {
+    int B; int out_mode; bool use_ctr; const float* ext_noise; int const_noise;
+};
+
+template <class P, int PRO, int EPI, int WN, int WK, int TNW>
+static int launch_gemm(dsg_handle* h, GemmArgs g) {
+    if (g.KS == 1) g.kb_per_split = g.KBtot;
+    const int NG = g.NT / (WN * TNW);
+    if (NG * WN * TNW != g.NT) return fail(DSG_E_INVALID, "gemm: NT not divisible by the workgroup tile");
+    if (WK > 1 && (g.KS != 1 || g.KBtot % WK)) return fail(DSG_E_INVALID, "gemm: k-blocks not divisible by the wave split");
+    if (g.KS < 1 || g.kb_per_split * g.KS < g.KBtot) return fail(DSG_E_INVALID, "gemm: split-K does not cover K");
+    hipLaunchKernelGGL((k_gemm<P, PRO, EPI, WN, WK, TNW>), dim3(xcd_grid(NG, g.MT * g.KS)), dim3(256), 0, h->stream, g);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+template <class P, int HD, int NKT>
+static int launch_attn_t(dsg_handle* h, const AttnArgs& a) {
+    const int nqt = cdiv(a.ntok, 16);
+    hipLaunchKernelGGL((k_attn<P, HD, NKT>), dim3(a.B * a.H * nqt), dim3(64), 0, h->stream, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+template <class P>
+static int launch_attn(dsg_handle* h, const AttnArgs& a) {
+    const int key = h->hd * 1000 + h->Tp / 16;
+    switch (key) {
+        case 32 * 1000 + 2: return launch_attn_t<P, 32, 2>(h, a);
+        case 64 * 1000 + 2: return launch_attn_t<P, 64, 2>(h, a);
+        case 64 * 1000 + 6: return launch_attn_t<P, 64, 6>(h, a);
+        case 96 * 1000 + 10: return launch_attn_t<P, 96, 10>(h, a);
+        case 128 * 1000 + 10: return launch_attn_t<P, 128, 10>(h, a);
+        default: return fail(DSG_E_NOT_IMPLEMENTED, "no attention instantiation for (head_dim, tokens) = (" +
+                                                        std::to_string(h->hd) + ", " + std::to_string(h->Tp) + ")");
+    }
+}
+
+template <class P>
+static int run_step(dsg_handle* h, const StepCtx& c) {
+    const int B = c.B, D = h->D, T = h->T, ntok = h->ntok;
+    const int Min = B * T, M = B * ntok;
+    const int MTin = cdiv(Min, 16), MT = cdiv(M, 16);
+    const int KB = P::KB;
+    GemmArgs z;
+    memset(&z, 0, sizeof(z));
+    z.KS = 1; z.kb_per_split = 0; z.B = B; z.ntok = ntok; z.Tp = h->Tp; z.H = h->H; z.hd = h->hd; z.T = T; z.J = h->J; z.Jp = h->Jp;
+    z.Jq = h->Jq; z.D = D;
+
+    {   // k_in: partial[s] = xs[:, chunk s] . Wfold[:, chunk s]^T
+        GemmArgs g = z;
+        g.M = Min; g.MT = MTin; g.NT = D / 16; g.KBtot = h->Jp / KB; g.KS = h->KSin; g.Wp = h->Wp_in;
+        g.kb_per_split = cdiv(g.KBtot, g.KS);
+        g.A = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; g.lda = h->Jp;
+        g.out = h->partial; g.ldo = D;
+        g.ctr_inc = c.use_ctr ? h->ctr : nullptr;
+        CHK((launch_gemm<P, PRO_DIRECT, EPI_PARTIAL, 4, 1, 1>(h, g)));
+    }
+    {   // k_loc
+        LocArgs a;
+        memset(&a, 0, sizeof(a));
+        a.partial = h->partial; a.KS = h->KSin; a.Min_pad = MTin * 16; a.Cf = h->Cf; a.TE2 = h->TE2; a.TE = h->TE;
+        a.emb1 = h->emb1; a.ctr = c.use_ctr ? h->ctr : nullptr; a.tmodel = h->st_tmodel; a.t_arr = h->t_arr;
+        a.rcos = h->rcos; a.rsin = h->rsin; a.mask = h->mask; a.mb = h->mb; a.B = B; a.T = T; a.D = D; a.Hl = h->Hl;
+        a.hd = h->hdl; a.W = h->W; a.X0 = h->X0; a.X0a = h->X0a;
+        hipLaunchKernelGGL((k_loc<P>), dim3(B * (T / h->W) * h->Hl), dim3(64), 0, h->stream, a);
+        HIPCHK(hipGetLastError());
+    }
+    for (int l = 0; l < h->L; ++l) {
+        const Layer& ly = h->layers[l];
+        {   // QKV projection (LayerNorm2 of the previous layer applied on read)
+            GemmArgs g = z;
+            g.M = M; g.MT = MT; g.NT = 3 * D / 16; g.KBtot = D / KB; g.Wp = ly.Wqkv; g.bias = ly.bqkv;
+            g.q = h->q; g.k = h->k; g.vt = h->vt;
+            if (l == 0) {
+                g.A = h->X0a; g.lda = D;
+                CHK((launch_gemm<P, PRO_DIRECT, EPI_QKV, 4, 1, 1>(h, g)));
+            } else {
+                g.X = h->pre2; g.ln_g = h->layers[l - 1].g2; g.ln_b = h->layers[l - 1].be2; g.Xn = h->Xn;
+                CHK((launch_gemm<P, PRO_LN, EPI_QKV, 4, 1, 1>(h, g)));
+            }
+        }
+        {   // attention
+            AttnArgs a;
+            a.q = h->q; a.k = h->k; a.vt = h->vt; a.out = h->attn; a.B = B; a.H = h->H; a.ntok = ntok; a.Tp = h->Tp;
+            a.D = D;
+            CHK(launch_attn<P>(h, a));
+        }
+        {   // out_proj + residual -> pre1
+            GemmArgs g = z;
+            g.M = M; g.MT = MT; g.NT = D / 16; g.KBtot = D / KB; g.Wp = ly.Wo; g.bias = ly.bo;
+            g.A = h->attn; g.lda = D; g.out = h->pre1; g.ldo = D; g.R = l == 0 ? h->X0 : h->Xn;
+            CHK((launch_gemm<P, PRO_DIRECT, EPI_RESID, 4, 1, 1>(h, g)));
+        }
+        {   // LayerNorm1-on-read + linear1 + GELU -> hidden ; X1 = LN1(pre1)
+            GemmArgs g = z;
+            g.M = M; g.MT = MT; g.NT = h->ff / 16; g.KBtot = D / KB; g.Wp = ly.W1; g.bias = ly.b1;
+            g.X = h->pre1; g.ln_g = ly.g1; g.ln_b = ly.be1; g.Xn = h->X1; g.out = h->hidden; g.ldo = h->ff;
+            CHK((launch_gemm<P, PRO_LN, EPI_GELU, 4, 1, 1>(h, g)));
+        }
+        {   // linear2 + residual -> pre2   (K = ff split over the 4 waves of the workgroup)
+            GemmArgs g = z;
+            g.M = M; g.MT = MT; g.NT = D / 16; g.KBtot = h->ff / KB; g.Wp = ly.W2; g.bias = ly.b2;
+            g.A = h->hidden; g.lda = h->ff; g.out = h->pre2; g.ldo = D; g.R = h->X1;
+            CHK((launch_gemm<P, PRO_DIRECT, EPI_RESID, 1, 4, 1>(h, g)));
+        }
+    }
+    {   // final LayerNorm-on-read + pose head + sampler update
+        GemmArgs g = z;
+        g.M = M; g.MT = MT; g.NT = h->Jp / 16; g.KBtot = D / KB; g.Wp = h->Wp_out; g.bias = h->b_out;
+        g.X = h->pre2; g.ln_g = h->layers[h->L - 1].g2; g.ln_b = h->layers[h->L - 1].be2; g.Xn = nullptr;
+        g.out_mode = c.out_mode; g.xs32 = h->xs32; g.xsA = h->prec == DSG_PREC_BF16 ? h->xsA : nullptr;
+        g.fwd_out = h->fwd_out; g.ctr = h->ctr;
+        g.st.tmodel = h->st_tmodel; g.st.c1 = h->st_c[0]; g.st.c2 = h->st_c[1]; g.st.c3 = h->st_c[2];
+        g.st.c4 = h->st_c[3]; g.st.c5 = h->st_c[4];
+        g.dyn = h->dyn; g.ext_noise = c.ext_noise; g.const_noise = c.const_noise;
+        CHK((launch_gemm<P, PRO_LN, EPI_OUT, 4, 1, 1>(h, g)));
+    }
+    return 0;
+}
+static int run_step_p(dsg_handle* h, const StepCtx& c) {
+    return h->prec == DSG_PREC_BF16 ? run_step<PBF16>(h, c) : run_step<PF32>(h, c);
+}
+
+static int launch_x_in(dsg_handle* h, const float* x, const float* init, int do_q, float qa, float qb, int use_philox,
+                       NoiseKey nk, unsigned draw, int B) {
+    XInArgs a;
+    a.x = x; a.init = init; a.do_q = do_q; a.qa = qa; a.qb = qb; a.use_philox = use_philox; a.nkey = nk; a.draw = draw;
+    a.B = B; a.J = h->J; a.Jp = h->Jp; a.Jq = h->Jq; a.T = h->T; a.xs32 = h->xs32;
+    a.xsA = h->prec == DSG_PREC_BF16 ? h->xsA : nullptr;
+    const size_t n = (size_t)B * h->T * (h->Jp / 4);
+    const int grid = (int)std::min<size_t>((n + 255) / 256, 2048);
+    if (h->prec == DSG_PREC_BF16) hipLaunchKernelGGL((k_x_in<PBF16>), dim3(grid), dim3(256), 0, h->stream, a);
+    else hipLaunchKernelGGL((k_x_in<PF32>), dim3(grid), dim3(256), 0, h->stream, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+static int launch_x_out(dsg_handle* h, float* dst_dev, int B) {
+    const size_t n = (size_t)B * h->J * h->T;
+    hipLaunchKernelGGL(k_x_out, dim3((int)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, h->stream, h->xs32,
+                       dst_dev, B, h->J, h->Jp, h->T);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int order_after(dsg_handle* h, void* user_stream) {
+    if (user_stream) {
+        HIPCHK(hipEventRecord(h->ev_in, (hipStream_t)user_stream));
+        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_in, 0));
+    }
+    return 0;
+}
+static int order_before(dsg_handle* h, void* user_stream) {
+    if (user_stream) {
+        HIPCHK(hipEventRecord(h->ev_out, h->stream));
+        HIPCHK(hipStreamWaitEvent((hipStream_t)user_stream, h->ev_out, 0));
+    }
+    return 0;
+}
+// bring a caller tensor to the device (returns the device pointer to use)
+static int to_dev(dsg_handle* h, const float* src, float* staging, size_t n, const float** out) {
+    if (!src) { *out = nullptr; return 0; }
+    if (is_device_ptr(src)) { *out = src; return 0; }
+    HIPCHK(hipMemcpyAsync(staging, src, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    *out = staging;
+    return 0;
+}
+static int from_dev(dsg_handle* h, float* dst, const float* src_dev, size_t n) {
+    if (is_device_ptr(dst)) {
+        HIPCHK(hipMemcpyAsync(dst, src_dev, n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    } else {
+        HIPCHK(hipMemcpyAsync(dst, src_dev, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return 0;
+}
+
+extern "C" int dsg_forward(dsg_handle* h, const float* x, const int64_t* t, float* out, int B, void* stream) {
+    if (!h || !x || !t || !out) return fail(DSG_E_INVALID, "dsg_forward: null argument");
+    if (!h->finalized || !h->cond_set) return fail(DSG_E_STATE, "dsg_forward before finalize / set_window_cond");
+    if (B != h->condB) return fail(DSG_E_INVALID, "batch differs from the batch of dsg_set_window_cond");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    CHK(order_after(h, stream));
+    std::vector<int> tt(B);
+    if (is_device_ptr(t)) {
+        std::vector<int64_t> th(B);
+        HIPCHK(hipMemcpy(th.data(), t, B * sizeof(int64_t), hipMemcpyDeviceToHost));
+        for (int i = 0; i < B; ++i) tt[i] = (int)th[i];
+    } else {
+        for (int i = 0; i < B; ++i) tt[i] = (int)t[i];
+    }
+    for (int i = 0; i < B; ++i)
+        if (tt[i] < 0 || tt[i] >= h->n_te) return fail(DSG_E_INVALID, "timestep out of range");
+    HIPCHK(hipMemcpyAsync(h->t_arr, tt.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));     // tt is a stack-lifetime staging buffer
+    const size_t n = (size_t)B * h->J * h->T;
+    const float* xd = nullptr;
+    CHK(to_dev(h, x, h->io_tmp, n, &xd));
+    NoiseKey nk = {0, 0, 0, 0};
+    CHK(launch_x_in(h, xd, nullptr, 0, 0.f, 0.f, 0, nk, 0, B));
+    StepCtx c; c.B = B; c.out_mode = OUT_FORWARD; c.use_ctr = false; c.ext_noise = nullptr; c.const_noise = 0;
+    CHK(run_step_p(h, c));
+    CHK(from_dev(h, out, h->fwd_out, n));
+    CHK(order_before(h, stream));
+    return 0;
+}
+
+// per-step coefficient tables in execution order (gaussian_diffusion.py:1617 `.float()` of the float64 tables)
+static int build_step_tables(dsg_handle* h, int mode, int skip, float eta, int* n_run_out) {
+    const Sched& s = h->sched;
+    if (s.n == 0) return fail(DSG_E_STATE, "dsg_sample before dsg_set_schedule");
+    if (skip < 0 || skip >= s.n) return fail(DSG_E_INVALID, "skip_timesteps out of range");
+    const int n_run = s.n - skip;
+    std::vector<int> tm(n_run);
+    std::vector<float> c[5];
+    for (auto& v : c) v.assign(n_run, 0.f);
+    for (int i = 0; i < n_run; ++i) {
+        const int idx = n_run - 1 - i;
+        tm[i] = s.tmap[idx];
+        const float nz = idx == 0 ? 0.f : 1.f;
+        if (mode == DSG_MODE_DDPM) {
+            c[0][i] = (float)s.coef1[idx];
+            c[1][i] = (float)s.coef2[idx];
+            c[2][i] = nz * expf(0.5f * (float)s.plogvar[idx]);
+        } else {
+            const float ab = (float)s.ac[idx], abp = (float)s.acp[idx];
+            const float sigma = eta * sqrtf((1.f - abp) / (1.f - ab)) * sqrtf(1.f - ab / abp);
+            c[0][i] = (float)s.sqrt_recip[idx];
+            c[1][i] = (float)s.sqrt_recipm1[idx];
+            c[2][i] = sqrtf(abp);
+            c[3][i] = sqrtf(1.f - abp - sigma * sigma);
+            c[4][i] = nz * sigma;
+        }
+    }
+    HIPCHK(hipMemcpyAsync(h->st_tmodel, tm.data(), n_run * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    for (int k = 0; k < 5; ++k)
+        HIPCHK(hipMemcpyAsync(h->st_c[k], c[k].data(), n_run * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *n_run_out = n_run;
+    return 0;
+}
+
+extern "C" int dsg_sample(dsg_handle* h, const dsg_sample_args* a, float* out, int B, void* stream) {
+    if (!h || !a || !out) return fail(DSG_E_INVALID, "dsg_sample: null argument");
+    if (!h->finalized || !h->cond_set) return fail(DSG_E_STATE, "dsg_sample before finalize / set_window_cond");
+    if (B != h->condB) return fail(DSG_E_INVALID, "batch differs from the batch of dsg_set_window_cond");
+    if (a->mode != DSG_MODE_DDPM && a->mode != DSG_MODE_DDIM) return fail(DSG_E_INVALID, "mode");
+    if (a->mode == DSG_MODE_DDIM && (a->n_dump > 0 || a->const_noise))
+        return fail(DSG_E_NOT_IMPLEMENTED, "ddim_sample_loop: dump_steps / const_noise (gaussian_diffusion.py:913-916)");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    CHK(order_after(h, stream));
+    int n_run = 0;
+    CHK(build_step_tables(h, a->mode, a->skip_timesteps, a->eta, &n_run));
+    const size_t n = (size_t)B * h->J * h->T;
+    NoiseKey nk;
+    nk.k0 = (unsigned)(a->seed & 0xffffffffu); nk.k1 = (unsigned)(a->seed >> 32);
+    nk.s0 = (unsigned)(a->stream_id & 0xffffffffu); nk.s1 = (unsigned)(a->stream_id >> 32);
+
+    // x_T (gaussian_diffusion.py:701-713)
+    const float *noise_d = nullptr, *init_d = nullptr;
+    CHK(to_dev(h, a->init_noise, h->io_tmp, n, &noise_d));
+    CHK(to_dev(h, a->init_image, h->io_tmp2, n, &init_d));
+    const int do_q = (a->skip_timesteps > 0 || a->init_image) ? 1 : 0;
+    const int i0 = n_run - 1;
+    CHK(launch_x_in(h, noise_d, init_d, do_q, (float)h->sched.sqrt_ac[i0], (float)h->sched.sqrt_1mac[i0],
+                    noise_d ? 0 : 1, nk, a->draw_base, B));
+    // replayed per-step noise
+    const float* ext = nullptr;
+    if (a->step_noise) {
+        const size_t ne = (size_t)n_run * n;
+        if (is_device_ptr(a->step_noise)) ext = a->step_noise;
+        else {
+            if (ne > h->ext_noise_cap) { CHK(dalloc(h, &h->ext_noise, ne, false)); h->ext_noise_cap = ne; }
+            HIPCHK(hipMemcpyAsync(h->ext_noise, a->step_noise, ne * sizeof(float), hipMemcpyHostToDevice, h->stream));
+            ext = h->ext_noise;
+        }
+    }
+    hipLaunchKernelGGL(k_ctr_set, dim3(1), dim3(64), 0, h->stream, h->ctr, -1);
+    HIPCHK(hipGetLastError());
+    {
+        const unsigned dyn[5] = {nk.k0, nk.k1, nk.s0, nk.s1, a->draw_base + 1u};
+        HIPCHK(hipMemcpyAsync(h->dyn, dyn, sizeof(dyn), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+
+    StepCtx c;
+    c.B = B; c.out_mode = a->mode == DSG_MODE_DDPM ? OUT_DDPM : OUT_DDIM; c.use_ctr = true; c.ext_noise = ext;
+    c.const_noise = a->const_noise;
+
+    int spg = h->cfg.steps_per_graph == 0 ? 20 : h->cfg.steps_per_graph;
+    const bool dumping = a->n_dump > 0 && a->dump_steps && a->dump_out;
+    if (dumping || ext) spg = -1;            // rare paths run eagerly (ext pointer / dump points are per call)
+    HIPCHK(hipEventRecord(h->ev_t0, h->stream));
+    int done = 0;
+    if (spg > 0 && n_run >= spg) {
+        // everything that varies between calls (step index, coefficients, noise key, conditioning) lives in device
+        // memory, so one captured graph per (batch, sampler, mask batch, const_noise) serves every window and clip
+        dsg_handle::GKey key = {B, c.out_mode, h->mb, c.const_noise};
+        auto it = h->graphs.find(key);
+        bool ok = true;
+        if (it == h->graphs.end()) {
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            hipError_t e = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal);
+            if (e == hipSuccess) {
+                int rc = 0;
+                for (int s = 0; s < spg && rc == 0; ++s) rc = run_step_p(h, c);
+                e = hipStreamEndCapture(h->stream, &graph);
+                if (rc != 0 || e != hipSuccess || !graph) ok = false;
+                if (ok && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) ok = false;
+            } else ok = false;
+            if (!ok) { (void)hipGetLastError(); if (graph) (void)hipGraphDestroy(graph); }
+            else {
+                dsg_handle::GVal v = {exec, graph, spg};
+                it = h->graphs.emplace(key, v).first;
+            }
+        }
+        if (ok) {
+            while (n_run - done >= spg) { HIPCHK(hipGraphLaunch(it->second.exec, h->stream)); done += spg; }
+        }
+    }
+    int di = 0;
+    for (; done < n_run; ++done) {
+        CHK(run_step_p(h, c));
+        if (dumping) {
+            while (di < a->n_dump && a->dump_steps[di] < done) ++di;
+            if (di < a->n_dump && a->dump_steps[di] == done) {
+                CHK(launch_x_out(h, h->fwd_out, B));
+                CHK(from_dev(h, a->dump_out + (size_t)di * n, h->fwd_out, n));
+                ++di;
+            }
+        }
+    }
+    HIPCHK(hipEventRecord(h->ev_t1, h->stream));
+    h->last_steps = n_run; h->timing_valid = true;
+    CHK(launch_x_out(h, h->fwd_out, B));
+    CHK(from_dev(h, out, h->fwd_out, n));
+    CHK(order_before(h, stream));
+    return 0;
+}
+
+extern "C" int dsg_sync(dsg_handle* h) {
+    if (!h) return fail(DSG_E_INVALID, "null handle");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+extern "C" int dsg_last_sample_ms(dsg_handle* h, float* ms, int* n_steps) {
+    if (!h || !ms) return fail(DSG_E_INVALID, "null argument");
+    if (!h->timing_valid) return fail(DSG_E_STATE, "no dsg_sample has run");
+    HIPCHK(hipEventSynchronize(h->ev_t1));
+    HIPCHK(hipEventElapsedTime(ms, h->ev_t0, h->ev_t1));
+    if (n_steps) *n_steps = h->last_steps;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// stand-alone fused sampler arithmetic on caller tensors
+// ---------------------------------------------------------------------------------------------------------
+static int elementwise(float* out, const float* p, const float* q, const float* z, const float* a, const float* c,
+                       const float* s, int B, int64_t per, void* stream) {
+    if (!out || !p || !a || B <= 0 || per <= 0) return fail(DSG_E_INVALID, "elementwise: bad argument");
+    if (!is_device_ptr(out) || !is_device_ptr(p) || (q && !is_device_ptr(q)) || (z && !is_device_ptr(z)))
+        return fail(DSG_E_INVALID, "elementwise kernels take device tensors");
+    float* coef = nullptr;
+    HIPCHK(hipMalloc((void**)&coef, 3 * B * sizeof(float)));
+    std::vector<float> hc(3 * B, 0.f);
+    for (int b = 0; b < B; ++b) { hc[b] = a[b]; hc[B + b] = c ? c[b] : 0.f; hc[2 * B + b] = s ? s[b] : 0.f; }
+    HIPCHK(hipMemcpy(coef, hc.data(), hc.size() * sizeof(float), hipMemcpyHostToDevice));
+    const size_t n = (size_t)B * per;
+    hipLaunchKernelGGL(k_axpbypcz, dim3((int)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                       out, p, q, z, coef, coef + B, coef + 2 * B, B, (size_t)per);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    HIPCHK(hipFree(coef));
+    return 0;
+}
+extern "C" int dsg_q_sample(float* out, const float* x_start, const float* noise, const float* sqrt_ac,
+                            const float* sqrt_1mac, int B, int64_t per, void* stream) {
+    return elementwise(out, x_start, noise, nullptr, sqrt_ac, sqrt_1mac, nullptr, B, per, stream);
+}
+extern "C" int dsg_predict_xstart_from_eps(float* out, const float* x_t, const float* eps, const float* sqrt_recip,
+                                           const float* sqrt_recipm1, int B, int64_t per, void* stream) {
+    std::vector<float> neg(B);
+    for (int b = 0; b < B; ++b) neg[b] = -sqrt_recipm1[b];
+    return elementwise(out, x_t, eps, nullptr, sqrt_recip, neg.data(), nullptr, B, per, stream);
+}
+extern "C" int dsg_posterior_step(float* out, const float* x_start, const float* x_t, const float* noise,
+                                  const float* coef1, const float* coef2, const float* sigma_nz, int B, int64_t per,
+                                  void* stream) {
+    return elementwise(out, x_start, x_t, noise, coef1, coef2, sigma_nz, B, per, stream);
+}
+extern "C" int dsg_ddim_step(float* out, const float* x_start, const float* x_t, const float* noise, const float* coef,
+                             int B, int64_t per, void* stream) {
+    if (!out || !x_start || !x_t || !coef || B <= 0 || per <= 0) return fail(DSG_E_INVALID, "ddim_step: bad argument");
+    if (!is_device_ptr(out) || !is_device_ptr(x_start) || !is_device_ptr(x_t) || (noise && !is_device_ptr(noise)))
+        return fail(DSG_E_INVALID, "elementwise kernels take device tensors");
+    float* dc = nullptr;
+    HIPCHK(hipMalloc((void**)&dc, 5 * B * sizeof(float)));
+    HIPCHK(hipMemcpy(dc, coef, 5 * B * sizeof(float), hipMemcpyHostToDevice));
+    const size_t n = (size_t)B * per;
+    hipLaunchKernelGGL(k_ddim_step, dim3((int)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                       out, x_start, x_t, noise, dc, B, (size_t)per);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    HIPCHK(hipFree(dc));
+    return 0;
+}

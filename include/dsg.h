@@ -1,0 +1,144 @@
+/* dsg.h -- C ABI of libdsg_hip.so: the MI355X-native DDPM/DDIM sampling path of DiffuseStyleGesture.
+ *
+ * The reference (YoungSeng/DiffuseStyleGesture) is pure Python on PyTorch; it has no FFI for this path.  The
+ * plugin surface it exposes is two Python call signatures, and every entry point below names the reference
+ * interface it stands in for (paths relative to /root/reference):
+ *
+ *   dsg_create / dsg_load_tensor / dsg_finalize_weights
+ *        MDM.__init__ + load_model_wo_clip(model, state_dict)       main/model/mdm.py:10-151, main/utils/model_util.py:8-12
+ *        (tensor names = the checkpoint's state_dict keys)
+ *   dsg_set_schedule
+ *        SpacedDiffusion(use_timesteps, betas=...)                   main/diffusion/respace.py:73-87,
+ *        GaussianDiffusion.__init__ tables                           main/diffusion/gaussian_diffusion.py:161-198
+ *   dsg_set_window_cond
+ *        the `y` dict of model_kwargs (style, seed, audio, mask_local) main/mydiffusion_zeggs/sample.py:227-251
+ *   dsg_forward
+ *        MDM.forward(x, timesteps, y)                                main/model/mdm.py:166-358
+ *                                                                    BEAT-TWH-main/model/mdm.py:134-267
+ *   dsg_sample
+ *        GaussianDiffusion.p_sample_loop / ddim_sample_loop          main/diffusion/gaussian_diffusion.py:608-671, :889-936
+ *   dsg_q_sample / dsg_predict_xstart_from_eps / dsg_posterior_step / dsg_ddim_step
+ *        q_sample :236-254, _predict_xstart_from_eps :400-405, q_posterior_mean_variance + p_sample :256-278/:542-557,
+ *        ddim_sample :773-792   (same file)
+ *
+ * Conventions: every function returns 0 on success or a negative DSG_E_* code; the message is available from
+ * dsg_last_error() (thread local).  No C++ exception crosses this boundary.  Pointers may be host or device
+ * pointers (detected with hipPointerGetAttributes); tensors are contiguous fp32 in the reference's layouts
+ * ([B, J, 1, T] for poses/noise, frames fastest).  A handle is bound to one device and is not thread safe;
+ * distinct handles are independent.  All work is enqueued on the handle's own stream and ordered after/before
+ * the optional caller stream (`stream`, a hipStream_t) with events.
+ */
+#ifndef DSG_H_
+#define DSG_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSG_VERSION 100
+
+enum {
+    DSG_OK = 0,
+    DSG_E_INVALID = -1,       /* ValueError in the shim */
+    DSG_E_RUNTIME = -2,       /* HIP runtime failure -> RuntimeError */
+    DSG_E_UNEXPECTED_KEY = -3,/* load_model_wo_clip: unexpected state_dict key */
+    DSG_E_MISSING_KEY = -4,   /* load_model_wo_clip: missing key at finalize */
+    DSG_E_NOT_IMPLEMENTED = -5,
+    DSG_E_STATE = -6          /* call order (e.g. sample before finalize / set_window_cond) */
+};
+
+enum { DSG_PREC_FP32 = 0, DSG_PREC_BF16 = 1 };
+enum { DSG_MODE_DDPM = 0, DSG_MODE_DDIM = 1 };
+
+typedef struct dsg_config {
+    int32_t variant;        /* 3 = cross_local_attention3_style1 (ZEGGS), 4 = cross_local_attention4 (BEAT/TWH) */
+    int32_t njoints;        /* J */
+    int32_t n_poses;        /* T, frames per window (multiple of `window`) */
+    int32_t n_seed;         /* S */
+    int32_t latent_dim;     /* D (multiple of 64, <= 512) */
+    int32_t audio_src_dim;  /* A_src */
+    int32_t audio_dim;      /* A */
+    int32_t style_dim_in;
+    int32_t window;         /* local attention window (<= 16) */
+    int32_t num_layers;
+    int32_t num_heads;      /* self-attention heads; head dim in {32, 64, 96, 128} */
+    int32_t ff_size;
+    int32_t local_heads;    /* 8 in the reference; head dim <= 64 */
+    int32_t pe_max_len;     /* rows of sequence_pos_encoder.pe (5000) */
+    int32_t train_steps;    /* rows of the time-embedding table = original diffusion steps (1000) */
+    int32_t max_batch;
+    int32_t precision;      /* DSG_PREC_* */
+    int32_t device;         /* HIP device ordinal */
+    int32_t steps_per_graph;/* denoising steps captured per hipGraph replay; 0 = default, -1 = no graphs (eager) */
+    int32_t reserved[5];
+} dsg_config;
+
+typedef struct dsg_handle dsg_handle;
+
+int dsg_version(void);
+const char* dsg_last_error(void);
+
+int dsg_create(const dsg_config* cfg, dsg_handle** out);
+int dsg_destroy(dsg_handle* h);
+
+/* dtype: 0 = float32.  shape/ndim are checked against the model dims. */
+int dsg_load_tensor(dsg_handle* h, const char* name, const void* data, const int64_t* shape, int ndim, int dtype);
+/* repack weights into MFMA fragment order (bf16 or fp32), fold input_process2 . poseEmbedding, build the
+ * [train_steps, D] time-embedding tables and rotary tables */
+int dsg_finalize_weights(dsg_handle* h);
+/* betas: the (respaced) beta schedule, float64[n]; timestep_map: original timestep of each kept step, int64[n] */
+int dsg_set_schedule(dsg_handle* h, const double* betas, const int64_t* timestep_map, int n);
+/* host-only helper (no device needed): the 11 float64[n] tables of GaussianDiffusion.__init__, written to
+ * out[11*n] in the order betas, alphas_cumprod, alphas_cumprod_prev, sqrt_alphas_cumprod,
+ * sqrt_one_minus_alphas_cumprod, sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod, posterior_variance,
+ * posterior_log_variance_clipped, posterior_mean_coef1, posterior_mean_coef2 */
+int dsg_schedule_tables(const double* betas, int n, double* out);
+
+/* style [B, style_dim_in]; seed [B, J, 1, S]; audio [B, T_a, A_src] (T_a = T for variant 3, T-S for variant 4);
+ * mask_local uint8 [mask_batch, T] (1 = keep), mask_batch in {1, B}; uncond != 0 -> uncond_info / y['uncond'] */
+int dsg_set_window_cond(dsg_handle* h, const float* style, const float* seed, const float* audio,
+                        const uint8_t* mask_local, int mask_batch, int B, int uncond);
+
+/* x, out: [B, J, 1, T] fp32; t: model timesteps int64[B] (each < train_steps) */
+int dsg_forward(dsg_handle* h, const float* x, const int64_t* t, float* out, int B, void* stream);
+
+typedef struct dsg_sample_args {
+    int32_t mode;             /* DSG_MODE_DDPM / DSG_MODE_DDIM */
+    int32_t skip_timesteps;
+    float eta;                /* DDIM only */
+    int32_t const_noise;      /* p_sample(const_noise=True): batch element 0's noise for everyone */
+    const float* init_noise;  /* nullable [B,J,1,T]: the reference's `noise=` argument (x_T) */
+    const float* step_noise;  /* nullable [n_run,B,J,1,T]: replayed per-step noise; else the Philox stream */
+    const float* init_image;  /* nullable [B,J,1,T] */
+    uint64_t seed;            /* Philox key */
+    uint64_t stream_id;       /* Philox stream (e.g. clip index) */
+    uint32_t draw_base;       /* draw index of x_T; step i uses draw_base + 1 + i */
+    int32_t n_dump;           /* dump_steps support: number of entries in dump_steps */
+    const int32_t* dump_steps;/* host int32[n_dump], ascending loop indices */
+    float* dump_out;          /* [n_dump,B,J,1,T] */
+    int32_t reserved[4];
+} dsg_sample_args;
+
+/* runs num_timesteps - skip_timesteps denoising steps for the conditioning set by dsg_set_window_cond;
+ * out [B,J,1,T] receives the final sample.  Asynchronous w.r.t. the host when `out` is device memory. */
+int dsg_sample(dsg_handle* h, const dsg_sample_args* args, float* out, int B, void* stream);
+int dsg_sync(dsg_handle* h);
+/* GPU time (HIP events on the handle's stream) of the step loop of the last dsg_sample, and its step count */
+int dsg_last_sample_ms(dsg_handle* h, float* ms, int* n_steps);
+
+/* fused sampler arithmetic on caller tensors (flat fp32 arrays of B*per_batch elements, per-batch scalars on host) */
+int dsg_q_sample(float* out, const float* x_start, const float* noise, const float* sqrt_ac, const float* sqrt_1mac,
+                 int B, int64_t per_batch, void* stream);
+int dsg_predict_xstart_from_eps(float* out, const float* x_t, const float* eps, const float* sqrt_recip,
+                                const float* sqrt_recipm1, int B, int64_t per_batch, void* stream);
+int dsg_posterior_step(float* out, const float* x_start, const float* x_t, const float* noise, const float* coef1,
+                       const float* coef2, const float* sigma_nz, int B, int64_t per_batch, void* stream);
+/* coef: host float[B*5] = {sqrt_recip, sqrt_recipm1, sqrt(abar_prev), sqrt(1-abar_prev-sigma^2), nonzero*sigma} */
+int dsg_ddim_step(float* out, const float* x_start, const float* x_t, const float* noise, const float* coef, int B,
+                  int64_t per_batch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSG_H_ */
