@@ -451,8 +451,10 @@ static int upload(dsg_handle* h, void* dst, const void* src, size_t bytes) {
     return 0;
 }
 
+static int order_after(dsg_handle* h, void* user_stream);
+
 extern "C" int dsg_set_window_cond(dsg_handle* h, const float* style, const float* seed, const float* audio,
-                                   const uint8_t* mask_local, int mask_batch, int B, int uncond) {
+                                   const uint8_t* mask_local, int mask_batch, int B, int uncond, void* stream) {
     if (!h) return fail(DSG_E_INVALID, "null handle");
     if (!h->finalized) return fail(DSG_E_STATE, "dsg_set_window_cond before dsg_finalize_weights");
     if (B <= 0 || B > h->Bmax) return fail(DSG_E_INVALID, "batch exceeds max_batch");
@@ -460,6 +462,7 @@ extern "C" int dsg_set_window_cond(dsg_handle* h, const float* style, const floa
     if (mask_local && !(mask_batch >= 1 && (B * h->Hl) % mask_batch == 0))
         return fail(DSG_E_INVALID, "mask_local batch must divide B*heads");
     HIPCHK(hipSetDevice(h->cfg.device));
+    CHK(order_after(h, stream));      // the caller's stream may still be producing seed / audio
     auto R = [&](const std::string& n) { return h->raw[n].d; };
     const int D = h->D, J = h->J, S = h->S, A = h->A, As = h->As, T = h->T, sdi = h->cfg.style_dim_in;
     const int W2ld = 2 * D + A;

@@ -98,8 +98,9 @@ class DSGDenoiser:
         if self.cfg.n_seed and tuple(seed.obj.shape) != (batch, self.cfg.njoints, 1, self.cfg.n_seed):
             raise ValueError(f"y['seed'] shape {tuple(seed.obj.shape)}")
         uncond = bool(uncond or y.get("uncond", False))
+        stream = L.current_stream_ptr() if L.is_torch(y["audio"]) else None
         self.lib.check(self.lib.cdll.dsg_set_window_cond(self.handle, style.p, seed.p, audio.p, mbuf.p, mb, batch,
-                                                         int(uncond)))
+                                                         int(uncond), stream))
 
     def _alloc_out(self, shape, use_torch):
         if use_torch:

@@ -1,0 +1,224 @@
+"""Clip orchestration and CLI of the sampling path -- the caller contract of the reference.
+
+Mirrors `inference()` / `main()` / the argparse block of `main/mydiffusion_zeggs/sample.py:210-420` (ZEGGS) and
+`BEAT-TWH-main/mydiffusion_beat_twh/sample.py:44-192` (DSG+): window split, per-window conditioning, seed hand-off,
+root-position continuity, the one-frame blend (the reference's `len(last_poses) == 1` quirk), stitching and
+de-normalisation.  The denoising itself is `sample_fn(model, shape, ...)` = `DSGDiffusion.p_sample_loop`, i.e. the
+HIP library.  Windows of one clip are serially dependent (window c is seeded by window c-1), clips are independent.
+"""
+from __future__ import annotations
+
+import argparse
+import math
+import os
+
+import numpy as np
+
+from . import lib as L
+
+style2onehot = {
+    'Happy': [1, 0, 0, 0, 0, 0], 'Sad': [0, 1, 0, 0, 0, 0], 'Neutral': [0, 0, 1, 0, 0, 0],
+    'Old': [0, 0, 0, 1, 0, 0], 'Angry': [0, 0, 0, 0, 1, 0], 'Relaxed': [0, 0, 0, 0, 0, 1],
+}
+
+
+def _xp(use_torch):
+    if use_torch:
+        import torch
+        return torch
+    return None
+
+
+def generate_clip(model, diffusion, feats, style, seed=123456, smoothing=True, skip_timesteps=0, sample_fn=None,
+                  stream_id=0, seed_pose=None, device=None):
+    """ZEGGS window loop (sample.py:236-296).  feats: sequence of K per-window WavLM features, each [B, T, A_src]
+    (torch cuda tensors or numpy); style: one-hot list or [B, 6] array.  Returns normalised poses
+    [B, K*stride - n_seed, J] (numpy float32) -- B independent clips advance in lock step."""
+    cfg = model.cfg
+    S, T, J = cfg.n_seed, cfg.n_poses, cfg.njoints
+    use_torch = L.is_torch(feats[0])
+    B = int(feats[0].shape[0])
+    sty = np.asarray(style, np.float32)
+    if sty.ndim == 1:
+        sty = np.repeat(sty[None], B, 0)
+    sample_fn = sample_fn or diffusion.p_sample_loop
+    diffusion.manual_seed(seed, stream_id)          # torch.manual_seed(seed) at sample.py:212
+    shape = (B, J, 1, T)
+    out = []
+    if use_torch:
+        import torch
+        dev = feats[0].device
+        mask = torch.ones(1, T, dtype=torch.bool, device=dev)
+        sty_t = torch.from_numpy(sty).to(dev)
+        zeros_seed = torch.zeros(B, J, 1, S, device=dev)
+    for c, feat in enumerate(feats):
+        if use_torch:
+            seedp = (zeros_seed if seed_pose is None else seed_pose) if c == 0 else out[-1][..., -S:].contiguous()
+            y = {"style": sty_t, "seed": seedp, "audio": feat, "mask_local": mask}
+        else:
+            seedp = (np.zeros((B, J, 1, S), np.float32) if seed_pose is None else seed_pose) if c == 0 \
+                else np.ascontiguousarray(out[-1][..., -S:])
+            y = {"style": sty, "seed": seedp, "audio": feat, "mask_local": np.ones((1, T), bool)}
+        s = sample_fn(model, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=skip_timesteps,
+                      init_image=None, progress=False, dump_steps=None, noise=None, const_noise=False)
+        if c > 0:
+            last = out[-1][..., -S:]
+            last = last.clone() if use_torch else last.copy()
+            out[-1] = out[-1][..., :-S]
+            if smoothing:
+                delta = (s[:, 0:3, :, 0] - last[:, 0:3, :, 0])[..., None]
+                s[:, 0:3] = s[:, 0:3] - delta
+            # `for j in range(len(last_poses))` with len() == batch dim of a [1, J, 1, S] tensor: only frame 0
+            s[..., 0] = last[..., 0] * 0.5 + s[..., 0] * 0.5
+        out.append(s)
+    out[-1] = out[-1][..., :-S]
+    if use_torch:
+        import torch
+        seq = torch.cat([o[:, :, 0, :] for o in out], dim=2).permute(0, 2, 1)      # [B, K*stride, J]
+        seq = seq[:, S:].contiguous().cpu().numpy()
+    else:
+        seq = np.concatenate([o[:, :, 0, :] for o in out], axis=2).transpose(0, 2, 1)[:, S:]
+    return np.ascontiguousarray(seq, dtype=np.float32)
+
+
+def generate_clip_dsgplus(model, diffusion, feats, style, seed0, real_n_frames, seed=123456, skip_timesteps=0,
+                          sample_fn=None, stream_id=0):
+    """DSG+ window loop (BEAT-TWH sample.py:98-192), attention4: zero-padded tail, no left audio context, GT seed for
+    window 0, no root shift, last window kept whole, first S frames dropped, crop, keep the first J/3 features."""
+    cfg = model.cfg
+    S, T, J = cfg.n_seed, cfg.n_poses, cfg.njoints
+    use_torch = L.is_torch(feats[0])
+    B = int(feats[0].shape[0])
+    sty = np.asarray(style, np.float32)
+    if sty.ndim == 1:
+        sty = np.repeat(sty[None], B, 0)
+    sample_fn = sample_fn or diffusion.p_sample_loop
+    diffusion.manual_seed(seed, stream_id)
+    shape = (B, J, 1, T)
+    out = []
+    if use_torch:
+        import torch
+        dev = feats[0].device
+        mask = torch.ones(1, T, dtype=torch.bool, device=dev)
+        sty = torch.from_numpy(sty).to(dev)
+    else:
+        mask = np.ones((1, T), bool)
+    for c, feat in enumerate(feats):
+        seedp = seed0 if c == 0 else out[-1][..., -S:]
+        seedp = seedp.contiguous() if use_torch else np.ascontiguousarray(seedp)
+        y = {"style": sty, "seed": seedp, "audio": feat, "mask_local": mask}
+        s = sample_fn(model, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=skip_timesteps,
+                      init_image=None, progress=False, dump_steps=None, noise=None, const_noise=False)
+        if c > 0:
+            last = out[-1][..., -S:]
+            last = last.clone() if use_torch else last.copy()
+            out[-1] = out[-1][..., :-S]
+            s[..., 0] = last[..., 0] * 0.5 + s[..., 0] * 0.5
+        out.append(s)
+    if use_torch:
+        import torch
+        seq = torch.cat([o[:, :, 0, :] for o in out], dim=2).permute(0, 2, 1).contiguous().cpu().numpy()
+    else:
+        seq = np.concatenate([o[:, :, 0, :] for o in out], axis=2).transpose(0, 2, 1)
+    seq = seq[:, S:][:, :real_n_frames]
+    return np.ascontiguousarray(seq[:, :, : J // 3], dtype=np.float32)
+
+
+def window_audio(audio, n_frames, n_poses=88, n_seed=8, sr=16000, fps=20):
+    """Audio slices per window with the n_seed-frame left context (sample.py:214-249): zeros for window 0, the
+    previous chunk's tail otherwise.  Returns (list of float32 arrays of (n_poses * sr/fps) samples, n_frames)."""
+    if n_frames == 0:
+        n_frames = audio.shape[0] * fps // sr
+    stride = n_poses - n_seed
+    if n_frames < stride:
+        k = 1
+    else:
+        k = math.floor(n_frames / stride)
+        n_frames = k * stride
+    spf = sr // fps
+    audio = np.asarray(audio[: n_frames * spf], np.float32)
+    chunks = audio.reshape(k, stride * spf)
+    outs = []
+    for c in range(k):
+        left = np.zeros(n_seed * spf, np.float32) if c == 0 else chunks[c - 1][-n_seed * spf:]
+        outs.append(np.concatenate([left, chunks[c]]))
+    return outs, n_frames
+
+
+def denormalise(poses, mean, std):
+    """sample.py:320-326: std clipped at 0.01."""
+    return np.multiply(poses, np.clip(std, a_min=0.01, a_max=None)) + mean
+
+
+def inference(args, wavlm_model, audio, sample_fn, model, n_frames=0, smoothing=False, SG_filter=False,
+              minibatch=False, skip_timesteps=0, n_seed=8, style=None, seed=123456, *, diffusion=None,
+              wav2wavlm=None, mean=None, std=None, pose_writer=None, save_path=None):
+    """Same positional signature as the reference `inference()` (sample.py:210).  `wav2wavlm(wavlm_model, wav)` must
+    return the [1, n_poses, 1024] WavLM features of one window (the WavLM encoder stays on PyTorch-ROCm, outside this
+    path); `pose_writer(out_poses, path, length, smoothing)` is the BVH writer.  Returns de-normalised poses."""
+    if not minibatch:
+        raise NotImplementedError("only the minibatch (windowed) path of inference() is on the sampling path")
+    if diffusion is None:
+        diffusion = sample_fn.__self__
+    wins, n_frames = window_audio(audio, n_frames, args.n_poses, n_seed)
+    feats = [wav2wavlm(wavlm_model, w) for w in wins]
+    poses = generate_clip(model, diffusion, feats, style, seed=seed, smoothing=smoothing,
+                          skip_timesteps=skip_timesteps, sample_fn=sample_fn)[0]
+    out_poses = denormalise(poses, mean, std) if mean is not None else poses
+    if pose_writer is not None and save_path is not None:
+        pose_writer(out_poses, save_path, length=n_frames - n_seed, smoothing=SG_filter)
+    return out_poses
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description='DiffuseStyleGesture')          # flags of sample.py:400-407
+    p.add_argument('--config', default='./configs/DiffuseStyleGesture.yml')
+    p.add_argument('--gpu', type=str, default='0')
+    p.add_argument('--no_cuda', type=list, default=['2'])
+    p.add_argument('--model_path', type=str, default='./model000450000.pt')
+    p.add_argument('--audiowavlm_path', type=str, default='')
+    p.add_argument('--max_len', type=int, default=0)
+    # framework additions
+    p.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    p.add_argument('--features_npy', default='', help='pre-extracted WavLM features [K, n_poses, 1024] (cached per clip)')
+    p.add_argument('--save_dir', default='sample_dir')
+    p.add_argument('--timestep_respacing', default='')
+    return p
+
+
+def main(argv=None):
+    import yaml
+    import torch
+    from .config import ZEGGS
+    from .diffusion import create_gaussian_diffusion
+    from .model import DSGDenoiser
+    args = build_parser().parse_args(argv)
+    cfg_yaml = {}
+    if os.path.exists(args.config):
+        with open(args.config) as f:
+            cfg_yaml = yaml.safe_load(f) or {}
+    n_poses = int(cfg_yaml.get("n_poses", ZEGGS.n_poses))
+    assert n_poses == ZEGGS.n_poses
+    dev = int(args.gpu)
+    torch.cuda.set_device(dev)
+    model = DSGDenoiser(ZEGGS, precision=args.precision, max_batch=1, device=dev)
+    state_dict = torch.load(args.model_path, map_location='cpu')
+    model.load_state_dict(state_dict)
+    diffusion = create_gaussian_diffusion(args.timestep_respacing)
+    name = os.path.basename(args.audiowavlm_path or args.features_npy)
+    style = style2onehot[name.split('_')[1]]                              # sample.py:378
+    if not args.features_npy:
+        raise SystemExit("WavLM feature extraction is outside this path: pass --features_npy (cached per clip)")
+    feats = np.load(args.features_npy).astype(np.float32)
+    if args.max_len:
+        feats = feats[: max(1, args.max_len // (n_poses - ZEGGS.n_seed))]
+    feats_t = [torch.from_numpy(f[None]).cuda(dev) for f in feats]
+    poses = generate_clip(model, diffusion, feats_t, style, seed=123456, smoothing=True)[0]
+    os.makedirs(args.save_dir, exist_ok=True)
+    out = os.path.join(args.save_dir, os.path.splitext(name)[0] + "_poses.npy")
+    np.save(out, poses)
+    print(out, poses.shape)
+
+
+if __name__ == '__main__':
+    main()

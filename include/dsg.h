@@ -98,7 +98,7 @@ int dsg_schedule_tables(const double* betas, int n, double* out);
 /* style [B, style_dim_in]; seed [B, J, 1, S]; audio [B, T_a, A_src] (T_a = T for variant 3, T-S for variant 4);
  * mask_local uint8 [mask_batch, T] (1 = keep), mask_batch in {1, B}; uncond != 0 -> uncond_info / y['uncond'] */
 int dsg_set_window_cond(dsg_handle* h, const float* style, const float* seed, const float* audio,
-                        const uint8_t* mask_local, int mask_batch, int B, int uncond);
+                        const uint8_t* mask_local, int mask_batch, int B, int uncond, void* stream);
 
 /* x, out: [B, J, 1, T] fp32; t: model timesteps int64[B] (each < train_steps) */
 int dsg_forward(dsg_handle* h, const float* x, const int64_t* t, float* out, int B, void* stream);

@@ -1,4 +1,5 @@
 import os
+import subprocess
 import sys
 
 import pytest
@@ -7,6 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+EMU_LIB = os.path.join(ROOT, "tests", "emu", "_build", "libdsg_emu.so")
+HIP_LIB = os.path.join(ROOT, "diffusestylegesture_amd", "csrc", "libdsg_hip.so")
 
 
 def pytest_configure(config):
@@ -16,3 +19,22 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def _make(target, path):
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", ROOT, target])
+    return path
+
+
+@pytest.fixture(scope="session")
+def hip_lib_path():
+    """The product library (hipcc cross-compiles gfx950 without a GPU; it loads on a CPU-only host)."""
+    return _make("all", HIP_LIB)
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    """TEST INFRASTRUCTURE: the product sources compiled for the host under the SIMT emulator (tests/emu)."""
+    from diffusestylegesture_amd import lib as L
+    return L.DSGLibrary(_make("emu", EMU_LIB))

@@ -1,0 +1,74 @@
+"""CPU: the C-ABI library loads and exports every symbol include/dsg.h declares; host-only logic (schedule tables,
+argument validation, respacing) is pinned against the goldens.  No device compute here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from diffusestylegesture_amd import lib as L
+from tests.conftest import ROOT
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "dsg.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dsg_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(hip_lib_path):
+    names = _declared_symbols()
+    assert len(names) >= 17 and "dsg_sample" in names and "dsg_forward" in names
+    cdll = C.CDLL(hip_lib_path)
+    for n in names:
+        assert hasattr(cdll, n), f"libdsg_hip.so does not export {n}"
+    assert set(names) == set(L.SYMBOLS), "ctypes binding and header disagree"
+    lib = L.DSGLibrary(hip_lib_path)
+    assert lib.cdll.dsg_version() == 100
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(L.DSGError, match="no CPU fallback"):
+        L.DSGLibrary(str(tmp_path / "libdsg_hip.so"))
+
+
+def test_schedule_tables_match_reference(hip_lib_path, golden_dir):
+    """dsg_schedule_tables (the host code dsg_set_schedule uses) vs tables dumped from the imported reference."""
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion, _TABLES
+    g1 = np.load(os.path.join(golden_dir, "g1_schedule.npz"))
+    lib = L.DSGLibrary(hip_lib_path)
+    full = create_gaussian_diffusion(library=lib)
+    d50 = create_gaussian_diffusion("ddim50", library=lib)
+    sect = create_gaussian_diffusion("10,15,20", library=lib)
+    for n in _TABLES:
+        np.testing.assert_allclose(getattr(full, n), g1["full_" + n], rtol=1e-13, atol=0)
+        np.testing.assert_allclose(getattr(d50, n), g1["ddim50_" + n], rtol=1e-13, atol=0)
+    assert full.timestep_map == list(range(1000)) and full.num_timesteps == 1000
+    assert d50.timestep_map == list(g1["ddim50_timestep_map"]) and d50.num_timesteps == 50
+    assert sect.timestep_map == list(g1["sect_timestep_map"])
+    np.testing.assert_allclose(sect.betas, g1["sect_betas"], rtol=1e-13)
+    assert full.posterior_mean_coef1[0] == 1.0 and full.posterior_mean_coef2[0] == 0.0
+
+
+def test_space_timesteps_errors():
+    from diffusestylegesture_amd.diffusion import space_timesteps, get_named_beta_schedule
+    assert space_timesteps(1000, "ddim50") == set(range(0, 1000, 20))
+    assert space_timesteps(300, [10, 15, 20]) == space_timesteps(300, "10,15,20")
+    with pytest.raises(ValueError):
+        space_timesteps(1000, "ddim999")
+    with pytest.raises(ValueError):
+        space_timesteps(10, [20])
+    with pytest.raises(NotImplementedError):
+        get_named_beta_schedule("sqrt", 10)
+    lin = get_named_beta_schedule("linear", 1000)
+    assert lin[0] == 0.0001 and abs(lin[-1] - 0.02) < 1e-15
+
+
+def test_window_audio_split():
+    from diffusestylegesture_amd.sample import window_audio
+    audio = np.arange(330 * 800, dtype=np.float32)
+    wins, n = window_audio(audio, 0)
+    assert n == 320 and len(wins) == 4 and all(len(w) == 88 * 800 for w in wins)
+    assert (wins[0][: 8 * 800] == 0).all() and wins[0][8 * 800] == 0.0 and wins[0][-1] == 80 * 800 - 1
+    assert wins[1][0] == 72 * 800 and wins[1][8 * 800] == 80 * 800

@@ -1,0 +1,159 @@
+"""CPU: the PRODUCT sources (csrc/dsg_hip.cpp + dsg_kernels.h) compiled for the host under the SIMT emulator
+(tests/emu, test infrastructure) and driven through the same ctypes shim, compared with the goldens produced by the
+imported reference.  This validates kernel indexing, fragment layouts, host sequencing and the shim before any GPU
+minute is spent; the real-hardware parity tests are tests/test_gpu_parity.py (-m gpu)."""
+import os
+
+import numpy as np
+import pytest
+
+from diffusestylegesture_amd import config as C
+from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+from diffusestylegesture_amd.model import DSGDenoiser
+from diffusestylegesture_amd.sample import generate_clip, denormalise
+from diffusestylegesture_amd.synth import synth_state_dict, synth_window_inputs
+from tests.util import rel_l2
+
+TOL = {"fp32": 1e-5, "bf16": 3e-2}
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+@pytest.fixture(scope="module")
+def tiny(emu_lib, golden_dir):
+    gt = _g(golden_dir, "gt_tiny_zeggs.npz")
+    sd = synth_state_dict(C.TINY, int(gt["wseed"]))
+    models = {}
+    for prec in ("fp32", "bf16"):
+        m = DSGDenoiser(C.TINY, precision=prec, max_batch=2, library=emu_lib)
+        m.load_state_dict(sd)
+        models[prec] = m
+    y = synth_window_inputs(C.TINY, 2, window=2, seed_pose_scale=0.3)
+    x = np.random.RandomState(99).randn(2, C.TINY.njoints, 1, C.TINY.n_poses).astype(np.float32)
+    return gt, models, y, x
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_forward_tiny_masks_uncond(tiny, prec):
+    gt, models, y, x = tiny
+    m = models[prec]
+    ts = np.array([998, 17])
+    assert rel_l2(m(x, ts, y), gt["fwd_allones"]) < TOL[prec]
+    assert rel_l2(m(x, ts, dict(y, mask_local=gt["mask1"])), gt["fwd_mask1"]) < TOL[prec]
+    assert rel_l2(m(x, ts, dict(y, mask_local=gt["mask2"])), gt["fwd_mask2"]) < TOL[prec]
+    assert rel_l2(m(x, ts, y, uncond_info=True), gt["fwd_uncond"]) < TOL[prec]
+    assert rel_l2(m(x, ts, y), gt["fwd_allones"]) < TOL[prec]        # conditioning is re-set per call
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_chains_tiny(tiny, emu_lib, prec):
+    gt, models, y, _ = tiny
+    m = models[prec]
+    shape = (2, C.TINY.njoints, 1, C.TINY.n_poses)
+    mk = {"y": y}
+    d = create_gaussian_diffusion(library=emu_lib)
+    d50 = create_gaussian_diffusion("ddim50", library=emu_lib)
+    tol = TOL[prec] * (3 if prec == "fp32" else 1)
+    s = d.manual_seed(77, 3).p_sample_loop(m, shape, clip_denoised=False, model_kwargs=mk, skip_timesteps=990)
+    assert rel_l2(s, gt["ddpm_skip990"]) < tol
+    init = np.random.RandomState(5).randn(*shape).astype(np.float32)
+    s = d.manual_seed(77, 4).p_sample_loop(m, shape, clip_denoised=False, model_kwargs=mk, skip_timesteps=992,
+                                           init_image=init)
+    assert rel_l2(s, gt["ddpm_init_skip992"]) < tol
+    s = d.manual_seed(77, 5).p_sample_loop(m, shape, clip_denoised=False, model_kwargs=mk, skip_timesteps=994,
+                                           const_noise=True)
+    assert rel_l2(s, gt["ddpm_const_noise"]) < tol
+    dump = d.manual_seed(77, 6).p_sample_loop(m, shape, clip_denoised=False, model_kwargs=mk, skip_timesteps=994,
+                                              dump_steps=[0, 3, 5])
+    assert rel_l2(np.stack(dump), gt["ddpm_dump035"]) < tol
+    s = d50.manual_seed(77, 8).ddim_sample_loop(m, shape, clip_denoised=False, model_kwargs=mk)
+    assert rel_l2(s, gt["ddim50_full"]) < tol
+    s = d50.manual_seed(77, 9).ddim_sample_loop(m, shape, clip_denoised=False, model_kwargs=mk, eta=1.0,
+                                                skip_timesteps=40)
+    assert rel_l2(s, gt["ddim50_eta1_skip40"]) < tol
+    # replayed noise (`noise=` and per-step noise pointers) reproduces the Philox-driven run
+    from oracle import philox
+    n_run = 6
+    ext = np.stack([philox.normal_bj1t(shape, 77, 1 + k, 3) for k in range(n_run)])
+    x_T = philox.normal_bj1t(shape, 77, 0, 3)
+    s1 = d.manual_seed(77, 3).p_sample_loop(m, shape, clip_denoised=False, model_kwargs=mk, skip_timesteps=994)
+    s2 = d.p_sample_loop(m, shape, noise=x_T, clip_denoised=False, model_kwargs=mk, skip_timesteps=994, step_noise=ext)
+    assert rel_l2(s2, s1) < 1e-5
+
+
+def test_error_behaviour(tiny, emu_lib):
+    gt, models, y, x = tiny
+    m = models["fp32"]
+    shape = (2, C.TINY.njoints, 1, C.TINY.n_poses)
+    d = create_gaussian_diffusion(library=emu_lib)
+    with pytest.raises(NotImplementedError):
+        d.ddim_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, dump_steps=[1])
+    with pytest.raises(NotImplementedError):
+        d.ddim_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, const_noise=True)
+    with pytest.raises(NotImplementedError):
+        d.p_sample_loop(m, shape, model_kwargs={"y": y})            # clip_denoised defaults to True
+    with pytest.raises(ValueError):
+        d.p_sample_loop(m, (2, 5, 1, 22), clip_denoised=False, model_kwargs={"y": y})
+    with pytest.raises(ValueError):
+        m(x, np.array([0, 1]), dict(y, audio=y["audio"][:, :5]))
+    with pytest.raises(ValueError):
+        m(x, np.array([0, 5000]), y)
+    m2 = DSGDenoiser(C.TINY, precision="fp32", max_batch=1, library=emu_lib)
+    sd = synth_state_dict(C.TINY, 1)
+    with pytest.raises(ValueError, match="unexpected key"):
+        m2.load_state_dict({"bogus.weight": np.zeros(3, np.float32)})
+    sd2 = dict(sd); sd2.pop("input_process2.bias")
+    with pytest.raises(ValueError, match="missing key"):
+        m2.load_state_dict(sd2)
+    with pytest.raises(ValueError, match="size mismatch"):
+        m2.load_state_dict({"input_process2.bias": np.zeros(3, np.float32)})
+    m2.load_state_dict(dict(sd, **{"clip_model.x": np.zeros(2, np.float32)}))      # tolerated like the reference
+
+
+def test_forward_tiny4_dsgplus(emu_lib, golden_dir):
+    g5 = _g(golden_dir, "g5_forward_dsgplus.npz")
+    cfg = C.TINY4
+    sd = synth_state_dict(cfg, int(g5["wseed"]))
+    y = synth_window_inputs(cfg, 2, window=3, seed_pose_scale=0.1)
+    x = np.random.RandomState(33).randn(2, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+    for prec in ("fp32", "bf16"):
+        m = DSGDenoiser(cfg, precision=prec, max_batch=2, library=emu_lib)
+        m.load_state_dict(sd)
+        assert rel_l2(m(x, np.array([500, 500]), y), g5["tiny4_out"]) < TOL[prec]
+        assert rel_l2(m(x, np.array([500, 500]), dict(y, uncond=True)), g5["tiny4_uncond"]) < TOL[prec]
+
+
+def test_forward_zeggs_full_dims(emu_lib, golden_dir):
+    g2 = _g(golden_dir, "g2_forward_zeggs.npz")
+    cfg = C.ZEGGS
+    sd = synth_state_dict(cfg, int(g2["wseed"]))
+    m = DSGDenoiser(cfg, precision="fp32", max_batch=2, library=emu_lib)
+    m.load_state_dict(sd)
+    for name, B, ts, sps in [("b1_t0", 1, [0], 0.0), ("b2_t999_3", 2, [999, 3], 0.5)]:
+        y = synth_window_inputs(cfg, B, window=1, seed_pose_scale=sps)
+        x = np.random.RandomState(4242 + B).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+        assert rel_l2(m(x, np.array(ts), y), g2[name + "_out"]) < TOL["fp32"]
+    mb = DSGDenoiser(cfg, precision="bf16", max_batch=1, library=emu_lib)
+    mb.load_state_dict(sd)
+    y = synth_window_inputs(cfg, 1, window=1, seed_pose_scale=0.5)
+    x = np.random.RandomState(4243).randn(1, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+    assert rel_l2(mb(x, np.array([999]), y), g2["b1_t999_out"]) < TOL["bf16"]
+
+
+def test_clip_orchestration_matches_reference_inference(emu_lib, golden_dir):
+    """generate_clip (window loop, seed hand-off, root shift, one-frame blend, stitching) + de-normalisation vs the
+    reference's own inference() output (G6), 4 windows x 3 DDPM steps, one noise stream across windows."""
+    g6 = _g(golden_dir, "g6_clip_zeggs.npz")
+    ms = _g(golden_dir, "zeggs_mean_std.npz")
+    cfg = C.ZEGGS
+    m = DSGDenoiser(cfg, precision="fp32", max_batch=1, library=emu_lib)
+    m.load_state_dict(synth_state_dict(cfg, int(g6["wseed"])))
+    d = create_gaussian_diffusion(library=emu_lib)
+    feats = [synth_window_inputs(cfg, 1, window=w)["audio"] for w in range(4)]
+    poses = generate_clip(m, d, feats, [1, 0, 0, 0, 0, 0], seed=int(g6["noise_seed"]), smoothing=True,
+                          skip_timesteps=int(g6["skip_timesteps"]))
+    assert poses.shape == (1, 312, 1141)
+    out = denormalise(poses[0], ms["mean"], ms["std"])
+    assert rel_l2(out, g6["poses_denorm"]) < 1e-5

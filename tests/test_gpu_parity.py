@@ -1,0 +1,220 @@
+"""MI355X parity tests (-m gpu): the HIP path, through the C ABI and the ctypes shim, against
+  (a) the committed goldens produced by the imported reference (tests/golden/*.npz), and
+  (b) the CPU oracle on the same seeded inputs, and
+  (c) size-independent properties at full ZEGGS / batch-16 sizes (determinism, graph == eager, batch consistency).
+Tolerances (rel-L2 on normalised poses): fp32 kernels 2e-5 per forward / 1e-4 after a 1000-step chain;
+bf16 kernels (bf16 MFMA operands, fp32 accumulate / state / LayerNorm / softmax) 3e-2."""
+import os
+
+import numpy as np
+import pytest
+
+from diffusestylegesture_amd import config as C
+from diffusestylegesture_amd.synth import synth_state_dict, synth_window_inputs
+from tests.util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL_FWD = {"fp32": 2e-5, "bf16": 3e-2}
+TOL_CHAIN = {"fp32": 1e-4, "bf16": 3e-2}
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from diffusestylegesture_amd import lib as L
+    return L.default_library()      # raises loudly if libdsg_hip.so is missing
+
+
+def _model(cfg, prec, max_batch=2, wseed=20240, spg=0):
+    from diffusestylegesture_amd.model import DSGDenoiser
+    m = DSGDenoiser(cfg, precision=prec, max_batch=max_batch, device=0, steps_per_graph=spg)
+    m.load_state_dict(synth_state_dict(cfg, wseed))
+    return m
+
+
+@pytest.fixture(scope="module")
+def zeggs(gpu):
+    return {p: _model(C.ZEGGS, p) for p in ("fp32", "bf16")}
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("name,B,ts,sps", [("b1_t0", 1, [0], 0.0), ("b1_t999", 1, [999], 0.5),
+                                           ("b2_t999_3", 2, [999, 3], 0.5)])
+def test_forward_zeggs_vs_reference(zeggs, golden_dir, prec, name, B, ts, sps):
+    g2 = _g(golden_dir, "g2_forward_zeggs.npz")
+    cfg = C.ZEGGS
+    y = synth_window_inputs(cfg, B, window=1, seed_pose_scale=sps)
+    x = np.random.RandomState(4242 + B).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+    out = zeggs[prec](x, np.array(ts), y)
+    assert np.isfinite(out).all()
+    assert rel_l2(out, g2[name + "_out"]) < TOL_FWD[prec]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("tag,skip", [("ddpm5", 995), ("ddpm25", 975), ("ddpm1000", 0)])
+def test_ddpm_chain_zeggs_vs_reference(zeggs, golden_dir, prec, tag, skip):
+    """p_sample_loop with the in-kernel Philox stream vs the reference driven with the same noise (G3 / G8)."""
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    g3 = _g(golden_dir, "g3_chains_zeggs.npz")
+    cfg = C.ZEGGS
+    shape = (1, cfg.njoints, 1, cfg.n_poses)
+    d = create_gaussian_diffusion().manual_seed(int(g3["noise_seed"]), 0)
+    s = d.p_sample_loop(zeggs[prec], shape, clip_denoised=False,
+                        model_kwargs={"y": synth_window_inputs(cfg, 1, window=0)}, skip_timesteps=skip)
+    assert rel_l2(s, g3[tag]) < TOL_CHAIN[prec]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("tag,skip,eta", [("ddim50", 0, 0.0), ("ddim5_eta05", 45, 0.5)])
+def test_ddim_chain_zeggs_vs_reference(zeggs, golden_dir, prec, tag, skip, eta):
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    g3 = _g(golden_dir, "g3_chains_zeggs.npz")
+    cfg = C.ZEGGS
+    shape = (1, cfg.njoints, 1, cfg.n_poses)
+    d = create_gaussian_diffusion("ddim50").manual_seed(int(g3["noise_seed"]), 7)
+    s = d.ddim_sample_loop(zeggs[prec], shape, clip_denoised=False,
+                           model_kwargs={"y": synth_window_inputs(cfg, 1, window=0)}, skip_timesteps=skip, eta=eta)
+    assert rel_l2(s, g3[tag]) < TOL_CHAIN[prec]
+
+
+def test_tiny_masks_uncond_chains(gpu, golden_dir):
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    gt = _g(golden_dir, "gt_tiny_zeggs.npz")
+    cfg = C.TINY
+    m = _model(cfg, "fp32", wseed=int(gt["wseed"]))
+    y = synth_window_inputs(cfg, 2, window=2, seed_pose_scale=0.3)
+    x = np.random.RandomState(99).randn(2, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+    ts = np.array([998, 17])
+    tol = TOL_FWD["fp32"]
+    assert rel_l2(m(x, ts, y), gt["fwd_allones"]) < tol
+    assert rel_l2(m(x, ts, dict(y, mask_local=gt["mask1"])), gt["fwd_mask1"]) < tol
+    assert rel_l2(m(x, ts, dict(y, mask_local=gt["mask2"])), gt["fwd_mask2"]) < tol
+    assert rel_l2(m(x, ts, y, uncond_info=True), gt["fwd_uncond"]) < tol
+    shape = (2, cfg.njoints, 1, cfg.n_poses)
+    mk = {"y": y}
+    d, d50 = create_gaussian_diffusion(), create_gaussian_diffusion("ddim50")
+    tol = TOL_CHAIN["fp32"]
+    assert rel_l2(d.manual_seed(77, 3).p_sample_loop(m, shape, clip_denoised=False, model_kwargs=mk,
+                                                     skip_timesteps=990), gt["ddpm_skip990"]) < tol
+    init = np.random.RandomState(5).randn(*shape).astype(np.float32)
+    assert rel_l2(d.manual_seed(77, 4).p_sample_loop(m, shape, clip_denoised=False, model_kwargs=mk,
+                                                     skip_timesteps=992, init_image=init), gt["ddpm_init_skip992"]) < tol
+    assert rel_l2(d.manual_seed(77, 5).p_sample_loop(m, shape, clip_denoised=False, model_kwargs=mk,
+                                                     skip_timesteps=994, const_noise=True), gt["ddpm_const_noise"]) < tol
+    dump = d.manual_seed(77, 6).p_sample_loop(m, shape, clip_denoised=False, model_kwargs=mk, skip_timesteps=994,
+                                              dump_steps=[0, 3, 5])
+    assert rel_l2(np.stack(dump), gt["ddpm_dump035"]) < tol
+    assert rel_l2(d50.manual_seed(77, 8).ddim_sample_loop(m, shape, clip_denoised=False, model_kwargs=mk),
+                  gt["ddim50_full"]) < tol
+    assert rel_l2(d50.manual_seed(77, 9).ddim_sample_loop(m, shape, clip_denoised=False, model_kwargs=mk, eta=1.0,
+                                                          skip_timesteps=40), gt["ddim50_eta1_skip40"]) < tol
+    assert rel_l2(d.manual_seed(77, 10).p_sample_loop(m, shape, clip_denoised=False, model_kwargs=mk,
+                                                      skip_timesteps=800), gt["ddpm200_tiny"]) < tol
+
+
+@pytest.mark.parametrize("cfg,ts", [(C.BEAT, 999), (C.TWH, 0), (C.TINY4, 500)])
+def test_forward_dsgplus_vs_reference(gpu, golden_dir, cfg, ts):
+    g5 = _g(golden_dir, "g5_forward_dsgplus.npz")
+    B = 1 if cfg.name != "tiny4" else 2
+    y = synth_window_inputs(cfg, B, window=3, seed_pose_scale=0.1)
+    x = np.random.RandomState(31 + B).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+    for prec in ("fp32", "bf16"):
+        m = _model(cfg, prec, max_batch=B, wseed=int(g5["wseed"]))
+        assert rel_l2(m(x, np.array([ts] * B), y), g5[cfg.name + "_out"]) < TOL_FWD[prec]
+
+
+def test_graph_equals_eager_and_deterministic(gpu):
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    cfg = C.ZEGGS
+    shape = (1, cfg.njoints, 1, cfg.n_poses)
+    y = synth_window_inputs(cfg, 1, window=2)
+    outs = []
+    for spg in (-1, 7, 20):      # eager, 7 steps per graph (+ eager tail), 20 steps per graph
+        m = _model(cfg, "bf16", max_batch=1, spg=spg)
+        d = create_gaussian_diffusion().manual_seed(5, 1)
+        outs.append(d.p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=940))
+        d.manual_seed(5, 1)
+        again = d.p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=940)
+        assert np.array_equal(outs[-1], again), "same seed must be bit-reproducible"
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]), "graph replay != eager launches"
+
+
+def test_batch16_consistency(gpu):
+    """B = 16 identical clips with shared noise must each equal the B = 1 result bit for bit (rows are independent)."""
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    from oracle import philox
+    cfg = C.ZEGGS
+    B = 16
+    y1 = synth_window_inputs(cfg, 1, window=1, seed_pose_scale=0.2)
+    yB = {k: (np.repeat(v, B, 0) if k != "mask_local" else v) for k, v in y1.items()}
+    x1 = philox.normal_bj1t((1, cfg.njoints, 1, cfg.n_poses), 3, 0, 0)
+    m = _model(cfg, "bf16", max_batch=B)
+    d = create_gaussian_diffusion().manual_seed(3, 0)
+    s1 = d.p_sample_loop(m, (1, cfg.njoints, 1, cfg.n_poses), noise=x1, clip_denoised=False, model_kwargs={"y": y1},
+                         skip_timesteps=960, const_noise=True)
+    d.manual_seed(3, 0)
+    sB = d.p_sample_loop(m, (B, cfg.njoints, 1, cfg.n_poses), noise=np.repeat(x1, B, 0), clip_denoised=False,
+                         model_kwargs={"y": yB}, skip_timesteps=960, const_noise=True)
+    for b in range(B):
+        assert np.array_equal(sB[b], s1[0]), f"batch element {b} differs"
+
+
+def test_clip_vs_reference_inference(gpu, golden_dir):
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    from diffusestylegesture_amd.sample import generate_clip, denormalise
+    import torch
+    g6 = _g(golden_dir, "g6_clip_zeggs.npz")
+    ms = _g(golden_dir, "zeggs_mean_std.npz")
+    cfg = C.ZEGGS
+    m = _model(cfg, "fp32", max_batch=1, wseed=int(g6["wseed"]))
+    d = create_gaussian_diffusion()
+    feats_np = [synth_window_inputs(cfg, 1, window=w)["audio"] for w in range(4)]
+    kw = dict(seed=int(g6["noise_seed"]), smoothing=True, skip_timesteps=int(g6["skip_timesteps"]))
+    poses = generate_clip(m, d, feats_np, [1, 0, 0, 0, 0, 0], **kw)
+    assert rel_l2(denormalise(poses[0], ms["mean"], ms["std"]), g6["poses_denorm"]) < 1e-5
+    poses_t = generate_clip(m, d, [torch.from_numpy(f).cuda() for f in feats_np], [1, 0, 0, 0, 0, 0], **kw)
+    assert np.array_equal(poses, poses_t), "torch-tensor (device pointer) path != numpy (host pointer) path"
+
+
+def test_elementwise_kernels_and_generic_loop(gpu, zeggs):
+    import torch
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    lib = gpu
+    rs = np.random.RandomState(0)
+    B, per = 3, 1141 * 88
+    a, b, z = (torch.from_numpy(rs.randn(B, per).astype(np.float32)).cuda() for _ in range(3))
+    c1, c2, c3 = (rs.rand(B).astype(np.float32) for _ in range(3))
+    out = torch.empty_like(a)
+    lib.check(lib.cdll.dsg_q_sample(out.data_ptr(), a.data_ptr(), z.data_ptr(), c1.ctypes.data, c2.ctypes.data, B, per, None))
+    ref = c1[:, None] * a.cpu().numpy() + c2[:, None] * z.cpu().numpy()
+    assert np.allclose(out.cpu().numpy(), ref, rtol=1e-6, atol=1e-6)
+    lib.check(lib.cdll.dsg_predict_xstart_from_eps(out.data_ptr(), a.data_ptr(), z.data_ptr(), c1.ctypes.data,
+                                                   c2.ctypes.data, B, per, None))
+    assert np.allclose(out.cpu().numpy(), c1[:, None] * a.cpu().numpy() - c2[:, None] * z.cpu().numpy(), rtol=1e-6, atol=1e-6)
+    lib.check(lib.cdll.dsg_posterior_step(out.data_ptr(), a.data_ptr(), b.data_ptr(), z.data_ptr(), c1.ctypes.data,
+                                          c2.ctypes.data, c3.ctypes.data, B, per, None))
+    ref = c1[:, None] * a.cpu().numpy() + c2[:, None] * b.cpu().numpy() + c3[:, None] * z.cpu().numpy()
+    assert np.allclose(out.cpu().numpy(), ref, rtol=1e-6, atol=1e-6)
+    # generic loop (any callable as `model`) with DDIM eta=0 is deterministic given x_T -> must match the fused loop
+    cfg = C.ZEGGS
+    m = zeggs["fp32"]
+    y = {k: torch.from_numpy(v).cuda() for k, v in synth_window_inputs(cfg, 1, window=0).items()}
+    shape = (1, cfg.njoints, 1, cfg.n_poses)
+    xT = torch.from_numpy(rs.randn(*shape).astype(np.float32)).cuda()
+    d50 = create_gaussian_diffusion("ddim50")
+    fused = d50.ddim_sample_loop(m, shape, noise=xT, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=44)
+
+    class Wrapped:       # not a DSGDenoiser -> generic loop
+        def __call__(self, x, t, y=None):
+            return m(x, t, y)
+
+        def parameters(self):
+            return iter([xT])
+    gen = d50.ddim_sample_loop(Wrapped(), shape, noise=xT, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=44)
+    assert rel_l2(gen.cpu().numpy(), fused.cpu().numpy()) < 1e-5
