@@ -576,7 +576,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
         a.emb1 = h->emb1; a.ctr = c.use_ctr ? h->ctr : nullptr; a.tmodel = h->st_tmodel; a.t_arr = h->t_arr;
         a.rcos = h->rcos; a.rsin = h->rsin; a.mask = h->mask; a.mb = h->mb; a.B = B; a.T = T; a.D = D; a.Hl = h->Hl;
         a.hd = h->hdl; a.W = h->W; a.X0 = h->X0; a.X0a = h->X0a;
-        hipLaunchKernelGGL((k_loc<P>), dim3(B * (T / h->W) * h->Hl), dim3(64), 0, h->stream, a);
+        hipLaunchKernelGGL((k_loc<P>), dim3(B * (T / h->W) * h->Hl), dim3(256), 0, h->stream, a);
         HIPCHK(hipGetLastError());
     }
     for (int l = 0; l < h->L; ++l) {
@@ -656,18 +656,16 @@ static int launch_x_out(dsg_handle* h, float* dst_dev, int B) {
     return 0;
 }
 
+// `user_stream` is the caller's hipStream_t; NULL is the legacy default stream (torch's default on ROCm), which does
+// NOT implicitly synchronise with the handle's non-blocking stream -- so the ordering events are always recorded.
 static int order_after(dsg_handle* h, void* user_stream) {
-    if (user_stream) {
-        HIPCHK(hipEventRecord(h->ev_in, (hipStream_t)user_stream));
-        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_in, 0));
-    }
+    HIPCHK(hipEventRecord(h->ev_in, (hipStream_t)user_stream));
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_in, 0));
     return 0;
 }
 static int order_before(dsg_handle* h, void* user_stream) {
-    if (user_stream) {
-        HIPCHK(hipEventRecord(h->ev_out, h->stream));
-        HIPCHK(hipStreamWaitEvent((hipStream_t)user_stream, h->ev_out, 0));
-    }
+    HIPCHK(hipEventRecord(h->ev_out, h->stream));
+    HIPCHK(hipStreamWaitEvent((hipStream_t)user_stream, h->ev_out, 0));
     return 0;
 }
 // bring a caller tensor to the device (returns the device pointer to use)

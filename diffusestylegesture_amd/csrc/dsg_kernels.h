@@ -275,6 +275,56 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
 #pragma unroll
     for (int t = 0; t < TNW; ++t) swapped[t] = !(EPI == EPI_QKV && ((nt0 + t) * 16) >= 2 * (g.H * g.hd));
 
+    // ---- epilogue operands (bias, residual, x_t, step coefficients, noise) do not depend on the main loop: fetch
+    //      them now so their latency overlaps the weight / activation fragment loads
+    f32x4 pb[TNW], pr[TNW], pz[TNW];
+    float pbs[TNW];
+    int step = 0;
+    float k1 = 0.f, k2 = 0.f, k3 = 0.f, k4 = 0.f, k5 = 0.f;
+    bool ovalid[TNW];
+    if constexpr (EPI == EPI_OUT) {
+        if (g.out_mode != OUT_FORWARD) {
+            step = *g.ctr;
+            k1 = g.st.c1[step]; k2 = g.st.c2[step]; k3 = g.st.c3[step];
+            if (g.out_mode == OUT_DDIM) { k4 = g.st.c4[step]; k5 = g.st.c5[step]; }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TNW; ++t) {
+        const int n0 = (nt0 + t) * 16;
+        pb[t] = pr[t] = pz[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        pbs[t] = 0.f; ovalid[t] = false;
+        if constexpr (EPI == EPI_RESID) {
+            pb[t] = *(const f32x4*)(g.bias + n0 + 4 * lg);
+            pr[t] = *(const f32x4*)(g.R + (size_t)(m0 + lr) * g.ldo + n0 + 4 * lg);     // rows are padded to the tile
+        } else if constexpr (EPI == EPI_GELU) {
+            pb[t] = *(const f32x4*)(g.bias + n0 + 4 * lg);
+        } else if constexpr (EPI == EPI_QKV) {
+            if (swapped[t]) pb[t] = *(const f32x4*)(g.bias + n0 + 4 * lg);
+            else pbs[t] = g.bias[n0 + lr];
+        } else if constexpr (EPI == EPI_OUT) {
+            const int m = m0 + lr, j0 = n0 + 4 * lg;
+            const int b = m / g.ntok, sx = m % g.ntok;
+            ovalid[t] = m < g.M && sx > 0 && j0 < g.J;
+            pb[t] = *(const f32x4*)(g.bias + j0);
+            if (ovalid[t] && g.out_mode != OUT_FORWARD) {
+                const int f = sx - 1;
+                pr[t] = *(const f32x4*)(g.xs32 + ((size_t)b * g.T + f) * g.Jp + j0);
+                const int bn = g.const_noise ? 0 : b;
+                if (g.ext_noise) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        pz[t][e] = (j0 + e < g.J)
+                                       ? g.ext_noise[(((size_t)step * g.B + bn) * g.J + j0 + e) * g.T + f] : 0.f;
+                } else {
+                    const NoiseKey nk = {g.dyn[0], g.dyn[1], g.dyn[2], g.dyn[3]};
+                    pz[t] = philox_normal4((unsigned)((((size_t)bn * g.T + f) * g.Jq + j0) >> 2),
+                                           g.dyn[4] + (unsigned)step, nk);
+                }
+            }
+        }
+    }
+
     // All fragment loads of a chunk are issued before the first MFMA of the chunk: at these sizes the kernel is
     // a latency chain (L2 / Infinity-Cache round trips), so the loads must be in flight together.
     constexpr int CH = 8;
@@ -325,18 +375,13 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
             if (m < g.M) *(f32x4*)((float*)g.out + ((size_t)ks * g.MT * 16 + m) * g.ldo + n0 + 4 * lg) = acc[t];
         } else if constexpr (EPI == EPI_RESID) {
             const int m = m0 + lr, n = n0 + 4 * lg;
-            if (m < g.M) {
-                const f32x4 b = *(const f32x4*)(g.bias + n);
-                const f32x4 rr = *(const f32x4*)(g.R + (size_t)m * g.ldo + n);
-                *(f32x4*)((float*)g.out + (size_t)m * g.ldo + n) = acc[t] + b + rr;
-            }
+            if (m < g.M) *(f32x4*)((float*)g.out + (size_t)m * g.ldo + n) = acc[t] + pb[t] + pr[t];
         } else if constexpr (EPI == EPI_GELU) {
             const int m = m0 + lr, n = n0 + 4 * lg;
             if (m < g.M) {
-                const f32x4 b = *(const f32x4*)(g.bias + n);
                 f32x4 y;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = gelu_erf<P>(acc[t][e] + b[e]);
+                for (int e = 0; e < 4; ++e) y[e] = gelu_erf<P>(acc[t][e] + pb[t][e]);
                 P::store4((elem*)g.out + (size_t)m * g.ldo + n, y);
             }
         } else if constexpr (EPI == EPI_QKV) {
@@ -346,70 +391,51 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
             if (swapped[t]) {                    // Q or K: [B][H][Tp][hd], 4 consecutive dims of one token
                 const int m = m0 + lr;
                 if (m < g.M) {
-                    const int b = m / g.ntok, s = m % g.ntok;
-                    const f32x4 bi = *(const f32x4*)(g.bias + n0 + 4 * lg);
-                    elem* dst = (elem*)(which == 0 ? g.q : g.k) + (((size_t)b * g.H + head) * g.Tp + s) * g.hd + d0 + 4 * lg;
-                    P::store4(dst, acc[t] + bi);
+                    const int b = m / g.ntok, sx = m % g.ntok;
+                    elem* dst = (elem*)(which == 0 ? g.q : g.k) + (((size_t)b * g.H + head) * g.Tp + sx) * g.hd + d0 + 4 * lg;
+                    P::store4(dst, acc[t] + pb[t]);
                 }
             } else {                             // V: transposed [B][H][hd][Tp], lane = one dim, 4 consecutive tokens
-                const float bi = g.bias[n0 + lr];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int m = m0 + 4 * lg + e;
                     if (m < g.M) {
-                        const int b = m / g.ntok, s = m % g.ntok;
-                        ((elem*)g.vt)[(((size_t)b * g.H + head) * g.hd + d0 + lr) * g.Tp + s] = P::cvt(acc[t][e] + bi);
+                        const int b = m / g.ntok, sx = m % g.ntok;
+                        ((elem*)g.vt)[(((size_t)b * g.H + head) * g.hd + d0 + lr) * g.Tp + sx] = P::cvt(acc[t][e] + pbs[t]);
                     }
                 }
             }
         } else if constexpr (EPI == EPI_OUT) {
             const int m = m0 + lr, j0 = n0 + 4 * lg;
-            const int b = m / g.ntok, s = m % g.ntok;
-            if (m < g.M && s > 0 && j0 < g.J) {
-                const int f = s - 1;
-                const f32x4 x0 = acc[t] + *(const f32x4*)(g.bias + j0);
+            const int b = m / g.ntok, sx = m % g.ntok;
+            if (ovalid[t]) {
+                const int f = sx - 1;
+                const f32x4 x0 = acc[t] + pb[t];
                 if (g.out_mode == OUT_FORWARD) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (j0 + e < g.J) g.fwd_out[((size_t)b * g.J + j0 + e) * g.T + f] = x0[e];
                 } else {
-                    const int step = *g.ctr;
-                    float* xp = g.xs32 + ((size_t)b * g.T + f) * g.Jp + j0;
-                    const f32x4 xt = *(const f32x4*)xp;
-                    f32x4 z;
-                    const int bn = g.const_noise ? 0 : b;
-                    if (g.ext_noise) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            z[e] = (j0 + e < g.J)
-                                       ? g.ext_noise[(((size_t)step * g.B + bn) * g.J + j0 + e) * g.T + f] : 0.f;
-                    } else {
-                        const NoiseKey nk = {g.dyn[0], g.dyn[1], g.dyn[2], g.dyn[3]};
-                        z = philox_normal4((unsigned)((((size_t)bn * g.T + f) * g.Jq + j0) >> 2),
-                                           g.dyn[4] + (unsigned)step, nk);
-                    }
+                    const f32x4 xt = pr[t], z = pz[t];
                     f32x4 xn;
                     if (g.out_mode == OUT_DDPM) {       // gaussian_diffusion.py:264-267, :557
-                        const float c1 = g.st.c1[step], c2 = g.st.c2[step], sg = g.st.c3[step];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float mean = c1 * x0[e] + c2 * xt[e];
-                            xn[e] = mean + sg * z[e];
+                            const float mean = k1 * x0[e] + k2 * xt[e];
+                            xn[e] = mean + k3 * z[e];
                         }
                     } else {                            // gaussian_diffusion.py:773-791
-                        const float rc = g.st.c1[step], rm1 = g.st.c2[step], sap = g.st.c3[step],
-                                    dir = g.st.c4[step], sg = g.st.c5[step];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float eps = (rc * xt[e] - x0[e]) / rm1;
-                            const float mean = x0[e] * sap + dir * eps;
-                            xn[e] = mean + sg * z[e];
+                            const float eps = (k1 * xt[e] - x0[e]) / k2;
+                            const float mean = x0[e] * k3 + k4 * eps;
+                            xn[e] = mean + k5 * z[e];
                         }
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (j0 + e >= g.J) xn[e] = 0.f;
-                    *(f32x4*)xp = xn;
+                    *(f32x4*)(g.xs32 + ((size_t)b * g.T + f) * g.Jp + j0) = xn;
                     if (g.xsA) P::store4((elem*)g.xsA + ((size_t)b * g.T + f) * g.Jp + j0, xn);
                 }
             }
@@ -441,94 +467,148 @@ struct LocArgs {
 };
 
 template <class P>
-__global__ __launch_bounds__(64) void k_loc(const LocArgs a) {
+__global__ __launch_bounds__(256) void k_loc(const LocArgs a) {
     typedef typename P::elem elem;
-    constexpr int MAXW = 16, MAXHD = 64;
-    __shared__ float raw[2 * MAXW][MAXHD];
-    __shared__ float rot[2 * MAXW][MAXHD];
-    __shared__ float sc[MAXW][2 * MAXW];
-    __shared__ float ob[MAXW][MAXHD];
+    constexpr int MAXW = 16, MAXHD = 64, NT = 256;
+    constexpr int NE1 = (2 * MAXW * MAXHD + NT - 1) / NT;     // tile elements per thread (<= 8)
+    constexpr int NE2 = (MAXW * MAXHD + NT - 1) / NT;         // output elements per thread (<= 4)
+    constexpr int NS = (MAXW * 2 * MAXW + NT - 1) / NT;       // scores per thread (<= 2)
+    __shared__ float raw[2 * MAXW][MAXHD + 1];
+    __shared__ float rot[2 * MAXW][MAXHD + 1];
+    __shared__ float sc[MAXW][2 * MAXW + 1];
+    __shared__ float ob[MAXW][MAXHD + 1];
     const int nW = a.T / a.W;
     int id = blockIdx.x;
     const int h = id % a.Hl; id /= a.Hl;
     const int w = id % nW; const int b = id / nW;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
     const int W = a.W, hd = a.hd, half = hd >> 1, W2 = 2 * W;
     const int t = a.ctr ? a.tmodel[*a.ctr] : a.t_arr[b];
     const int col0 = h * hd;
     const int ntok = a.T + 1;
+    const int n1 = W2 * hd, n2 = W * hd, ns = W * W2;
 
-    if (w == 0)                                            // token row (position 0: rotary is the identity)
-        for (int d = lane; d < hd; d += 64) {
-            const float v = a.emb1[(size_t)b * a.D + col0 + d] + a.TE[(size_t)t * a.D + col0 + d];
-            a.X0[(size_t)(b * ntok) * a.D + col0 + d] = v;
-            ((elem*)a.X0a)[(size_t)(b * ntok) * a.D + col0 + d] = P::cvt(v);
+    // ---- every global load of the block is issued up front (the kernel is a latency chain otherwise)
+    float v1[NE1], c1[NE1], s1[NE1];
+#pragma unroll
+    for (int i = 0; i < NE1; ++i) {
+        const int e = tid + NT * i;
+        v1[i] = 0.f; c1[i] = 1.f; s1[i] = 0.f;
+        if (e < n1) {
+            const int r = e / hd, d = e % hd, f = (w - 1) * W + r;
+            if (f >= 0) {
+                const size_t row = (size_t)b * a.T + f;
+                const int dd = d < half ? d : d - half;
+                v1[i] = a.Cf[row * a.D + col0 + d] + a.TE2[(size_t)t * a.D + col0 + d];
+                c1[i] = a.rcos[f * half + dd]; s1[i] = a.rsin[f * half + dd];
+            }
         }
-    for (int e = lane; e < W2 * hd; e += 64) {
-        const int r = e / hd, d = e % hd;
-        const int f = (w - 1) * W + r;
-        float v = 0.f;
-        if (f >= 0) {
-            const size_t row = (size_t)b * a.T + f;
-            v = a.Cf[row * a.D + col0 + d] + a.TE2[(size_t)t * a.D + col0 + d];
-            for (int s = 0; s < a.KS; ++s) v += a.partial[((size_t)s * a.Min_pad + row) * a.D + col0 + d];
+    }
+    for (int s = 0; s < a.KS; ++s) {
+#pragma unroll
+        for (int i = 0; i < NE1; ++i) {
+            const int e = tid + NT * i;
+            if (e < n1) {
+                const int r = e / hd, d = e % hd, f = (w - 1) * W + r;
+                if (f >= 0) v1[i] += a.partial[((size_t)s * a.Min_pad + (size_t)b * a.T + f) * a.D + col0 + d];
+            }
         }
-        raw[r][d] = v;
+    }
+    float c2[NE2], s2[NE2];
+#pragma unroll
+    for (int i = 0; i < NE2; ++i) {
+        const int e = tid + NT * i;
+        c2[i] = 1.f; s2[i] = 0.f;
+        if (e < n2) {
+            const int q = e / hd, d = e % hd, pos = w * W + q + 1;
+            const int dd = d < half ? d : d - half;
+            c2[i] = a.rcos[pos * half + dd]; s2[i] = a.rsin[pos * half + dd];
+        }
+    }
+    const int mrow = (int)(((long long)(b * a.Hl + h)) / ((long long)a.B * a.Hl / a.mb));
+    bool keep[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int e = tid + NT * i;
+        keep[i] = false;
+        if (e < ns) {
+            const int j = e % W2, fk = (w - 1) * W + j;
+            keep[i] = (fk >= 0) && (a.mask[(size_t)mrow * a.T + fk] != 0);   // look_around pads the key mask with False
+        }
+    }
+    float tokv = 0.f;
+    if (w == 0 && tid < hd) tokv = a.emb1[(size_t)b * a.D + col0 + tid] + a.TE[(size_t)t * a.D + col0 + tid];
+
+    if (w == 0 && tid < hd) {                              // token row (position 0: rotary is the identity)
+        a.X0[(size_t)(b * ntok) * a.D + col0 + tid] = tokv;
+        ((elem*)a.X0a)[(size_t)(b * ntok) * a.D + col0 + tid] = P::cvt(tokv);
+    }
+#pragma unroll
+    for (int i = 0; i < NE1; ++i) {
+        const int e = tid + NT * i;
+        if (e < n1) raw[e / hd][e % hd] = v1[i];
     }
     __syncthreads();
-    for (int e = lane; e < W2 * hd; e += 64) {
-        const int r = e / hd, d = e % hd;
-        const int f = (w - 1) * W + r;
-        float v = -1.0f;                                   // look_around pad_value (local_attention.py:94,134)
-        if (f >= 0) {
-            const int dd = d < half ? d : d - half;
-            const float c = a.rcos[f * half + dd], s = a.rsin[f * half + dd];
-            const float other = d < half ? -raw[r][d + half] : raw[r][d - half];
-            v = raw[r][d] * c + other * s;
+#pragma unroll
+    for (int i = 0; i < NE1; ++i) {
+        const int e = tid + NT * i;
+        if (e < n1) {
+            const int r = e / hd, d = e % hd, f = (w - 1) * W + r;
+            float v = -1.0f;                               // look_around pad_value (local_attention.py:94,134)
+            if (f >= 0) {
+                const float other = d < half ? -raw[r][d + half] : raw[r][d - half];
+                v = raw[r][d] * c1[i] + other * s1[i];
+            }
+            rot[r][d] = v;
         }
-        rot[r][d] = v;
     }
     __syncthreads();
     const float scale = 1.0f / sqrtf((float)hd);
-    const int mrow = (int)(((long long)(b * a.Hl + h)) / ((long long)a.B * a.Hl / a.mb));
-    for (int e = lane; e < W * W2; e += 64) {
-        const int i = e / W2, j = e % W2;
-        const int fq = w * W + i, fk = (w - 1) * W + j;
-        float s = 0.f;
-        for (int d = 0; d < hd; ++d) s += rot[W + i][d] * rot[j][d];
-        s *= scale;
-        bool masked = (fk >= 0) && (fq < fk);              // causal (pad index -1 is never "in the future")
-        const bool keep = (fk >= 0) && (a.mask[(size_t)mrow * a.T + fk] != 0);
-        if (!keep) masked = true;                          // key mask, look_around pads it with False
-        sc[i][j] = masked ? -DSG_FLT_MAX : s;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int e = tid + NT * i;
+        if (e < ns) {
+            const int q = e / W2, j = e % W2;
+            const int fq = w * W + q, fk = (w - 1) * W + j;
+            float s = 0.f;
+            for (int d = 0; d < hd; ++d) s += rot[W + q][d] * rot[j][d];
+            s *= scale;
+            const bool masked = ((fk >= 0) && (fq < fk)) || !keep[i];   // causal | key mask
+            sc[q][j] = masked ? -DSG_FLT_MAX : s;
+        }
     }
     __syncthreads();
-    if (lane < W) {
+    if (tid < W) {
         float mx = -DSG_FLT_MAX;
-        for (int j = 0; j < W2; ++j) mx = fmaxf(mx, sc[lane][j]);
+        for (int j = 0; j < W2; ++j) mx = fmaxf(mx, sc[tid][j]);
         float sum = 0.f;
-        for (int j = 0; j < W2; ++j) { const float p = expf(sc[lane][j] - mx); sc[lane][j] = p; sum += p; }
+        for (int j = 0; j < W2; ++j) { const float p = expf(sc[tid][j] - mx); sc[tid][j] = p; sum += p; }
         const float inv = 1.0f / sum;
-        for (int j = 0; j < W2; ++j) sc[lane][j] *= inv;
+        for (int j = 0; j < W2; ++j) sc[tid][j] *= inv;
     }
     __syncthreads();
-    for (int e = lane; e < W * hd; e += 64) {
-        const int i = e / hd, d = e % hd;
-        float o = 0.f;
-        for (int j = 0; j < W2; ++j) o += sc[i][j] * rot[j][d];
-        ob[i][d] = o;
+#pragma unroll
+    for (int i = 0; i < NE2; ++i) {
+        const int e = tid + NT * i;
+        if (e < n2) {
+            const int q = e / hd, d = e % hd;
+            float o = 0.f;
+            for (int j = 0; j < W2; ++j) o += sc[q][j] * rot[j][d];
+            ob[q][d] = o;
+        }
     }
     __syncthreads();
-    for (int e = lane; e < W * hd; e += 64) {
-        const int i = e / hd, d = e % hd;
-        const int f = w * W + i, pos = f + 1;
-        const int dd = d < half ? d : d - half;
-        const float c = a.rcos[pos * half + dd], s = a.rsin[pos * half + dd];
-        const float other = d < half ? -ob[i][d + half] : ob[i][d - half];
-        const float v = ob[i][d] * c + other * s;
-        const size_t o = (size_t)(b * ntok + 1 + f) * a.D + col0 + d;
-        a.X0[o] = v;
-        ((elem*)a.X0a)[o] = P::cvt(v);
+#pragma unroll
+    for (int i = 0; i < NE2; ++i) {
+        const int e = tid + NT * i;
+        if (e < n2) {
+            const int q = e / hd, d = e % hd, f = w * W + q;
+            const float other = d < half ? -ob[q][d + half] : ob[q][d - half];
+            const float v = ob[q][d] * c2[i] + other * s2[i];
+            const size_t o = (size_t)(b * ntok + 1 + f) * a.D + col0 + d;
+            a.X0[o] = v;
+            ((elem*)a.X0a)[o] = P::cvt(v);
+        }
     }
 }
 
@@ -571,6 +651,24 @@ __global__ __launch_bounds__(64) void k_attn(const AttnArgs a) {
             s[nt] = P::mma(kf, qf[kb], s[nt]);       // D[key = 4*lg + r][query = lr]
         }
     }
+    // V^T fragments are fetched before the softmax arithmetic so their latency hides under it
+    constexpr int ND = HD / 16;                      // 16-dim output tiles
+    constexpr int NVF = P::E == 4 ? NKT : NKT / 2;   // PV k-blocks
+    f32x4 vfr[ND][NVF];
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) {
+        const elem* vrow = VT + (size_t)(dt * 16 + lr) * a.Tp;
+#pragma unroll
+        for (int kb = 0; kb < NVF; ++kb) {
+            if constexpr (P::E == 4) {
+                vfr[dt][kb] = *(const f32x4*)(vrow + kb * 16 + 4 * lg);
+            } else {
+                const f32x2 v0 = *(const f32x2*)(vrow + (2 * kb) * 16 + 4 * lg);        // 4 bf16 = 8 bytes
+                const f32x2 v1 = *(const f32x2*)(vrow + (2 * kb + 1) * 16 + 4 * lg);
+                vfr[dt][kb] = (f32x4){v0[0], v0[1], v1[0], v1[1]};
+            }
+        }
+    }
     const float scale = 1.0f / sqrtf((float)HD);
     float mx = -DSG_FLT_MAX;
 #pragma unroll
@@ -598,34 +696,26 @@ __global__ __launch_bounds__(64) void k_attn(const AttnArgs a) {
     sum += __shfl_xor(sum, 32);
     const float inv = 1.0f / sum;
 
-    constexpr int ND = HD / 16;                      // 16-dim output tiles
     const int q = qt * 16 + lr;
+    f32x4 pfr[NVF];                                  // P^T fragments: exactly the values this lane already holds
+#pragma unroll
+    for (int kb = 0; kb < NVF; ++kb) {
+        if constexpr (P::E == 4) {
+            pfr[kb] = s[kb];
+        } else {
+            static_assert(P::E == 4 || (NKT % 2) == 0, "bf16 pairs key tiles");
+            typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+            u16x8 pp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pp[e] = f2bf(s[2 * kb][e]); pp[4 + e] = f2bf(s[2 * kb + 1][e]); }
+            pfr[kb] = __builtin_bit_cast(f32x4, pp);
+        }
+    }
 #pragma unroll
     for (int dt = 0; dt < ND; ++dt) {
         f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const elem* vrow = VT + (size_t)(dt * 16 + lr) * a.Tp;
-        if constexpr (P::E == 4) {
 #pragma unroll
-            for (int nt = 0; nt < NKT; ++nt) {
-                const f32x4 vf = *(const f32x4*)(vrow + nt * 16 + 4 * lg);
-                o = P::mma(vf, s[nt], o);            // D[dim = 4*lg + r][query = lr]
-            }
-        } else {
-            static_assert(P::E == 4 || (NKT % 2) == 0, "bf16 pairs key tiles");
-#pragma unroll
-            for (int kb = 0; kb < NKT / 2; ++kb) {
-                const u16x4 v0 = *(const u16x4*)(vrow + (2 * kb) * 16 + 4 * lg);
-                const u16x4 v1 = *(const u16x4*)(vrow + (2 * kb + 1) * 16 + 4 * lg);
-                typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
-                u16x8 vv, pp;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    vv[e] = v0[e]; vv[4 + e] = v1[e];
-                    pp[e] = f2bf(s[2 * kb][e]); pp[4 + e] = f2bf(s[2 * kb + 1][e]);
-                }
-                o = P::mma(__builtin_bit_cast(f32x4, vv), __builtin_bit_cast(f32x4, pp), o);
-            }
-        }
+        for (int kb = 0; kb < NVF; ++kb) o = P::mma(vfr[dt][kb], pfr[kb], o);     // D[dim = 4*lg + r][query = lr]
         if (q < a.ntok) {
             f32x4 y;
 #pragma unroll

@@ -68,6 +68,12 @@ class DSGLibrary:
                 f"{path} not found: build the HIP library first (`make` or `python -c 'import __graft_entry__ as g; "
                 f"g.build()'`).  There is no CPU fallback for the sampling path.")
         self.path = path
+        # torch (when installed) must own the HIP runtime of the process: the library exchanges hipStream_t handles and
+        # device pointers with it, and a second libamdhip64 initialised first leaves the later one without devices
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         self.cdll = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(self.cdll, name)          # AttributeError if the library does not export it
