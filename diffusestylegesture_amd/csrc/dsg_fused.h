@@ -1,0 +1,568 @@
+// dsg_fused.h -- latency-mode kernels: the same arithmetic as dsg_kernels.h, regrouped so that one denoising step is
+// 2 + 3*L launches instead of 3 + 5*L.  At batch 1 every launch is a latency chain (kernel boundary + cold L2 +
+// load -> MFMA -> store), so the lever is the NUMBER of dependent launches, not FLOPs: the fused kernels recompute
+// small things redundantly (K/V of a head per query tile, out_proj + LayerNorm per hidden slice, the pose embedding
+// of the previous window's frames) to avoid an all-to-all hand-off.
+//
+//   k_inloc     = k_in + k_loc      pose-embedding GEMM for {previous, own} window x one local head (K split over
+//                                   the 4 waves, reduced in LDS) -> rotary -> local attention -> token -> rotary
+//   k_qkv_attn  = [LayerNorm2-on-read] + in_proj for ONE self-attention head (K, V of all tokens; Q of one 16-query
+//                 tile) + softmax(QK^T/sqrt(hd))V, all staged in LDS; grid = batch x heads x query tiles
+//   k_mid       = out_proj + residual + LayerNorm1 (rows owned whole by the workgroup) + linear1 slice + GELU
+//   (linear2 + residual and the pose head + sampler update stay k_gemm<RESID> / k_gemm<OUT> of dsg_kernels.h)
+// Reference arithmetic: main/model/mdm.py:196-233 and torch's TransformerEncoderLayer (post-norm) -- see dsg_kernels.h.
+#pragma once
+#include "dsg_kernels.h"
+
+namespace dsg {
+
+// ---------------------------------------------------------------------------------------------------------
+// k_inloc
+// ---------------------------------------------------------------------------------------------------------
+struct InLocArgs {
+    const void* xs;         // [B*T (+pad)][Jp] P::elem state (bf16 shadow, or the fp32 master in fp32 mode)
+    int Jp;
+    const void* Wp;         // packed folded weight [D/16][KBtot][64][16 B]
+    int KBtot;
+    LocArgs loc;            // Cf, TE2, TE, emb1, ctr/tmodel/t_arr, rotary tables, mask, dims, X0/X0a (partial unused)
+    int* ctr_inc;           // first kernel of a step: block 0 advances step counter B (see k_inloc)
+};
+
+template <class P>
+__global__ __launch_bounds__(256) void k_inloc(const InLocArgs g) {
+    typedef typename P::elem elem;
+    const LocArgs& a = g.loc;
+    constexpr int MAXW = 16, MAXHD = 64, NT = 256;
+    constexpr int NE1 = (2 * MAXW * MAXHD + NT - 1) / NT;
+    constexpr int NE2 = (MAXW * MAXHD + NT - 1) / NT;
+    constexpr int NS = (MAXW * 2 * MAXW + NT - 1) / NT;
+    constexpr int MAXNL = 4;                                   // 16-col tiles per local head (hd <= 64)
+    __shared__ __attribute__((aligned(16))) float red[4][2][MAXNL][64][4];   // per-wave partial accumulators
+    __shared__ float raw[2 * MAXW][MAXHD + 1];
+    __shared__ float rot[2 * MAXW][MAXHD + 1];
+    __shared__ float sc[MAXW][2 * MAXW + 1];
+    __shared__ float ob[MAXW][MAXHD + 1];
+    const int nW = a.T / a.W;
+    int id = blockIdx.x;
+    const int h = id % a.Hl; id /= a.Hl;
+    const int w = id % nW; const int b = id / nW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
+    // two step counters make the hand-over race free: this kernel READS ctrA (a.ctr) and ADVANCES ctrB (read only by
+    // the last kernel of the step, which in turn advances ctrA) -- no kernel reads the counter it increments
+    if (g.ctr_inc && blockIdx.x == 0 && tid == 0) *g.ctr_inc += 1;
+    const int W = a.W, hd = a.hd, half = hd >> 1, W2 = 2 * W;
+    const int col0 = h * hd;
+    const int ntok = a.T + 1;
+    const int n1 = W2 * hd, n2 = W * hd, ns = W * W2;
+    const int f0 = (w - 1) * W;
+
+    // ---- (1) window constants, rotary tables and the key mask: issued first so they fly under the GEMM loads
+    const int tt = a.ctr ? a.tmodel[*a.ctr] : a.t_arr[b];
+    float v1[NE1], c1[NE1], s1[NE1];
+#pragma unroll
+    for (int i = 0; i < NE1; ++i) {
+        const int e = tid + NT * i;
+        v1[i] = 0.f; c1[i] = 1.f; s1[i] = 0.f;
+        if (e < n1) {
+            const int r = e / hd, d = e % hd, f = f0 + r;
+            if (f >= 0) {
+                const size_t row = (size_t)b * a.T + f;
+                const int dd = d < half ? d : d - half;
+                v1[i] = a.Cf[row * a.D + col0 + d] + a.TE2[(size_t)tt * a.D + col0 + d];
+                c1[i] = a.rcos[f * half + dd]; s1[i] = a.rsin[f * half + dd];
+            }
+        }
+    }
+    float c2[NE2], s2[NE2];
+#pragma unroll
+    for (int i = 0; i < NE2; ++i) {
+        const int e = tid + NT * i;
+        c2[i] = 1.f; s2[i] = 0.f;
+        if (e < n2) {
+            const int q = e / hd, d = e % hd, pos = w * W + q + 1;
+            const int dd = d < half ? d : d - half;
+            c2[i] = a.rcos[pos * half + dd]; s2[i] = a.rsin[pos * half + dd];
+        }
+    }
+    const int mrow = (int)(((long long)(b * a.Hl + h)) / ((long long)a.B * a.Hl / a.mb));
+    bool keep[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int e = tid + NT * i;
+        keep[i] = false;
+        if (e < ns) {
+            const int j = e % W2, fk = f0 + j;
+            keep[i] = (fk >= 0) && (a.mask[(size_t)mrow * a.T + fk] != 0);
+        }
+    }
+    float tokv = 0.f;
+    if (w == 0 && tid < hd) tokv = a.emb1[(size_t)b * a.D + col0 + tid] + a.TE[(size_t)tt * a.D + col0 + tid];
+    if (w == 0 && tid < hd) {
+        a.X0[(size_t)(b * ntok) * a.D + col0 + tid] = tokv;
+        ((elem*)a.X0a)[(size_t)(b * ntok) * a.D + col0 + tid] = P::cvt(tokv);
+    }
+
+    // ---- (2) pose-embedding GEMM for the 2W frames x this head's columns; this wave's share of K
+    const int nl = hd >= 16 ? hd / 16 : 1;                     // 16-col tiles covering the head
+    const int ntile0 = col0 / 16;
+    const int kbw = (g.KBtot + 3) / 4;
+    const int kb_lo = wave * kbw, kb_hi = min(kb_lo + kbw, g.KBtot);
+    f32x4 acc[2][MAXNL];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < MAXNL; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const elem* arow[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        int f = f0 + mt * 16 + lr;
+        f = f < 0 ? 0 : (f > a.T - 1 ? a.T - 1 : f);          // rows outside the window pair are computed and ignored
+        arow[mt] = (const elem*)g.xs + ((size_t)b * a.T + f) * g.Jp + P::E * lg;
+    }
+    const f32x4* wbase = (const f32x4*)g.Wp + lane;
+    constexpr int CH = 9;
+    for (int kb0 = kb_lo; kb0 < kb_hi; kb0 += CH) {
+        f32x4 af[CH][2], bf[CH][MAXNL];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int kb = kb0 + c;
+            if (kb < kb_hi) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) af[c][mt] = *(const f32x4*)(arow[mt] + (size_t)kb * P::KB);
+#pragma unroll
+                for (int nt = 0; nt < MAXNL; ++nt)
+                    if (nt < nl) bf[c][nt] = wbase[((size_t)(ntile0 + nt) * g.KBtot + kb) * 64];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (kb0 + c < kb_hi) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < MAXNL; ++nt)
+                        if (nt < nl) acc[mt][nt] = P::mma(af[c][mt], bf[c][nt], acc[mt][nt]);   // D[row 4lg+r][col lr]
+            }
+        }
+    }
+
+    // ---- (3) reduce the 4 K-slices and assemble the [2W][hd] tile
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < MAXNL; ++nt)
+            if (nt < nl) *(f32x4*)&red[wave][mt][nt][lane][0] = acc[mt][nt];
+    __syncthreads();
+    const int cshift = col0 - ntile0 * 16;                     // head narrower than a tile: offset inside the tile
+#pragma unroll
+    for (int i = 0; i < NE1; ++i) {
+        const int e = tid + NT * i;
+        if (e < n1) {
+            const int r = e / hd, d = e % hd;
+            const int mt = r >> 4, rr = r & 15, cc = d + cshift, nt = cc >> 4, cl = cc & 15;
+            const int ln = (rr >> 2) * 16 + cl, rg = rr & 3;   // D[row = 4*lg + reg][col = lr]
+            float v = v1[i];
+            v += (red[0][mt][nt][ln][rg] + red[1][mt][nt][ln][rg]) + (red[2][mt][nt][ln][rg] + red[3][mt][nt][ln][rg]);
+            raw[r][d] = v;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NE1; ++i) {
+        const int e = tid + NT * i;
+        if (e < n1) {
+            const int r = e / hd, d = e % hd, f = f0 + r;
+            float v = -1.0f;                               // look_around pad_value (local_attention.py:94,134)
+            if (f >= 0) {
+                const float other = d < half ? -raw[r][d + half] : raw[r][d - half];
+                v = raw[r][d] * c1[i] + other * s1[i];
+            }
+            rot[r][d] = v;
+        }
+    }
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)hd);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int e = tid + NT * i;
+        if (e < ns) {
+            const int q = e / W2, j = e % W2;
+            const int fq = w * W + q, fk = f0 + j;
+            float s = 0.f;
+            for (int d = 0; d < hd; ++d) s += rot[W + q][d] * rot[j][d];
+            s *= scale;
+            const bool masked = ((fk >= 0) && (fq < fk)) || !keep[i];
+            sc[q][j] = masked ? -DSG_FLT_MAX : s;
+        }
+    }
+    __syncthreads();
+    if (tid < W) {
+        float mx = -DSG_FLT_MAX;
+        for (int j = 0; j < W2; ++j) mx = fmaxf(mx, sc[tid][j]);
+        float sum = 0.f;
+        for (int j = 0; j < W2; ++j) { const float p = expf(sc[tid][j] - mx); sc[tid][j] = p; sum += p; }
+        const float inv = 1.0f / sum;
+        for (int j = 0; j < W2; ++j) sc[tid][j] *= inv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NE2; ++i) {
+        const int e = tid + NT * i;
+        if (e < n2) {
+            const int q = e / hd, d = e % hd;
+            float o = 0.f;
+            for (int j = 0; j < W2; ++j) o += sc[q][j] * rot[j][d];
+            ob[q][d] = o;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NE2; ++i) {
+        const int e = tid + NT * i;
+        if (e < n2) {
+            const int q = e / hd, d = e % hd, f = w * W + q;
+            const float other = d < half ? -ob[q][d + half] : ob[q][d - half];
+            const float v = ob[q][d] * c2[i] + other * s2[i];
+            const size_t o = (size_t)(b * ntok + 1 + f) * a.D + col0 + d;
+            a.X0[o] = v;
+            ((elem*)a.X0a)[o] = P::cvt(v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_qkv_attn
+// ---------------------------------------------------------------------------------------------------------
+struct QkvAttnArgs {
+    const void* Xa;         // layer 0: encoder input rows, P::elem [rows][D] (no LayerNorm)
+    const float* X;         // layer > 0: pre-LayerNorm rows fp32 [rows][D]
+    const float* ln_g; const float* ln_b;
+    float* Xn;              // layer > 0: LayerNorm output rows (fp32), written by the head-0 workgroups
+    const void* Wp;         // packed in_proj weight [3D/16][KD][64][16 B]
+    const float* bias;      // [3D]
+    void* out;              // [rows][D] P::elem attention output (heads concatenated)
+    int B, H, ntok;
+};
+
+template <class P, int HD, int NKT, int DD>
+__global__ __launch_bounds__(256) void k_qkv_attn(const QkvAttnArgs g) {
+    typedef typename P::elem elem;
+    constexpr int ES = (int)sizeof(elem);
+    constexpr int Tp = NKT * 16;
+    constexpr int KD = DD / P::KB;                   // k-blocks of the projection
+    constexpr int KH = HD / P::KB;                   // k-blocks of QK^T
+    constexpr int NTH = HD / 16;                     // 16-col tiles per head (2 or 4)
+    constexpr int MSPLIT = 4 / NTH;                  // waves sharing one n-tile split the row tiles
+    static_assert(NTH == 2 || NTH == 4, "head dim 32 or 64");
+    constexpr int XP = DD * ES + 16, KP = HD * ES + 16, VP = Tp * ES + 16;
+    __shared__ __attribute__((aligned(16))) char lds[Tp * XP + Tp * KP + HD * VP + 16 * KP];
+    char* const xs = lds;
+    char* const kk = xs + Tp * XP;
+    char* const vt = kk + Tp * KP;
+    char* const qq = vt + HD * VP;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
+    int id = blockIdx.x;
+    const int nqt = (g.ntok + 15) >> 4;
+    const int qt = id % nqt; id /= nqt;
+    const int h = id % g.H; const int b = id / g.H;
+    const size_t row0 = (size_t)b * g.ntok;
+
+    // ---- (1) this wave's weight fragments: n-tile (wave % NTH) of Q, K and V of head h -- issued first
+    const int wnt = wave % NTH, wms = wave / NTH;
+    const f32x4* wbase = (const f32x4*)g.Wp + lane;
+    f32x4 wf[3][KD];
+#pragma unroll
+    for (int mat = 0; mat < 3; ++mat) {
+        const int nt = (mat * DD + h * HD) / 16 + wnt;
+#pragma unroll
+        for (int kb = 0; kb < KD; ++kb) wf[mat][kb] = wbase[((size_t)nt * KD + kb) * 64];
+    }
+    const f32x4 bq = *(const f32x4*)(g.bias + 0 * DD + h * HD + wnt * 16 + 4 * lg);
+    const f32x4 bk = *(const f32x4*)(g.bias + 1 * DD + h * HD + wnt * 16 + 4 * lg);
+    const float bv = g.bias[2 * DD + h * HD + wnt * 16 + lr];
+
+    // ---- (2) token rows of this batch element -> LDS (LayerNorm-on-read for layers > 0)
+    if (g.X) {
+        constexpr int NCH = DD / 64;                 // float4 chunks per thread per row
+        const int row = tid >> 4, c = tid & 15;
+        f32x4 v[NKT][NCH];
+#pragma unroll
+        for (int p = 0; p < NKT; ++p)
+#pragma unroll
+            for (int i = 0; i < NCH; ++i)
+                v[p][i] = *(const f32x4*)(g.X + (row0 + p * 16 + row) * DD + c * 4 + 64 * i);
+        f32x4 gg[NCH], bb[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            gg[i] = *(const f32x4*)(g.ln_g + c * 4 + 64 * i);
+            bb[i] = *(const f32x4*)(g.ln_b + c * 4 + 64 * i);
+        }
+#pragma unroll
+        for (int p = 0; p < NKT; ++p) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) s += (v[p][i][0] + v[p][i][1]) + (v[p][i][2] + v[p][i][3]);
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+            const float mean = s / (float)DD;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = v[p][i][e] - mean; q += d * d; }
+            q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4); q += __shfl_xor(q, 8);
+            const float rstd = 1.0f / sqrtf(q / (float)DD + 1e-5f);
+            const int srow = p * 16 + row;
+            const bool wr = g.Xn && h == 0 && p == qt && srow < g.ntok;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int col = c * 4 + 64 * i;
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = (v[p][i][e] - mean) * rstd * gg[i][e] + bb[i][e];
+                P::store4((elem*)(xs + srow * XP) + col, y);
+                if (wr) *(f32x4*)(g.Xn + (row0 + srow) * DD + col) = y;
+            }
+        }
+    } else {
+        constexpr int CPR = DD * ES / 16;            // 16-byte chunks per row
+        constexpr int NCP = Tp * CPR / 256;
+        static_assert((Tp * CPR) % 256 == 0, "copy tiling");
+        f32x4 v[NCP];
+#pragma unroll
+        for (int i = 0; i < NCP; ++i) {
+            const int e = tid + 256 * i, r = e / CPR, cc = e % CPR;
+            v[i] = *(const f32x4*)((const char*)g.Xa + ((row0 + r) * DD) * ES + cc * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < NCP; ++i) {
+            const int e = tid + 256 * i, r = e / CPR, cc = e % CPR;
+            *(f32x4*)(xs + r * XP + cc * 16) = v[i];
+        }
+    }
+    __syncthreads();
+
+    // ---- (3) K_h, V_h for every token and Q_h for this query tile (results stay in LDS)
+    for (int mt = wms; mt < NKT; mt += MSPLIT) {
+        f32x4 af[KD];
+#pragma unroll
+        for (int kb = 0; kb < KD; ++kb) af[kb] = *(const f32x4*)(xs + (mt * 16 + lr) * XP + (kb * P::KB + P::E * lg) * ES);
+        f32x4 ck = (f32x4){0.f, 0.f, 0.f, 0.f}, cv = ck;
+#pragma unroll
+        for (int kb = 0; kb < KD; ++kb) {
+            ck = P::mma(wf[1][kb], af[kb], ck);      // D[dim 4lg+r][token lr]
+            cv = P::mma(af[kb], wf[2][kb], cv);      // D[token 4lg+r][dim lr]
+        }
+        P::store4((elem*)(kk + (mt * 16 + lr) * KP) + wnt * 16 + 4 * lg, ck + bk);
+        f32x4 vv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vv[e] = cv[e] + bv;
+        P::store4((elem*)(vt + (wnt * 16 + lr) * VP) + mt * 16 + 4 * lg, vv);
+        if (mt == qt) {
+            f32x4 cq = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < KD; ++kb) cq = P::mma(wf[0][kb], af[kb], cq);
+            P::store4((elem*)(qq + lr * KP) + wnt * 16 + 4 * lg, cq + bq);
+        }
+    }
+    __syncthreads();
+
+    // ---- (4) attention for the 16 queries of this tile; every wave forms the scores, wave w owns output dims
+    f32x4 qf[KH];
+#pragma unroll
+    for (int kb = 0; kb < KH; ++kb) qf[kb] = *(const f32x4*)(qq + lr * KP + (kb * P::KB + P::E * lg) * ES);
+    f32x4 s[NKT];
+#pragma unroll
+    for (int nt = 0; nt < NKT; ++nt) {
+        s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KH; ++kb) {
+            const f32x4 kf = *(const f32x4*)(kk + (nt * 16 + lr) * KP + (kb * P::KB + P::E * lg) * ES);
+            s[nt] = P::mma(kf, qf[kb], s[nt]);       // D[key 4lg+r][query lr]
+        }
+    }
+    const float scale = 1.0f / sqrtf((float)HD);
+    float mx = -DSG_FLT_MAX;
+#pragma unroll
+    for (int nt = 0; nt < NKT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = nt * 16 + 4 * lg + r;
+            const float v = key < g.ntok ? s[nt][r] * scale : -DSG_FLT_MAX;
+            s[nt][r] = v;
+            mx = fmaxf(mx, v);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NKT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = nt * 16 + 4 * lg + r;
+            const float p = key < g.ntok ? expf(s[nt][r] - mx) : 0.f;
+            s[nt][r] = p;
+            sum += p;
+        }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    if (wave < NTH) {
+        const int dt = wave;
+        f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const char* vrow = vt + (dt * 16 + lr) * VP;
+        if constexpr (P::E == 4) {
+#pragma unroll
+            for (int nt = 0; nt < NKT; ++nt) o = P::mma(*(const f32x4*)(vrow + (nt * 16 + 4 * lg) * ES), s[nt], o);
+        } else {
+            static_assert(P::E == 4 || (NKT % 2) == 0, "bf16 pairs key tiles");
+#pragma unroll
+            for (int kb = 0; kb < NKT / 2; ++kb) {
+                const f32x2 v0 = *(const f32x2*)(vrow + ((2 * kb) * 16 + 4 * lg) * ES);
+                const f32x2 v1 = *(const f32x2*)(vrow + ((2 * kb + 1) * 16 + 4 * lg) * ES);
+                typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+                u16x8 pp;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { pp[e] = f2bf(s[2 * kb][e]); pp[4 + e] = f2bf(s[2 * kb + 1][e]); }
+                o = P::mma((f32x4){v0[0], v0[1], v1[0], v1[1]}, __builtin_bit_cast(f32x4, pp), o);
+            }
+        }
+        const int q = qt * 16 + lr;
+        if (q < g.ntok) {
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = o[e] * inv;
+            P::store4((elem*)g.out + (row0 + q) * DD + h * HD + dt * 16 + 4 * lg, y);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_mid: pre1 = R + attn.Wo^T + bo ; x1 = LayerNorm1(pre1) ; hidden[:, slice] = gelu(x1.W1[slice]^T + b1)
+// ---------------------------------------------------------------------------------------------------------
+struct MidArgs {
+    const void* A;          // attention output rows P::elem [rows][D]
+    const float* R;         // residual rows fp32 [rows][D]
+    const void* Wo; const float* bo;
+    const float* ln_g; const float* ln_b;
+    const void* W1; const float* b1;
+    float* X1;              // LayerNorm1 output rows (fp32), written by hidden-slice 0
+    void* hidden;           // [rows][ff] P::elem
+    int M, MT, ff;
+};
+
+template <class P, int DT>      // DT = D / 64 : 16-col tiles of the out_proj output per wave
+__global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
+    typedef typename P::elem elem;
+    constexpr int ES = (int)sizeof(elem);
+    constexpr int D = DT * 64;
+    constexpr int KD = D / P::KB;
+    constexpr int XP = D * ES + 16;
+    constexpr int CH = 8;
+    __shared__ __attribute__((aligned(16))) char a1[16 * XP];
+    __shared__ float red[2][4][16];
+    const int NGH = g.ff / 64;
+    int ng, mt;
+    if (!xcd_map(NGH, g.MT, ng, mt)) return;
+    const int m0 = mt * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
+    const f32x4* wo = (const f32x4*)g.Wo + lane;
+    const f32x4* w1 = (const f32x4*)g.W1 + lane;
+    const elem* arow = (const elem*)g.A + (size_t)(m0 + lr) * D + P::E * lg;
+
+    // ---- epilogue operands first
+    f32x4 pbo[DT], pr[DT], pg[DT], pbt[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+        const int n = (wave * DT + t) * 16 + 4 * lg;
+        pbo[t] = *(const f32x4*)(g.bo + n);
+        pr[t] = *(const f32x4*)(g.R + (size_t)(m0 + lr) * D + n);
+        pg[t] = *(const f32x4*)(g.ln_g + n);
+        pbt[t] = *(const f32x4*)(g.ln_b + n);
+    }
+    const int n1t = ng * 4 + wave;                   // this wave's 16-col tile of the hidden layer
+    const f32x4 pb1 = *(const f32x4*)(g.b1 + n1t * 16 + 4 * lg);
+    f32x4 w1f[KD <= CH ? KD : 1];
+    if constexpr (KD <= CH) {
+#pragma unroll
+        for (int kb = 0; kb < KD; ++kb) w1f[kb] = w1[((size_t)n1t * KD + kb) * 64];
+    }
+
+    // ---- out_proj: this wave's DT tiles x all of K
+    f32x4 acc[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb0 = 0; kb0 < KD; kb0 += CH) {
+        f32x4 af[CH], bf[CH][DT];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (kb0 + c < KD) {
+                af[c] = *(const f32x4*)(arow + (size_t)(kb0 + c) * P::KB);
+#pragma unroll
+                for (int t = 0; t < DT; ++t) bf[c][t] = wo[((size_t)(wave * DT + t) * KD + kb0 + c) * 64];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            if (kb0 + c < KD) {
+#pragma unroll
+                for (int t = 0; t < DT; ++t) acc[t] = P::mma(bf[c][t], af[c], acc[t]);      // D[n 4lg+r][row lr]
+            }
+    }
+    // ---- residual + LayerNorm1 over whole rows (row lr: 4 lane groups x 4 waves hold its D values)
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) { acc[t] = acc[t] + pbo[t] + pr[t]; s += (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]); }
+    s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+    if (lg == 0) red[0][wave][lr] = s;
+    __syncthreads();
+    const float mean = ((red[0][0][lr] + red[0][1][lr]) + (red[0][2][lr] + red[0][3][lr])) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = acc[t][e] - mean; q += d * d; }
+    q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+    if (lg == 0) red[1][wave][lr] = q;
+    __syncthreads();
+    const float var = ((red[1][0][lr] + red[1][1][lr]) + (red[1][2][lr] + red[1][3][lr])) / (float)D;
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    const bool wr = ng == 0 && (m0 + lr) < g.M;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+        const int n = (wave * DT + t) * 16 + 4 * lg;
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = (acc[t][e] - mean) * rstd * pg[t][e] + pbt[t][e];
+        P::store4((elem*)(a1 + lr * XP) + n, y);
+        if (wr) *(f32x4*)(g.X1 + (size_t)(m0 + lr) * D + n) = y;
+    }
+    __syncthreads();
+    // ---- linear1 slice + GELU
+    f32x4 c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (KD <= CH) {
+#pragma unroll
+        for (int kb = 0; kb < KD; ++kb)
+            c1 = P::mma(w1f[kb], *(const f32x4*)(a1 + lr * XP + (kb * P::KB + P::E * lg) * ES), c1);
+    } else {
+#pragma unroll
+        for (int kb0 = 0; kb0 < KD; kb0 += CH) {
+            f32x4 bf[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) if (kb0 + c < KD) bf[c] = w1[((size_t)n1t * KD + kb0 + c) * 64];
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                if (kb0 + c < KD)
+                    c1 = P::mma(bf[c], *(const f32x4*)(a1 + lr * XP + ((kb0 + c) * P::KB + P::E * lg) * ES), c1);
+        }
+    }
+    if (m0 + lr < g.M) {
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = gelu_erf<P>(c1[e] + pb1[e]);
+        P::store4((elem*)g.hidden + (size_t)(m0 + lr) * g.ff + n1t * 16 + 4 * lg, y);
+    }
+}
+
+}  // namespace dsg

@@ -1,12 +1,13 @@
 // dsg_hip.cpp -- host side of libdsg_hip.so (C ABI in include/dsg.h): weight ingestion / repacking, per-window
 // conditioning, the per-step launch sequence, hipGraph capture of the step loop, and the sampler entry points.
 // See dsg_kernels.h for the kernels and the reference file:line each one replaces.
-#include "dsg_kernels.h"
+#include "dsg_fused.h"
 #include "../../include/dsg.h"
 
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -122,7 +123,9 @@ struct dsg_handle {
           *X1 = nullptr, *fwd_out = nullptr, *io_tmp = nullptr, *io_tmp2 = nullptr, *ext_noise = nullptr;
     size_t ext_noise_cap = 0;
     void *xsA = nullptr, *X0a = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *attn = nullptr, *hidden = nullptr;
-    int* ctr = nullptr; int* t_arr = nullptr; unsigned* dyn = nullptr;
+    int* ctr = nullptr;                  // ctr[0] = step counter A, ctr[1] = step counter B (see k_inloc / k_gemm)
+    int* t_arr = nullptr; unsigned* dyn = nullptr;
+    int latency_mode = -1;               // -1 auto (fused kernels when the batch is small), 0 never, 1 always
     int* st_tmodel = nullptr; float* st_c[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int st_cap = 0;
     Sched sched;
@@ -235,6 +238,8 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     h->n_te = c->train_steps > 0 ? c->train_steps : 1000;
     if (h->n_te > c->pe_max_len) { delete h; return fail(DSG_E_INVALID, "train_steps > pe_max_len"); }
     h->layers.resize(h->L);
+    h->latency_mode = c->latency_mode == 1 ? 0 : (c->latency_mode == 2 ? 1 : -1);
+    if (const char* e = getenv("DSG_LATENCY_MODE")) h->latency_mode = atoi(e);
     *out = h;
 
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -244,7 +249,8 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     HIPCHK(hipEventCreate(&h->ev_t1));
 
     const int B = h->Bmax, D = h->D;
-    const size_t Min_pad = rup(B * h->T, 16), M_pad = rup(B * ntok, 16);
+    // row buffers carry one extra padded token block: the fused attention kernel reads Tp rows per batch element
+    const size_t Min_pad = rup(B * h->T, 16) + 16, M_pad = rup(B * ntok, 16) + Tp;
     CHK(dalloc(h, &h->xs32, (size_t)B * h->T * h->Jp + 16 * h->Jp));
     if (h->prec == DSG_PREC_BF16) CHK(dalloc_bytes(h, &h->xsA, ((size_t)Min_pad * h->Jp) * h->es));
     CHK(dalloc(h, &h->partial, (size_t)h->KSin * Min_pad * D));
@@ -549,6 +555,46 @@ static int launch_attn(dsg_handle* h, const AttnArgs& a) {
     }
 }
 
+template <class P, int HD, int NKT, int DD>
+static int launch_qkv_attn_t(dsg_handle* h, const QkvAttnArgs& a) {
+    const int nqt = cdiv(a.ntok, 16);
+    hipLaunchKernelGGL((k_qkv_attn<P, HD, NKT, DD>), dim3(a.B * a.H * nqt), dim3(256), 0, h->stream, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// fused LayerNorm + in_proj + attention exists for the shapes whose token block fits in LDS
+static bool have_qkv_attn(const dsg_handle* h) {
+    return (h->hd == 64 && h->Tp == 96 && h->D == 256) || (h->hd == 32 && h->Tp == 32 && (h->D == 128 || h->D == 64));
+}
+template <class P>
+static int launch_qkv_attn(dsg_handle* h, const QkvAttnArgs& a) {
+    if (h->hd == 64 && h->Tp == 96 && h->D == 256) return launch_qkv_attn_t<P, 64, 6, 256>(h, a);
+    if (h->hd == 32 && h->Tp == 32 && h->D == 128) return launch_qkv_attn_t<P, 32, 2, 128>(h, a);
+    if (h->hd == 32 && h->Tp == 32 && h->D == 64) return launch_qkv_attn_t<P, 32, 2, 64>(h, a);
+    return fail(DSG_E_NOT_IMPLEMENTED, "no fused qkv+attention instantiation");
+}
+template <class P, int DT>
+static int launch_mid_t(dsg_handle* h, const MidArgs& a) {
+    hipLaunchKernelGGL((k_mid<P, DT>), dim3(xcd_grid(a.ff / 64, a.MT)), dim3(256), 0, h->stream, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+template <class P>
+static int launch_mid(dsg_handle* h, const MidArgs& a) {
+    switch (h->D / 64) {
+        case 1: return launch_mid_t<P, 1>(h, a);
+        case 2: return launch_mid_t<P, 2>(h, a);
+        case 4: return launch_mid_t<P, 4>(h, a);
+        case 6: return launch_mid_t<P, 6>(h, a);
+        case 8: return launch_mid_t<P, 8>(h, a);
+        default: return fail(DSG_E_NOT_IMPLEMENTED, "k_mid: latent_dim / 64 must be 1, 2, 4, 6 or 8");
+    }
+}
+static bool use_latency_mode(const dsg_handle* h, int B) {
+    if (h->latency_mode >= 0) return h->latency_mode != 0;
+    return B <= 4;          // redundant recompute pays only while every launch is a latency chain
+}
+
 template <class P>
 static int run_step(dsg_handle* h, const StepCtx& c) {
     const int B = c.B, D = h->D, T = h->T, ntok = h->ntok;
@@ -560,56 +606,80 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
     z.KS = 1; z.kb_per_split = 0; z.B = B; z.ntok = ntok; z.Tp = h->Tp; z.H = h->H; z.hd = h->hd; z.T = T; z.J = h->J; z.Jp = h->Jp;
     z.Jq = h->Jq; z.D = D;
 
-    {   // k_in: partial[s] = xs[:, chunk s] . Wfold[:, chunk s]^T
-        GemmArgs g = z;
-        g.M = Min; g.MT = MTin; g.NT = D / 16; g.KBtot = h->Jp / KB; g.KS = h->KSin; g.Wp = h->Wp_in;
-        g.kb_per_split = cdiv(g.KBtot, g.KS);
-        g.A = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; g.lda = h->Jp;
-        g.out = h->partial; g.ldo = D;
-        g.ctr_inc = c.use_ctr ? h->ctr : nullptr;
-        CHK((launch_gemm<P, PRO_DIRECT, EPI_PARTIAL, 4, 1, 1>(h, g)));
-    }
-    {   // k_loc
-        LocArgs a;
-        memset(&a, 0, sizeof(a));
-        a.partial = h->partial; a.KS = h->KSin; a.Min_pad = MTin * 16; a.Cf = h->Cf; a.TE2 = h->TE2; a.TE = h->TE;
-        a.emb1 = h->emb1; a.ctr = c.use_ctr ? h->ctr : nullptr; a.tmodel = h->st_tmodel; a.t_arr = h->t_arr;
-        a.rcos = h->rcos; a.rsin = h->rsin; a.mask = h->mask; a.mb = h->mb; a.B = B; a.T = T; a.D = D; a.Hl = h->Hl;
-        a.hd = h->hdl; a.W = h->W; a.X0 = h->X0; a.X0a = h->X0a;
-        hipLaunchKernelGGL((k_loc<P>), dim3(B * (T / h->W) * h->Hl), dim3(256), 0, h->stream, a);
+    const bool lat = use_latency_mode(h, B);
+    LocArgs la;
+    memset(&la, 0, sizeof(la));
+    la.partial = h->partial; la.KS = h->KSin; la.Min_pad = MTin * 16; la.Cf = h->Cf; la.TE2 = h->TE2; la.TE = h->TE;
+    la.emb1 = h->emb1; la.ctr = c.use_ctr ? h->ctr : nullptr; la.tmodel = h->st_tmodel; la.t_arr = h->t_arr;
+    la.rcos = h->rcos; la.rsin = h->rsin; la.mask = h->mask; la.mb = h->mb; la.B = B; la.T = T; la.D = D; la.Hl = h->Hl;
+    la.hd = h->hdl; la.W = h->W; la.X0 = h->X0; la.X0a = h->X0a;
+    if (lat) {          // pose embedding + local attention in one launch
+        InLocArgs a;
+        a.xs = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; a.Jp = h->Jp; a.Wp = h->Wp_in; a.KBtot = h->Jp / KB;
+        a.loc = la; a.ctr_inc = c.use_ctr ? h->ctr + 1 : nullptr;
+        hipLaunchKernelGGL((k_inloc<P>), dim3(B * (T / h->W) * h->Hl), dim3(256), 0, h->stream, a);
+        HIPCHK(hipGetLastError());
+    } else {
+        {   // k_in: partial[s] = xs[:, chunk s] . Wfold[:, chunk s]^T
+            GemmArgs g = z;
+            g.M = Min; g.MT = MTin; g.NT = D / 16; g.KBtot = h->Jp / KB; g.KS = h->KSin; g.Wp = h->Wp_in;
+            g.kb_per_split = cdiv(g.KBtot, g.KS);
+            g.A = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; g.lda = h->Jp;
+            g.out = h->partial; g.ldo = D;
+            g.ctr_inc = c.use_ctr ? h->ctr + 1 : nullptr;
+            CHK((launch_gemm<P, PRO_DIRECT, EPI_PARTIAL, 4, 1, 1>(h, g)));
+        }
+        hipLaunchKernelGGL((k_loc<P>), dim3(B * (T / h->W) * h->Hl), dim3(256), 0, h->stream, la);
         HIPCHK(hipGetLastError());
     }
+    const bool fuse_attn = lat && have_qkv_attn(h);
     for (int l = 0; l < h->L; ++l) {
         const Layer& ly = h->layers[l];
-        {   // QKV projection (LayerNorm2 of the previous layer applied on read)
-            GemmArgs g = z;
-            g.M = M; g.MT = MT; g.NT = 3 * D / 16; g.KBtot = D / KB; g.Wp = ly.Wqkv; g.bias = ly.bqkv;
-            g.q = h->q; g.k = h->k; g.vt = h->vt;
-            if (l == 0) {
-                g.A = h->X0a; g.lda = D;
-                CHK((launch_gemm<P, PRO_DIRECT, EPI_QKV, 4, 1, 1>(h, g)));
-            } else {
-                g.X = h->pre2; g.ln_g = h->layers[l - 1].g2; g.ln_b = h->layers[l - 1].be2; g.Xn = h->Xn;
-                CHK((launch_gemm<P, PRO_LN, EPI_QKV, 4, 1, 1>(h, g)));
+        if (fuse_attn) {   // [LayerNorm2] + in_proj + attention per (batch, head, query tile)
+            QkvAttnArgs a;
+            memset(&a, 0, sizeof(a));
+            if (l == 0) a.Xa = h->X0a;
+            else { a.X = h->pre2; a.ln_g = h->layers[l - 1].g2; a.ln_b = h->layers[l - 1].be2; a.Xn = h->Xn; }
+            a.Wp = ly.Wqkv; a.bias = ly.bqkv; a.out = h->attn; a.B = B; a.H = h->H; a.ntok = ntok;
+            CHK(launch_qkv_attn<P>(h, a));
+        } else {
+            {   // QKV projection (LayerNorm2 of the previous layer applied on read)
+                GemmArgs g = z;
+                g.M = M; g.MT = MT; g.NT = 3 * D / 16; g.KBtot = D / KB; g.Wp = ly.Wqkv; g.bias = ly.bqkv;
+                g.q = h->q; g.k = h->k; g.vt = h->vt;
+                if (l == 0) {
+                    g.A = h->X0a; g.lda = D;
+                    CHK((launch_gemm<P, PRO_DIRECT, EPI_QKV, 4, 1, 1>(h, g)));
+                } else {
+                    g.X = h->pre2; g.ln_g = h->layers[l - 1].g2; g.ln_b = h->layers[l - 1].be2; g.Xn = h->Xn;
+                    CHK((launch_gemm<P, PRO_LN, EPI_QKV, 4, 1, 1>(h, g)));
+                }
+            }
+            {   // attention
+                AttnArgs a;
+                a.q = h->q; a.k = h->k; a.vt = h->vt; a.out = h->attn; a.B = B; a.H = h->H; a.ntok = ntok; a.Tp = h->Tp;
+                a.D = D;
+                CHK(launch_attn<P>(h, a));
             }
         }
-        {   // attention
-            AttnArgs a;
-            a.q = h->q; a.k = h->k; a.vt = h->vt; a.out = h->attn; a.B = B; a.H = h->H; a.ntok = ntok; a.Tp = h->Tp;
-            a.D = D;
-            CHK(launch_attn<P>(h, a));
-        }
-        {   // out_proj + residual -> pre1
-            GemmArgs g = z;
-            g.M = M; g.MT = MT; g.NT = D / 16; g.KBtot = D / KB; g.Wp = ly.Wo; g.bias = ly.bo;
-            g.A = h->attn; g.lda = D; g.out = h->pre1; g.ldo = D; g.R = l == 0 ? h->X0 : h->Xn;
-            CHK((launch_gemm<P, PRO_DIRECT, EPI_RESID, 4, 1, 1>(h, g)));
-        }
-        {   // LayerNorm1-on-read + linear1 + GELU -> hidden ; X1 = LN1(pre1)
-            GemmArgs g = z;
-            g.M = M; g.MT = MT; g.NT = h->ff / 16; g.KBtot = D / KB; g.Wp = ly.W1; g.bias = ly.b1;
-            g.X = h->pre1; g.ln_g = ly.g1; g.ln_b = ly.be1; g.Xn = h->X1; g.out = h->hidden; g.ldo = h->ff;
-            CHK((launch_gemm<P, PRO_LN, EPI_GELU, 4, 1, 1>(h, g)));
+        if (lat) {      // out_proj + residual + LayerNorm1 + linear1 slice + GELU
+            MidArgs a;
+            a.A = h->attn; a.R = l == 0 ? h->X0 : h->Xn; a.Wo = ly.Wo; a.bo = ly.bo; a.ln_g = ly.g1; a.ln_b = ly.be1;
+            a.W1 = ly.W1; a.b1 = ly.b1; a.X1 = h->X1; a.hidden = h->hidden; a.M = M; a.MT = MT; a.ff = h->ff;
+            CHK(launch_mid<P>(h, a));
+        } else {
+            {   // out_proj + residual -> pre1
+                GemmArgs g = z;
+                g.M = M; g.MT = MT; g.NT = D / 16; g.KBtot = D / KB; g.Wp = ly.Wo; g.bias = ly.bo;
+                g.A = h->attn; g.lda = D; g.out = h->pre1; g.ldo = D; g.R = l == 0 ? h->X0 : h->Xn;
+                CHK((launch_gemm<P, PRO_DIRECT, EPI_RESID, 4, 1, 1>(h, g)));
+            }
+            {   // LayerNorm1-on-read + linear1 + GELU -> hidden ; X1 = LN1(pre1)
+                GemmArgs g = z;
+                g.M = M; g.MT = MT; g.NT = h->ff / 16; g.KBtot = D / KB; g.Wp = ly.W1; g.bias = ly.b1;
+                g.X = h->pre1; g.ln_g = ly.g1; g.ln_b = ly.be1; g.Xn = h->X1; g.out = h->hidden; g.ldo = h->ff;
+                CHK((launch_gemm<P, PRO_LN, EPI_GELU, 4, 1, 1>(h, g)));
+            }
         }
         {   // linear2 + residual -> pre2   (K = ff split over the 4 waves of the workgroup)
             GemmArgs g = z;
@@ -623,7 +693,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
         g.M = M; g.MT = MT; g.NT = h->Jp / 16; g.KBtot = D / KB; g.Wp = h->Wp_out; g.bias = h->b_out;
         g.X = h->pre2; g.ln_g = h->layers[h->L - 1].g2; g.ln_b = h->layers[h->L - 1].be2; g.Xn = nullptr;
         g.out_mode = c.out_mode; g.xs32 = h->xs32; g.xsA = h->prec == DSG_PREC_BF16 ? h->xsA : nullptr;
-        g.fwd_out = h->fwd_out; g.ctr = h->ctr;
+        g.fwd_out = h->fwd_out; g.ctr = h->ctr + 1; g.ctr_inc = c.use_ctr ? h->ctr : nullptr;
         g.st.tmodel = h->st_tmodel; g.st.c1 = h->st_c[0]; g.st.c2 = h->st_c[1]; g.st.c3 = h->st_c[2];
         g.st.c4 = h->st_c[3]; g.st.c5 = h->st_c[4];
         g.dyn = h->dyn; g.ext_noise = c.ext_noise; g.const_noise = c.const_noise;
@@ -786,7 +856,8 @@ extern "C" int dsg_sample(dsg_handle* h, const dsg_sample_args* a, float* out, i
             ext = h->ext_noise;
         }
     }
-    hipLaunchKernelGGL(k_ctr_set, dim3(1), dim3(64), 0, h->stream, h->ctr, -1);
+    hipLaunchKernelGGL(k_ctr_set, dim3(1), dim3(64), 0, h->stream, h->ctr, 0);
+    hipLaunchKernelGGL(k_ctr_set, dim3(1), dim3(64), 0, h->stream, h->ctr + 1, -1);
     HIPCHK(hipGetLastError());
     {
         const unsigned dyn[5] = {nk.k0, nk.k1, nk.s0, nk.s1, a->draw_base + 1u};

@@ -166,14 +166,14 @@ struct GemmArgs {
     float* xs32;            // [B][T][Jp] fp32 master state (in/out)
     void* xsA;              // [B][T][Jp] P::elem shadow for k_in (bf16 mode) or null
     float* fwd_out;         // OUT_FORWARD: [B][J][T]
-    const int* ctr;         // device step counter
+    const int* ctr;         // device step counter B (EPI_OUT)
     StepTables st;
     const unsigned* dyn;    // device: {seed lo, seed hi, stream lo, stream hi, draw index of step 0} -- kept out of
                             // the kernel arguments so a captured graph is reusable across windows / clips
     const float* ext_noise; // optional [n_steps][B][J][T] replayed noise, else null
     int B;
     int const_noise;
-    int* ctr_inc;           // EPI_PARTIAL (k_in, first kernel of a step): block 0 advances the step counter
+    int* ctr_inc;           // EPI_PARTIAL: advances step counter B; EPI_OUT: advances step counter A (block 0)
 };
 
 // block -> (n_group, r) with n_group pinned to an XCD (block b is observed to run on XCD b % 8), so a weight
@@ -209,8 +209,10 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
     const int mt = r % g.MT, ks = r / g.MT;
     const int m0 = mt * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if constexpr (EPI == EPI_PARTIAL) {
-        // nobody in this kernel reads the counter; the previous step's readers are behind a kernel boundary
+    if constexpr (EPI == EPI_PARTIAL || EPI == EPI_OUT) {
+        // Two step counters: A is read by the first kernel(s) of a step (k_loc / k_inloc) and advanced by the LAST
+        // kernel (EPI_OUT); B is read by the last kernel and advanced by the FIRST (EPI_PARTIAL / k_inloc).  No kernel
+        // reads the counter it advances, and a kernel boundary separates every advance from the next read.
         if (g.ctr_inc && ng == 0 && r == 0 && tid == 0) *g.ctr_inc += 1;
     }
     const int wn = wave % WN, wk = wave / WN;
@@ -454,7 +456,7 @@ struct LocArgs {
     const float* TE2;       // [n_te][D]   W2a . time_embed(t)
     const float* TE;        // [n_te][D]   time_embed(t)
     const float* emb1;      // [B][D]      style (+ seed) token embedding
-    const int* ctr;         // step counter (sampling) or null
+    const int* ctr;         // step counter A (sampling) or null
     const int* tmodel;      // tmodel[step]   (sampling)
     const int* t_arr;       // per-batch model timestep (forward) used when ctr == null
     const float* rcos;      // [T+1][hd/2]

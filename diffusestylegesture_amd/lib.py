@@ -22,7 +22,7 @@ class dsg_config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "variant", "njoints", "n_poses", "n_seed", "latent_dim", "audio_src_dim", "audio_dim", "style_dim_in",
         "window", "num_layers", "num_heads", "ff_size", "local_heads", "pe_max_len", "train_steps", "max_batch",
-        "precision", "device", "steps_per_graph")] + [("reserved", C.c_int32 * 5)]
+        "precision", "device", "steps_per_graph", "latency_mode")] + [("reserved", C.c_int32 * 4)]
 
 
 class dsg_sample_args(C.Structure):

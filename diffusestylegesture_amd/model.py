@@ -17,7 +17,7 @@ from .config import DSGConfig
 
 class DSGDenoiser:
     def __init__(self, cfg: DSGConfig, precision: str = "bf16", max_batch: int = 1, device: int = 0,
-                 steps_per_graph: int = 0, library: L.DSGLibrary | None = None):
+                 steps_per_graph: int = 0, library: L.DSGLibrary | None = None, latency_mode: str = "auto"):
         self.cfg = cfg
         self.lib = library or L.default_library()
         self.njoints, self.nfeats = cfg.njoints, 1
@@ -31,6 +31,7 @@ class DSGDenoiser:
         c.pe_max_len, c.train_steps, c.max_batch = cfg.pe_max_len, 1000, max_batch
         c.precision = {"fp32": L.PREC_FP32, "bf16": L.PREC_BF16}[precision]
         c.device, c.steps_per_graph = device, steps_per_graph
+        c.latency_mode = {"auto": 0, "off": 1, "on": 2}[latency_mode]
         h = C.c_void_p()
         self.lib.check(self.lib.cdll.dsg_create(C.byref(c), C.byref(h)))
         self.handle = h

@@ -83,6 +83,23 @@ def test_chains_tiny(tiny, emu_lib, prec):
     assert rel_l2(s2, s1) < 1e-5
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_throughput_kernels_tiny(tiny, emu_lib, prec):
+    """The un-fused (batched / throughput) kernel set, which `auto` only selects for batch > 4."""
+    gt, _, y, x = tiny
+    m = DSGDenoiser(C.TINY, precision=prec, max_batch=2, library=emu_lib, latency_mode="off")
+    m.load_state_dict(synth_state_dict(C.TINY, int(gt["wseed"])))
+    assert rel_l2(m(x, np.array([998, 17]), dict(y, mask_local=gt["mask2"])), gt["fwd_mask2"]) < TOL[prec]
+    d = create_gaussian_diffusion(library=emu_lib)
+    shape = (2, C.TINY.njoints, 1, C.TINY.n_poses)
+    s = d.manual_seed(77, 3).p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=990)
+    assert rel_l2(s, gt["ddpm_skip990"]) < TOL[prec] * 3
+    d50 = create_gaussian_diffusion("ddim50", library=emu_lib)
+    s = d50.manual_seed(77, 9).ddim_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, eta=1.0,
+                                                skip_timesteps=40)
+    assert rel_l2(s, gt["ddim50_eta1_skip40"]) < TOL[prec] * 3
+
+
 def test_error_behaviour(tiny, emu_lib):
     gt, models, y, x = tiny
     m = models["fp32"]
