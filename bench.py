@@ -18,6 +18,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")      # see diffusestylegesture_amd/__init__.py
 
 import numpy as np
 import torch
@@ -117,9 +118,8 @@ def main():
         poses = one_clip(a.warmup + i)
         step_us.append(diffusion.last_step_time_us())
     if dist is not None:        # the only exchange of the path: finished poses -> rank 0 (RCCL over xGMI)
-        mine = torch.from_numpy(poses).cuda(local)
-        bufs = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
-        dist.gather(mine, bufs, dst=0)
+        from diffusestylegesture_amd.parallel import gather_poses
+        gather_poses(poses, world * B, dist, dst=0, device=f"cuda:{local}")
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -150,7 +150,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 5), "traffic": None,
                          "algorithmic_bytes_per_denoise_step": abytes,
-                         "note": "one denoising step = 43 dependent kernel launches (hipGraph); achieved = "
+                         "note": "one denoising step = 26 dependent kernel launches (latency mode); achieved = "
                                  "algorithmic bytes / HIP-event time per step on the library stream"},
         }
         if world == 1 and not a.no_cpu_baseline:

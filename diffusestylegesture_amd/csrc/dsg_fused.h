@@ -28,21 +28,17 @@ struct InLocArgs {
     int* ctr_inc;           // first kernel of a step: block 0 advances step counter B (see k_inloc)
 };
 
-template <class P>
+template <class P, int HD, int W>
 __global__ __launch_bounds__(256) void k_inloc(const InLocArgs g) {
     typedef typename P::elem elem;
     const LocArgs& a = g.loc;
-    constexpr int MAXW = 16, MAXHD = 64, NT = 256;
-    constexpr int NE1 = (2 * MAXW * MAXHD + NT - 1) / NT;
-    constexpr int NE2 = (MAXW * MAXHD + NT - 1) / NT;
-    constexpr int NS = (MAXW * 2 * MAXW + NT - 1) / NT;
-    constexpr int MAXNL = 4;                                   // 16-col tiles per local head (hd <= 64)
-    __shared__ __attribute__((aligned(16))) float red[4][2][MAXNL][64][4];   // per-wave partial accumulators
-    __shared__ float raw[2 * MAXW][MAXHD + 1];
-    __shared__ float rot[2 * MAXW][MAXHD + 1];
-    __shared__ float sc[MAXW][2 * MAXW + 1];
-    __shared__ float ob[MAXW][MAXHD + 1];
-    const int nW = a.T / a.W;
+    constexpr int W2 = 2 * W, half = HD / 2, NP1 = W2 * half, NPI = (NP1 + 255) / 256;
+    constexpr int NSI = (W * 32 + 255) / 256, NP2 = W * half, NPO = (NP2 + 255) / 256;
+    constexpr int NL = HD >= 16 ? HD / 16 : 1;                 // 16-col tiles covering the head
+    __shared__ __attribute__((aligned(16))) float red[4][2][NL][64][4];      // per-wave partial accumulators
+    __shared__ float rot[W2][HD + 1];
+    __shared__ float sc[W][W2 + 2];
+    const int nW = a.T / W;
     int id = blockIdx.x;
     const int h = id % a.Hl; id /= a.Hl;
     const int w = id % nW; const int b = id / nW;
@@ -50,68 +46,54 @@ __global__ __launch_bounds__(256) void k_inloc(const InLocArgs g) {
     // two step counters make the hand-over race free: this kernel READS ctrA (a.ctr) and ADVANCES ctrB (read only by
     // the last kernel of the step, which in turn advances ctrA) -- no kernel reads the counter it increments
     if (g.ctr_inc && blockIdx.x == 0 && tid == 0) *g.ctr_inc += 1;
-    const int W = a.W, hd = a.hd, half = hd >> 1, W2 = 2 * W;
-    const int col0 = h * hd;
-    const int ntok = a.T + 1;
-    const int n1 = W2 * hd, n2 = W * hd, ns = W * W2;
-    const int f0 = (w - 1) * W;
+    const int col0 = h * HD, ntok = a.T + 1, f0 = (w - 1) * W;
+    const int t = a.ctr ? a.tmodel[*a.ctr] : a.t_arr[b];
 
     // ---- (1) window constants, rotary tables and the key mask: issued first so they fly under the GEMM loads
-    const int tt = a.ctr ? a.tmodel[*a.ctr] : a.t_arr[b];
-    float v1[NE1], c1[NE1], s1[NE1];
+    float lo[NPI], hi[NPI], c1[NPI], s1[NPI];
 #pragma unroll
-    for (int i = 0; i < NE1; ++i) {
-        const int e = tid + NT * i;
-        v1[i] = 0.f; c1[i] = 1.f; s1[i] = 0.f;
-        if (e < n1) {
-            const int r = e / hd, d = e % hd, f = f0 + r;
+    for (int i = 0; i < NPI; ++i) {
+        const int p = tid + 256 * i;
+        lo[i] = hi[i] = 0.f; c1[i] = 1.f; s1[i] = 0.f;
+        if (p < NP1) {
+            const int r = p / half, dd = p % half, f = f0 + r;
             if (f >= 0) {
-                const size_t row = (size_t)b * a.T + f;
-                const int dd = d < half ? d : d - half;
-                v1[i] = a.Cf[row * a.D + col0 + d] + a.TE2[(size_t)tt * a.D + col0 + d];
+                const size_t base = ((size_t)b * a.T + f) * a.D + col0 + dd;
+                lo[i] = a.Cf[base] + a.TE2[(size_t)t * a.D + col0 + dd];
+                hi[i] = a.Cf[base + half] + a.TE2[(size_t)t * a.D + col0 + dd + half];
                 c1[i] = a.rcos[f * half + dd]; s1[i] = a.rsin[f * half + dd];
             }
         }
     }
-    float c2[NE2], s2[NE2];
+    float c2[NPO], s2[NPO];
 #pragma unroll
-    for (int i = 0; i < NE2; ++i) {
-        const int e = tid + NT * i;
+    for (int i = 0; i < NPO; ++i) {
+        const int p = tid + 256 * i;
         c2[i] = 1.f; s2[i] = 0.f;
-        if (e < n2) {
-            const int q = e / hd, d = e % hd, pos = w * W + q + 1;
-            const int dd = d < half ? d : d - half;
-            c2[i] = a.rcos[pos * half + dd]; s2[i] = a.rsin[pos * half + dd];
-        }
+        if (p < NP2) { const int pos = w * W + p / half + 1; c2[i] = a.rcos[pos * half + p % half]; s2[i] = a.rsin[pos * half + p % half]; }
     }
     const int mrow = (int)(((long long)(b * a.Hl + h)) / ((long long)a.B * a.Hl / a.mb));
-    bool keep[NS];
+    bool keep[NSI];
 #pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        const int e = tid + NT * i;
-        keep[i] = false;
-        if (e < ns) {
-            const int j = e % W2, fk = f0 + j;
-            keep[i] = (fk >= 0) && (a.mask[(size_t)mrow * a.T + fk] != 0);
-        }
+    for (int i = 0; i < NSI; ++i) {
+        const int idx = tid + 256 * i, q = idx >> 5, j = idx & 31, fk = f0 + j;
+        keep[i] = (q < W) && (j < W2) && (fk >= 0) && (a.mask[(size_t)mrow * a.T + fk] != 0);
     }
-    float tokv = 0.f;
-    if (w == 0 && tid < hd) tokv = a.emb1[(size_t)b * a.D + col0 + tid] + a.TE[(size_t)tt * a.D + col0 + tid];
-    if (w == 0 && tid < hd) {
+    if (w == 0 && tid < HD) {
+        const float tokv = a.emb1[(size_t)b * a.D + col0 + tid] + a.TE[(size_t)t * a.D + col0 + tid];
         a.X0[(size_t)(b * ntok) * a.D + col0 + tid] = tokv;
         ((elem*)a.X0a)[(size_t)(b * ntok) * a.D + col0 + tid] = P::cvt(tokv);
     }
 
     // ---- (2) pose-embedding GEMM for the 2W frames x this head's columns; this wave's share of K
-    const int nl = hd >= 16 ? hd / 16 : 1;                     // 16-col tiles covering the head
     const int ntile0 = col0 / 16;
     const int kbw = (g.KBtot + 3) / 4;
     const int kb_lo = wave * kbw, kb_hi = min(kb_lo + kbw, g.KBtot);
-    f32x4 acc[2][MAXNL];
+    f32x4 acc[2][NL];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < MAXNL; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NL; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const elem* arow[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -122,7 +104,7 @@ __global__ __launch_bounds__(256) void k_inloc(const InLocArgs g) {
     const f32x4* wbase = (const f32x4*)g.Wp + lane;
     constexpr int CH = 9;
     for (int kb0 = kb_lo; kb0 < kb_hi; kb0 += CH) {
-        f32x4 af[CH][2], bf[CH][MAXNL];
+        f32x4 af[CH][2], bf[CH][NL];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const int kb = kb0 + c;
@@ -130,8 +112,7 @@ __global__ __launch_bounds__(256) void k_inloc(const InLocArgs g) {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) af[c][mt] = *(const f32x4*)(arow[mt] + (size_t)kb * P::KB);
 #pragma unroll
-                for (int nt = 0; nt < MAXNL; ++nt)
-                    if (nt < nl) bf[c][nt] = wbase[((size_t)(ntile0 + nt) * g.KBtot + kb) * 64];
+                for (int nt = 0; nt < NL; ++nt) bf[c][nt] = wbase[((size_t)(ntile0 + nt) * g.KBtot + kb) * 64];
             }
         }
 #pragma unroll
@@ -140,94 +121,35 @@ __global__ __launch_bounds__(256) void k_inloc(const InLocArgs g) {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < MAXNL; ++nt)
-                        if (nt < nl) acc[mt][nt] = P::mma(af[c][mt], bf[c][nt], acc[mt][nt]);   // D[row 4lg+r][col lr]
+                    for (int nt = 0; nt < NL; ++nt) acc[mt][nt] = P::mma(af[c][mt], bf[c][nt], acc[mt][nt]);   // D[row 4lg+r][col lr]
             }
         }
     }
 
-    // ---- (3) reduce the 4 K-slices and assemble the [2W][hd] tile
+    // ---- (3) reduce the 4 K-slices, add the constants, apply the rotary -> rot
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < MAXNL; ++nt)
-            if (nt < nl) *(f32x4*)&red[wave][mt][nt][lane][0] = acc[mt][nt];
+        for (int nt = 0; nt < NL; ++nt) *(f32x4*)&red[wave][mt][nt][lane][0] = acc[mt][nt];
     __syncthreads();
     const int cshift = col0 - ntile0 * 16;                     // head narrower than a tile: offset inside the tile
 #pragma unroll
-    for (int i = 0; i < NE1; ++i) {
-        const int e = tid + NT * i;
-        if (e < n1) {
-            const int r = e / hd, d = e % hd;
-            const int mt = r >> 4, rr = r & 15, cc = d + cshift, nt = cc >> 4, cl = cc & 15;
-            const int ln = (rr >> 2) * 16 + cl, rg = rr & 3;   // D[row = 4*lg + reg][col = lr]
-            float v = v1[i];
-            v += (red[0][mt][nt][ln][rg] + red[1][mt][nt][ln][rg]) + (red[2][mt][nt][ln][rg] + red[3][mt][nt][ln][rg]);
-            raw[r][d] = v;
-        }
-    }
-    __syncthreads();
+    for (int i = 0; i < NPI; ++i) {
+        const int p = tid + 256 * i;
+        if (p < NP1) {
+            const int r = p / half, dd = p % half, f = f0 + r;
+            const int mt = r >> 4, rr = r & 15, rg = rr & 3;
+            const int cl = dd + cshift, ch = dd + half + cshift;
+            const int lnl = (rr >> 2) * 16 + (cl & 15), lnh = (rr >> 2) * 16 + (ch & 15);     // D[row 4*lg + reg][col lr]
+            float vl = lo[i], vh = hi[i];
 #pragma unroll
-    for (int i = 0; i < NE1; ++i) {
-        const int e = tid + NT * i;
-        if (e < n1) {
-            const int r = e / hd, d = e % hd, f = f0 + r;
-            float v = -1.0f;                               // look_around pad_value (local_attention.py:94,134)
-            if (f >= 0) {
-                const float other = d < half ? -raw[r][d + half] : raw[r][d - half];
-                v = raw[r][d] * c1[i] + other * s1[i];
-            }
-            rot[r][d] = v;
+            for (int wv = 0; wv < 4; ++wv) { vl += red[wv][mt][cl >> 4][lnl][rg]; vh += red[wv][mt][ch >> 4][lnh][rg]; }
+            rot[r][dd] = f >= 0 ? vl * c1[i] - vh * s1[i] : -1.0f;
+            rot[r][dd + half] = f >= 0 ? vh * c1[i] + vl * s1[i] : -1.0f;
         }
     }
     __syncthreads();
-    const float scale = 1.0f / sqrtf((float)hd);
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        const int e = tid + NT * i;
-        if (e < ns) {
-            const int q = e / W2, j = e % W2;
-            const int fq = w * W + q, fk = f0 + j;
-            float s = 0.f;
-            for (int d = 0; d < hd; ++d) s += rot[W + q][d] * rot[j][d];
-            s *= scale;
-            const bool masked = ((fk >= 0) && (fq < fk)) || !keep[i];
-            sc[q][j] = masked ? -DSG_FLT_MAX : s;
-        }
-    }
-    __syncthreads();
-    if (tid < W) {
-        float mx = -DSG_FLT_MAX;
-        for (int j = 0; j < W2; ++j) mx = fmaxf(mx, sc[tid][j]);
-        float sum = 0.f;
-        for (int j = 0; j < W2; ++j) { const float p = expf(sc[tid][j] - mx); sc[tid][j] = p; sum += p; }
-        const float inv = 1.0f / sum;
-        for (int j = 0; j < W2; ++j) sc[tid][j] *= inv;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NE2; ++i) {
-        const int e = tid + NT * i;
-        if (e < n2) {
-            const int q = e / hd, d = e % hd;
-            float o = 0.f;
-            for (int j = 0; j < W2; ++j) o += sc[q][j] * rot[j][d];
-            ob[q][d] = o;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NE2; ++i) {
-        const int e = tid + NT * i;
-        if (e < n2) {
-            const int q = e / hd, d = e % hd, f = w * W + q;
-            const float other = d < half ? -ob[q][d + half] : ob[q][d - half];
-            const float v = ob[q][d] * c2[i] + other * s2[i];
-            const size_t o = (size_t)(b * ntok + 1 + f) * a.D + col0 + d;
-            a.X0[o] = v;
-            ((elem*)a.X0a)[o] = P::cvt(v);
-        }
-    }
+    local_attn_tail<P, HD, W>(a, rot, sc, b, w, h, keep, c2, s2);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -126,6 +126,7 @@ struct dsg_handle {
     int* ctr = nullptr;                  // ctr[0] = step counter A, ctr[1] = step counter B (see k_inloc / k_gemm)
     int* t_arr = nullptr; unsigned* dyn = nullptr;
     int latency_mode = -1;               // -1 auto (fused kernels when the batch is small), 0 never, 1 always
+    bool fuse_attn = false;
     int* st_tmodel = nullptr; float* st_c[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int st_cap = 0;
     Sched sched;
@@ -240,6 +241,7 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     h->layers.resize(h->L);
     h->latency_mode = c->latency_mode == 1 ? 0 : (c->latency_mode == 2 ? 1 : -1);
     if (const char* e = getenv("DSG_LATENCY_MODE")) h->latency_mode = atoi(e);
+    if (const char* e = getenv("DSG_FUSE_ATTN")) h->fuse_attn = atoi(e) != 0;
     *out = h;
 
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -277,7 +279,7 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     CHK(dalloc(h, &h->c_seed, (size_t)B * h->J * (h->S > 0 ? h->S : 1)));
     CHK(dalloc(h, &h->c_audio, (size_t)B * h->Ta * h->As));
     CHK(dalloc(h, &h->mask, (size_t)B * h->T));
-    CHK(dalloc(h, &h->ctr, 4));
+    CHK(dalloc(h, &h->ctr, 8));
     CHK(dalloc(h, &h->dyn, 8));
     CHK(dalloc(h, &h->t_arr, (size_t)B));
     // the xs32 master is read as a GEMM operand in fp32 mode: rows padded to a 16-row tile exist (allocated above)
@@ -555,6 +557,20 @@ static int launch_attn(dsg_handle* h, const AttnArgs& a) {
     }
 }
 
+// k_loc / k_inloc are instantiated per (local head dim, window)
+#define DSG_LOC_DISPATCH(KERNEL, ARGS, GRID)                                                                         \
+    do {                                                                                                             \
+        const int key_ = h->hdl * 100 + h->W;                                                                        \
+        if (key_ == 32 * 100 + 11) hipLaunchKernelGGL((KERNEL<P, 32, 11>), GRID, dim3(256), 0, h->stream, ARGS);     \
+        else if (key_ == 48 * 100 + 15) hipLaunchKernelGGL((KERNEL<P, 48, 15>), GRID, dim3(256), 0, h->stream, ARGS);\
+        else if (key_ == 64 * 100 + 15) hipLaunchKernelGGL((KERNEL<P, 64, 15>), GRID, dim3(256), 0, h->stream, ARGS);\
+        else if (key_ == 16 * 100 + 11) hipLaunchKernelGGL((KERNEL<P, 16, 11>), GRID, dim3(256), 0, h->stream, ARGS);\
+        else if (key_ == 8 * 100 + 15) hipLaunchKernelGGL((KERNEL<P, 8, 15>), GRID, dim3(256), 0, h->stream, ARGS);  \
+        else return fail(DSG_E_NOT_IMPLEMENTED, "no local-attention instantiation for (head dim, window) = (" +      \
+                                                    std::to_string(h->hdl) + ", " + std::to_string(h->W) + ")");     \
+        HIPCHK(hipGetLastError());                                                                                   \
+    } while (0)
+
 template <class P, int HD, int NKT, int DD>
 static int launch_qkv_attn_t(dsg_handle* h, const QkvAttnArgs& a) {
     const int nqt = cdiv(a.ntok, 16);
@@ -617,8 +633,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
         InLocArgs a;
         a.xs = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; a.Jp = h->Jp; a.Wp = h->Wp_in; a.KBtot = h->Jp / KB;
         a.loc = la; a.ctr_inc = c.use_ctr ? h->ctr + 1 : nullptr;
-        hipLaunchKernelGGL((k_inloc<P>), dim3(B * (T / h->W) * h->Hl), dim3(256), 0, h->stream, a);
-        HIPCHK(hipGetLastError());
+        DSG_LOC_DISPATCH(k_inloc, a, dim3(B * (T / h->W) * h->Hl));
     } else {
         {   // k_in: partial[s] = xs[:, chunk s] . Wfold[:, chunk s]^T
             GemmArgs g = z;
@@ -629,10 +644,11 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
             g.ctr_inc = c.use_ctr ? h->ctr + 1 : nullptr;
             CHK((launch_gemm<P, PRO_DIRECT, EPI_PARTIAL, 4, 1, 1>(h, g)));
         }
-        hipLaunchKernelGGL((k_loc<P>), dim3(B * (T / h->W) * h->Hl), dim3(256), 0, h->stream, la);
-        HIPCHK(hipGetLastError());
+        DSG_LOC_DISPATCH(k_loc, la, dim3(B * (T / h->W) * h->Hl));
     }
-    const bool fuse_attn = lat && have_qkv_attn(h);
+    // k_qkv_attn is correct but, measured on MI355X (profiles/r01_c_*), its 192 KB per workgroup and 6x redundant K/V
+    // GEMM make it slower (15 us) than LN+QKV followed by k_attn (6.2 + 4.6 us): opt-in only (DSG_FUSE_ATTN=1)
+    const bool fuse_attn = lat && have_qkv_attn(h) && h->fuse_attn;
     for (int l = 0; l < h->L; ++l) {
         const Layer& ly = h->layers[l];
         if (fuse_attn) {   // [LayerNorm2] + in_proj + attention per (batch, head, query tile)
@@ -701,6 +717,99 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
     }
     return 0;
 }
+// ---- diagnostics: time a chain of ONE phase kernel (graph replay) to separate launch floor, kernel body and
+//      weight coldness.  which: 0 null, 1 out_proj GEMM of layer 0 (same weights every launch), 2 out_proj cycling
+//      over the layers, 3 LN+linear1+GELU cycling, 4 linear2 cycling, 5 k_attn, 6 k_loc, 7 k_in, 8 pose head (forward),
+//      9 LN+QKV cycling, 10 k_mid cycling, 11 k_qkv_attn cycling, 12 k_inloc
+template <class P>
+static int debug_launch(dsg_handle* h, int which, int i, int B) {
+    const int D = h->D, T = h->T, ntok = h->ntok, M = B * ntok, MT = cdiv(M, 16), Min = B * T, MTin = cdiv(Min, 16);
+    const int KB = P::KB;
+    GemmArgs z;
+    memset(&z, 0, sizeof(z));
+    z.KS = 1; z.B = B; z.ntok = ntok; z.Tp = h->Tp; z.H = h->H; z.hd = h->hd; z.T = T; z.J = h->J; z.Jp = h->Jp;
+    z.Jq = h->Jq; z.D = D;
+    const Layer& ly = h->layers[(which == 1) ? 0 : i % h->L];
+    LocArgs la;
+    memset(&la, 0, sizeof(la));
+    la.partial = h->partial; la.KS = h->KSin; la.Min_pad = MTin * 16; la.Cf = h->Cf; la.TE2 = h->TE2; la.TE = h->TE;
+    la.emb1 = h->emb1; la.ctr = nullptr; la.tmodel = h->st_tmodel; la.t_arr = h->t_arr;
+    la.rcos = h->rcos; la.rsin = h->rsin; la.mask = h->mask; la.mb = h->mb; la.B = B; la.T = T; la.D = D; la.Hl = h->Hl;
+    la.hd = h->hdl; la.W = h->W; la.X0 = h->X0; la.X0a = h->X0a;
+    switch (which) {
+        case 0: hipLaunchKernelGGL(k_ctr_inc, dim3(96), dim3(256), 0, h->stream, h->ctr + 2); return 0;
+        case 1: case 2: {
+            GemmArgs g = z; g.M = M; g.MT = MT; g.NT = D / 16; g.KBtot = D / KB; g.Wp = ly.Wo; g.bias = ly.bo;
+            g.A = h->attn; g.lda = D; g.out = (i & 1) ? h->pre1 : h->pre2; g.ldo = D; g.R = h->X0;
+            return launch_gemm<P, PRO_DIRECT, EPI_RESID, 4, 1, 1>(h, g); }
+        case 3: {
+            GemmArgs g = z; g.M = M; g.MT = MT; g.NT = h->ff / 16; g.KBtot = D / KB; g.Wp = ly.W1; g.bias = ly.b1;
+            g.X = h->pre1; g.ln_g = ly.g1; g.ln_b = ly.be1; g.Xn = h->X1; g.out = h->hidden; g.ldo = h->ff;
+            return launch_gemm<P, PRO_LN, EPI_GELU, 4, 1, 1>(h, g); }
+        case 4: {
+            GemmArgs g = z; g.M = M; g.MT = MT; g.NT = D / 16; g.KBtot = h->ff / KB; g.Wp = ly.W2; g.bias = ly.b2;
+            g.A = h->hidden; g.lda = h->ff; g.out = h->pre2; g.ldo = D; g.R = h->X1;
+            return launch_gemm<P, PRO_DIRECT, EPI_RESID, 1, 4, 1>(h, g); }
+        case 5: {
+            AttnArgs a; a.q = h->q; a.k = h->k; a.vt = h->vt; a.out = h->attn; a.B = B; a.H = h->H; a.ntok = ntok;
+            a.Tp = h->Tp; a.D = D; return launch_attn<P>(h, a); }
+        case 6: DSG_LOC_DISPATCH(k_loc, la, dim3(B * (T / h->W) * h->Hl)); return 0;
+        case 7: {
+            GemmArgs g = z; g.M = Min; g.MT = MTin; g.NT = D / 16; g.KBtot = h->Jp / KB; g.KS = h->KSin; g.Wp = h->Wp_in;
+            g.kb_per_split = cdiv(g.KBtot, g.KS); g.A = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; g.lda = h->Jp;
+            g.out = h->partial; g.ldo = D; return launch_gemm<P, PRO_DIRECT, EPI_PARTIAL, 4, 1, 1>(h, g); }
+        case 8: {
+            GemmArgs g = z; g.M = M; g.MT = MT; g.NT = h->Jp / 16; g.KBtot = D / KB; g.Wp = h->Wp_out; g.bias = h->b_out;
+            g.X = h->pre2; g.ln_g = ly.g2; g.ln_b = ly.be2; g.out_mode = OUT_FORWARD; g.xs32 = h->xs32; g.fwd_out = h->fwd_out;
+            g.ctr = h->ctr + 1; g.st.c1 = h->st_c[0]; g.st.c2 = h->st_c[1]; g.st.c3 = h->st_c[2]; g.dyn = h->dyn;
+            return launch_gemm<P, PRO_LN, EPI_OUT, 4, 1, 1>(h, g); }
+        case 9: {
+            GemmArgs g = z; g.M = M; g.MT = MT; g.NT = 3 * D / 16; g.KBtot = D / KB; g.Wp = ly.Wqkv; g.bias = ly.bqkv;
+            g.q = h->q; g.k = h->k; g.vt = h->vt; g.X = h->pre2; g.ln_g = ly.g2; g.ln_b = ly.be2; g.Xn = h->Xn;
+            return launch_gemm<P, PRO_LN, EPI_QKV, 4, 1, 1>(h, g); }
+        case 10: {
+            MidArgs a; a.A = h->attn; a.R = h->Xn; a.Wo = ly.Wo; a.bo = ly.bo; a.ln_g = ly.g1; a.ln_b = ly.be1;
+            a.W1 = ly.W1; a.b1 = ly.b1; a.X1 = h->X1; a.hidden = h->hidden; a.M = M; a.MT = MT; a.ff = h->ff;
+            return launch_mid<P>(h, a); }
+        case 11: {
+            if (!have_qkv_attn(h)) return fail(DSG_E_NOT_IMPLEMENTED, "no fused attention for these dims");
+            QkvAttnArgs a; memset(&a, 0, sizeof(a));
+            a.X = h->pre2; a.ln_g = ly.g2; a.ln_b = ly.be2; a.Xn = h->Xn; a.Wp = ly.Wqkv; a.bias = ly.bqkv; a.out = h->attn;
+            a.B = B; a.H = h->H; a.ntok = ntok; return launch_qkv_attn<P>(h, a); }
+        case 12: {
+            InLocArgs a; a.xs = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; a.Jp = h->Jp; a.Wp = h->Wp_in;
+            a.KBtot = h->Jp / KB; a.loc = la; a.ctr_inc = nullptr;
+            DSG_LOC_DISPATCH(k_inloc, a, dim3(B * (T / h->W) * h->Hl)); return 0; }
+        default: return fail(DSG_E_INVALID, "debug_chain: unknown kernel id");
+    }
+}
+extern "C" int dsg_debug_chain(dsg_handle* h, int which, int n, int use_graph, int B, float* us_per_launch) {
+    if (!h || !h->finalized || !h->cond_set) return fail(DSG_E_STATE, "debug_chain needs a finalized, conditioned handle");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    auto one = [&](int i) { return h->prec == DSG_PREC_BF16 ? debug_launch<PBF16>(h, which, i, B) : debug_launch<PF32>(h, which, i, B); };
+    const int G = 64;
+    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+    if (use_graph) {
+        HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < G; ++i) CHK(one(i));
+        HIPCHK(hipStreamEndCapture(h->stream, &graph));
+        HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    }
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        HIPCHK(hipEventRecord(h->ev_t0, h->stream));
+        if (use_graph) for (int i = 0; i < n / G; ++i) HIPCHK(hipGraphLaunch(exec, h->stream));
+        else for (int i = 0; i < n; ++i) CHK(one(i));
+        HIPCHK(hipEventRecord(h->ev_t1, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        float ms; HIPCHK(hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
+        best = std::min(best, 1000.f * ms / (use_graph ? (n / G) * G : n));
+    }
+    if (exec) { (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph); }
+    *us_per_launch = best;
+    return 0;
+}
+
 static int run_step_p(dsg_handle* h, const StepCtx& c) {
     return h->prec == DSG_PREC_BF16 ? run_step<PBF16>(h, c) : run_step<PF32>(h, c);
 }

@@ -226,45 +226,6 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
     const int kb_lo = kb_lo_wg + wk * kb_per_w;
     const int kb_hi = WK > 1 ? kb_lo + kb_per_w : kb_hi_wg;
 
-    // ---- prologue: LayerNorm-on-read (rows are owned whole: K == D)
-    int pitch = 0;
-    if constexpr (PRO == PRO_LN) {
-        const int D = g.D;
-        pitch = DSG_LDS_ROW_BYTES(D, ES);
-        const int row = tid >> 4, c = tid & 15;
-        const float* xr = g.X + (size_t)(m0 + row) * D;
-        f32x4 v[8];
-        const int nch = D >> 6;                       // D / 64 float4 chunks per thread
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (i < nch) { v[i] = *(const f32x4*)(xr + c * 4 + 64 * i); s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
-        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
-        const float mean = s / (float)D;
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (i < nch) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { float d = v[i][e] - mean; q += d * d; }
-            }
-        q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4); q += __shfl_xor(q, 8);
-        const float rstd = 1.0f / sqrtf(q / (float)D + 1e-5f);
-        const bool wr = (g.Xn != nullptr) && ng == 0 && (m0 + row) < g.M;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (i < nch) {
-                const int col = c * 4 + 64 * i;
-                const f32x4 gg = *(const f32x4*)(g.ln_g + col), bb = *(const f32x4*)(g.ln_b + col);
-                f32x4 y;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
-                P::store4((elem*)(lds_a + row * pitch) + col, y);
-                if (wr) *(f32x4*)(g.Xn + (size_t)(m0 + row) * D + col) = y;
-            }
-        __syncthreads();
-    }
-
     // ---- main loop
     f32x4 acc[TNW];
 #pragma unroll
@@ -277,6 +238,20 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
 #pragma unroll
     for (int t = 0; t < TNW; ++t) swapped[t] = !(EPI == EPI_QKV && ((nt0 + t) * 16) >= 2 * (g.H * g.hd));
 
+    // All fragment loads of a chunk are issued before its first MFMA, and the NEXT chunk's weight fragments are
+    // requested while the current chunk's MFMAs run: at these sizes a kernel is a latency chain, so every load that
+    // does not depend on the prologue (weights, bias, residual, x_t, noise) is in flight before the LayerNorm starts.
+    constexpr int CH = 8;
+    f32x4 bf[CH][TNW];
+    auto load_b = [&](int kb0) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            if (kb0 + c < kb_hi) {
+#pragma unroll
+                for (int t = 0; t < TNW; ++t) bf[c][t] = wbase[((size_t)(nt0 + t) * g.KBtot + kb0 + c) * 64];
+            }
+    };
+    load_b(kb_lo);
     // ---- epilogue operands (bias, residual, x_t, step coefficients, noise) do not depend on the main loop: fetch
     //      them now so their latency overlaps the weight / activation fragment loads
     f32x4 pb[TNW], pr[TNW], pz[TNW];
@@ -327,17 +302,51 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
         }
     }
 
-    // All fragment loads of a chunk are issued before the first MFMA of the chunk: at these sizes the kernel is
-    // a latency chain (L2 / Infinity-Cache round trips), so the loads must be in flight together.
-    constexpr int CH = 8;
+    // ---- prologue: LayerNorm-on-read (rows are owned whole: K == D)
+    int pitch = 0;
+    if constexpr (PRO == PRO_LN) {
+        const int D = g.D;
+        pitch = DSG_LDS_ROW_BYTES(D, ES);
+        const int row = tid >> 4, c = tid & 15;
+        const float* xr = g.X + (size_t)(m0 + row) * D;
+        f32x4 v[8];
+        const int nch = D >> 6;                       // D / 64 float4 chunks per thread
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < nch) { v[i] = *(const f32x4*)(xr + c * 4 + 64 * i); s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+        const float mean = s / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < nch) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { float d = v[i][e] - mean; q += d * d; }
+            }
+        q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4); q += __shfl_xor(q, 8);
+        const float rstd = 1.0f / sqrtf(q / (float)D + 1e-5f);
+        const bool wr = (g.Xn != nullptr) && ng == 0 && (m0 + row) < g.M;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < nch) {
+                const int col = c * 4 + 64 * i;
+                const f32x4 gg = *(const f32x4*)(g.ln_g + col), bb = *(const f32x4*)(g.ln_b + col);
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
+                P::store4((elem*)(lds_a + row * pitch) + col, y);
+                if (wr) *(f32x4*)(g.Xn + (size_t)(m0 + row) * D + col) = y;
+            }
+        __syncthreads();
+    }
+
     for (int kb0 = kb_lo; kb0 < kb_hi; kb0 += CH) {
-        f32x4 af[CH], bf[CH][TNW];
+        f32x4 af[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const int kb = kb0 + c;
             if (kb < kb_hi) {
-#pragma unroll
-                for (int t = 0; t < TNW; ++t) bf[c][t] = wbase[((size_t)(nt0 + t) * g.KBtot + kb) * 64];
                 if constexpr (PRO == PRO_DIRECT) af[c] = *(const f32x4*)(arow + (size_t)kb * P::KB);
                 else af[c] = *(const f32x4*)(lds_a + lr * pitch + (kb * P::KB + P::E * lg) * ES);
             }
@@ -350,6 +359,7 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
                     acc[t] = swapped[t] ? P::mma(bf[c][t], af[c], acc[t]) : P::mma(af[c], bf[c][t], acc[t]);
             }
         }
+        if (kb0 + CH < kb_hi) load_b(kb0 + CH);
     }
 
     // ---- in-workgroup split-K reduction (deterministic order)
@@ -463,155 +473,134 @@ struct LocArgs {
     const float* rsin;
     const unsigned char* mask;   // [mb][T] key mask (1 = keep)
     int mb;
-    int B, T, D, Hl, hd, W;
+    int B, T, D, Hl, hd, W;   // hd / W must match the kernel's template arguments
     float* X0;              // [M_pad][D] fp32, row = b*(T+1) + 1 + f ; row b*(T+1) = token
     void* X0a;              // same in P::elem (GEMM operand copy)
 };
 
-template <class P>
+// Shared tail of k_loc / k_inloc.  `rot` holds the rotary-embedded [2W][HD] tile (pad rows = -1).  Phase A: one thread
+// per (query, key) pair forms the masked score, the 32 lanes of a query row reduce max / sum with shuffles; phase B:
+// one thread per (query, dim pair) forms the attention output and applies the second rotary (position + 1).
+template <class P, int HD, int W>
+__device__ __forceinline__ void local_attn_tail(const LocArgs& a, float (&rot)[2 * W][HD + 1], float (&sc)[W][2 * W + 2],
+                                                int b, int w, int h, const bool (&keep)[(W * 32 + 255) / 256],
+                                                const float (&c2)[(W * (HD / 2) + 255) / 256],
+                                                const float (&s2)[(W * (HD / 2) + 255) / 256]) {
+    typedef typename P::elem elem;
+    constexpr int W2 = 2 * W, half = HD / 2, NSI = (W * 32 + 255) / 256, NP2 = W * half, NPO = (NP2 + 255) / 256;
+    static_assert(W2 <= 32, "a query row of scores fits in 32 lanes");
+    const int tid = threadIdx.x;
+    const int f0 = (w - 1) * W;
+    const float scale = 1.0f / sqrtf((float)HD);
+#pragma unroll
+    for (int i = 0; i < NSI; ++i) {
+        const int idx = tid + 256 * i;
+        const int q = idx >> 5, j = idx & 31;
+        const bool inq = q < W, valid = inq && j < W2;
+        float sv = -DSG_FLT_MAX;
+        if (valid) {
+            float d = 0.f;
+#pragma unroll 8
+            for (int e = 0; e < HD; ++e) d += rot[W + q][e] * rot[j][e];
+            const int fq = w * W + q, fk = f0 + j;
+            const bool masked = ((fk >= 0) && (fq < fk)) || !keep[i];   // causal | key mask (pads are masked keys)
+            sv = masked ? -DSG_FLT_MAX : d * scale;
+        }
+        float mx = sv;                                   // every lane takes part in the shuffles
+        mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 4));
+        mx = fmaxf(mx, __shfl_xor(mx, 8)); mx = fmaxf(mx, __shfl_xor(mx, 16));
+        const float pv = valid ? expf(sv - mx) : 0.f;
+        float sum = pv;
+        sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
+        sum += __shfl_xor(sum, 8); sum += __shfl_xor(sum, 16);
+        if (valid) sc[q][j] = pv / sum;
+    }
+    __syncthreads();
+    const int ntok = a.T + 1, col0 = h * HD;
+#pragma unroll
+    for (int i = 0; i < NPO; ++i) {
+        const int p = tid + 256 * i;
+        if (p < NP2) {
+            const int q = p / half, dd = p % half;
+            float lo = 0.f, hi = 0.f;
+#pragma unroll
+            for (int j = 0; j < W2; ++j) { const float pj = sc[q][j]; lo += pj * rot[j][dd]; hi += pj * rot[j][dd + half]; }
+            const float vlo = lo * c2[i] - hi * s2[i], vhi = hi * c2[i] + lo * s2[i];
+            const size_t o = (size_t)(b * ntok + 1 + w * W + q) * a.D + col0 + dd;
+            a.X0[o] = vlo; a.X0[o + half] = vhi;
+            ((elem*)a.X0a)[o] = P::cvt(vlo); ((elem*)a.X0a)[o + half] = P::cvt(vhi);
+        }
+    }
+}
+
+template <class P, int HD, int W>
 __global__ __launch_bounds__(256) void k_loc(const LocArgs a) {
     typedef typename P::elem elem;
-    constexpr int MAXW = 16, MAXHD = 64, NT = 256;
-    constexpr int NE1 = (2 * MAXW * MAXHD + NT - 1) / NT;     // tile elements per thread (<= 8)
-    constexpr int NE2 = (MAXW * MAXHD + NT - 1) / NT;         // output elements per thread (<= 4)
-    constexpr int NS = (MAXW * 2 * MAXW + NT - 1) / NT;       // scores per thread (<= 2)
-    __shared__ float raw[2 * MAXW][MAXHD + 1];
-    __shared__ float rot[2 * MAXW][MAXHD + 1];
-    __shared__ float sc[MAXW][2 * MAXW + 1];
-    __shared__ float ob[MAXW][MAXHD + 1];
-    const int nW = a.T / a.W;
+    constexpr int W2 = 2 * W, half = HD / 2, NP1 = W2 * half, NPI = (NP1 + 255) / 256;
+    constexpr int NSI = (W * 32 + 255) / 256, NP2 = W * half, NPO = (NP2 + 255) / 256, MAXKS = 9;
+    __shared__ float rot[W2][HD + 1];
+    __shared__ float sc[W][W2 + 2];
+    const int nW = a.T / W;
     int id = blockIdx.x;
     const int h = id % a.Hl; id /= a.Hl;
     const int w = id % nW; const int b = id / nW;
     const int tid = threadIdx.x;
-    const int W = a.W, hd = a.hd, half = hd >> 1, W2 = 2 * W;
     const int t = a.ctr ? a.tmodel[*a.ctr] : a.t_arr[b];
-    const int col0 = h * hd;
-    const int ntok = a.T + 1;
-    const int n1 = W2 * hd, n2 = W * hd, ns = W * W2;
+    const int col0 = h * HD, ntok = a.T + 1, f0 = (w - 1) * W;
 
-    // ---- every global load of the block is issued up front (the kernel is a latency chain otherwise)
-    float v1[NE1], c1[NE1], s1[NE1];
+    // ---- every global load of the block is issued up front
+    float lo[NPI], hi[NPI], c1[NPI], s1[NPI];
 #pragma unroll
-    for (int i = 0; i < NE1; ++i) {
-        const int e = tid + NT * i;
-        v1[i] = 0.f; c1[i] = 1.f; s1[i] = 0.f;
-        if (e < n1) {
-            const int r = e / hd, d = e % hd, f = (w - 1) * W + r;
+    for (int i = 0; i < NPI; ++i) {
+        const int p = tid + 256 * i;
+        lo[i] = hi[i] = 0.f; c1[i] = 1.f; s1[i] = 0.f;
+        if (p < NP1) {
+            const int r = p / half, dd = p % half, f = f0 + r;
             if (f >= 0) {
-                const size_t row = (size_t)b * a.T + f;
-                const int dd = d < half ? d : d - half;
-                v1[i] = a.Cf[row * a.D + col0 + d] + a.TE2[(size_t)t * a.D + col0 + d];
+                const size_t base = ((size_t)b * a.T + f) * a.D + col0 + dd;
+                lo[i] = a.Cf[base] + a.TE2[(size_t)t * a.D + col0 + dd];
+                hi[i] = a.Cf[base + half] + a.TE2[(size_t)t * a.D + col0 + dd + half];
                 c1[i] = a.rcos[f * half + dd]; s1[i] = a.rsin[f * half + dd];
+#pragma unroll
+                for (int s = 0; s < MAXKS; ++s)
+                    if (s < a.KS) {
+                        const size_t pb = ((size_t)s * a.Min_pad + (size_t)b * a.T + f) * a.D + col0 + dd;
+                        lo[i] += a.partial[pb]; hi[i] += a.partial[pb + half];
+                    }
             }
         }
     }
-    for (int s = 0; s < a.KS; ++s) {
+    float c2[NPO], s2[NPO];
 #pragma unroll
-        for (int i = 0; i < NE1; ++i) {
-            const int e = tid + NT * i;
-            if (e < n1) {
-                const int r = e / hd, d = e % hd, f = (w - 1) * W + r;
-                if (f >= 0) v1[i] += a.partial[((size_t)s * a.Min_pad + (size_t)b * a.T + f) * a.D + col0 + d];
-            }
-        }
-    }
-    float c2[NE2], s2[NE2];
-#pragma unroll
-    for (int i = 0; i < NE2; ++i) {
-        const int e = tid + NT * i;
+    for (int i = 0; i < NPO; ++i) {
+        const int p = tid + 256 * i;
         c2[i] = 1.f; s2[i] = 0.f;
-        if (e < n2) {
-            const int q = e / hd, d = e % hd, pos = w * W + q + 1;
-            const int dd = d < half ? d : d - half;
-            c2[i] = a.rcos[pos * half + dd]; s2[i] = a.rsin[pos * half + dd];
-        }
+        if (p < NP2) { const int pos = w * W + p / half + 1; c2[i] = a.rcos[pos * half + p % half]; s2[i] = a.rsin[pos * half + p % half]; }
     }
     const int mrow = (int)(((long long)(b * a.Hl + h)) / ((long long)a.B * a.Hl / a.mb));
-    bool keep[NS];
+    bool keep[NSI];
 #pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        const int e = tid + NT * i;
-        keep[i] = false;
-        if (e < ns) {
-            const int j = e % W2, fk = (w - 1) * W + j;
-            keep[i] = (fk >= 0) && (a.mask[(size_t)mrow * a.T + fk] != 0);   // look_around pads the key mask with False
-        }
+    for (int i = 0; i < NSI; ++i) {
+        const int idx = tid + 256 * i, q = idx >> 5, j = idx & 31, fk = f0 + j;
+        keep[i] = (q < W) && (j < W2) && (fk >= 0) && (a.mask[(size_t)mrow * a.T + fk] != 0);
     }
-    float tokv = 0.f;
-    if (w == 0 && tid < hd) tokv = a.emb1[(size_t)b * a.D + col0 + tid] + a.TE[(size_t)t * a.D + col0 + tid];
-
-    if (w == 0 && tid < hd) {                              // token row (position 0: rotary is the identity)
+    if (w == 0 && tid < HD) {                              // token row (position 0: rotary is the identity)
+        const float tokv = a.emb1[(size_t)b * a.D + col0 + tid] + a.TE[(size_t)t * a.D + col0 + tid];
         a.X0[(size_t)(b * ntok) * a.D + col0 + tid] = tokv;
         ((elem*)a.X0a)[(size_t)(b * ntok) * a.D + col0 + tid] = P::cvt(tokv);
     }
 #pragma unroll
-    for (int i = 0; i < NE1; ++i) {
-        const int e = tid + NT * i;
-        if (e < n1) raw[e / hd][e % hd] = v1[i];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NE1; ++i) {
-        const int e = tid + NT * i;
-        if (e < n1) {
-            const int r = e / hd, d = e % hd, f = (w - 1) * W + r;
-            float v = -1.0f;                               // look_around pad_value (local_attention.py:94,134)
-            if (f >= 0) {
-                const float other = d < half ? -raw[r][d + half] : raw[r][d - half];
-                v = raw[r][d] * c1[i] + other * s1[i];
-            }
-            rot[r][d] = v;
+    for (int i = 0; i < NPI; ++i) {
+        const int p = tid + 256 * i;
+        if (p < NP1) {
+            const int r = p / half, dd = p % half, f = f0 + r;
+            // rotary (rotary.py:20-27); rows before the sequence start are look_around's pad_value -1
+            rot[r][dd] = f >= 0 ? lo[i] * c1[i] - hi[i] * s1[i] : -1.0f;
+            rot[r][dd + half] = f >= 0 ? hi[i] * c1[i] + lo[i] * s1[i] : -1.0f;
         }
     }
     __syncthreads();
-    const float scale = 1.0f / sqrtf((float)hd);
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        const int e = tid + NT * i;
-        if (e < ns) {
-            const int q = e / W2, j = e % W2;
-            const int fq = w * W + q, fk = (w - 1) * W + j;
-            float s = 0.f;
-            for (int d = 0; d < hd; ++d) s += rot[W + q][d] * rot[j][d];
-            s *= scale;
-            const bool masked = ((fk >= 0) && (fq < fk)) || !keep[i];   // causal | key mask
-            sc[q][j] = masked ? -DSG_FLT_MAX : s;
-        }
-    }
-    __syncthreads();
-    if (tid < W) {
-        float mx = -DSG_FLT_MAX;
-        for (int j = 0; j < W2; ++j) mx = fmaxf(mx, sc[tid][j]);
-        float sum = 0.f;
-        for (int j = 0; j < W2; ++j) { const float p = expf(sc[tid][j] - mx); sc[tid][j] = p; sum += p; }
-        const float inv = 1.0f / sum;
-        for (int j = 0; j < W2; ++j) sc[tid][j] *= inv;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NE2; ++i) {
-        const int e = tid + NT * i;
-        if (e < n2) {
-            const int q = e / hd, d = e % hd;
-            float o = 0.f;
-            for (int j = 0; j < W2; ++j) o += sc[q][j] * rot[j][d];
-            ob[q][d] = o;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NE2; ++i) {
-        const int e = tid + NT * i;
-        if (e < n2) {
-            const int q = e / hd, d = e % hd, f = w * W + q;
-            const float other = d < half ? -ob[q][d + half] : ob[q][d - half];
-            const float v = ob[q][d] * c2[i] + other * s2[i];
-            const size_t o = (size_t)(b * ntok + 1 + f) * a.D + col0 + d;
-            a.X0[o] = v;
-            ((elem*)a.X0a)[o] = P::cvt(v);
-        }
-    }
+    local_attn_tail<P, HD, W>(a, rot, sc, b, w, h, keep, c2, s2);
 }
 
 // ---------------------------------------------------------------------------------------------------------
