@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k_inloc(const InLocArgs g) {
     int id = blockIdx.x;
     const int h = id % a.Hl; id /= a.Hl;
     const int w = id % nW; const int b = id / nW;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
     // two step counters make the hand-over race free: this kernel READS ctrA (a.ctr) and ADVANCES ctrB (read only by
     // the last kernel of the step, which in turn advances ctrA) -- no kernel reads the counter it increments
     if (g.ctr_inc && blockIdx.x == 0 && tid == 0) *g.ctr_inc += 1;
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void k_qkv_attn(const QkvAttnArgs g) {
     char* const vt = kk + Tp * KP;
     char* const qq = vt + HD * VP;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
     int id = blockIdx.x;
     const int nqt = (g.ntok + 15) >> 4;
     const int qt = id % nqt; id /= nqt;
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
     int ng, mt;
     if (!xcd_map(NGH, g.MT, ng, mt)) return;
     const int m0 = mt * 16;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
     const f32x4* wo = (const f32x4*)g.Wo + lane;
     const f32x4* w1 = (const f32x4*)g.W1 + lane;
     const elem* arow = (const elem*)g.A + (size_t)(m0 + lr) * D + P::E * lg;

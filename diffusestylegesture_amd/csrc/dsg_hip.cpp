@@ -783,6 +783,28 @@ static int debug_launch(dsg_handle* h, int which, int i, int B) {
         default: return fail(DSG_E_INVALID, "debug_chain: unknown kernel id");
     }
 }
+// copies an internal buffer to the host (raw bytes) -- used to bisect GPU-vs-emulator differences
+extern "C" int dsg_debug_read(dsg_handle* h, const char* name, void* out, long long max_bytes, long long* n_bytes) {
+    if (!h || !name || !out) return fail(DSG_E_INVALID, "null");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t B = h->Bmax, D = h->D, M = rup((int)(B * h->ntok), 16), Min = rup((int)(B * h->T), 16), es = h->es;
+    std::map<std::string, std::pair<const void*, size_t>> m = {
+        {"partial", {h->partial, (size_t)h->KSin * Min * D * 4}}, {"X0", {h->X0, M * D * 4}}, {"X0a", {h->X0a, M * D * es}},
+        {"q", {h->q, B * h->H * h->Tp * h->hd * es}}, {"k", {h->k, B * h->H * h->Tp * h->hd * es}},
+        {"vt", {h->vt, B * h->H * h->Tp * h->hd * es}}, {"attn", {h->attn, M * D * es}}, {"pre1", {h->pre1, M * D * 4}},
+        {"X1", {h->X1, M * D * 4}}, {"Xn", {h->Xn, M * D * 4}}, {"hidden", {h->hidden, M * h->ff * es}},
+        {"pre2", {h->pre2, M * D * 4}}, {"fwd_out", {h->fwd_out, B * h->J * h->T * 4}},
+        {"xs32", {h->xs32, B * h->T * h->Jp * 4}}, {"xsA", {h->xsA, h->xsA ? Min * h->Jp * es : 0}},
+        {"Cf", {h->Cf, B * h->T * D * 4}}, {"emb1", {h->emb1, B * D * 4}}};
+    auto it = m.find(name);
+    if (it == m.end() || !it->second.first) return fail(DSG_E_INVALID, "unknown buffer");
+    size_t n = std::min<size_t>(it->second.second, (size_t)max_bytes);
+    HIPCHK(hipMemcpy(out, it->second.first, n, hipMemcpyDeviceToHost));
+    if (n_bytes) *n_bytes = (long long)n;
+    return 0;
+}
+
 extern "C" int dsg_debug_chain(dsg_handle* h, int which, int n, int use_graph, int B, float* us_per_launch) {
     if (!h || !h->finalized || !h->cond_set) return fail(DSG_E_STATE, "debug_chain needs a finalized, conditioned handle");
     HIPCHK(hipSetDevice(h->cfg.device));
@@ -978,7 +1000,10 @@ extern "C" int dsg_sample(dsg_handle* h, const dsg_sample_args* a, float* out, i
     c.B = B; c.out_mode = a->mode == DSG_MODE_DDPM ? OUT_DDPM : OUT_DDIM; c.use_ctr = true; c.ext_noise = ext;
     c.const_noise = a->const_noise;
 
-    int spg = h->cfg.steps_per_graph == 0 ? 20 : h->cfg.steps_per_graph;
+    // steps_per_graph: 0 = default.  Measured on MI355X / ROCm 7.2 (profiles/r01_c_step_timing.log): stream-ordered
+    // launches with device-resident kernargs run the 26-launch step in 228 us, hipGraph replay of the same launches
+    // in 244-249 us -- so the default is eager launches and graphs stay opt-in (steps_per_graph > 0).
+    int spg = h->cfg.steps_per_graph == 0 ? -1 : h->cfg.steps_per_graph;
     const bool dumping = a->n_dump > 0 && a->dump_steps && a->dump_out;
     if (dumping || ext) spg = -1;            // rare paths run eagerly (ext pointer / dump points are per call)
     HIPCHK(hipEventRecord(h->ev_t0, h->stream));

@@ -80,6 +80,11 @@ struct PBF16 {                      // bf16 storage, v_mfma_f32_16x16x32_bf16, f
 };
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// The wave index must be PROVABLY wave-uniform (an SGPR): loop bounds and predicates derived from threadIdx.x >> 6 are
+// otherwise treated as divergent, the compiler predicates the loop body through EXEC, and v_mfma IGNORES EXEC -- a
+// "skipped" MFMA of a partial k-chunk then runs on uninitialised fragments (seen on gfx950: NaNs in the last split-K
+// slice; invisible under emulation).  readfirstlane makes every such branch a scalar branch.
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 // ---------------------------------------------------------------------------------------------------------
 // Philox4x32-10 + Box-Muller: the framework's noise stream (restated for the CPU in oracle/philox.py)
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
     if (!xcd_map(NG, g.MT * g.KS, ng, r)) return;
     const int mt = r % g.MT, ks = r / g.MT;
     const int m0 = mt * 16;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
     if constexpr (EPI == EPI_PARTIAL || EPI == EPI_OUT) {
         // Two step counters: A is read by the first kernel(s) of a step (k_loc / k_inloc) and advanced by the LAST
         // kernel (EPI_OUT); B is read by the last kernel and advanced by the FIRST (EPI_PARTIAL / k_inloc).  No kernel

@@ -70,7 +70,7 @@ typedef struct dsg_config {
     int32_t max_batch;
     int32_t precision;      /* DSG_PREC_* */
     int32_t device;         /* HIP device ordinal */
-    int32_t steps_per_graph;/* denoising steps captured per hipGraph replay; 0 = default, -1 = no graphs (eager) */
+    int32_t steps_per_graph;/* > 0: denoising steps captured per hipGraph replay; 0 = default (eager: measured faster), -1 = eager */
     int32_t latency_mode;   /* 0 = auto (fused redundant-compute kernels when batch <= 4), 1 = never, 2 = always */
     int32_t reserved[4];
 } dsg_config;

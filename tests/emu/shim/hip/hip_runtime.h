@@ -46,6 +46,7 @@ void dfree(void* p);
 #define gridDim (emu::cur()->gdim)
 
 static inline void __syncthreads() { emu::syncthreads(); }
+#define __builtin_amdgcn_readfirstlane(x) (x)
 static inline float __shfl_xor(float v, int m) {
     return __builtin_bit_cast(float, emu::shfl_xor_u32(__builtin_bit_cast(unsigned, v), m));
 }
