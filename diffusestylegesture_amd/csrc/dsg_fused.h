@@ -25,13 +25,19 @@ struct InLocArgs {
     const void* Wp;         // packed folded weight [D/16][KBtot][64][16 B]
     int KBtot;
     LocArgs loc;            // Cf, TE2, TE, emb1, ctr/tmodel/t_arr, rotary tables, mask, dims, X0/X0a (partial unused)
-    int* ctr_inc;           // first kernel of a step: block 0 advances step counter B (see k_inloc)
+    StepCtl* ctl_upd;       // first kernel of a step: block 0 advances the B side of the step control at its end
+    StepTables st; int n_tab;
 };
 
 template <class P, int HD, int W>
 __global__ __launch_bounds__(256) void k_inloc(const InLocArgs g) {
     typedef typename P::elem elem;
+    preload_kernargs(g);
     const LocArgs& a = g.loc;
+    if (blockIdx.x == gridDim.x - 1) {      // one EXTRA workgroup does the step bookkeeping (see StepCtl), off the critical path
+        if (g.ctl_upd && threadIdx.x == 0) step_advance_B(g.ctl_upd, g.st, g.n_tab);
+        return;
+    }
     constexpr int W2 = 2 * W, half = HD / 2, NP1 = W2 * half, NPI = (NP1 + 255) / 256;
     constexpr int NSI = (W * 32 + 255) / 256, NP2 = W * half, NPO = (NP2 + 255) / 256;
     constexpr int NL = HD >= 16 ? HD / 16 : 1;                 // 16-col tiles covering the head
@@ -43,47 +49,38 @@ __global__ __launch_bounds__(256) void k_inloc(const InLocArgs g) {
     const int h = id % a.Hl; id /= a.Hl;
     const int w = id % nW; const int b = id / nW;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
-    // two step counters make the hand-over race free: this kernel READS ctrA (a.ctr) and ADVANCES ctrB (read only by
-    // the last kernel of the step, which in turn advances ctrA) -- no kernel reads the counter it increments
-    if (g.ctr_inc && blockIdx.x == 0 && tid == 0) *g.ctr_inc += 1;
     const int col0 = h * HD, ntok = a.T + 1, f0 = (w - 1) * W;
-    const int t = a.ctr ? a.tmodel[*a.ctr] : a.t_arr[b];
+    const int* tp = a.ctl ? &a.ctl->tA : a.t_arr + b;      // select the ADDRESS, then one unconditional load
+    const int t = *tp;
 
-    // ---- (1) window constants, rotary tables and the key mask: issued first so they fly under the GEMM loads
+    // ---- (1) window constants, rotary tables and the key mask: issued first, unconditionally (clamped indices)
     float lo[NPI], hi[NPI], c1[NPI], s1[NPI];
 #pragma unroll
     for (int i = 0; i < NPI; ++i) {
-        const int p = tid + 256 * i;
-        lo[i] = hi[i] = 0.f; c1[i] = 1.f; s1[i] = 0.f;
-        if (p < NP1) {
-            const int r = p / half, dd = p % half, f = f0 + r;
-            if (f >= 0) {
-                const size_t base = ((size_t)b * a.T + f) * a.D + col0 + dd;
-                lo[i] = a.Cf[base] + a.TE2[(size_t)t * a.D + col0 + dd];
-                hi[i] = a.Cf[base + half] + a.TE2[(size_t)t * a.D + col0 + dd + half];
-                c1[i] = a.rcos[f * half + dd]; s1[i] = a.rsin[f * half + dd];
-            }
-        }
+        const int p = min(tid + 256 * i, NP1 - 1);
+        const int r = p / half, dd = p % half, f = max(f0 + r, 0);
+        const size_t base = ((size_t)b * a.T + f) * a.D + col0 + dd;
+        lo[i] = a.Cf[base];
+        hi[i] = a.Cf[base + half];
+        c1[i] = a.rcos[f * half + dd]; s1[i] = a.rsin[f * half + dd];
     }
     float c2[NPO], s2[NPO];
 #pragma unroll
     for (int i = 0; i < NPO; ++i) {
-        const int p = tid + 256 * i;
-        c2[i] = 1.f; s2[i] = 0.f;
-        if (p < NP2) { const int pos = w * W + p / half + 1; c2[i] = a.rcos[pos * half + p % half]; s2[i] = a.rsin[pos * half + p % half]; }
+        const int p = min(tid + 256 * i, NP2 - 1);
+        const int pos = w * W + p / half + 1;
+        c2[i] = a.rcos[pos * half + p % half]; s2[i] = a.rsin[pos * half + p % half];
     }
     const int mrow = (int)(((long long)(b * a.Hl + h)) / ((long long)a.B * a.Hl / a.mb));
     bool keep[NSI];
 #pragma unroll
     for (int i = 0; i < NSI; ++i) {
         const int idx = tid + 256 * i, q = idx >> 5, j = idx & 31, fk = f0 + j;
-        keep[i] = (q < W) && (j < W2) && (fk >= 0) && (a.mask[(size_t)mrow * a.T + fk] != 0);
+        const unsigned char mk = a.mask[(size_t)mrow * a.T + min(max(fk, 0), a.T - 1)];
+        keep[i] = ((int)(q < W) & (int)(j < W2) & (int)(fk >= 0) & (int)(mk != 0)) != 0;
     }
-    if (w == 0 && tid < HD) {
-        const float tokv = a.emb1[(size_t)b * a.D + col0 + tid] + a.TE[(size_t)t * a.D + col0 + tid];
-        a.X0[(size_t)(b * ntok) * a.D + col0 + tid] = tokv;
-        ((elem*)a.X0a)[(size_t)(b * ntok) * a.D + col0 + tid] = P::cvt(tokv);
-    }
+    const int tc = min(tid, HD - 1);
+    float tokv = a.emb1[(size_t)b * a.D + col0 + tc];
 
     // ---- (2) pose-embedding GEMM for the 2W frames x this head's columns; this wave's share of K
     const int ntile0 = col0 / 16;
@@ -103,27 +100,45 @@ __global__ __launch_bounds__(256) void k_inloc(const InLocArgs g) {
     }
     const f32x4* wbase = (const f32x4*)g.Wp + lane;
     constexpr int CH = 9;
+    const int kb_last = g.KBtot - 1;
+    f32x4 af[CH][2], bf[CH][NL];
+    auto load_chunk = [&](int kb0) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int kb = min(kb0 + c, kb_last);                  // clamped, never predicated
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) af[c][mt] = *(const f32x4*)(arow[mt] + (size_t)kb * P::KB);
+#pragma unroll
+            for (int nt = 0; nt < NL; ++nt) bf[c][nt] = wbase[((size_t)(ntile0 + nt) * g.KBtot + kb) * 64];
+        }
+    };
+    load_chunk(kb_lo);
+    // the only loads that depend on the model timestep go out AFTER the GEMM fragments (t was requested first)
+    float te_lo[NPI], te_hi[NPI];
+#pragma unroll
+    for (int i = 0; i < NPI; ++i) {
+        const int p = min(tid + 256 * i, NP1 - 1), dd = p % half;
+        te_lo[i] = a.TE2[(size_t)t * a.D + col0 + dd];
+        te_hi[i] = a.TE2[(size_t)t * a.D + col0 + dd + half];
+    }
+    tokv += a.TE[(size_t)t * a.D + col0 + tc];
     for (int kb0 = kb_lo; kb0 < kb_hi; kb0 += CH) {
-        f32x4 af[CH][2], bf[CH][NL];
+        DSG_LOADS_ISSUED();
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            const int kb = kb0 + c;
-            if (kb < kb_hi) {
+            const bool live = kb0 + c < kb_hi;
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) af[c][mt] = *(const f32x4*)(arow[mt] + (size_t)kb * P::KB);
+            for (int mt = 0; mt < 2; ++mt) {
+                const f32x4 av = live ? af[c][mt] : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int nt = 0; nt < NL; ++nt) bf[c][nt] = wbase[((size_t)(ntile0 + nt) * g.KBtot + kb) * 64];
+                for (int nt = 0; nt < NL; ++nt) acc[mt][nt] = P::mma(av, bf[c][nt], acc[mt][nt]);   // D[row 4lg+r][col lr]
             }
         }
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            if (kb0 + c < kb_hi) {
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NL; ++nt) acc[mt][nt] = P::mma(af[c][mt], bf[c][nt], acc[mt][nt]);   // D[row 4lg+r][col lr]
-            }
-        }
+        if (kb0 + CH < kb_hi) load_chunk(kb0 + CH);
+    }
+    if (w == 0 && tid < HD) {
+        a.X0[(size_t)(b * ntok) * a.D + col0 + tid] = tokv;
+        ((elem*)a.X0a)[(size_t)(b * ntok) * a.D + col0 + tid] = P::cvt(tokv);
     }
 
     // ---- (3) reduce the 4 K-slices, add the constants, apply the rotary -> rot
@@ -141,7 +156,7 @@ __global__ __launch_bounds__(256) void k_inloc(const InLocArgs g) {
             const int mt = r >> 4, rr = r & 15, rg = rr & 3;
             const int cl = dd + cshift, ch = dd + half + cshift;
             const int lnl = (rr >> 2) * 16 + (cl & 15), lnh = (rr >> 2) * 16 + (ch & 15);     // D[row 4*lg + reg][col lr]
-            float vl = lo[i], vh = hi[i];
+            float vl = lo[i] + te_lo[i], vh = hi[i] + te_hi[i];
 #pragma unroll
             for (int wv = 0; wv < 4; ++wv) { vl += red[wv][mt][cl >> 4][lnl][rg]; vh += red[wv][mt][ch >> 4][lnh][rg]; }
             rot[r][dd] = f >= 0 ? vl * c1[i] - vh * s1[i] : -1.0f;
@@ -383,6 +398,7 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
     constexpr int CH = 8;
     __shared__ __attribute__((aligned(16))) char a1[16 * XP];
     __shared__ float red[2][4][16];
+    preload_kernargs(g);
     const int NGH = g.ff / 64;
     int ng, mt;
     if (!xcd_map(NGH, g.MT, ng, mt)) return;
@@ -425,6 +441,7 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
                 for (int t = 0; t < DT; ++t) bf[c][t] = wo[((size_t)(wave * DT + t) * KD + kb0 + c) * 64];
             }
         }
+        DSG_LOADS_ISSUED();
 #pragma unroll
         for (int c = 0; c < CH; ++c)
             if (kb0 + c < KD) {

@@ -123,12 +123,13 @@ struct dsg_handle {
           *X1 = nullptr, *fwd_out = nullptr, *io_tmp = nullptr, *io_tmp2 = nullptr, *ext_noise = nullptr;
     size_t ext_noise_cap = 0;
     void *xsA = nullptr, *X0a = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *attn = nullptr, *hidden = nullptr;
-    int* ctr = nullptr;                  // ctr[0] = step counter A, ctr[1] = step counter B (see k_inloc / k_gemm)
+    int* ctr = nullptr;                  // scratch counter for diagnostics
+    StepCtl* ctl = nullptr;              // device-resident step control (dsg_kernels.h: StepCtl)
     int* t_arr = nullptr; unsigned* dyn = nullptr;
     int latency_mode = -1;               // -1 auto (fused kernels when the batch is small), 0 never, 1 always
     bool fuse_attn = false;
     int* st_tmodel = nullptr; float* st_c[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    int st_cap = 0;
+    int st_cap = 0, n_run = 1;
     Sched sched;
     // graphs: key = (B, out_mode, ext_noise?, const_noise) -> exec
     struct GKey { int B, mode, mb, cn; bool operator<(const GKey& o) const {
@@ -280,6 +281,7 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     CHK(dalloc(h, &h->c_audio, (size_t)B * h->Ta * h->As));
     CHK(dalloc(h, &h->mask, (size_t)B * h->T));
     CHK(dalloc(h, &h->ctr, 8));
+    CHK(dalloc(h, &h->ctl, 1));
     CHK(dalloc(h, &h->dyn, 8));
     CHK(dalloc(h, &h->t_arr, (size_t)B));
     // the xs32 master is read as a GEMM operand in fp32 mode: rows padded to a 16-row tile exist (allocated above)
@@ -531,7 +533,9 @@ static int launch_gemm(dsg_handle* h, GemmArgs g) {
     if (NG * WN * TNW != g.NT) return fail(DSG_E_INVALID, "gemm: NT not divisible by the workgroup tile");
     if (WK > 1 && (g.KS != 1 || g.KBtot % WK)) return fail(DSG_E_INVALID, "gemm: k-blocks not divisible by the wave split");
     if (g.KS < 1 || g.kb_per_split * g.KS < g.KBtot) return fail(DSG_E_INVALID, "gemm: split-K does not cover K");
-    hipLaunchKernelGGL((k_gemm<P, PRO, EPI, WN, WK, TNW>), dim3(xcd_grid(NG, g.MT * g.KS)), dim3(256), 0, h->stream, g);
+    // EPI_PARTIAL / EPI_OUT carry one extra workgroup for the step bookkeeping
+    const int extra = (EPI == EPI_PARTIAL || EPI == EPI_OUT) ? 1 : 0;
+    hipLaunchKernelGGL((k_gemm<P, PRO, EPI, WN, WK, TNW>), dim3(xcd_grid(NG, g.MT * g.KS) + extra), dim3(256), 0, h->stream, g);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -611,6 +615,12 @@ static bool use_latency_mode(const dsg_handle* h, int B) {
     return B <= 4;          // redundant recompute pays only while every launch is a latency chain
 }
 
+static StepTables step_tables(const dsg_handle* h) {
+    StepTables st;
+    st.tmodel = h->st_tmodel; st.c1 = h->st_c[0]; st.c2 = h->st_c[1]; st.c3 = h->st_c[2]; st.c4 = h->st_c[3]; st.c5 = h->st_c[4];
+    return st;
+}
+
 template <class P>
 static int run_step(dsg_handle* h, const StepCtx& c) {
     const int B = c.B, D = h->D, T = h->T, ntok = h->ntok;
@@ -626,14 +636,14 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
     LocArgs la;
     memset(&la, 0, sizeof(la));
     la.partial = h->partial; la.KS = h->KSin; la.Min_pad = MTin * 16; la.Cf = h->Cf; la.TE2 = h->TE2; la.TE = h->TE;
-    la.emb1 = h->emb1; la.ctr = c.use_ctr ? h->ctr : nullptr; la.tmodel = h->st_tmodel; la.t_arr = h->t_arr;
+    la.emb1 = h->emb1; la.ctl = c.use_ctr ? h->ctl : nullptr; la.t_arr = h->t_arr;
     la.rcos = h->rcos; la.rsin = h->rsin; la.mask = h->mask; la.mb = h->mb; la.B = B; la.T = T; la.D = D; la.Hl = h->Hl;
     la.hd = h->hdl; la.W = h->W; la.X0 = h->X0; la.X0a = h->X0a;
     if (lat) {          // pose embedding + local attention in one launch
         InLocArgs a;
         a.xs = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; a.Jp = h->Jp; a.Wp = h->Wp_in; a.KBtot = h->Jp / KB;
-        a.loc = la; a.ctr_inc = c.use_ctr ? h->ctr + 1 : nullptr;
-        DSG_LOC_DISPATCH(k_inloc, a, dim3(B * (T / h->W) * h->Hl));
+        a.loc = la; a.ctl_upd = c.use_ctr ? h->ctl : nullptr; a.st = step_tables(h); a.n_tab = h->n_run;
+        DSG_LOC_DISPATCH(k_inloc, a, dim3(B * (T / h->W) * h->Hl + 1));
     } else {
         {   // k_in: partial[s] = xs[:, chunk s] . Wfold[:, chunk s]^T
             GemmArgs g = z;
@@ -641,7 +651,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
             g.kb_per_split = cdiv(g.KBtot, g.KS);
             g.A = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; g.lda = h->Jp;
             g.out = h->partial; g.ldo = D;
-            g.ctr_inc = c.use_ctr ? h->ctr + 1 : nullptr;
+            g.ctl = c.use_ctr ? h->ctl : nullptr; g.st = step_tables(h); g.n_tab = h->n_run;
             CHK((launch_gemm<P, PRO_DIRECT, EPI_PARTIAL, 4, 1, 1>(h, g)));
         }
         DSG_LOC_DISPATCH(k_loc, la, dim3(B * (T / h->W) * h->Hl));
@@ -709,9 +719,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
         g.M = M; g.MT = MT; g.NT = h->Jp / 16; g.KBtot = D / KB; g.Wp = h->Wp_out; g.bias = h->b_out;
         g.X = h->pre2; g.ln_g = h->layers[h->L - 1].g2; g.ln_b = h->layers[h->L - 1].be2; g.Xn = nullptr;
         g.out_mode = c.out_mode; g.xs32 = h->xs32; g.xsA = h->prec == DSG_PREC_BF16 ? h->xsA : nullptr;
-        g.fwd_out = h->fwd_out; g.ctr = h->ctr + 1; g.ctr_inc = c.use_ctr ? h->ctr : nullptr;
-        g.st.tmodel = h->st_tmodel; g.st.c1 = h->st_c[0]; g.st.c2 = h->st_c[1]; g.st.c3 = h->st_c[2];
-        g.st.c4 = h->st_c[3]; g.st.c5 = h->st_c[4];
+        g.fwd_out = h->fwd_out; g.ctl = c.use_ctr ? h->ctl : nullptr; g.st = step_tables(h); g.n_tab = h->n_run;
         g.dyn = h->dyn; g.ext_noise = c.ext_noise; g.const_noise = c.const_noise;
         CHK((launch_gemm<P, PRO_LN, EPI_OUT, 4, 1, 1>(h, g)));
     }
@@ -733,11 +741,11 @@ static int debug_launch(dsg_handle* h, int which, int i, int B) {
     LocArgs la;
     memset(&la, 0, sizeof(la));
     la.partial = h->partial; la.KS = h->KSin; la.Min_pad = MTin * 16; la.Cf = h->Cf; la.TE2 = h->TE2; la.TE = h->TE;
-    la.emb1 = h->emb1; la.ctr = nullptr; la.tmodel = h->st_tmodel; la.t_arr = h->t_arr;
+    la.emb1 = h->emb1; la.ctl = nullptr; la.t_arr = h->t_arr;
     la.rcos = h->rcos; la.rsin = h->rsin; la.mask = h->mask; la.mb = h->mb; la.B = B; la.T = T; la.D = D; la.Hl = h->Hl;
     la.hd = h->hdl; la.W = h->W; la.X0 = h->X0; la.X0a = h->X0a;
     switch (which) {
-        case 0: hipLaunchKernelGGL(k_ctr_inc, dim3(96), dim3(256), 0, h->stream, h->ctr + 2); return 0;
+        case 0: hipLaunchKernelGGL(k_ctr_inc, dim3(96), dim3(256), 0, h->stream, h->ctr); return 0;
         case 1: case 2: {
             GemmArgs g = z; g.M = M; g.MT = MT; g.NT = D / 16; g.KBtot = D / KB; g.Wp = ly.Wo; g.bias = ly.bo;
             g.A = h->attn; g.lda = D; g.out = (i & 1) ? h->pre1 : h->pre2; g.ldo = D; g.R = h->X0;
@@ -761,7 +769,7 @@ static int debug_launch(dsg_handle* h, int which, int i, int B) {
         case 8: {
             GemmArgs g = z; g.M = M; g.MT = MT; g.NT = h->Jp / 16; g.KBtot = D / KB; g.Wp = h->Wp_out; g.bias = h->b_out;
             g.X = h->pre2; g.ln_g = ly.g2; g.ln_b = ly.be2; g.out_mode = OUT_FORWARD; g.xs32 = h->xs32; g.fwd_out = h->fwd_out;
-            g.ctr = h->ctr + 1; g.st.c1 = h->st_c[0]; g.st.c2 = h->st_c[1]; g.st.c3 = h->st_c[2]; g.dyn = h->dyn;
+            g.ctl = nullptr; g.st = step_tables(h); g.n_tab = 1; g.dyn = h->dyn;
             return launch_gemm<P, PRO_LN, EPI_OUT, 4, 1, 1>(h, g); }
         case 9: {
             GemmArgs g = z; g.M = M; g.MT = MT; g.NT = 3 * D / 16; g.KBtot = D / KB; g.Wp = ly.Wqkv; g.bias = ly.bqkv;
@@ -778,8 +786,8 @@ static int debug_launch(dsg_handle* h, int which, int i, int B) {
             a.B = B; a.H = h->H; a.ntok = ntok; return launch_qkv_attn<P>(h, a); }
         case 12: {
             InLocArgs a; a.xs = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; a.Jp = h->Jp; a.Wp = h->Wp_in;
-            a.KBtot = h->Jp / KB; a.loc = la; a.ctr_inc = nullptr;
-            DSG_LOC_DISPATCH(k_inloc, a, dim3(B * (T / h->W) * h->Hl)); return 0; }
+            a.KBtot = h->Jp / KB; a.loc = la; a.ctl_upd = nullptr; a.st = step_tables(h); a.n_tab = 1;
+            DSG_LOC_DISPATCH(k_inloc, a, dim3(B * (T / h->W) * h->Hl + 1)); return 0; }
         default: return fail(DSG_E_INVALID, "debug_chain: unknown kernel id");
     }
 }
@@ -949,6 +957,7 @@ static int build_step_tables(dsg_handle* h, int mode, int skip, float eta, int* 
         HIPCHK(hipMemcpyAsync(h->st_c[k], c[k].data(), n_run * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     *n_run_out = n_run;
+    h->n_run = n_run;
     return 0;
 }
 
@@ -987,8 +996,7 @@ extern "C" int dsg_sample(dsg_handle* h, const dsg_sample_args* a, float* out, i
             ext = h->ext_noise;
         }
     }
-    hipLaunchKernelGGL(k_ctr_set, dim3(1), dim3(64), 0, h->stream, h->ctr, 0);
-    hipLaunchKernelGGL(k_ctr_set, dim3(1), dim3(64), 0, h->stream, h->ctr + 1, -1);
+    hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(64), 0, h->stream, h->ctl, h->st_tmodel);
     HIPCHK(hipGetLastError());
     {
         const unsigned dyn[5] = {nk.k0, nk.k1, nk.s0, nk.s1, a->draw_base + 1u};

@@ -80,6 +80,22 @@ struct PBF16 {                      // bf16 storage, v_mfma_f32_16x16x32_bf16, f
 };
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// Load phases are written branch-free (clamped addresses, select afterwards): a load under a runtime predicate makes
+// hipcc place `s_waitcnt vmcnt(0)` at every join, which turns N independent loads into N serial memory round trips
+// (seen in the ISA as L w L w L w ...; the LayerNorm GEMMs had 17-19 of them).  LOADS_ISSUED() additionally stops the
+// scheduler from sinking loads below the first use.
+#define DSG_LOADS_ISSUED() __builtin_amdgcn_sched_barrier(0)
+// hipcc fetches kernel arguments lazily, one s_load batch (+ s_waitcnt lgkmcnt(0)) per region that first needs them;
+// the kernarg segment is freshly written for every launch, so each batch is a scalar-cache MISS -- several serial
+// misses per kernel.  Touching one dword per 64-byte line of the argument struct at the top of the kernel makes all
+// those misses overlap; the later s_loads then hit the scalar cache.
+template <class T>
+__device__ __forceinline__ void preload_kernargs(const T& a) {
+    const unsigned* p = (const unsigned*)&a;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; i += 16) { const unsigned v = p[i]; asm volatile("" ::"r"(v)); }
+    { const unsigned v = p[sizeof(T) / 4 - 1]; asm volatile("" ::"r"(v)); }
+}
 // The wave index must be PROVABLY wave-uniform (an SGPR): loop bounds and predicates derived from threadIdx.x >> 6 are
 // otherwise treated as divergent, the compiler predicates the loop body through EXEC, and v_mfma IGNORES EXEC -- a
 // "skipped" MFMA of a partial k-chunk then runs on uninitialised fragments (seen on gfx950: NaNs in the last split-K
@@ -124,6 +140,16 @@ __device__ __forceinline__ f32x4 philox_normal4(unsigned q, unsigned draw, Noise
 // ---------------------------------------------------------------------------------------------------------
 // per-step control block (device memory): lets ONE captured hipGraph serve every step
 // ---------------------------------------------------------------------------------------------------------
+// Device-resident step control.  The FIRST kernel of a step reads {tA}; at its END its block 0 advances the B side
+// (stepB, coefficients of that step).  The LAST kernel reads the B side; at its END its block 0 advances the A side
+// (stepA, tA = model timestep of the next step).  No kernel reads what it writes, a kernel boundary separates every
+// write from the next read, and readers need ONE load level (no ctr -> table -> table chains on the critical path).
+struct StepCtl {
+    int stepA, tA;             // read by k_loc / k_inloc
+    int stepB;                 // read by the sampler epilogue (noise draw index, replayed-noise slot)
+    float k1, k2, k3, k4, k5;  // coefficients of step stepB (see StepTables)
+};
+
 struct StepTables {            // execution-ordered, one entry per step that will run
     const int*   tmodel;       // model timestep fed to the denoiser (timestep_map[idx])
     const float* c1;           // DDPM: posterior_mean_coef1        | DDIM: sqrt_recip_alphas_cumprod
@@ -132,6 +158,21 @@ struct StepTables {            // execution-ordered, one entry per step that wil
     const float* c4;           //                                    | DDIM: sqrt(1 - abar_prev - sigma^2)
     const float* c5;           //                                    | DDIM: nonzero * sigma
 };
+
+__device__ __forceinline__ void step_advance_B(StepCtl* c, const StepTables& st, int n) {
+    const int s = c->stepB + 1, i = s < n ? s : n - 1;
+    const float a1 = st.c1[i], a2 = st.c2[i], a3 = st.c3[i], a4 = st.c4[i], a5 = st.c5[i];   // loads first, then stores
+    c->stepB = s;
+    c->k1 = a1; c->k2 = a2; c->k3 = a3; c->k4 = a4; c->k5 = a5;
+}
+__device__ __forceinline__ void step_advance_A(StepCtl* c, const StepTables& st, int n) {
+    const int s = c->stepA + 1;
+    c->stepA = s;
+    c->tA = st.tmodel[s < n ? s : n - 1];
+}
+__global__ void k_ctl_init(StepCtl* c, const int* tmodel) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { c->stepA = 0; c->tA = tmodel[0]; c->stepB = -1; c->k1 = c->k2 = c->k3 = c->k4 = c->k5 = 0.f; }
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // GEMM  (skinny-M, weight-stationary-per-XCD):  Out[m][n] = sum_k Act[m][k] * W[n][k]  (+ epilogue)
@@ -171,14 +212,15 @@ struct GemmArgs {
     float* xs32;            // [B][T][Jp] fp32 master state (in/out)
     void* xsA;              // [B][T][Jp] P::elem shadow for k_in (bf16 mode) or null
     float* fwd_out;         // OUT_FORWARD: [B][J][T]
-    const int* ctr;         // device step counter B (EPI_OUT)
-    StepTables st;
+    StepCtl* ctl;           // step control block (EPI_OUT reads the B side and advances the A side; EPI_PARTIAL
+                            // advances the B side); null outside the sampling loop
+    StepTables st;          // tables the block-0 bookkeeping reads (n_tab entries)
+    int n_tab;
     const unsigned* dyn;    // device: {seed lo, seed hi, stream lo, stream hi, draw index of step 0} -- kept out of
                             // the kernel arguments so a captured graph is reusable across windows / clips
     const float* ext_noise; // optional [n_steps][B][J][T] replayed noise, else null
     int B;
     int const_noise;
-    int* ctr_inc;           // EPI_PARTIAL: advances step counter B; EPI_OUT: advances step counter A (block 0)
 };
 
 // block -> (n_group, r) with n_group pinned to an XCD (block b is observed to run on XCD b % 8), so a weight
@@ -208,18 +250,24 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
     __shared__ __attribute__((aligned(16))) char lds_a[PRO == PRO_LN ? 16 * (512 * 4 + 16) : 16];
     __shared__ __attribute__((aligned(16))) float lds_red[WK > 1 ? (WK - 1) * WN * TNW * 64 * 4 : 4];
 
+    preload_kernargs(g);
     const int NG = g.NT / (WN * TNW);
+    if constexpr (EPI == EPI_PARTIAL || EPI == EPI_OUT) {
+        // step bookkeeping runs in ONE EXTRA workgroup (the last block id), concurrently with the real work and off
+        // every critical path; see StepCtl for why this is race free
+        if (blockIdx.x == gridDim.x - 1) {
+            if (g.ctl && threadIdx.x == 0) {
+                if constexpr (EPI == EPI_PARTIAL) step_advance_B(g.ctl, g.st, g.n_tab);
+                else if (g.out_mode != OUT_FORWARD) step_advance_A(g.ctl, g.st, g.n_tab);
+            }
+            return;
+        }
+    }
     int ng, r;
     if (!xcd_map(NG, g.MT * g.KS, ng, r)) return;
     const int mt = r % g.MT, ks = r / g.MT;
     const int m0 = mt * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
-    if constexpr (EPI == EPI_PARTIAL || EPI == EPI_OUT) {
-        // Two step counters: A is read by the first kernel(s) of a step (k_loc / k_inloc) and advanced by the LAST
-        // kernel (EPI_OUT); B is read by the last kernel and advanced by the FIRST (EPI_PARTIAL / k_inloc).  No kernel
-        // reads the counter it advances, and a kernel boundary separates every advance from the next read.
-        if (g.ctr_inc && ng == 0 && r == 0 && tid == 0) *g.ctr_inc += 1;
-    }
     const int wn = wave % WN, wk = wave / WN;
     const int lr = lane & 15, lg = lane >> 4;
     const int nt0 = (ng * WN + wn) * TNW;
@@ -248,13 +296,14 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
     // does not depend on the prologue (weights, bias, residual, x_t, noise) is in flight before the LayerNorm starts.
     constexpr int CH = 8;
     f32x4 bf[CH][TNW];
+    const int kb_last = g.KBtot - 1;
     auto load_b = [&](int kb0) {
 #pragma unroll
-        for (int c = 0; c < CH; ++c)
-            if (kb0 + c < kb_hi) {
+        for (int c = 0; c < CH; ++c) {
+            const int kb = min(kb0 + c, kb_last);           // clamped, never predicated
 #pragma unroll
-                for (int t = 0; t < TNW; ++t) bf[c][t] = wbase[((size_t)(nt0 + t) * g.KBtot + kb0 + c) * 64];
-            }
+            for (int t = 0; t < TNW; ++t) bf[c][t] = wbase[((size_t)(nt0 + t) * g.KBtot + kb) * 64];
+        }
     };
     load_b(kb_lo);
     // ---- epilogue operands (bias, residual, x_t, step coefficients, noise) do not depend on the main loop: fetch
@@ -266,9 +315,8 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
     bool ovalid[TNW];
     if constexpr (EPI == EPI_OUT) {
         if (g.out_mode != OUT_FORWARD) {
-            step = *g.ctr;
-            k1 = g.st.c1[step]; k2 = g.st.c2[step]; k3 = g.st.c3[step];
-            if (g.out_mode == OUT_DDIM) { k4 = g.st.c4[step]; k5 = g.st.c5[step]; }
+            step = g.ctl->stepB;
+            k1 = g.ctl->k1; k2 = g.ctl->k2; k3 = g.ctl->k3; k4 = g.ctl->k4; k5 = g.ctl->k5;
         }
     }
 #pragma unroll
@@ -282,16 +330,19 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
         } else if constexpr (EPI == EPI_GELU) {
             pb[t] = *(const f32x4*)(g.bias + n0 + 4 * lg);
         } else if constexpr (EPI == EPI_QKV) {
-            if (swapped[t]) pb[t] = *(const f32x4*)(g.bias + n0 + 4 * lg);
-            else pbs[t] = g.bias[n0 + lr];
+            pb[t] = *(const f32x4*)(g.bias + n0 + 4 * lg);      // both forms loaded unconditionally (no branchy loads)
+            pbs[t] = g.bias[n0 + lr];
         } else if constexpr (EPI == EPI_OUT) {
             const int m = m0 + lr, j0 = n0 + 4 * lg;
             const int b = m / g.ntok, sx = m % g.ntok;
             ovalid[t] = m < g.M && sx > 0 && j0 < g.J;
             pb[t] = *(const f32x4*)(g.bias + j0);
+            {   // x_t: unconditional load from a clamped (always valid) row; unused when the lane is not `ovalid`
+                const int bc = b < g.B ? b : g.B - 1, fc = sx > 0 ? sx - 1 : 0;
+                pr[t] = *(const f32x4*)(g.xs32 + ((size_t)bc * g.T + fc) * g.Jp + j0);
+            }
             if (ovalid[t] && g.out_mode != OUT_FORWARD) {
                 const int f = sx - 1;
-                pr[t] = *(const f32x4*)(g.xs32 + ((size_t)b * g.T + f) * g.Jp + j0);
                 const int bn = g.const_noise ? 0 : b;
                 if (g.ext_noise) {
 #pragma unroll
@@ -314,21 +365,31 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
         pitch = DSG_LDS_ROW_BYTES(D, ES);
         const int row = tid >> 4, c = tid & 15;
         const float* xr = g.X + (size_t)(m0 + row) * D;
-        f32x4 v[8];
-        const int nch = D >> 6;                       // D / 64 float4 chunks per thread
+        const int nch = D >> 6;                       // D / 64 float4 chunks per thread (<= 8)
+        f32x4 v[8], gg[8], bb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {                 // unconditional loads: chunks beyond D re-read chunk 0
+            const int col = c * 4 + 64 * (i < nch ? i : 0);
+            v[i] = *(const f32x4*)(xr + col);
+            gg[i] = *(const f32x4*)(g.ln_g + col);
+            bb[i] = *(const f32x4*)(g.ln_b + col);
+        }
+        DSG_LOADS_ISSUED();
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (i < nch) { v[i] = *(const f32x4*)(xr + c * 4 + 64 * i); s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+        for (int i = 0; i < 8; ++i) {
+            const float wgt = i < nch ? 1.f : 0.f;
+            s += wgt * ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3]));
+        }
         s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
         const float mean = s / (float)D;
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (i < nch) {
+        for (int i = 0; i < 8; ++i) {
+            const float wgt = i < nch ? 1.f : 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { float d = v[i][e] - mean; q += d * d; }
-            }
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += wgt * d * d; }
+        }
         q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4); q += __shfl_xor(q, 8);
         const float rstd = 1.0f / sqrtf(q / (float)D + 1e-5f);
         const bool wr = (g.Xn != nullptr) && ng == 0 && (m0 + row) < g.M;
@@ -336,10 +397,9 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
         for (int i = 0; i < 8; ++i)
             if (i < nch) {
                 const int col = c * 4 + 64 * i;
-                const f32x4 gg = *(const f32x4*)(g.ln_g + col), bb = *(const f32x4*)(g.ln_b + col);
                 f32x4 y;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
+                for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * gg[i][e] + bb[i][e];
                 P::store4((elem*)(lds_a + row * pitch) + col, y);
                 if (wr) *(f32x4*)(g.Xn + (size_t)(m0 + row) * D + col) = y;
             }
@@ -350,19 +410,18 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
         f32x4 af[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            const int kb = kb0 + c;
-            if (kb < kb_hi) {
-                if constexpr (PRO == PRO_DIRECT) af[c] = *(const f32x4*)(arow + (size_t)kb * P::KB);
-                else af[c] = *(const f32x4*)(lds_a + lr * pitch + (kb * P::KB + P::E * lg) * ES);
-            }
+            const int kb = min(kb0 + c, kb_last);
+            if constexpr (PRO == PRO_DIRECT) af[c] = *(const f32x4*)(arow + (size_t)kb * P::KB);
+            else af[c] = *(const f32x4*)(lds_a + lr * pitch + (kb * P::KB + P::E * lg) * ES);
         }
+        DSG_LOADS_ISSUED();
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            if (kb0 + c < kb_hi) {
+            const bool live = kb0 + c < kb_hi;              // wave-uniform; out-of-range blocks contribute zeros
+            const f32x4 a = live ? af[c] : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int t = 0; t < TNW; ++t)
-                    acc[t] = swapped[t] ? P::mma(bf[c][t], af[c], acc[t]) : P::mma(af[c], bf[c][t], acc[t]);
-            }
+            for (int t = 0; t < TNW; ++t)
+                acc[t] = swapped[t] ? P::mma(bf[c][t], a, acc[t]) : P::mma(a, bf[c][t], acc[t]);
         }
         if (kb0 + CH < kb_hi) load_b(kb0 + CH);
     }
@@ -471,9 +530,8 @@ struct LocArgs {
     const float* TE2;       // [n_te][D]   W2a . time_embed(t)
     const float* TE;        // [n_te][D]   time_embed(t)
     const float* emb1;      // [B][D]      style (+ seed) token embedding
-    const int* ctr;         // step counter A (sampling) or null
-    const int* tmodel;      // tmodel[step]   (sampling)
-    const int* t_arr;       // per-batch model timestep (forward) used when ctr == null
+    const StepCtl* ctl;     // sampling: model timestep = ctl->tA ; null -> t_arr
+    const int* t_arr;       // per-batch model timestep (forward)
     const float* rcos;      // [T+1][hd/2]
     const float* rsin;
     const unsigned char* mask;   // [mb][T] key mask (1 = keep)
@@ -545,52 +603,60 @@ __global__ __launch_bounds__(256) void k_loc(const LocArgs a) {
     constexpr int NSI = (W * 32 + 255) / 256, NP2 = W * half, NPO = (NP2 + 255) / 256, MAXKS = 9;
     __shared__ float rot[W2][HD + 1];
     __shared__ float sc[W][W2 + 2];
+    preload_kernargs(a);
     const int nW = a.T / W;
     int id = blockIdx.x;
     const int h = id % a.Hl; id /= a.Hl;
     const int w = id % nW; const int b = id / nW;
     const int tid = threadIdx.x;
-    const int t = a.ctr ? a.tmodel[*a.ctr] : a.t_arr[b];
+    const int* tp = a.ctl ? &a.ctl->tA : a.t_arr + b;      // select the ADDRESS, then one unconditional load
+    const int t = *tp;
     const int col0 = h * HD, ntok = a.T + 1, f0 = (w - 1) * W;
 
-    // ---- every global load of the block is issued up front
+    // ---- every global load of the block is issued up front, unconditionally (clamped indices, selects afterwards)
     float lo[NPI], hi[NPI], c1[NPI], s1[NPI];
 #pragma unroll
     for (int i = 0; i < NPI; ++i) {
-        const int p = tid + 256 * i;
-        lo[i] = hi[i] = 0.f; c1[i] = 1.f; s1[i] = 0.f;
-        if (p < NP1) {
-            const int r = p / half, dd = p % half, f = f0 + r;
-            if (f >= 0) {
-                const size_t base = ((size_t)b * a.T + f) * a.D + col0 + dd;
-                lo[i] = a.Cf[base] + a.TE2[(size_t)t * a.D + col0 + dd];
-                hi[i] = a.Cf[base + half] + a.TE2[(size_t)t * a.D + col0 + dd + half];
-                c1[i] = a.rcos[f * half + dd]; s1[i] = a.rsin[f * half + dd];
+        const int p = min(tid + 256 * i, NP1 - 1);
+        const int r = p / half, dd = p % half, f = max(f0 + r, 0);
+        const size_t base = ((size_t)b * a.T + f) * a.D + col0 + dd;
+        lo[i] = a.Cf[base];
+        hi[i] = a.Cf[base + half];
+        c1[i] = a.rcos[f * half + dd]; s1[i] = a.rsin[f * half + dd];
 #pragma unroll
-                for (int s = 0; s < MAXKS; ++s)
-                    if (s < a.KS) {
-                        const size_t pb = ((size_t)s * a.Min_pad + (size_t)b * a.T + f) * a.D + col0 + dd;
-                        lo[i] += a.partial[pb]; hi[i] += a.partial[pb + half];
-                    }
-            }
+        for (int s = 0; s < MAXKS; ++s) {
+            const float wgt = s < a.KS ? 1.f : 0.f;
+            const size_t pb = ((size_t)min(s, a.KS - 1) * a.Min_pad + (size_t)b * a.T + f) * a.D + col0 + dd;
+            lo[i] += wgt * a.partial[pb]; hi[i] += wgt * a.partial[pb + half];
         }
     }
     float c2[NPO], s2[NPO];
 #pragma unroll
     for (int i = 0; i < NPO; ++i) {
-        const int p = tid + 256 * i;
-        c2[i] = 1.f; s2[i] = 0.f;
-        if (p < NP2) { const int pos = w * W + p / half + 1; c2[i] = a.rcos[pos * half + p % half]; s2[i] = a.rsin[pos * half + p % half]; }
+        const int p = min(tid + 256 * i, NP2 - 1);
+        const int pos = w * W + p / half + 1;
+        c2[i] = a.rcos[pos * half + p % half]; s2[i] = a.rsin[pos * half + p % half];
     }
     const int mrow = (int)(((long long)(b * a.Hl + h)) / ((long long)a.B * a.Hl / a.mb));
     bool keep[NSI];
 #pragma unroll
     for (int i = 0; i < NSI; ++i) {
         const int idx = tid + 256 * i, q = idx >> 5, j = idx & 31, fk = f0 + j;
-        keep[i] = (q < W) && (j < W2) && (fk >= 0) && (a.mask[(size_t)mrow * a.T + fk] != 0);
+        const unsigned char mk = a.mask[(size_t)mrow * a.T + min(max(fk, 0), a.T - 1)];
+        keep[i] = ((int)(q < W) & (int)(j < W2) & (int)(fk >= 0) & (int)(mk != 0)) != 0;   // bitwise: keeps the load unconditional
     }
+    const int tc = min(tid, HD - 1);
+    float tokv = a.emb1[(size_t)b * a.D + col0 + tc];
+    // the loads that depend on the model timestep go out last (t itself was requested first)
+#pragma unroll
+    for (int i = 0; i < NPI; ++i) {
+        const int p = min(tid + 256 * i, NP1 - 1), dd = p % half;
+        lo[i] += a.TE2[(size_t)t * a.D + col0 + dd];
+        hi[i] += a.TE2[(size_t)t * a.D + col0 + dd + half];
+    }
+    tokv += a.TE[(size_t)t * a.D + col0 + tc];
+    DSG_LOADS_ISSUED();
     if (w == 0 && tid < HD) {                              // token row (position 0: rotary is the identity)
-        const float tokv = a.emb1[(size_t)b * a.D + col0 + tid] + a.TE[(size_t)t * a.D + col0 + tid];
         a.X0[(size_t)(b * ntok) * a.D + col0 + tid] = tokv;
         ((elem*)a.X0a)[(size_t)(b * ntok) * a.D + col0 + tid] = P::cvt(tokv);
     }
@@ -624,6 +690,7 @@ template <class P, int HD, int NKT>
 __global__ __launch_bounds__(64) void k_attn(const AttnArgs a) {
     typedef typename P::elem elem;
     constexpr int KD = HD / P::KB;                   // k-blocks over the head dim
+    preload_kernargs(a);
     const int lane = threadIdx.x, lr = lane & 15, lg = lane >> 4;
     int id = blockIdx.x;
     const int nqt = (a.ntok + 15) >> 4;
@@ -634,20 +701,14 @@ __global__ __launch_bounds__(64) void k_attn(const AttnArgs a) {
     const elem* K = (const elem*)a.k + bh * a.Tp * HD;
     const elem* VT = (const elem*)a.vt + bh * HD * a.Tp;
 
-    f32x4 qf[KD];
+    // ---- all operand fragments (Q, K, V^T) are requested before the first MFMA
+    f32x4 qf[KD], kf[NKT][KD];
 #pragma unroll
     for (int kb = 0; kb < KD; ++kb) qf[kb] = *(const f32x4*)(Q + (size_t)(qt * 16 + lr) * HD + kb * P::KB + P::E * lg);
-    f32x4 s[NKT];
 #pragma unroll
-    for (int nt = 0; nt < NKT; ++nt) {
-        s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NKT; ++nt)
 #pragma unroll
-        for (int kb = 0; kb < KD; ++kb) {
-            const f32x4 kf = *(const f32x4*)(K + (size_t)(nt * 16 + lr) * HD + kb * P::KB + P::E * lg);
-            s[nt] = P::mma(kf, qf[kb], s[nt]);       // D[key = 4*lg + r][query = lr]
-        }
-    }
-    // V^T fragments are fetched before the softmax arithmetic so their latency hides under it
+        for (int kb = 0; kb < KD; ++kb) kf[nt][kb] = *(const f32x4*)(K + (size_t)(nt * 16 + lr) * HD + kb * P::KB + P::E * lg);
     constexpr int ND = HD / 16;                      // 16-dim output tiles
     constexpr int NVF = P::E == 4 ? NKT : NKT / 2;   // PV k-blocks
     f32x4 vfr[ND][NVF];
@@ -664,6 +725,14 @@ __global__ __launch_bounds__(64) void k_attn(const AttnArgs a) {
                 vfr[dt][kb] = (f32x4){v0[0], v0[1], v1[0], v1[1]};
             }
         }
+    }
+    DSG_LOADS_ISSUED();
+    f32x4 s[NKT];
+#pragma unroll
+    for (int nt = 0; nt < NKT; ++nt) {
+        s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KD; ++kb) s[nt] = P::mma(kf[nt][kb], qf[kb], s[nt]);       // D[key = 4*lg + r][query = lr]
     }
     const float scale = 1.0f / sqrtf((float)HD);
     float mx = -DSG_FLT_MAX;

@@ -47,6 +47,7 @@ void dfree(void* p);
 
 static inline void __syncthreads() { emu::syncthreads(); }
 #define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
 static inline float __shfl_xor(float v, int m) {
     return __builtin_bit_cast(float, emu::shfl_xor_u32(__builtin_bit_cast(unsigned, v), m));
 }
