@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
     constexpr int D = DT * 64;
     constexpr int KD = D / P::KB;
     constexpr int XP = D * ES + 16;
-    constexpr int CH = 8;
+    constexpr int CH = DT >= 6 ? 4 : 8;              // fragments in flight per chunk (DT tiles each): bounded by the register file
     __shared__ __attribute__((aligned(16))) char a1[16 * XP];
     __shared__ float red[2][4][16];
     preload_kernargs(g);

@@ -701,38 +701,58 @@ __global__ __launch_bounds__(64) void k_attn(const AttnArgs a) {
     const elem* K = (const elem*)a.k + bh * a.Tp * HD;
     const elem* VT = (const elem*)a.vt + bh * HD * a.Tp;
 
-    // ---- all operand fragments (Q, K, V^T) are requested before the first MFMA
-    f32x4 qf[KD], kf[NKT][KD];
-#pragma unroll
-    for (int kb = 0; kb < KD; ++kb) qf[kb] = *(const f32x4*)(Q + (size_t)(qt * 16 + lr) * HD + kb * P::KB + P::E * lg);
-#pragma unroll
-    for (int nt = 0; nt < NKT; ++nt)
-#pragma unroll
-        for (int kb = 0; kb < KD; ++kb) kf[nt][kb] = *(const f32x4*)(K + (size_t)(nt * 16 + lr) * HD + kb * P::KB + P::E * lg);
+    // ---- operand fragments.  When everything fits in registers (PRELOAD) all of Q, K, V^T is requested before the
+    //      first MFMA (one memory round trip); the large DSG+ shapes would spill, so they stream K per key tile and
+    //      fetch V^T while the softmax runs.
     constexpr int ND = HD / 16;                      // 16-dim output tiles
     constexpr int NVF = P::E == 4 ? NKT : NKT / 2;   // PV k-blocks
-    f32x4 vfr[ND][NVF];
+    constexpr bool PRELOAD = (KD + NKT * KD + ND * NVF) * 4 <= 360;
+    f32x4 qf[KD];
 #pragma unroll
-    for (int dt = 0; dt < ND; ++dt) {
-        const elem* vrow = VT + (size_t)(dt * 16 + lr) * a.Tp;
+    for (int kb = 0; kb < KD; ++kb) qf[kb] = *(const f32x4*)(Q + (size_t)(qt * 16 + lr) * HD + kb * P::KB + P::E * lg);
+    auto load_v = [&](f32x4 (&vfr)[ND][NVF]) {
 #pragma unroll
-        for (int kb = 0; kb < NVF; ++kb) {
-            if constexpr (P::E == 4) {
-                vfr[dt][kb] = *(const f32x4*)(vrow + kb * 16 + 4 * lg);
-            } else {
-                const f32x2 v0 = *(const f32x2*)(vrow + (2 * kb) * 16 + 4 * lg);        // 4 bf16 = 8 bytes
-                const f32x2 v1 = *(const f32x2*)(vrow + (2 * kb + 1) * 16 + 4 * lg);
-                vfr[dt][kb] = (f32x4){v0[0], v0[1], v1[0], v1[1]};
+        for (int dt = 0; dt < ND; ++dt) {
+            const elem* vrow = VT + (size_t)(dt * 16 + lr) * a.Tp;
+#pragma unroll
+            for (int kb = 0; kb < NVF; ++kb) {
+                if constexpr (P::E == 4) {
+                    vfr[dt][kb] = *(const f32x4*)(vrow + kb * 16 + 4 * lg);
+                } else {
+                    const f32x2 v0 = *(const f32x2*)(vrow + (2 * kb) * 16 + 4 * lg);        // 4 bf16 = 8 bytes
+                    const f32x2 v1 = *(const f32x2*)(vrow + (2 * kb + 1) * 16 + 4 * lg);
+                    vfr[dt][kb] = (f32x4){v0[0], v0[1], v1[0], v1[1]};
+                }
             }
         }
-    }
-    DSG_LOADS_ISSUED();
+    };
+    f32x4 vfr[ND][NVF];
     f32x4 s[NKT];
+    if constexpr (PRELOAD) {
+        f32x4 kf[NKT][KD];
 #pragma unroll
-    for (int nt = 0; nt < NKT; ++nt) {
-        s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NKT; ++nt)
 #pragma unroll
-        for (int kb = 0; kb < KD; ++kb) s[nt] = P::mma(kf[nt][kb], qf[kb], s[nt]);       // D[key = 4*lg + r][query = lr]
+            for (int kb = 0; kb < KD; ++kb) kf[nt][kb] = *(const f32x4*)(K + (size_t)(nt * 16 + lr) * HD + kb * P::KB + P::E * lg);
+        load_v(vfr);
+        DSG_LOADS_ISSUED();
+#pragma unroll
+        for (int nt = 0; nt < NKT; ++nt) {
+            s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < KD; ++kb) s[nt] = P::mma(kf[nt][kb], qf[kb], s[nt]);   // D[key = 4*lg + r][query = lr]
+        }
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < NKT; ++nt) {
+            s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < KD; ++kb) {
+                const f32x4 kf = *(const f32x4*)(K + (size_t)(nt * 16 + lr) * HD + kb * P::KB + P::E * lg);
+                s[nt] = P::mma(kf, qf[kb], s[nt]);
+            }
+        }
+        load_v(vfr);
     }
     const float scale = 1.0f / sqrtf((float)HD);
     float mx = -DSG_FLT_MAX;

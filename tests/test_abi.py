@@ -72,3 +72,23 @@ def test_window_audio_split():
     assert n == 320 and len(wins) == 4 and all(len(w) == 88 * 800 for w in wins)
     assert (wins[0][: 8 * 800] == 0).all() and wins[0][8 * 800] == 0.0 and wins[0][-1] == 80 * 800 - 1
     assert wins[1][0] == 72 * 800 and wins[1][8 * 800] == 80 * 800
+
+
+def test_no_kernel_spills_to_scratch():
+    """Every gfx950 kernel must fit the register file: a spilling instantiation is slow, and on hardware the two
+    spilling shapes seen during bring-up (fp32 attention <128,10>, k_mid<8>) also produced wrong results."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "diffusestylegesture_amd", "csrc", "dsg_hip.cpp")
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-pass-failed", "--cuda-device-only",
+                          "-c", src, "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    names = re.findall(r"Function Name: (\S+)", out.stderr)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
+    assert len(names) == len(scratch) and len(names) > 40
+    bad = [(n, s) for n, s in zip(names, scratch) if s != 0]
+    assert not bad, bad
