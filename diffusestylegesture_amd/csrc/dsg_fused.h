@@ -240,14 +240,14 @@ __global__ __launch_bounds__(256) void k_qkv_attn(const QkvAttnArgs g) {
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < NCH; ++i) s += (v[p][i][0] + v[p][i][1]) + (v[p][i][2] + v[p][i][3]);
-            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+            s = row16_sum(s);
             const float mean = s / (float)DD;
             float q = 0.f;
 #pragma unroll
             for (int i = 0; i < NCH; ++i)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { const float d = v[p][i][e] - mean; q += d * d; }
-            q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4); q += __shfl_xor(q, 8);
+            q = row16_sum(q);
             const float rstd = 1.0f / sqrtf(q / (float)DD + 1e-5f);
             const int srow = p * 16 + row;
             const bool wr = g.Xn && h == 0 && p == qt && srow < g.ntok;
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void k_qkv_attn(const QkvAttnArgs g) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int key = nt * 16 + 4 * lg + r;
-            const float p = key < g.ntok ? expf(s[nt][r] - mx) : 0.f;
+            const float p = key < g.ntok ? P::exp_sm(s[nt][r] - mx) : 0.f;
             s[nt][r] = p;
             sum += p;
         }

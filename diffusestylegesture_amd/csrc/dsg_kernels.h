@@ -48,12 +48,31 @@ __device__ __forceinline__ bf16_t f2bf(float f) {          // round-to-nearest-e
 }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __builtin_bit_cast(float, ((unsigned)h) << 16); }
 
+// 16-lane ("DPP row") butterfly reductions: quad_perm xor-1, xor-2, row_half_mirror, row_mirror -- four DPP moves
+// (a few cycles each) instead of four ds_bpermute round trips through the LDS crossbar.
+__device__ __forceinline__ float dpp_f(float v, int ctrl_sel) {
+    const int x = __builtin_bit_cast(int, v);
+    int r;
+    switch (ctrl_sel) {
+        case 0: r = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true); break;     // quad_perm [1,0,3,2]
+        case 1: r = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true); break;     // quad_perm [2,3,0,1]
+        case 2: r = __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true); break;    // row_half_mirror
+        default: r = __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true); break;   // row_mirror
+    }
+    return __builtin_bit_cast(float, r);
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f(v, 0); v += dpp_f(v, 1); v += dpp_f(v, 2); v += dpp_f(v, 3);
+    return v;
+}
+
 struct PF32 {                       // fp32 storage, v_mfma_f32_16x16x4_f32
     typedef float elem;
     static constexpr int E = 4;     // elements per 16-byte fragment
     static constexpr int KB = 16;   // k-values per k-block (4 lane groups x E)
     static __device__ __forceinline__ elem cvt(float f) { return f; }
     static __device__ __forceinline__ float up(elem e) { return e; }
+    static __device__ __forceinline__ float exp_sm(float x) { return expf(x); }         // softmax exp: accurate
     static __device__ __forceinline__ f32x4 mma(f32x4 a, f32x4 b, f32x4 c) {
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
@@ -69,6 +88,7 @@ struct PBF16 {                      // bf16 storage, v_mfma_f32_16x16x32_bf16, f
     static constexpr int KB = 32;
     static __device__ __forceinline__ elem cvt(float f) { return f2bf(f); }
     static __device__ __forceinline__ float up(elem e) { return bf2f(e); }
+    static __device__ __forceinline__ float exp_sm(float x) { return __expf(x); }       // softmax exp: v_exp_f32 (P is rounded to bf16 anyway)
     static __device__ __forceinline__ f32x4 mma(f32x4 a, f32x4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
                                                        c, 0, 0, 0);
@@ -381,7 +401,7 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
             const float wgt = i < nch ? 1.f : 0.f;
             s += wgt * ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3]));
         }
-        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+        s = row16_sum(s);
         const float mean = s / (float)D;
         float q = 0.f;
 #pragma unroll
@@ -390,7 +410,7 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += wgt * d * d; }
         }
-        q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4); q += __shfl_xor(q, 8);
+        q = row16_sum(q);
         const float rstd = 1.0f / sqrtf(q / (float)D + 1e-5f);
         const bool wr = (g.Xn != nullptr) && ng == 0 && (m0 + row) < g.M;
 #pragma unroll
@@ -773,7 +793,7 @@ __global__ __launch_bounds__(64) void k_attn(const AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int key = nt * 16 + 4 * lg + r;
-            const float p = key < a.ntok ? expf(s[nt][r] - mx) : 0.f;
+            const float p = key < a.ntok ? P::exp_sm(s[nt][r] - mx) : 0.f;
             s[nt][r] = p;
             sum += p;
         }

@@ -48,6 +48,18 @@ void dfree(void* p);
 static inline void __syncthreads() { emu::syncthreads(); }
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+static inline int emu_update_dpp(int src, int ctrl) {
+    // exchange across the wave, then pick the source lane the DPP control selects (row = 16 lanes)
+    const int lane = (int)(threadIdx.x & 63);
+    int srcl = lane;
+    if (ctrl == 0xB1) srcl = lane ^ 1;                       // quad_perm [1,0,3,2]
+    else if (ctrl == 0x4E) srcl = lane ^ 2;                  // quad_perm [2,3,0,1]
+    else if (ctrl == 0x141) srcl = (lane & ~7) | (7 - (lane & 7));      // row_half_mirror
+    else if (ctrl == 0x140) srcl = (lane & ~15) | (15 - (lane & 15));   // row_mirror
+    return (int)emu::shfl_xor_u32((unsigned)src, lane ^ srcl);
+}
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rmask, bmask, bc) emu_update_dpp(src, ctrl)
+#define __expf(x) std::exp((float)(x))
 static inline float __shfl_xor(float v, int m) {
     return __builtin_bit_cast(float, emu::shfl_xor_u32(__builtin_bit_cast(unsigned, v), m));
 }
