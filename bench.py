@@ -33,6 +33,8 @@ def parse():
     p.add_argument("--sampler", default="ddpm", choices=["ddpm", "ddim50"])
     p.add_argument("--batch", type=int, default=1, help="clips advanced in lock step per GPU")
     p.add_argument("--steps-per-graph", type=int, default=0)
+    p.add_argument("--config", default="zeggs", choices=["zeggs", "beat", "twh"],
+                   help="zeggs = headline (BASELINE config[1]); beat/twh = DiffuseStyleGesture+ dims, 1830-frame clip (config[4])")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-baseline-steps", type=int, default=400)
     return p.parse_args()
@@ -85,22 +87,31 @@ def main():
     from diffusestylegesture_amd.sample import generate_clip
     from diffusestylegesture_amd.synth import synth_state_dict, synth_window_inputs
 
-    cfg = C.ZEGGS
+    cfg = C.CONFIGS[a.config]
     B = a.batch
     model = DSGDenoiser(cfg, precision=a.precision, max_batch=B, device=local, steps_per_graph=a.steps_per_graph)
     model.load_state_dict(synth_state_dict(cfg, 20240))
     diffusion = create_gaussian_diffusion("ddim50" if a.sampler == "ddim50" else "")
-    n_windows = 4
     sample_fn = diffusion.ddim_sample_loop if a.sampler == "ddim50" else diffusion.p_sample_loop
-    # synthetic per-window WavLM features, resident in HBM before the clock starts (clip index = rank*B + b)
+    if a.config == "zeggs":
+        n_windows = 4
+        frames_per_clip = n_windows * cfg.stride                                # 320 nominal (312 emitted)
+    else:
+        frames_per_clip = 1830                                                  # BEAT-TWH sample.py:56, max_len=0
+        n_windows = -(-frames_per_clip // cfg.stride)                           # ceil -> 16 windows
+    # synthetic per-window audio features, resident in HBM before the clock starts (clip index = rank*B + b)
     feats = [torch.from_numpy(synth_window_inputs(cfg, B, window=w, clip0=rank * B)["audio"]).cuda(local)
              for w in range(n_windows)]
-    style = [1, 0, 0, 0, 0, 0]
-    frames_per_clip = n_windows * cfg.stride                                    # 320 nominal (312 emitted)
+    style = [1] + [0] * (cfg.style_dim_in - 1)
 
     def one_clip(i):
-        return generate_clip(model, diffusion, feats, style, seed=123456 + i, smoothing=True, sample_fn=sample_fn,
-                             stream_id=rank)
+        if a.config == "zeggs":
+            return generate_clip(model, diffusion, feats, style, seed=123456 + i, smoothing=True, sample_fn=sample_fn,
+                                 stream_id=rank)
+        from diffusestylegesture_amd.sample import generate_clip_dsgplus
+        seed0 = torch.from_numpy(synth_window_inputs(cfg, B, window=0, clip0=rank * B, seed_pose_scale=0.1)["seed"]).cuda(local)
+        return generate_clip_dsgplus(model, diffusion, feats, style, seed0, frames_per_clip, seed=123456 + i,
+                                     sample_fn=sample_fn, stream_id=rank)
 
     def sync():
         torch.cuda.synchronize()
@@ -133,27 +144,29 @@ def main():
         us = float(np.mean(step_us))
         # algorithmic bytes per denoising step (SURVEY s8d / DESIGN.md): per-step weights in the compute dtype +
         # fp32 state I/O (x_t in, noise in, x_{t-1} out) per clip in the batch
-        wbytes = 7.183e6 * (2 if a.precision == "bf16" else 4)
-        abytes = wbytes + 1.205e6 * B
+        # per-step weight parameters / fp32 state bytes per clip
+        wparams, sbytes = {"zeggs": (7.183e6, 1.205e6), "beat": (13.25e6, 3.694e6), "twh": (20.23e6, 4.018e6)}[a.config]
+        wbytes = wparams * (2 if a.precision == "bf16" else 4)
+        abytes = wbytes + sbytes * B
         achieved = abytes / (us * 1e-6) / 1e9
         out = {
-            "metric": "gesture frames/sec, 1000-step DDPM, 320-frame ZEGGS clip" if a.sampler == "ddpm"
-            else "gesture frames/sec, 50-step DDIM, 320-frame ZEGGS clips",
+            "metric": (f"gesture frames/sec, {'1000-step DDPM' if a.sampler == 'ddpm' else '50-step DDIM'}, "
+                       + ("320-frame ZEGGS clip" if a.config == "zeggs" else f"1830-frame {a.config.upper()} clip (DSG+)")),
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1000.0 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
-            "config": {"workload": f"1xMI355X per rank, batch={B}, 320-frame ZEGGS clip (4 windows x "
-                                   f"{n_denoise} denoising steps), {a.sampler.upper()} {a.precision}",
+            "config": {"workload": f"1xMI355X per rank, batch={B}, {frames_per_clip}-frame {a.config.upper()} clip "
+                                   f"({n_windows} windows x {n_denoise} denoising steps), {a.sampler.upper()} {a.precision}",
                        "clips_per_gpu": B, "frames_emitted_per_clip": int(poses.shape[1]),
                        "denoise_steps_per_window": n_denoise, "parallelism": f"clips x{world}"},
             "us_per_denoise_step": round(us, 2),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 5), "traffic": None,
                          "algorithmic_bytes_per_denoise_step": abytes,
-                         "note": "one denoising step = 26 dependent kernel launches (latency mode); achieved = "
+                         "note": "one denoising step = 2 + 3*L dependent kernel launches (latency mode); achieved = "
                                  "algorithmic bytes / HIP-event time per step on the library stream"},
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.config == "zeggs" and a.sampler == "ddpm":
             out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_steps)
         print(json.dumps(out), flush=True)
     if dist is not None:

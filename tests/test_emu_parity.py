@@ -142,6 +142,33 @@ def test_forward_tiny4_dsgplus(emu_lib, golden_dir):
         assert rel_l2(m(x, np.array([500, 500]), dict(y, uncond=True)), g5["tiny4_uncond"]) < TOL[prec]
 
 
+def test_dsgplus_clip_tiny4_vs_oracle(emu_lib):
+    """DSG+ window loop (ceil windows, seed hand-off, one-frame blend, crop, first third of the features)."""
+    from diffusestylegesture_amd.sample import generate_clip_dsgplus
+    from oracle import philox, sampler
+    from oracle.mdm import MDMOracle
+    from oracle.schedule import OracleDiffusion
+    cfg = C.TINY4
+    sd = synth_state_dict(cfg, 9)
+    m = DSGDenoiser(cfg, precision="fp32", max_batch=1, library=emu_lib)
+    m.load_state_dict(sd)
+    d = create_gaussian_diffusion(library=emu_lib)
+    ref, od = MDMOracle(sd, cfg), OracleDiffusion()
+    shape = (1, cfg.njoints, 1, cfg.n_poses)
+    feats = [synth_window_inputs(cfg, 1, window=w)["audio"] for w in range(3)]
+    seed0 = synth_window_inputs(cfg, 1, window=0, seed_pose_scale=0.2)["seed"]
+    real_n = 61
+    got = generate_clip_dsgplus(m, d, feats, [1, 0, 0], seed0, real_n, seed=5, skip_timesteps=996)
+    per = 5
+
+    def sample_window(c, yy):
+        nf = lambda k: philox.normal_bj1t(shape, 5, c * per + k, 0)
+        return sampler.p_sample_loop(od, ref, shape, nf, {"y": yy}, skip_timesteps=996)
+    want = sampler.dsgplus_clip(sample_window, cfg, feats, [1, 0, 0], seed0, real_n)
+    assert got.shape == (1, real_n, cfg.njoints // 3)
+    assert rel_l2(got[0], want) < 1e-5
+
+
 def test_forward_zeggs_full_dims(emu_lib, golden_dir):
     g2 = _g(golden_dir, "g2_forward_zeggs.npz")
     cfg = C.ZEGGS

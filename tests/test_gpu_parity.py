@@ -129,6 +129,40 @@ def test_forward_dsgplus_vs_reference(gpu, golden_dir, cfg, ts):
         assert rel_l2(m(x, np.array([ts] * B), y), g5[cfg.name + "_out"]) < TOL_FWD[prec]
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_dsgplus_chain_and_clip_vs_oracle(gpu, prec):
+    """DiffuseStyleGesture+ (BEAT dims, attention4): 12-step DDPM chain and a 3-window clip (ceil windows, GT-style seed,
+    one-frame blend, crop, first third of the features) against the CPU oracle with the same Philox noise."""
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    from diffusestylegesture_amd.sample import generate_clip_dsgplus
+    from oracle import philox, sampler
+    from oracle.mdm import MDMOracle
+    from oracle.schedule import OracleDiffusion
+    cfg = C.BEAT
+    sd = synth_state_dict(cfg, 20240)
+    m = _model(cfg, prec, max_batch=1)
+    ref = MDMOracle(sd, cfg)
+    od = OracleDiffusion()
+    shape = (1, cfg.njoints, 1, cfg.n_poses)
+    y = synth_window_inputs(cfg, 1, window=2, seed_pose_scale=0.1)
+    d = create_gaussian_diffusion().manual_seed(11, 4)
+    s = d.p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=988)
+    r = sampler.p_sample_loop(od, ref, shape, sampler.philox_noise_fn(shape, 11, 4), {"y": y}, skip_timesteps=988)
+    assert rel_l2(s, r) < TOL_CHAIN[prec]
+    feats = [synth_window_inputs(cfg, 1, window=w)["audio"] for w in range(3)]
+    seed0 = synth_window_inputs(cfg, 1, window=0, seed_pose_scale=0.1)["seed"]
+    real_n = 300
+    got = generate_clip_dsgplus(m, d, feats, [1, 0], seed0, real_n, seed=5, skip_timesteps=997)
+    per = 4
+
+    def sample_window(c, yy):
+        nf = lambda k: philox.normal_bj1t(shape, 5, c * per + k, 0)
+        return sampler.p_sample_loop(od, ref, shape, nf, {"y": yy}, skip_timesteps=997)
+    want = sampler.dsgplus_clip(sample_window, cfg, feats, [1, 0], seed0, real_n)
+    assert got.shape == (1, real_n, cfg.njoints // 3)
+    assert rel_l2(got[0], want) < TOL_CHAIN[prec]
+
+
 def test_graph_equals_eager_and_deterministic(gpu):
     from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
     cfg = C.ZEGGS
