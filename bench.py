@@ -149,6 +149,12 @@ def main():
         wbytes = wparams * (2 if a.precision == "bf16" else 4)
         abytes = wbytes + sbytes * B
         achieved = abytes / (us * 1e-6) / 1e9
+        # HBM-side traffic per step from the rocprofv3 PMC passes (tools/pmc_traffic.py; FETCH_SIZE doubled as the
+        # MI355X guide prescribes for wide coalesced reads), measured for the headline configuration only
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r01_g_traffic_zeggs_b1_bf16.json")
+        if a.config == "zeggs" and a.precision == "bf16" and B == 1 and os.path.exists(tf):
+            traffic = json.load(open(tf))["traffic_bytes_per_step_fetch_x2"]
         out = {
             "metric": (f"gesture frames/sec, {'1000-step DDPM' if a.sampler == 'ddpm' else '50-step DDIM'}, "
                        + ("320-frame ZEGGS clip" if a.config == "zeggs" else f"1830-frame {a.config.upper()} clip (DSG+)")),
@@ -161,7 +167,7 @@ def main():
                        "denoise_steps_per_window": n_denoise, "parallelism": f"clips x{world}"},
             "us_per_denoise_step": round(us, 2),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(achieved / 8000.0, 5), "traffic": None,
+                         "frac": round(achieved / 8000.0, 5), "traffic": traffic,
                          "algorithmic_bytes_per_denoise_step": abytes,
                          "note": "one denoising step = 2 + 3*L dependent kernel launches (latency mode); achieved = "
                                  "algorithmic bytes / HIP-event time per step on the library stream"},
