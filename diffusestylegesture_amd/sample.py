@@ -215,9 +215,14 @@ def main(argv=None):
     feats_t = [torch.from_numpy(f[None]).cuda(dev) for f in feats]
     poses = generate_clip(model, diffusion, feats_t, style, seed=123456, smoothing=True)[0]
     os.makedirs(args.save_dir, exist_ok=True)
-    out = os.path.join(args.save_dir, os.path.splitext(name)[0] + "_poses.npy")
-    np.save(out, poses)
-    print(out, poses.shape)
+    stem = os.path.join(args.save_dir, os.path.splitext(name)[0])
+    np.save(stem + "_poses.npy", poses)
+    # de-normalise (sample.py:320-326) and write the .bvh (process_zeggs_bvh.py:219) like the reference's main()
+    from .bvh import pose2bvh
+    ms = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "zeggs_mean_std.npz"))
+    out_poses = denormalise(poses, ms["mean"], ms["std"])
+    pose2bvh(out_poses, stem + ".bvh", length=out_poses.shape[0], smoothing=True)
+    print(stem + ".bvh", out_poses.shape)
 
 
 if __name__ == '__main__':

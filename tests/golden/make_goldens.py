@@ -4,6 +4,7 @@
     python tests/golden/make_goldens.py zeggs      # main/ (DiffuseStyleGesture, ZEGGS dims + tiny dims)
     python tests/golden/make_goldens.py dsgplus    # BEAT-TWH-main/ (DiffuseStyleGesture+)
     python tests/golden/make_goldens.py clip       # main/mydiffusion_zeggs/sample.py inference() (G6)
+    python tests/golden/make_goldens.py bvh        # main/process/process_zeggs_bvh.py pose2bvh (G7, needs G6)
 
 The two reference trees use the same module names, hence one process per tree.  Nothing from
 /root/reference is copied: the script imports it, feeds it seeded synthetic weights / inputs
@@ -295,6 +296,32 @@ def gen_clip():
     print("G6", captured["poses"].shape, draws)
 
 
+def gen_bvh():
+    """G7: the reference's own pose2bvh (Savitzky-Golay, orthogonalisation, quaternion/Euler, x3 repeat, text writer) on the
+    de-normalised poses of G6; stores the hierarchy text and every motion channel value."""
+    import tempfile
+    sys.modules["omegaconf"] = types.ModuleType("omegaconf")
+    sys.modules["omegaconf"].DictConfig = dict
+    sys.path[:0] = [REF + "/main/process", REF + "/ubisoft-laforge-ZeroEGGS-main/ZEGGS"]
+    os.chdir(REF + "/main/process")
+    import process_zeggs_bvh as R
+    poses = np.load(os.path.join(HERE, "g6_clip_zeggs.npz"))["poses_denorm"]
+    tmp = tempfile.mkdtemp()
+    out = {}
+    for sm in (True, False):
+        p = os.path.join(tmp, f"ref_{sm}.bvh")
+        R.pose2bvh(poses, p, length=312, smoothing=sm)
+        head, motion = open(p).read().split("MOTION\n")
+        rows = motion.strip().split("\n")
+        vals = np.array([[float(v) for v in r.split()] for r in rows[2:]], dtype=np.float64)
+        if sm:
+            out.update(header=np.array(head), frames_line=np.array(rows[0]), frametime_line=np.array(rows[1]),
+                       motion_smooth=vals.astype(np.float32))
+        else:
+            out["motion_raw_first_last"] = np.concatenate([vals[:9], vals[-9:]]).astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "g7_bvh_zeggs.npz"), **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1]
-    {"zeggs": gen_zeggs, "dsgplus": gen_dsgplus, "clip": gen_clip}[which]()
+    {"zeggs": gen_zeggs, "dsgplus": gen_dsgplus, "clip": gen_clip, "bvh": gen_bvh}[which]()
