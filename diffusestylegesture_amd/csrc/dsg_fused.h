@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_inloc(const InLocArgs g) {
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NL; ++nt) *(f32x4*)&red[wave][mt][nt][lane][0] = acc[mt][nt];
-    __syncthreads();
+    DSG_LDS_BARRIER();
     const int cshift = col0 - ntile0 * 16;                     // head narrower than a tile: offset inside the tile
 #pragma unroll
     for (int i = 0; i < NPI; ++i) {
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void k_inloc(const InLocArgs g) {
             rot[r][dd + half] = f >= 0 ? vh * c1[i] + vl * s1[i] : -1.0f;
         }
     }
-    __syncthreads();
+    DSG_LDS_BARRIER();
     local_attn_tail<P, HD, W>(a, rot, sc, b, w, h, keep, c2, s2);
 }
 
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void k_qkv_attn(const QkvAttnArgs g) {
             *(f32x4*)(xs + r * XP + cc * 16) = v[i];
         }
     }
-    __syncthreads();
+    DSG_LDS_BARRIER();
 
     // ---- (3) K_h, V_h for every token and Q_h for this query tile (results stay in LDS)
     for (int mt = wms; mt < NKT; mt += MSPLIT) {
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void k_qkv_attn(const QkvAttnArgs g) {
             P::store4((elem*)(qq + lr * KP) + wnt * 16 + 4 * lg, cq + bq);
         }
     }
-    __syncthreads();
+    DSG_LDS_BARRIER();
 
     // ---- (4) attention for the 16 queries of this tile; every wave forms the scores, wave w owns output dims
     f32x4 qf[KH];
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
     for (int t = 0; t < DT; ++t) { acc[t] = acc[t] + pbo[t] + pr[t]; s += (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]); }
     s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
     if (lg == 0) red[0][wave][lr] = s;
-    __syncthreads();
+    DSG_LDS_BARRIER();
     const float mean = ((red[0][0][lr] + red[0][1][lr]) + (red[0][2][lr] + red[0][3][lr])) / (float)D;
     float q = 0.f;
 #pragma unroll
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
         for (int e = 0; e < 4; ++e) { const float d = acc[t][e] - mean; q += d * d; }
     q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
     if (lg == 0) red[1][wave][lr] = q;
-    __syncthreads();
+    DSG_LDS_BARRIER();
     const float var = ((red[1][0][lr] + red[1][1][lr]) + (red[1][2][lr] + red[1][3][lr])) / (float)D;
     const float rstd = 1.0f / sqrtf(var + 1e-5f);
     const bool wr = ng == 0 && (m0 + lr) < g.M;
@@ -475,9 +475,9 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[e] = (acc[t][e] - mean) * rstd * pg[t][e] + pbt[t][e];
         P::store4((elem*)(a1 + lr * XP) + n, y);
-        if (wr) *(f32x4*)(g.X1 + (size_t)(m0 + lr) * D + n) = y;
+        acc[t] = y;                                   // written to X1 at the very end (keeps stores out of the vmcnt queue)
     }
-    __syncthreads();
+    DSG_LDS_BARRIER();
     // ---- linear1 slice + GELU
     f32x4 c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
     if constexpr (KD <= CH) {
@@ -501,6 +501,10 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[e] = gelu_erf<P>(c1[e] + pb1[e]);
         P::store4((elem*)g.hidden + (size_t)(m0 + lr) * g.ff + n1t * 16 + 4 * lg, y);
+    }
+    if (wr) {
+#pragma unroll
+        for (int t = 0; t < DT; ++t) *(f32x4*)(g.X1 + (size_t)(m0 + lr) * D + (wave * DT + t) * 16 + 4 * lg) = acc[t];
     }
 }
 

@@ -744,6 +744,9 @@ static int debug_launch(dsg_handle* h, int which, int i, int B) {
     la.emb1 = h->emb1; la.ctl = nullptr; la.t_arr = h->t_arr;
     la.rcos = h->rcos; la.rsin = h->rsin; la.mask = h->mask; la.mb = h->mb; la.B = B; la.T = T; la.D = D; la.Hl = h->Hl;
     la.hd = h->hdl; la.W = h->W; la.X0 = h->X0; la.X0a = h->X0a;
+    if (which == 20) return debug_launch<P>(h, (i & 1) ? 1 : 4, i, B);                 // alternate 2 kernels
+    if (which == 21) { const int seq[4] = {1, 4, 7, 9}; return debug_launch<P>(h, seq[i & 3], i, B); }   // 4 kernels
+    if (which == 22) { const int seq[6] = {12, 9, 5, 10, 4, 8}; return debug_launch<P>(h, seq[i % 6], i, B); } // the step's 6 kernels
     switch (which) {
         case 0: hipLaunchKernelGGL(k_ctr_inc, dim3(96), dim3(256), 0, h->stream, h->ctr); return 0;
         case 1: case 2: {
@@ -788,6 +791,25 @@ static int debug_launch(dsg_handle* h, int which, int i, int B) {
             InLocArgs a; a.xs = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; a.Jp = h->Jp; a.Wp = h->Wp_in;
             a.KBtot = h->Jp / KB; a.loc = la; a.ctl_upd = nullptr; a.st = step_tables(h); a.n_tab = 1;
             DSG_LOC_DISPATCH(k_inloc, a, dim3(B * (T / h->W) * h->Hl + 1)); return 0; }
+        case 13: case 14: case 113: case 114: {     // 1xx = prepare (upload the argument blocks), xx = launch
+            static GemmArgs* dargs = nullptr;
+            if (!dargs) HIPCHK(hipMalloc((void**)&dargs, 16 * sizeof(GemmArgs)));
+            const bool prep = which >= 100;
+            const int w2 = which % 100;
+            GemmArgs g = z; g.M = M; g.MT = MT;
+            if (w2 == 13) {
+                g.NT = D / 16; g.KBtot = D / KB; g.Wp = ly.Wo; g.bias = ly.bo; g.A = h->attn; g.lda = D;
+                g.out = (i & 1) ? h->pre1 : h->pre2; g.ldo = D; g.R = h->X0; g.kb_per_split = g.KBtot;
+                if (prep) { HIPCHK(hipMemcpy(dargs + (i % 16), &g, sizeof(g), hipMemcpyHostToDevice)); return 0; }
+                hipLaunchKernelGGL((k_gemm_p<P, PRO_DIRECT, EPI_RESID, 4, 1, 1>), dim3(xcd_grid(g.NT / 4, MT)), dim3(256), 0, h->stream, dargs + (i % 16));
+            } else {
+                g.NT = 3 * D / 16; g.KBtot = D / KB; g.Wp = ly.Wqkv; g.bias = ly.bqkv; g.q = h->q; g.k = h->k; g.vt = h->vt;
+                g.X = h->pre2; g.ln_g = ly.g2; g.ln_b = ly.be2; g.Xn = h->Xn; g.kb_per_split = g.KBtot;
+                if (prep) { HIPCHK(hipMemcpy(dargs + (i % 16), &g, sizeof(g), hipMemcpyHostToDevice)); return 0; }
+                hipLaunchKernelGGL((k_gemm_p<P, PRO_LN, EPI_QKV, 4, 1, 1>), dim3(xcd_grid(g.NT / 4, MT)), dim3(256), 0, h->stream, dargs + (i % 16));
+            }
+            HIPCHK(hipGetLastError());
+            return 0; }
         default: return fail(DSG_E_INVALID, "debug_chain: unknown kernel id");
     }
 }
@@ -818,6 +840,10 @@ extern "C" int dsg_debug_chain(dsg_handle* h, int which, int n, int use_graph, i
     HIPCHK(hipSetDevice(h->cfg.device));
     auto one = [&](int i) { return h->prec == DSG_PREC_BF16 ? debug_launch<PBF16>(h, which, i, B) : debug_launch<PF32>(h, which, i, B); };
     const int G = 64;
+    if (which == 13 || which == 14) {
+        const int wp = which + 100;
+        for (int i = 0; i < 16; ++i) CHK((h->prec == DSG_PREC_BF16 ? debug_launch<PBF16>(h, wp, i, B) : debug_launch<PF32>(h, wp, i, B)));
+    }
     hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
     if (use_graph) {
         HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));

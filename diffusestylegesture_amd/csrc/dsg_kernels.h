@@ -40,12 +40,10 @@ typedef unsigned short bf16_t;
 // ---------------------------------------------------------------------------------------------------------
 // precision policies
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bf16_t f2bf(float f) {          // round-to-nearest-even, NaN preserved
-    unsigned u = __builtin_bit_cast(unsigned, f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// float -> bf16, round-to-nearest-even: gfx950 has it in hardware (v_cvt_pk_bf16_f32, two values per instruction).
+// A hand-rolled integer RNE with a NaN branch costs ~12 instructions and an EXEC-mask branch per value -- at one wave
+// per SIMD every instruction is ~4 cycles of latency on the critical path, and k_attn alone converts 24 values/lane.
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __builtin_bit_cast(float, ((unsigned)h) << 16); }
 
 // 16-lane ("DPP row") butterfly reductions: quad_perm xor-1, xor-2, row_half_mirror, row_mirror -- four DPP moves
@@ -94,8 +92,8 @@ struct PBF16 {                      // bf16 storage, v_mfma_f32_16x16x32_bf16, f
                                                        c, 0, 0, 0);
     }
     static __device__ __forceinline__ void store4(elem* p, f32x4 v) {
-        u16x4 o; o[0] = f2bf(v[0]); o[1] = f2bf(v[1]); o[2] = f2bf(v[2]); o[3] = f2bf(v[3]);
-        *(u16x4*)p = o;
+        typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+        *(bf16x4v*)p = __builtin_convertvector(v, bf16x4v);
     }
 };
 
@@ -105,6 +103,16 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // (seen in the ISA as L w L w L w ...; the LayerNorm GEMMs had 17-19 of them).  LOADS_ISSUED() additionally stops the
 // scheduler from sinking loads below the first use.
 #define DSG_LOADS_ISSUED() __builtin_amdgcn_sched_barrier(0)
+// Workgroup barrier for LDS hand-offs only.  __syncthreads() also drains every outstanding VECTOR memory operation
+// (s_waitcnt vmcnt(0)): in-flight weight loads and the acknowledgement of global stores issued before it.  Nothing in
+// these kernels communicates through global memory inside a launch, so the fences are restricted to the LDS address
+// space ("local"): they keep the compiler from moving LDS accesses across the barrier and emit lgkmcnt(0) only.
+#define DSG_LDS_BARRIER()                                                      \
+    do {                                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");        \
+        __builtin_amdgcn_s_barrier();                                          \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");        \
+    } while (0)
 // hipcc fetches kernel arguments lazily, one s_load batch (+ s_waitcnt lgkmcnt(0)) per region that first needs them;
 // the kernarg segment is freshly written for every launch, so each batch is a scalar-cache MISS -- several serial
 // misses per kernel.  Touching one dword per 64-byte line of the argument struct at the top of the kernel makes all
@@ -263,7 +271,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 
 // WN x WK = 4 waves: WN waves side by side along N (TNW 16-col tiles each), WK-way split of K inside the workgroup.
 template <class P, int PRO, int EPI, int WN, int WK, int TNW>
-__global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& g) {
     typedef typename P::elem elem;
     static_assert(WN * WK == 4, "4 waves");
     constexpr int ES = (int)sizeof(elem);
@@ -380,13 +388,15 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
 
     // ---- prologue: LayerNorm-on-read (rows are owned whole: K == D)
     int pitch = 0;
+    f32x4 v[PRO == PRO_LN ? 8 : 1];
+    bool wr = false;
     if constexpr (PRO == PRO_LN) {
         const int D = g.D;
         pitch = DSG_LDS_ROW_BYTES(D, ES);
         const int row = tid >> 4, c = tid & 15;
         const float* xr = g.X + (size_t)(m0 + row) * D;
         const int nch = D >> 6;                       // D / 64 float4 chunks per thread (<= 8)
-        f32x4 v[8], gg[8], bb[8];
+        f32x4 gg[8], bb[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {                 // unconditional loads: chunks beyond D re-read chunk 0
             const int col = c * 4 + 64 * (i < nch ? i : 0);
@@ -412,7 +422,7 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
         }
         q = row16_sum(q);
         const float rstd = 1.0f / sqrtf(q / (float)D + 1e-5f);
-        const bool wr = (g.Xn != nullptr) && ng == 0 && (m0 + row) < g.M;
+        wr = (g.Xn != nullptr) && ng == 0 && (m0 + row) < g.M;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             if (i < nch) {
@@ -421,9 +431,9 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * gg[i][e] + bb[i][e];
                 P::store4((elem*)(lds_a + row * pitch) + col, y);
-                if (wr) *(f32x4*)(g.Xn + (size_t)(m0 + row) * D + col) = y;
+                v[i] = y;
             }
-        __syncthreads();
+        DSG_LDS_BARRIER();
     }
 
     for (int kb0 = kb_lo; kb0 < kb_hi; kb0 += CH) {
@@ -446,6 +456,18 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
         if (kb0 + CH < kb_hi) load_b(kb0 + CH);
     }
 
+    // The normalised rows go back to global memory only now: a global store issued before the MFMA phase would sit
+    // in the same vmcnt queue as the weight loads (stores and loads retire out of order with each other, so the
+    // compiler has to wait vmcnt(0), i.e. for the store acknowledgements, before the first fragment is usable).
+    if constexpr (PRO == PRO_LN) {
+        if (wr) {
+            const int row = tid >> 4, c = tid & 15;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i < (g.D >> 6)) *(f32x4*)(g.Xn + (size_t)(m0 + row) * g.D + c * 4 + 64 * i) = v[i];
+        }
+    }
+
     // ---- in-workgroup split-K reduction (deterministic order)
     if constexpr (WK > 1) {
         if (wk > 0) {
@@ -453,7 +475,7 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
             for (int t = 0; t < TNW; ++t)
                 *(f32x4*)(lds_red + ((((wk - 1) * WN + wn) * TNW + t) * 64 + lane) * 4) = acc[t];
         }
-        __syncthreads();
+        DSG_LDS_BARRIER();
         if (wk > 0) return;
 #pragma unroll
         for (int w2 = 1; w2 < WK; ++w2)
@@ -539,6 +561,12 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
     }
 }
 
+template <class P, int PRO, int EPI, int WN, int WK, int TNW>
+__global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) { gemm_body<P, PRO, EPI, WN, WK, TNW>(g); }
+// experiment: the same body with the argument block in device memory (8-byte kernarg)
+template <class P, int PRO, int EPI, int WN, int WK, int TNW>
+__global__ __launch_bounds__(256) void k_gemm_p(const GemmArgs* __restrict__ gp) { gemm_body<P, PRO, EPI, WN, WK, TNW>(*gp); }
+
 // ---------------------------------------------------------------------------------------------------------
 // k_loc: per (batch, window, local head).  h = sum_s partial_s + Cframe + TE2[t]; rotary(pos = frame);
 //        causal local attention over {previous window, own window} with q = k = v; prepend token; rotary(pos+1)
@@ -598,7 +626,7 @@ __device__ __forceinline__ void local_attn_tail(const LocArgs& a, float (&rot)[2
         sum += __shfl_xor(sum, 8); sum += __shfl_xor(sum, 16);
         if (valid) sc[q][j] = pv / sum;
     }
-    __syncthreads();
+    DSG_LDS_BARRIER();
     const int ntok = a.T + 1, col0 = h * HD;
 #pragma unroll
     for (int i = 0; i < NPO; ++i) {
@@ -690,7 +718,7 @@ __global__ __launch_bounds__(256) void k_loc(const LocArgs a) {
             rot[r][dd + half] = f >= 0 ? hi[i] * c1[i] + lo[i] * s1[i] : -1.0f;
         }
     }
-    __syncthreads();
+    DSG_LDS_BARRIER();
     local_attn_tail<P, HD, W>(a, rot, sc, b, w, h, keep, c2, s2);
 }
 

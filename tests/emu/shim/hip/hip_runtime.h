@@ -48,6 +48,8 @@ void dfree(void* p);
 static inline void __syncthreads() { emu::syncthreads(); }
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_fence(...) ((void)0)
+#define __builtin_amdgcn_s_barrier() emu::syncthreads()
 static inline int emu_update_dpp(int src, int ctrl) {
     // exchange across the wave, then pick the source lane the DPP control selects (row = 16 lanes)
     const int lane = (int)(threadIdx.x & 63);
