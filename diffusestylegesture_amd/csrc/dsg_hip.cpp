@@ -127,6 +127,7 @@ struct dsg_handle {
     StepCtl* ctl = nullptr;              // device-resident step control (dsg_kernels.h: StepCtl)
     int* t_arr = nullptr; unsigned* dyn = nullptr;
     int latency_mode = -1;               // -1 auto (fused kernels when the batch is small), 0 never, 1 always
+    int dbg_skip = 0;                    // DSG_DEBUG_SKIP bit mask: timing experiments only (results become garbage)
     bool fuse_attn = false;
     int* st_tmodel = nullptr; float* st_c[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int st_cap = 0, n_run = 1;
@@ -242,6 +243,7 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     h->layers.resize(h->L);
     h->latency_mode = c->latency_mode == 1 ? 0 : (c->latency_mode == 2 ? 1 : -1);
     if (const char* e = getenv("DSG_LATENCY_MODE")) h->latency_mode = atoi(e);
+    if (const char* e = getenv("DSG_DEBUG_SKIP")) h->dbg_skip = atoi(e);
     if (const char* e = getenv("DSG_FUSE_ATTN")) h->fuse_attn = atoi(e) != 0;
     *out = h;
 
@@ -639,7 +641,9 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
     la.emb1 = h->emb1; la.ctl = c.use_ctr ? h->ctl : nullptr; la.t_arr = h->t_arr;
     la.rcos = h->rcos; la.rsin = h->rsin; la.mask = h->mask; la.mb = h->mb; la.B = B; la.T = T; la.D = D; la.Hl = h->Hl;
     la.hd = h->hdl; la.W = h->W; la.X0 = h->X0; la.X0a = h->X0a;
-    if (lat) {          // pose embedding + local attention in one launch
+    const int skip = h->dbg_skip;      // drop-one timing experiments: 1 in/loc, 2 QKV, 4 attention, 8 mid, 16 linear2, 32 head
+    if (skip & 1) {
+    } else if (lat) {          // pose embedding + local attention in one launch
         InLocArgs a;
         a.xs = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; a.Jp = h->Jp; a.Wp = h->Wp_in; a.KBtot = h->Jp / KB;
         a.loc = la; a.ctl_upd = c.use_ctr ? h->ctl : nullptr; a.st = step_tables(h); a.n_tab = h->n_run;
@@ -660,7 +664,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
     // GEMM make it slower (15 us) than LN+QKV followed by k_attn (6.2 + 4.6 us): opt-in only (DSG_FUSE_ATTN=1)
     const bool fuse_attn = lat && have_qkv_attn(h) && h->fuse_attn;
     for (int l = 0; l < h->L; ++l) {
-        const Layer& ly = h->layers[l];
+        const Layer& ly = h->layers[(skip & 64) ? 0 : l];      // 64: every layer reads layer 0's weights (L2 residency experiment)
         if (fuse_attn) {   // [LayerNorm2] + in_proj + attention per (batch, head, query tile)
             QkvAttnArgs a;
             memset(&a, 0, sizeof(a));
@@ -669,7 +673,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
             a.Wp = ly.Wqkv; a.bias = ly.bqkv; a.out = h->attn; a.B = B; a.H = h->H; a.ntok = ntok;
             CHK(launch_qkv_attn<P>(h, a));
         } else {
-            {   // QKV projection (LayerNorm2 of the previous layer applied on read)
+            if (!(skip & 2)) {   // QKV projection (LayerNorm2 of the previous layer applied on read)
                 GemmArgs g = z;
                 g.M = M; g.MT = MT; g.NT = 3 * D / 16; g.KBtot = D / KB; g.Wp = ly.Wqkv; g.bias = ly.bqkv;
                 g.q = h->q; g.k = h->k; g.vt = h->vt;
@@ -681,14 +685,15 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                     CHK((launch_gemm<P, PRO_LN, EPI_QKV, 4, 1, 1>(h, g)));
                 }
             }
-            {   // attention
+            if (!(skip & 4)) {   // attention
                 AttnArgs a;
                 a.q = h->q; a.k = h->k; a.vt = h->vt; a.out = h->attn; a.B = B; a.H = h->H; a.ntok = ntok; a.Tp = h->Tp;
                 a.D = D;
                 CHK(launch_attn<P>(h, a));
             }
         }
-        if (lat) {      // out_proj + residual + LayerNorm1 + linear1 slice + GELU
+        if (skip & 8) {
+        } else if (lat) {      // out_proj + residual + LayerNorm1 + linear1 slice + GELU
             MidArgs a;
             a.A = h->attn; a.R = l == 0 ? h->X0 : h->Xn; a.Wo = ly.Wo; a.bo = ly.bo; a.ln_g = ly.g1; a.ln_b = ly.be1;
             a.W1 = ly.W1; a.b1 = ly.b1; a.X1 = h->X1; a.hidden = h->hidden; a.M = M; a.MT = MT; a.ff = h->ff;
@@ -707,14 +712,14 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                 CHK((launch_gemm<P, PRO_LN, EPI_GELU, 4, 1, 1>(h, g)));
             }
         }
-        {   // linear2 + residual -> pre2   (K = ff split over the 4 waves of the workgroup)
+        if (!(skip & 16)) {   // linear2 + residual -> pre2   (K = ff split over the 4 waves of the workgroup)
             GemmArgs g = z;
             g.M = M; g.MT = MT; g.NT = D / 16; g.KBtot = h->ff / KB; g.Wp = ly.W2; g.bias = ly.b2;
             g.A = h->hidden; g.lda = h->ff; g.out = h->pre2; g.ldo = D; g.R = h->X1;
             CHK((launch_gemm<P, PRO_DIRECT, EPI_RESID, 1, 4, 1>(h, g)));
         }
     }
-    {   // final LayerNorm-on-read + pose head + sampler update
+    if (!(skip & 32)) {   // final LayerNorm-on-read + pose head + sampler update
         GemmArgs g = z;
         g.M = M; g.MT = MT; g.NT = h->Jp / 16; g.KBtot = D / KB; g.Wp = h->Wp_out; g.bias = h->b_out;
         g.X = h->pre2; g.ln_g = h->layers[h->L - 1].g2; g.ln_b = h->layers[h->L - 1].be2; g.Xn = nullptr;

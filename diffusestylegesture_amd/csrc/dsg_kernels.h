@@ -269,6 +269,54 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 
 #define DSG_LDS_ROW_BYTES(K, ES) ((K) * (ES) + 16)
 
+// LayerNorm of 16 rows by 256 lanes (16 lanes per row, NCH float4 chunks per lane), result to LDS in the MFMA element
+// type and kept in v[] (fp32) for the write-back.  NCH > 0: exact width, no dead work.  NCH == 0: any D <= 512 that is
+// a multiple of 64 (loads clamped to chunk 0 and weighted out, so the load phase stays branch-free).
+template <class P, int NCH>
+__device__ __forceinline__ void ln_rows(const GemmArgs& g, int m0, int tid, char* lds_a, int pitch, f32x4 (&v)[8]) {
+    typedef typename P::elem elem;
+    constexpr int N = NCH > 0 ? NCH : 8;
+    const int D = g.D;
+    const int row = tid >> 4, c = tid & 15;
+    const float* xr = g.X + (size_t)(m0 + row) * D;
+    const int nch = NCH > 0 ? NCH : (D >> 6);
+    f32x4 gg[N], bb[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int col = c * 4 + 64 * (i < nch ? i : 0);
+        v[i] = *(const f32x4*)(xr + col);
+        gg[i] = *(const f32x4*)(g.ln_g + col);
+        bb[i] = *(const f32x4*)(g.ln_b + col);
+    }
+    DSG_LOADS_ISSUED();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float wgt = (NCH > 0 || i < nch) ? 1.f : 0.f;
+        s += wgt * ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3]));
+    }
+    s = row16_sum(s);
+    const float mean = s / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float wgt = (NCH > 0 || i < nch) ? 1.f : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += wgt * d * d; }
+    }
+    q = row16_sum(q);
+    const float rstd = 1.0f / sqrtf(q / (float)D + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        if (NCH > 0 || i < nch) {
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * gg[i][e] + bb[i][e];
+            P::store4((elem*)(lds_a + row * pitch) + c * 4 + 64 * i, y);
+            v[i] = y;
+        }
+}
+
 // WN x WK = 4 waves: WN waves side by side along N (TNW 16-col tiles each), WK-way split of K inside the workgroup.
 template <class P, int PRO, int EPI, int WN, int WK, int TNW>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
@@ -391,48 +439,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
     f32x4 v[PRO == PRO_LN ? 8 : 1];
     bool wr = false;
     if constexpr (PRO == PRO_LN) {
-        const int D = g.D;
-        pitch = DSG_LDS_ROW_BYTES(D, ES);
-        const int row = tid >> 4, c = tid & 15;
-        const float* xr = g.X + (size_t)(m0 + row) * D;
-        const int nch = D >> 6;                       // D / 64 float4 chunks per thread (<= 8)
-        f32x4 gg[8], bb[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {                 // unconditional loads: chunks beyond D re-read chunk 0
-            const int col = c * 4 + 64 * (i < nch ? i : 0);
-            v[i] = *(const f32x4*)(xr + col);
-            gg[i] = *(const f32x4*)(g.ln_g + col);
-            bb[i] = *(const f32x4*)(g.ln_b + col);
-        }
-        DSG_LOADS_ISSUED();
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float wgt = i < nch ? 1.f : 0.f;
-            s += wgt * ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3]));
-        }
-        s = row16_sum(s);
-        const float mean = s / (float)D;
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float wgt = i < nch ? 1.f : 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += wgt * d * d; }
-        }
-        q = row16_sum(q);
-        const float rstd = 1.0f / sqrtf(q / (float)D + 1e-5f);
-        wr = (g.Xn != nullptr) && ng == 0 && (m0 + row) < g.M;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (i < nch) {
-                const int col = c * 4 + 64 * i;
-                f32x4 y;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * gg[i][e] + bb[i][e];
-                P::store4((elem*)(lds_a + row * pitch) + col, y);
-                v[i] = y;
-            }
+        pitch = DSG_LDS_ROW_BYTES(g.D, ES);
+        wr = (g.Xn != nullptr) && ng == 0 && (m0 + (tid >> 4)) < g.M;
+        const int nch = g.D >> 6;                     // D / 64 float4 chunks per thread; one straight-line copy per width
+        if (nch == 4) ln_rows<P, 4>(g, m0, tid, lds_a, pitch, v);
+        else if (nch == 6) ln_rows<P, 6>(g, m0, tid, lds_a, pitch, v);
+        else if (nch == 8) ln_rows<P, 8>(g, m0, tid, lds_a, pitch, v);
+        else ln_rows<P, 0>(g, m0, tid, lds_a, pitch, v);
         DSG_LDS_BARRIER();
     }
 
