@@ -8,15 +8,20 @@ EMU := tests/emu/_build/libdsg_emu.so
 
 all: $(LIB)
 
-$(LIB): $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h include/dsg.h
+$(LIB): $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h include/dsg.h
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed $(CSRC)/dsg_hip.cpp -o $@
 
+# diagnostics build: the same sources with cycle stamps at the phase boundaries of the step kernels (tools/stamps.py)
+stamps: $(CSRC)/libdsg_hip_stamps.so
+$(CSRC)/libdsg_hip_stamps.so: $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h include/dsg.h
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed -DDSG_STAMPS=1 $(CSRC)/dsg_hip.cpp -o $@
+
 emu: $(EMU)
-$(EMU): $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h include/dsg.h tests/emu/shim/hip/hip_runtime.h tests/emu/emu_rt.cpp
+$(EMU): $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h include/dsg.h tests/emu/shim/hip/hip_runtime.h tests/emu/emu_rt.cpp
 	mkdir -p tests/emu/_build
 	$(HOSTCXX) -O2 -g -std=c++17 -fPIC -shared -pthread -Itests/emu/shim -DDSG_EMU=1 \
 	    $(CSRC)/dsg_hip.cpp tests/emu/emu_rt.cpp -o $@
 
 clean:
 	rm -f $(LIB) $(EMU)
-.PHONY: all emu clean
+.PHONY: all emu stamps clean

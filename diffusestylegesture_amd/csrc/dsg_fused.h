@@ -34,8 +34,8 @@ __global__ __launch_bounds__(256) void k_inloc(const InLocArgs g) {
     typedef typename P::elem elem;
     preload_kernargs(g);
     const LocArgs& a = g.loc;
-    if (blockIdx.x == gridDim.x - 1) {      // one EXTRA workgroup does the step bookkeeping (see StepCtl), off the critical path
-        if (g.ctl_upd && threadIdx.x == 0) step_advance_B(g.ctl_upd, g.st, g.n_tab);
+    if (blockIdx.z == gridDim.z - 1) {      // an EXTRA grid slice: its first workgroup does the step bookkeeping (see StepCtl), off the critical path
+        if (g.ctl_upd && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) step_advance_B(g.ctl_upd, g.st, g.n_tab);
         return;
     }
     constexpr int W2 = 2 * W, half = HD / 2, NP1 = W2 * half, NPI = (NP1 + 255) / 256;
@@ -44,10 +44,7 @@ __global__ __launch_bounds__(256) void k_inloc(const InLocArgs g) {
     __shared__ __attribute__((aligned(16))) float red[4][2][NL][64][4];      // per-wave partial accumulators
     __shared__ float rot[W2][HD + 1];
     __shared__ float sc[W][W2 + 2];
-    const int nW = a.T / W;
-    int id = blockIdx.x;
-    const int h = id % a.Hl; id /= a.Hl;
-    const int w = id % nW; const int b = id / nW;
+    const int h = blockIdx.x, w = blockIdx.y, b = blockIdx.z;            // grid (local heads, windows, batch [+1 bookkeeping])
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
     const int col0 = h * HD, ntok = a.T + 1, f0 = (w - 1) * W;
     const int* tp = a.ctl ? &a.ctl->tA : a.t_arr + b;      // select the ADDRESS, then one unconditional load
@@ -71,7 +68,7 @@ __global__ __launch_bounds__(256) void k_inloc(const InLocArgs g) {
         const int pos = w * W + p / half + 1;
         c2[i] = a.rcos[pos * half + p % half]; s2[i] = a.rsin[pos * half + p % half];
     }
-    const int mrow = (int)(((long long)(b * a.Hl + h)) / ((long long)a.B * a.Hl / a.mb));
+    const int mrow = fdiv(b * a.Hl + h, a.inv_mask_div);
     bool keep[NSI];
 #pragma unroll
     for (int i = 0; i < NSI; ++i) {
@@ -199,10 +196,7 @@ __global__ __launch_bounds__(256) void k_qkv_attn(const QkvAttnArgs g) {
     char* const qq = vt + HD * VP;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
-    int id = blockIdx.x;
-    const int nqt = (g.ntok + 15) >> 4;
-    const int qt = id % nqt; id /= nqt;
-    const int h = id % g.H; const int b = id / g.H;
+    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;          // grid (query tiles, heads, batch)
     const size_t row0 = (size_t)b * g.ntok;
 
     // ---- (1) this wave's weight fragments: n-tile (wave % NTH) of Q, K and V of head h -- issued first
@@ -398,10 +392,12 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
     constexpr int CH = DT >= 6 ? 4 : 8;              // fragments in flight per chunk (DT tiles each): bounded by the register file
     __shared__ __attribute__((aligned(16))) char a1[16 * XP];
     __shared__ float red[2][4][16];
+    DSG_STAMP(0, 0);
     preload_kernargs(g);
+    DSG_STAMP_SCALAR_WAIT(0, 8);
     const int NGH = g.ff / 64;
-    int ng, mt;
-    if (!xcd_map(NGH, g.MT, ng, mt)) return;
+    const int ng = xcd_ngroup(), mt = blockIdx.y;
+    if (ng >= NGH) return;
     const int m0 = mt * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
     const f32x4* wo = (const f32x4*)g.Wo + lane;
@@ -442,11 +438,13 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
             }
         }
         DSG_LOADS_ISSUED();
+        if (kb0 == 0) DSG_STAMP(0, 1);
 #pragma unroll
         for (int c = 0; c < CH; ++c)
             if (kb0 + c < KD) {
 #pragma unroll
                 for (int t = 0; t < DT; ++t) acc[t] = P::mma(bf[c][t], af[c], acc[t]);      // D[n 4lg+r][row lr]
+                if (c == 0 && kb0 == 0) DSG_STAMP(0, 2);
             }
     }
     // ---- residual + LayerNorm1 over whole rows (row lr: 4 lane groups x 4 waves hold its D values)
@@ -455,6 +453,7 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
     for (int t = 0; t < DT; ++t) { acc[t] = acc[t] + pbo[t] + pr[t]; s += (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]); }
     s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
     if (lg == 0) red[0][wave][lr] = s;
+    DSG_STAMP(0, 3);
     DSG_LDS_BARRIER();
     const float mean = ((red[0][0][lr] + red[0][1][lr]) + (red[0][2][lr] + red[0][3][lr])) / (float)D;
     float q = 0.f;
@@ -477,7 +476,9 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
         P::store4((elem*)(a1 + lr * XP) + n, y);
         acc[t] = y;                                   // written to X1 at the very end (keeps stores out of the vmcnt queue)
     }
+    DSG_STAMP(0, 4);
     DSG_LDS_BARRIER();
+    DSG_STAMP(0, 5);
     // ---- linear1 slice + GELU
     f32x4 c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
     if constexpr (KD <= CH) {
@@ -496,6 +497,7 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
                     c1 = P::mma(bf[c], *(const f32x4*)(a1 + lr * XP + ((kb0 + c) * P::KB + P::E * lg) * ES), c1);
         }
     }
+    DSG_STAMP(0, 6);
     if (m0 + lr < g.M) {
         f32x4 y;
 #pragma unroll
@@ -506,6 +508,7 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
 #pragma unroll
         for (int t = 0; t < DT; ++t) *(f32x4*)(g.X1 + (size_t)(m0 + lr) * D + (wave * DT + t) * 16 + 4 * lg) = acc[t];
     }
+    DSG_STAMP(0, 7);
 }
 
 }  // namespace dsg

@@ -535,9 +535,10 @@ static int launch_gemm(dsg_handle* h, GemmArgs g) {
     if (NG * WN * TNW != g.NT) return fail(DSG_E_INVALID, "gemm: NT not divisible by the workgroup tile");
     if (WK > 1 && (g.KS != 1 || g.KBtot % WK)) return fail(DSG_E_INVALID, "gemm: k-blocks not divisible by the wave split");
     if (g.KS < 1 || g.kb_per_split * g.KS < g.KBtot) return fail(DSG_E_INVALID, "gemm: split-K does not cover K");
-    // EPI_PARTIAL / EPI_OUT carry one extra workgroup for the step bookkeeping
+    // EPI_PARTIAL / EPI_OUT carry one extra grid row whose first workgroup does the step bookkeeping
     const int extra = (EPI == EPI_PARTIAL || EPI == EPI_OUT) ? 1 : 0;
-    hipLaunchKernelGGL((k_gemm<P, PRO, EPI, WN, WK, TNW>), dim3(xcd_grid(NG, g.MT * g.KS) + extra), dim3(256), 0, h->stream, g);
+    g.inv_ntok = fastdiv_inv(g.ntok); g.inv_hd = fastdiv_inv(g.hd);
+    hipLaunchKernelGGL((k_gemm<P, PRO, EPI, WN, WK, TNW>), dim3(xcd_grid_x(NG), g.MT + extra, g.KS), dim3(256), 0, h->stream, g);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -545,7 +546,7 @@ static int launch_gemm(dsg_handle* h, GemmArgs g) {
 template <class P, int HD, int NKT>
 static int launch_attn_t(dsg_handle* h, const AttnArgs& a) {
     const int nqt = cdiv(a.ntok, 16);
-    hipLaunchKernelGGL((k_attn<P, HD, NKT>), dim3(a.B * a.H * nqt), dim3(64), 0, h->stream, a);
+    hipLaunchKernelGGL((k_attn<P, HD, NKT>), dim3(nqt, a.H, a.B), dim3(64), 0, h->stream, a);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -580,7 +581,7 @@ static int launch_attn(dsg_handle* h, const AttnArgs& a) {
 template <class P, int HD, int NKT, int DD>
 static int launch_qkv_attn_t(dsg_handle* h, const QkvAttnArgs& a) {
     const int nqt = cdiv(a.ntok, 16);
-    hipLaunchKernelGGL((k_qkv_attn<P, HD, NKT, DD>), dim3(a.B * a.H * nqt), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL((k_qkv_attn<P, HD, NKT, DD>), dim3(nqt, a.H, a.B), dim3(256), 0, h->stream, a);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -597,7 +598,7 @@ static int launch_qkv_attn(dsg_handle* h, const QkvAttnArgs& a) {
 }
 template <class P, int DT>
 static int launch_mid_t(dsg_handle* h, const MidArgs& a) {
-    hipLaunchKernelGGL((k_mid<P, DT>), dim3(xcd_grid(a.ff / 64, a.MT)), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL((k_mid<P, DT>), dim3(xcd_grid_x(a.ff / 64), a.MT), dim3(256), 0, h->stream, a);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -639,7 +640,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
     memset(&la, 0, sizeof(la));
     la.partial = h->partial; la.KS = h->KSin; la.Min_pad = MTin * 16; la.Cf = h->Cf; la.TE2 = h->TE2; la.TE = h->TE;
     la.emb1 = h->emb1; la.ctl = c.use_ctr ? h->ctl : nullptr; la.t_arr = h->t_arr;
-    la.rcos = h->rcos; la.rsin = h->rsin; la.mask = h->mask; la.mb = h->mb; la.B = B; la.T = T; la.D = D; la.Hl = h->Hl;
+    la.rcos = h->rcos; la.rsin = h->rsin; la.mask = h->mask; la.mb = h->mb; la.inv_mask_div = fastdiv_inv((int)((long long)B * h->Hl / h->mb)); la.B = B; la.T = T; la.D = D; la.Hl = h->Hl;
     la.hd = h->hdl; la.W = h->W; la.X0 = h->X0; la.X0a = h->X0a;
     const int skip = h->dbg_skip;      // drop-one timing experiments: 1 in/loc, 2 QKV, 4 attention, 8 mid, 16 linear2, 32 head
     if (skip & 1) {
@@ -647,7 +648,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
         InLocArgs a;
         a.xs = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; a.Jp = h->Jp; a.Wp = h->Wp_in; a.KBtot = h->Jp / KB;
         a.loc = la; a.ctl_upd = c.use_ctr ? h->ctl : nullptr; a.st = step_tables(h); a.n_tab = h->n_run;
-        DSG_LOC_DISPATCH(k_inloc, a, dim3(B * (T / h->W) * h->Hl + 1));
+        DSG_LOC_DISPATCH(k_inloc, a, dim3(h->Hl, T / h->W, B + 1));
     } else {
         {   // k_in: partial[s] = xs[:, chunk s] . Wfold[:, chunk s]^T
             GemmArgs g = z;
@@ -658,7 +659,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
             g.ctl = c.use_ctr ? h->ctl : nullptr; g.st = step_tables(h); g.n_tab = h->n_run;
             CHK((launch_gemm<P, PRO_DIRECT, EPI_PARTIAL, 4, 1, 1>(h, g)));
         }
-        DSG_LOC_DISPATCH(k_loc, la, dim3(B * (T / h->W) * h->Hl));
+        DSG_LOC_DISPATCH(k_loc, la, dim3(h->Hl, T / h->W, B));
     }
     // k_qkv_attn is correct but, measured on MI355X (profiles/r01_c_*), its 192 KB per workgroup and 6x redundant K/V
     // GEMM make it slower (15 us) than LN+QKV followed by k_attn (6.2 + 4.6 us): opt-in only (DSG_FUSE_ATTN=1)
@@ -747,7 +748,7 @@ static int debug_launch(dsg_handle* h, int which, int i, int B) {
     memset(&la, 0, sizeof(la));
     la.partial = h->partial; la.KS = h->KSin; la.Min_pad = MTin * 16; la.Cf = h->Cf; la.TE2 = h->TE2; la.TE = h->TE;
     la.emb1 = h->emb1; la.ctl = nullptr; la.t_arr = h->t_arr;
-    la.rcos = h->rcos; la.rsin = h->rsin; la.mask = h->mask; la.mb = h->mb; la.B = B; la.T = T; la.D = D; la.Hl = h->Hl;
+    la.rcos = h->rcos; la.rsin = h->rsin; la.mask = h->mask; la.mb = h->mb; la.inv_mask_div = fastdiv_inv((int)((long long)B * h->Hl / h->mb)); la.B = B; la.T = T; la.D = D; la.Hl = h->Hl;
     la.hd = h->hdl; la.W = h->W; la.X0 = h->X0; la.X0a = h->X0a;
     if (which == 20) return debug_launch<P>(h, (i & 1) ? 1 : 4, i, B);                 // alternate 2 kernels
     if (which == 21) { const int seq[4] = {1, 4, 7, 9}; return debug_launch<P>(h, seq[i & 3], i, B); }   // 4 kernels
@@ -769,7 +770,7 @@ static int debug_launch(dsg_handle* h, int which, int i, int B) {
         case 5: {
             AttnArgs a; a.q = h->q; a.k = h->k; a.vt = h->vt; a.out = h->attn; a.B = B; a.H = h->H; a.ntok = ntok;
             a.Tp = h->Tp; a.D = D; return launch_attn<P>(h, a); }
-        case 6: DSG_LOC_DISPATCH(k_loc, la, dim3(B * (T / h->W) * h->Hl)); return 0;
+        case 6: DSG_LOC_DISPATCH(k_loc, la, dim3(h->Hl, T / h->W, B)); return 0;
         case 7: {
             GemmArgs g = z; g.M = Min; g.MT = MTin; g.NT = D / 16; g.KBtot = h->Jp / KB; g.KS = h->KSin; g.Wp = h->Wp_in;
             g.kb_per_split = cdiv(g.KBtot, g.KS); g.A = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; g.lda = h->Jp;
@@ -795,7 +796,7 @@ static int debug_launch(dsg_handle* h, int which, int i, int B) {
         case 12: {
             InLocArgs a; a.xs = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; a.Jp = h->Jp; a.Wp = h->Wp_in;
             a.KBtot = h->Jp / KB; a.loc = la; a.ctl_upd = nullptr; a.st = step_tables(h); a.n_tab = 1;
-            DSG_LOC_DISPATCH(k_inloc, a, dim3(B * (T / h->W) * h->Hl + 1)); return 0; }
+            DSG_LOC_DISPATCH(k_inloc, a, dim3(h->Hl, T / h->W, B + 1)); return 0; }
         case 13: case 14: case 113: case 114: {     // 1xx = prepare (upload the argument blocks), xx = launch
             static GemmArgs* dargs = nullptr;
             if (!dargs) HIPCHK(hipMalloc((void**)&dargs, 16 * sizeof(GemmArgs)));
@@ -806,12 +807,12 @@ static int debug_launch(dsg_handle* h, int which, int i, int B) {
                 g.NT = D / 16; g.KBtot = D / KB; g.Wp = ly.Wo; g.bias = ly.bo; g.A = h->attn; g.lda = D;
                 g.out = (i & 1) ? h->pre1 : h->pre2; g.ldo = D; g.R = h->X0; g.kb_per_split = g.KBtot;
                 if (prep) { HIPCHK(hipMemcpy(dargs + (i % 16), &g, sizeof(g), hipMemcpyHostToDevice)); return 0; }
-                hipLaunchKernelGGL((k_gemm_p<P, PRO_DIRECT, EPI_RESID, 4, 1, 1>), dim3(xcd_grid(g.NT / 4, MT)), dim3(256), 0, h->stream, dargs + (i % 16));
+                hipLaunchKernelGGL((k_gemm_p<P, PRO_DIRECT, EPI_RESID, 4, 1, 1>), dim3(xcd_grid_x(g.NT / 4), MT), dim3(256), 0, h->stream, dargs + (i % 16));
             } else {
                 g.NT = 3 * D / 16; g.KBtot = D / KB; g.Wp = ly.Wqkv; g.bias = ly.bqkv; g.q = h->q; g.k = h->k; g.vt = h->vt;
                 g.X = h->pre2; g.ln_g = ly.g2; g.ln_b = ly.be2; g.Xn = h->Xn; g.kb_per_split = g.KBtot;
                 if (prep) { HIPCHK(hipMemcpy(dargs + (i % 16), &g, sizeof(g), hipMemcpyHostToDevice)); return 0; }
-                hipLaunchKernelGGL((k_gemm_p<P, PRO_LN, EPI_QKV, 4, 1, 1>), dim3(xcd_grid(g.NT / 4, MT)), dim3(256), 0, h->stream, dargs + (i % 16));
+                hipLaunchKernelGGL((k_gemm_p<P, PRO_LN, EPI_QKV, 4, 1, 1>), dim3(xcd_grid_x(g.NT / 4), MT), dim3(256), 0, h->stream, dargs + (i % 16));
             }
             HIPCHK(hipGetLastError());
             return 0; }
@@ -837,6 +838,19 @@ extern "C" int dsg_debug_read(dsg_handle* h, const char* name, void* out, long l
     size_t n = std::min<size_t>(it->second.second, (size_t)max_bytes);
     HIPCHK(hipMemcpy(out, it->second.first, n, hipMemcpyDeviceToHost));
     if (n_bytes) *n_bytes = (long long)n;
+    return 0;
+}
+
+// cycle stamps of the last launch of each step kernel (only in the -DDSG_STAMPS build; zeros otherwise)
+extern "C" int dsg_debug_stamps(dsg_handle* h, long long* out, int n) {
+    if (!h || !out) return fail(DSG_E_INVALID, "null");
+    memset(out, 0, sizeof(long long) * n);
+#ifdef DSG_STAMPS
+    HIPCHK(hipStreamSynchronize(h->stream));
+    long long tmp[8 * 16];
+    HIPCHK(hipMemcpyFromSymbol(tmp, HIP_SYMBOL(dsg::g_stamps), sizeof(tmp)));
+    memcpy(out, tmp, sizeof(long long) * std::min(n, 8 * 16));
+#endif
     return 0;
 }
 

@@ -103,6 +103,21 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // (seen in the ISA as L w L w L w ...; the LayerNorm GEMMs had 17-19 of them).  LOADS_ISSUED() additionally stops the
 // scheduler from sinking loads below the first use.
 #define DSG_LOADS_ISSUED() __builtin_amdgcn_sched_barrier(0)
+// Optional cycle stamps (make stamps -> libdsg_hip_stamps.so, tools/stamps.py): wave 0 of workgroup 8 records
+// s_memtime at a few phase boundaries of the step kernels.  Compiled out of the product library.
+#ifdef DSG_STAMPS
+__device__ long long g_stamps[8][16];
+#define DSG_STAMP(k, i)                                                                               \
+    do {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        if (blockIdx.x == 0 && blockIdx.y == 1 && blockIdx.z == 0 && threadIdx.x == 0) g_stamps[k][i] = __builtin_readcyclecounter();     \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    } while (0)
+#define DSG_STAMP_SCALAR_WAIT(k, i) do { __builtin_amdgcn_s_waitcnt(0xC07F); DSG_STAMP(k, i); } while (0)
+#else
+#define DSG_STAMP(k, i) ((void)0)
+#define DSG_STAMP_SCALAR_WAIT(k, i) ((void)0)
+#endif
 // Workgroup barrier for LDS hand-offs only.  __syncthreads() also drains every outstanding VECTOR memory operation
 // (s_waitcnt vmcnt(0)): in-flight weight loads and the acknowledgement of global stores issued before it.  Nothing in
 // these kernels communicates through global memory inside a launch, so the fences are restricted to the LDS address
@@ -234,6 +249,7 @@ struct GemmArgs {
     // EPI_QKV
     void* q; void* k; void* vt;
     int ntok, Tp, H, hd;    // tokens per batch element, padded tokens, heads, head dim
+    unsigned inv_ntok, inv_hd;   // fastdiv_inv(ntok), fastdiv_inv(hd)
     // EPI_OUT
     int out_mode;           // OUT_FORWARD / OUT_DDPM / OUT_DDIM
     int J, Jp, Jq, T;       // pose dim, padded (row pitch of xs), noise pitch, frames
@@ -251,18 +267,17 @@ struct GemmArgs {
     int const_noise;
 };
 
-// block -> (n_group, r) with n_group pinned to an XCD (block b is observed to run on XCD b % 8), so a weight
-// slice is always fetched through the same XCD's L2 and stays resident there across the 1000 steps.
-__device__ __forceinline__ bool xcd_map(int NG, int R, int& ng, int& r) {
-    const int id = blockIdx.x;
-    const int xcd = id & 7, j = id >> 3;
-    const int cmax = (NG + 7) >> 3;
-    const int loc = j % cmax;
-    r = j / cmax;
-    ng = xcd + 8 * loc;
-    return ng < NG && r < R;
-}
-__host__ __device__ inline int xcd_grid(int NG, int R) { return 8 * ((NG + 7) / 8) * R; }
+// Workgroup -> n-group with the n-group pinned to an XCD (workgroups are dealt round-robin to the 8 XCDs in linear
+// launch order; gridDim.x is a multiple of 8, so blockIdx.x & 7 is the XCD): a weight slice is always fetched through
+// the same XCD's L2 and stays resident there across the 1000 steps.  Row tile / k-split come from blockIdx.y / .z --
+// the hardware hands them over for free, whereas decomposing a flat id costs integer divisions (~40 instructions
+// each, and at one wave per SIMD every instruction is ~2 ns of critical path).
+__device__ __forceinline__ int xcd_ngroup() { return (int)(blockIdx.x & 7) + 8 * (int)(blockIdx.x >> 3); }
+__host__ __device__ inline int xcd_grid_x(int NG) { return 8 * ((NG + 7) / 8); }
+
+// x / d for 0 <= x, x * d < 2^32, as one v_mul_hi_u32: inv = ceil(2^32 / d) (host: fastdiv_inv; d == 1 -> inv 0)
+__device__ __forceinline__ int fdiv(int x, unsigned inv) { return inv ? (int)__umulhi((unsigned)x, inv) : x; }
+__host__ __device__ inline unsigned fastdiv_inv(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1u) / (unsigned)d); }
 
 template <class P>
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -326,22 +341,23 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
     __shared__ __attribute__((aligned(16))) char lds_a[PRO == PRO_LN ? 16 * (512 * 4 + 16) : 16];
     __shared__ __attribute__((aligned(16))) float lds_red[WK > 1 ? (WK - 1) * WN * TNW * 64 * 4 : 4];
 
+    DSG_STAMP(1 + EPI, 0);
     preload_kernargs(g);
+    DSG_STAMP_SCALAR_WAIT(1 + EPI, 6);
     const int NG = g.NT / (WN * TNW);
+    const int ng = xcd_ngroup(), mt = blockIdx.y, ks = blockIdx.z;
     if constexpr (EPI == EPI_PARTIAL || EPI == EPI_OUT) {
-        // step bookkeeping runs in ONE EXTRA workgroup (the last block id), concurrently with the real work and off
-        // every critical path; see StepCtl for why this is race free
-        if (blockIdx.x == gridDim.x - 1) {
-            if (g.ctl && threadIdx.x == 0) {
+        // step bookkeeping runs in ONE EXTRA workgroup (first block of an extra grid row), concurrently with the real
+        // work and off every critical path; see StepCtl for why this is race free
+        if (mt == g.MT) {
+            if (g.ctl && blockIdx.x == 0 && ks == 0 && threadIdx.x == 0) {
                 if constexpr (EPI == EPI_PARTIAL) step_advance_B(g.ctl, g.st, g.n_tab);
                 else if (g.out_mode != OUT_FORWARD) step_advance_A(g.ctl, g.st, g.n_tab);
             }
             return;
         }
     }
-    int ng, r;
-    if (!xcd_map(NG, g.MT * g.KS, ng, r)) return;
-    const int mt = r % g.MT, ks = r / g.MT;
+    if (ng >= NG) return;
     const int m0 = mt * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
     const int wn = wave % WN, wk = wave / WN;
@@ -410,7 +426,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
             pbs[t] = g.bias[n0 + lr];
         } else if constexpr (EPI == EPI_OUT) {
             const int m = m0 + lr, j0 = n0 + 4 * lg;
-            const int b = m / g.ntok, sx = m % g.ntok;
+            const int b = fdiv(m, g.inv_ntok), sx = m - b * g.ntok;
             ovalid[t] = m < g.M && sx > 0 && j0 < g.J;
             pb[t] = *(const f32x4*)(g.bias + j0);
             {   // x_t: unconditional load from a clamped (always valid) row; unused when the lane is not `ovalid`
@@ -448,6 +464,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
         else ln_rows<P, 0>(g, m0, tid, lds_a, pitch, v);
         DSG_LDS_BARRIER();
     }
+    DSG_STAMP(1 + EPI, 2);
 
     for (int kb0 = kb_lo; kb0 < kb_hi; kb0 += CH) {
         f32x4 af[CH];
@@ -458,6 +475,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
             else af[c] = *(const f32x4*)(lds_a + lr * pitch + (kb * P::KB + P::E * lg) * ES);
         }
         DSG_LOADS_ISSUED();
+        if (kb0 == kb_lo) DSG_STAMP(1 + EPI, 1);
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const bool live = kb0 + c < kb_hi;              // wave-uniform; out-of-range blocks contribute zeros
@@ -465,9 +483,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
 #pragma unroll
             for (int t = 0; t < TNW; ++t)
                 acc[t] = swapped[t] ? P::mma(bf[c][t], a, acc[t]) : P::mma(a, bf[c][t], acc[t]);
+            if (c == 0 && kb0 == kb_lo) DSG_STAMP(1 + EPI, 3);
         }
         if (kb0 + CH < kb_hi) load_b(kb0 + CH);
     }
+    DSG_STAMP(1 + EPI, 4);
 
     // The normalised rows go back to global memory only now: a global store issued before the MFMA phase would sit
     // in the same vmcnt queue as the weight loads (stores and loads retire out of order with each other, so the
@@ -517,12 +537,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
             }
         } else if constexpr (EPI == EPI_QKV) {
             const int Dm = g.H * g.hd;
-            const int which = n0 / Dm, nn = n0 % Dm;
-            const int head = nn / g.hd, d0 = nn % g.hd;
+            const int which = (n0 >= Dm) + (n0 >= 2 * Dm), nn = n0 - which * Dm;
+            const int head = fdiv(nn, g.inv_hd), d0 = nn - head * g.hd;
             if (swapped[t]) {                    // Q or K: [B][H][Tp][hd], 4 consecutive dims of one token
                 const int m = m0 + lr;
                 if (m < g.M) {
-                    const int b = m / g.ntok, sx = m % g.ntok;
+                    const int b = fdiv(m, g.inv_ntok), sx = m - b * g.ntok;
                     elem* dst = (elem*)(which == 0 ? g.q : g.k) + (((size_t)b * g.H + head) * g.Tp + sx) * g.hd + d0 + 4 * lg;
                     P::store4(dst, acc[t] + pb[t]);
                 }
@@ -531,14 +551,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
                 for (int e = 0; e < 4; ++e) {
                     const int m = m0 + 4 * lg + e;
                     if (m < g.M) {
-                        const int b = m / g.ntok, sx = m % g.ntok;
+                        const int b = fdiv(m, g.inv_ntok), sx = m - b * g.ntok;
                         ((elem*)g.vt)[(((size_t)b * g.H + head) * g.hd + d0 + lr) * g.Tp + sx] = P::cvt(acc[t][e] + pbs[t]);
                     }
                 }
             }
         } else if constexpr (EPI == EPI_OUT) {
             const int m = m0 + lr, j0 = n0 + 4 * lg;
-            const int b = m / g.ntok, sx = m % g.ntok;
+            const int b = fdiv(m, g.inv_ntok), sx = m - b * g.ntok;
             if (ovalid[t]) {
                 const int f = sx - 1;
                 const f32x4 x0 = acc[t] + pb[t];
@@ -572,6 +592,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
             }
         }
     }
+    DSG_STAMP(1 + EPI, 5);
 }
 
 template <class P, int PRO, int EPI, int WN, int WK, int TNW>
@@ -597,6 +618,7 @@ struct LocArgs {
     const float* rsin;
     const unsigned char* mask;   // [mb][T] key mask (1 = keep)
     int mb;
+    unsigned inv_mask_div;       // fastdiv_inv(B * Hl / mb): (b, head) -> mask row
     int B, T, D, Hl, hd, W;   // hd / W must match the kernel's template arguments
     float* X0;              // [M_pad][D] fp32, row = b*(T+1) + 1 + f ; row b*(T+1) = token
     void* X0a;              // same in P::elem (GEMM operand copy)
@@ -665,10 +687,7 @@ __global__ __launch_bounds__(256) void k_loc(const LocArgs a) {
     __shared__ float rot[W2][HD + 1];
     __shared__ float sc[W][W2 + 2];
     preload_kernargs(a);
-    const int nW = a.T / W;
-    int id = blockIdx.x;
-    const int h = id % a.Hl; id /= a.Hl;
-    const int w = id % nW; const int b = id / nW;
+    const int h = blockIdx.x, w = blockIdx.y, b = blockIdx.z;            // grid (local heads, windows, batch)
     const int tid = threadIdx.x;
     const int* tp = a.ctl ? &a.ctl->tA : a.t_arr + b;      // select the ADDRESS, then one unconditional load
     const int t = *tp;
@@ -698,7 +717,7 @@ __global__ __launch_bounds__(256) void k_loc(const LocArgs a) {
         const int pos = w * W + p / half + 1;
         c2[i] = a.rcos[pos * half + p % half]; s2[i] = a.rsin[pos * half + p % half];
     }
-    const int mrow = (int)(((long long)(b * a.Hl + h)) / ((long long)a.B * a.Hl / a.mb));
+    const int mrow = fdiv(b * a.Hl + h, a.inv_mask_div);
     bool keep[NSI];
 #pragma unroll
     for (int i = 0; i < NSI; ++i) {
@@ -753,10 +772,7 @@ __global__ __launch_bounds__(64) void k_attn(const AttnArgs a) {
     constexpr int KD = HD / P::KB;                   // k-blocks over the head dim
     preload_kernargs(a);
     const int lane = threadIdx.x, lr = lane & 15, lg = lane >> 4;
-    int id = blockIdx.x;
-    const int nqt = (a.ntok + 15) >> 4;
-    const int qt = id % nqt; id /= nqt;
-    const int h = id % a.H; const int b = id / a.H;
+    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;          // grid (query tiles, heads, batch)
     const size_t bh = (size_t)b * a.H + h;
     const elem* Q = (const elem*)a.q + bh * a.Tp * HD;
     const elem* K = (const elem*)a.k + bh * a.Tp * HD;

@@ -74,6 +74,7 @@ static inline void sincospif(float x, float* s, float* c) {
     *s = (float)std::sin(a);
     *c = (float)std::cos(a);
 }
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }
 
