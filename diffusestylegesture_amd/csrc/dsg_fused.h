@@ -404,48 +404,58 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
     const f32x4* w1 = (const f32x4*)g.W1 + lane;
     const elem* arow = (const elem*)g.A + (size_t)(m0 + lr) * D + P::E * lg;
 
-    // ---- epilogue operands first
-    f32x4 pbo[DT], pr[DT], pg[DT], pbt[DT];
-#pragma unroll
-    for (int t = 0; t < DT; ++t) {
-        const int n = (wave * DT + t) * 16 + 4 * lg;
-        pbo[t] = *(const f32x4*)(g.bo + n);
-        pr[t] = *(const f32x4*)(g.R + (size_t)(m0 + lr) * D + n);
-        pg[t] = *(const f32x4*)(g.ln_g + n);
-        pbt[t] = *(const f32x4*)(g.ln_b + n);
-    }
-    const int n1t = ng * 4 + wave;                   // this wave's 16-col tile of the hidden layer
-    const f32x4 pb1 = *(const f32x4*)(g.b1 + n1t * 16 + 4 * lg);
+    // ---- out_proj as a software pipeline.  The load phase of this kernel is bound by the CU's texture-address path
+    //      (~65 x 1 KB wave loads per wave, 4 waves: measured ~90 cycles per load instruction), so the order of issue IS
+    //      the schedule: weight / activation fragments first, PD k-blocks ahead of the MFMA that consumes them (the MFMAs
+    //      then run in the shadow of the remaining load issue), and the operands of the later phases (bias + residual,
+    //      LayerNorm scale/shift, linear1 fragments) last, in the order they are needed.
+    constexpr int PD0 = DT >= 6 ? 2 : 4;             // k-blocks in flight ahead of the MFMA (register budget)
+    constexpr int PD = PD0 < KD ? PD0 : KD;
+    f32x4 af[KD], bf[KD][DT];
+    f32x4 pbo[DT], pr[DT], pg[DT], pbt[DT], pb1;
     f32x4 w1f[KD <= CH ? KD : 1];
-    if constexpr (KD <= CH) {
+    const int n1t = ng * 4 + wave;                   // this wave's 16-col tile of the hidden layer
 #pragma unroll
-        for (int kb = 0; kb < KD; ++kb) w1f[kb] = w1[((size_t)n1t * KD + kb) * 64];
+    for (int kb = 0; kb < PD; ++kb) {
+        af[kb] = *(const f32x4*)(arow + (size_t)kb * P::KB);
+#pragma unroll
+        for (int t = 0; t < DT; ++t) bf[kb][t] = wo[((size_t)(wave * DT + t) * KD + kb) * 64];
     }
-
-    // ---- out_proj: this wave's DT tiles x all of K
     f32x4 acc[DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kb0 = 0; kb0 < KD; kb0 += CH) {
-        f32x4 af[CH], bf[CH][DT];
+    for (int kb = 0; kb < KD; ++kb) {
+        if (kb + PD < KD) {
+            af[kb + PD] = *(const f32x4*)(arow + (size_t)(kb + PD) * P::KB);
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            if (kb0 + c < KD) {
-                af[c] = *(const f32x4*)(arow + (size_t)(kb0 + c) * P::KB);
+            for (int t = 0; t < DT; ++t) bf[kb + PD][t] = wo[((size_t)(wave * DT + t) * KD + kb + PD) * 64];
+        }
+        if (kb + PD == KD) {                          // all fragments requested: now the operands of the later phases
 #pragma unroll
-                for (int t = 0; t < DT; ++t) bf[c][t] = wo[((size_t)(wave * DT + t) * KD + kb0 + c) * 64];
+            for (int t = 0; t < DT; ++t) {
+                const int n = (wave * DT + t) * 16 + 4 * lg;
+                pbo[t] = *(const f32x4*)(g.bo + n);
+                pr[t] = *(const f32x4*)(g.R + (size_t)(m0 + lr) * D + n);
             }
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                const int n = (wave * DT + t) * 16 + 4 * lg;
+                pg[t] = *(const f32x4*)(g.ln_g + n);
+                pbt[t] = *(const f32x4*)(g.ln_b + n);
+            }
+            if constexpr (KD <= CH) {
+#pragma unroll
+                for (int k2 = 0; k2 < KD; ++k2) w1f[k2] = w1[((size_t)n1t * KD + k2) * 64];
+            }
+            pb1 = *(const f32x4*)(g.b1 + n1t * 16 + 4 * lg);
         }
         DSG_LOADS_ISSUED();
-        if (kb0 == 0) DSG_STAMP(0, 1);
+        if (kb == 0) DSG_STAMP(0, 1);
 #pragma unroll
-        for (int c = 0; c < CH; ++c)
-            if (kb0 + c < KD) {
-#pragma unroll
-                for (int t = 0; t < DT; ++t) acc[t] = P::mma(bf[c][t], af[c], acc[t]);      // D[n 4lg+r][row lr]
-                if (c == 0 && kb0 == 0) DSG_STAMP(0, 2);
-            }
+        for (int t = 0; t < DT; ++t) acc[t] = P::mma(bf[kb][t], af[kb], acc[t]);      // D[n 4lg+r][row lr]
+        if (kb == 0) DSG_STAMP(0, 2);
+        DSG_LOADS_ISSUED();
     }
     // ---- residual + LayerNorm1 over whole rows (row lr: 4 lane groups x 4 waves hold its D values)
     float s = 0.f;

@@ -62,6 +62,7 @@ static inline int emu_update_dpp(int src, int ctrl) {
 }
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rmask, bmask, bc) emu_update_dpp(src, ctrl)
 #define __expf(x) std::exp((float)(x))
+#define __builtin_amdgcn_rcpf(x) (1.0f / (float)(x))
 static inline float __shfl_xor(float v, int m) {
     return __builtin_bit_cast(float, emu::shfl_xor_u32(__builtin_bit_cast(unsigned, v), m));
 }
