@@ -382,6 +382,84 @@ struct MidArgs {
     int M, MT, ff;
 };
 
+// Shared tail of k_mid / k_attn_mid: acc = out_proj result tiles of this wave (D[n = 4*lg + r][row = lr]); adds bias +
+// residual, LayerNorm1 over whole rows (the 4 waves hold a row between them), stages the normalised rows in LDS,
+// linear1 slice + GELU -> hidden, X1 written by hidden-slice 0.
+template <class P, int DT>
+__device__ __forceinline__ void mid_tail(const MidArgs& g, f32x4 (&acc)[DT], const f32x4 (&pbo)[DT], const f32x4 (&pr)[DT],
+                                         const f32x4 (&pg)[DT], const f32x4 (&pbt)[DT], const f32x4 pb1,
+                                         const f32x4 (&w1f)[(DT * 64 / P::KB) <= (DT >= 6 ? 4 : 8) ? (DT * 64 / P::KB) : 1],
+                                         const f32x4* w1, char* a1, float (&red)[2][4][16], int m0, int ng, int n1t, int wave,
+                                         int lr, int lg) {
+    typedef typename P::elem elem;
+    constexpr int ES = (int)sizeof(elem);
+    constexpr int D = DT * 64;
+    constexpr int KD = D / P::KB;
+    constexpr int XP = D * ES + 16;
+    constexpr int CH = DT >= 6 ? 4 : 8;
+    // ---- residual + LayerNorm1 over whole rows (row lr: 4 lane groups x 4 waves hold its D values)
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) { acc[t] = acc[t] + pbo[t] + pr[t]; s += (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]); }
+    s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+    if (lg == 0) red[0][wave][lr] = s;
+    DSG_STAMP(0, 3);
+    DSG_LDS_BARRIER();
+    const float mean = ((red[0][0][lr] + red[0][1][lr]) + (red[0][2][lr] + red[0][3][lr])) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = acc[t][e] - mean; q += d * d; }
+    q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+    if (lg == 0) red[1][wave][lr] = q;
+    DSG_LDS_BARRIER();
+    const float var = ((red[1][0][lr] + red[1][1][lr]) + (red[1][2][lr] + red[1][3][lr])) / (float)D;
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    const bool wr = ng == 0 && (m0 + lr) < g.M;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+        const int n = (wave * DT + t) * 16 + 4 * lg;
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = (acc[t][e] - mean) * rstd * pg[t][e] + pbt[t][e];
+        P::store4((elem*)(a1 + lr * XP) + n, y);
+        acc[t] = y;                                   // written to X1 at the very end (keeps stores out of the vmcnt queue)
+    }
+    DSG_STAMP(0, 4);
+    DSG_LDS_BARRIER();
+    DSG_STAMP(0, 5);
+    // ---- linear1 slice + GELU
+    f32x4 c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (KD <= CH) {
+#pragma unroll
+        for (int kb = 0; kb < KD; ++kb)
+            c1 = P::mma(w1f[kb], *(const f32x4*)(a1 + lr * XP + (kb * P::KB + P::E * lg) * ES), c1);
+    } else {
+#pragma unroll
+        for (int kb0 = 0; kb0 < KD; kb0 += CH) {
+            f32x4 bf[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) if (kb0 + c < KD) bf[c] = w1[((size_t)n1t * KD + kb0 + c) * 64];
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                if (kb0 + c < KD)
+                    c1 = P::mma(bf[c], *(const f32x4*)(a1 + lr * XP + ((kb0 + c) * P::KB + P::E * lg) * ES), c1);
+        }
+    }
+    DSG_STAMP(0, 6);
+    if (m0 + lr < g.M) {
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = gelu_erf<P>(c1[e] + pb1[e]);
+        P::store4((elem*)g.hidden + (size_t)(m0 + lr) * g.ff + n1t * 16 + 4 * lg, y);
+    }
+    if (wr) {
+#pragma unroll
+        for (int t = 0; t < DT; ++t) *(f32x4*)(g.X1 + (size_t)(m0 + lr) * D + (wave * DT + t) * 16 + 4 * lg) = acc[t];
+    }
+}
+
 template <class P, int DT>      // DT = D / 64 : 16-col tiles of the out_proj output per wave
 __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
     typedef typename P::elem elem;
@@ -457,67 +535,210 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
         if (kb == 0) DSG_STAMP(0, 2);
         DSG_LOADS_ISSUED();
     }
-    // ---- residual + LayerNorm1 over whole rows (row lr: 4 lane groups x 4 waves hold its D values)
-    float s = 0.f;
+    mid_tail<P, DT>(g, acc, pbo, pr, pg, pbt, pb1, w1f, w1, a1, red, m0, ng, n1t, wave, lr, lg);
+    DSG_STAMP(0, 7);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// k_attn_mid: self-attention of the workgroup's 16 query rows (wave = head, H == 4, one batch element) staged in LDS,
+// then exactly k_mid (out_proj + residual + LayerNorm1 + linear1 slice + GELU).  One launch less per layer: at batch 1
+// a dependent launch costs ~3 us before any work, the attention itself ~1 us, and -- the 16 hidden-slices of a row tile
+// recompute it -- idle CUs are free.  The load phase is bound by the CU's texture-address path, so the issue order is
+// the schedule: Q/K/V^T fragments, then the first out_proj weight k-blocks (in flight during the softmax), then the
+// operands of the later phases in the order they are needed.
+// ---------------------------------------------------------------------------------------------------------
+struct AttnMidArgs {
+    MidArgs mid;                                      // mid.A is unused (the attention output never leaves LDS)
+    const void* q; const void* k; const void* vt;     // [H][Tp][hd], [H][Tp][hd], [H][hd][Tp]  (batch element 0)
+    int ntok, Tp;
+};
+
+template <class P, int DT, int NKT>      // D = 64 DT, H = 4, hd = 16 DT, Tp = 16 NKT
+__global__ __launch_bounds__(256) void k_attn_mid(const AttnMidArgs ga) {
+    typedef typename P::elem elem;
+    constexpr int ES = (int)sizeof(elem);
+    constexpr int D = DT * 64, HD = DT * 16;
+    constexpr int KD = D / P::KB;                    // k-blocks of the out_proj / linear1 reductions
+    constexpr int KDH = HD / P::KB;                  // k-blocks over the head dim
+    constexpr int XP = D * ES + 16;
+    constexpr int CH = DT >= 6 ? 4 : 8;
+    constexpr int ND = HD / 16;
+    constexpr int NVF = P::E == 4 ? NKT : NKT / 2;   // PV k-blocks
+    constexpr int PD = 4;                            // out_proj k-blocks in flight ahead of the MFMA
+    constexpr int PDA = KD <= 8 ? KD : PD;           // ... of which this many are requested before the attention math
+    static_assert(KDH >= 1 && PDA >= PD && PDA <= KD, "shape");
+    static_assert(P::E == 4 || (NKT % 2) == 0, "bf16 pairs key tiles");
+    __shared__ __attribute__((aligned(16))) char aT[16 * XP];      // attention output rows (MFMA element type)
+    __shared__ __attribute__((aligned(16))) char a1[16 * XP];      // LayerNorm1 output rows
+    __shared__ float red[2][4][16];
+    DSG_STAMP(0, 0);
+    preload_kernargs(ga);
+    const MidArgs& g = ga.mid;
+    const int NGH = g.ff / 64;
+    const int ng = xcd_ngroup(), mt = blockIdx.y;
+    if (ng >= NGH) return;
+    const int m0 = mt * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
+    const f32x4* wo = (const f32x4*)g.Wo + lane;
+    const f32x4* w1 = (const f32x4*)g.W1 + lane;
+    const int h = wave;                              // head of this wave
+    const elem* Q = (const elem*)ga.q + (size_t)h * ga.Tp * HD;
+    const elem* K = (const elem*)ga.k + (size_t)h * ga.Tp * HD;
+    const elem* VT = (const elem*)ga.vt + (size_t)h * HD * ga.Tp;
+
+    // ---- (1) attention operand fragments
+    f32x4 qf[KDH], kf[NKT][KDH], vfr[ND][NVF];
 #pragma unroll
-    for (int t = 0; t < DT; ++t) { acc[t] = acc[t] + pbo[t] + pr[t]; s += (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]); }
-    s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
-    if (lg == 0) red[0][wave][lr] = s;
-    DSG_STAMP(0, 3);
-    DSG_LDS_BARRIER();
-    const float mean = ((red[0][0][lr] + red[0][1][lr]) + (red[0][2][lr] + red[0][3][lr])) / (float)D;
-    float q = 0.f;
+    for (int kb = 0; kb < KDH; ++kb) qf[kb] = *(const f32x4*)(Q + (size_t)(m0 + lr) * HD + kb * P::KB + P::E * lg);
 #pragma unroll
-    for (int t = 0; t < DT; ++t)
+    for (int nt = 0; nt < NKT; ++nt)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const float d = acc[t][e] - mean; q += d * d; }
-    q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
-    if (lg == 0) red[1][wave][lr] = q;
-    DSG_LDS_BARRIER();
-    const float var = ((red[1][0][lr] + red[1][1][lr]) + (red[1][2][lr] + red[1][3][lr])) / (float)D;
-    const float rstd = 1.0f / sqrtf(var + 1e-5f);
-    const bool wr = ng == 0 && (m0 + lr) < g.M;
+        for (int kb = 0; kb < KDH; ++kb) kf[nt][kb] = *(const f32x4*)(K + (size_t)(nt * 16 + lr) * HD + kb * P::KB + P::E * lg);
 #pragma unroll
-    for (int t = 0; t < DT; ++t) {
-        const int n = (wave * DT + t) * 16 + 4 * lg;
-        f32x4 y;
+    for (int dt = 0; dt < ND; ++dt) {
+        const elem* vrow = VT + (size_t)(dt * 16 + lr) * ga.Tp;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = (acc[t][e] - mean) * rstd * pg[t][e] + pbt[t][e];
-        P::store4((elem*)(a1 + lr * XP) + n, y);
-        acc[t] = y;                                   // written to X1 at the very end (keeps stores out of the vmcnt queue)
-    }
-    DSG_STAMP(0, 4);
-    DSG_LDS_BARRIER();
-    DSG_STAMP(0, 5);
-    // ---- linear1 slice + GELU
-    f32x4 c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if constexpr (KD <= CH) {
-#pragma unroll
-        for (int kb = 0; kb < KD; ++kb)
-            c1 = P::mma(w1f[kb], *(const f32x4*)(a1 + lr * XP + (kb * P::KB + P::E * lg) * ES), c1);
-    } else {
-#pragma unroll
-        for (int kb0 = 0; kb0 < KD; kb0 += CH) {
-            f32x4 bf[CH];
-#pragma unroll
-            for (int c = 0; c < CH; ++c) if (kb0 + c < KD) bf[c] = w1[((size_t)n1t * KD + kb0 + c) * 64];
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-                if (kb0 + c < KD)
-                    c1 = P::mma(bf[c], *(const f32x4*)(a1 + lr * XP + ((kb0 + c) * P::KB + P::E * lg) * ES), c1);
+        for (int kb = 0; kb < NVF; ++kb) {
+            if constexpr (P::E == 4) {
+                vfr[dt][kb] = *(const f32x4*)(vrow + kb * 16 + 4 * lg);
+            } else {
+                const f32x2 v0 = *(const f32x2*)(vrow + (2 * kb) * 16 + 4 * lg);        // 4 bf16 = 8 bytes
+                const f32x2 v1 = *(const f32x2*)(vrow + (2 * kb + 1) * 16 + 4 * lg);
+                vfr[dt][kb] = (f32x4){v0[0], v0[1], v1[0], v1[1]};
+            }
         }
     }
-    DSG_STAMP(0, 6);
-    if (m0 + lr < g.M) {
+    DSG_LOADS_ISSUED();
+    DSG_STAMP(0, 9);
+    // ---- (2) everything the later phases need is requested WHILE the attention math runs, a few loads per slot: a wave
+    //      issues in order, and a burst of ~70 loads stalls it in the issue stage for as long as the texture path needs
+    //      to drain them (~100 cycles each with 4 waves loading) -- time in which no softmax instruction can run.
+    //      Spread between the softmax stages the same loads cost nothing and have arrived when out_proj starts.
+    f32x4 bf[KD][DT];
+    f32x4 pbo[DT], pr[DT], pg[DT], pbt[DT], pb1;
+    f32x4 w1f[KD <= CH ? KD : 1];
+    const int n1t = ng * 4 + wave;                   // this wave's 16-col tile of the hidden layer
+    constexpr int G = PDA + 4;                       // load groups: PDA weight k-blocks, bias+residual, LN scale+shift, linear1 fragments, linear1 bias
+    constexpr int S = 2 * NKT + ND;                  // slots: after each key tile of the max pass, of the exp pass, after each PV tile
+    auto issue_group = [&](int gi) {
+        if (gi < PDA) {
+#pragma unroll
+            for (int t = 0; t < DT; ++t) bf[gi][t] = wo[((size_t)(wave * DT + t) * KD + gi) * 64];
+        } else if (gi == PDA) {
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                const int n = (wave * DT + t) * 16 + 4 * lg;
+                pbo[t] = *(const f32x4*)(g.bo + n);
+                pr[t] = *(const f32x4*)(g.R + (size_t)(m0 + lr) * D + n);
+            }
+        } else if (gi == PDA + 1) {
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                const int n = (wave * DT + t) * 16 + 4 * lg;
+                pg[t] = *(const f32x4*)(g.ln_g + n);
+                pbt[t] = *(const f32x4*)(g.ln_b + n);
+            }
+        } else if (gi == PDA + 2) {
+            if constexpr (KD <= CH) {
+#pragma unroll
+                for (int k2 = 0; k2 < KD; ++k2) w1f[k2] = w1[((size_t)n1t * KD + k2) * 64];
+            }
+        } else {
+            pb1 = *(const f32x4*)(g.b1 + n1t * 16 + 4 * lg);
+        }
+    };
+#define DSG_ISSUE_SLOT(slot)                                                                  \
+    do {                                                                                      \
+        _Pragma("unroll") for (int gi = ((slot) * G) / S; gi < (((slot) + 1) * G) / S; ++gi) issue_group(gi); \
+        DSG_LOADS_ISSUED();                                                                   \
+    } while (0)
+
+    // ---- (3) S^T = K Q^T, softmax over the keys (D[key = 4*lg + r][query = lr])
+    f32x4 s[NKT];
+#pragma unroll
+    for (int nt = 0; nt < NKT; ++nt) {
+        s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KDH; ++kb) s[nt] = P::mma(kf[nt][kb], qf[kb], s[nt]);
+    }
+    DSG_STAMP(0, 10);
+    const float scale = 1.0f / sqrtf((float)HD);
+    float mx = -DSG_FLT_MAX;
+#pragma unroll
+    for (int nt = 0; nt < NKT; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = nt * 16 + 4 * lg + r;
+            const float v = key < ga.ntok ? s[nt][r] * scale : -DSG_FLT_MAX;
+            s[nt][r] = v;
+            mx = fmaxf(mx, v);
+        }
+        DSG_ISSUE_SLOT(nt);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NKT; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = nt * 16 + 4 * lg + r;
+            const float pv = key < ga.ntok ? P::exp_sm(s[nt][r] - mx) : 0.f;
+            s[nt][r] = pv;
+            sum += pv;
+        }
+        DSG_ISSUE_SLOT(NKT + nt);
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    f32x4 pfr[NVF];                                  // P^T fragments: exactly the values this lane already holds
+#pragma unroll
+    for (int kb = 0; kb < NVF; ++kb) {
+        if constexpr (P::E == 4) {
+            pfr[kb] = s[kb];
+        } else {
+            typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+            u16x8 pp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pp[e] = f2bf(s[2 * kb][e]); pp[4 + e] = f2bf(s[2 * kb + 1][e]); }
+            pfr[kb] = __builtin_bit_cast(f32x4, pp);
+        }
+    }
+    DSG_STAMP(0, 11);
+    // ---- (4) O^T = V^T P^T  -> LDS rows (the same rounding point as the global attention buffer of k_attn)
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) {
+        f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < NVF; ++kb) o = P::mma(vfr[dt][kb], pfr[kb], o);     // D[dim = 4*lg + r][query = lr]
         f32x4 y;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = gelu_erf<P>(c1[e] + pb1[e]);
-        P::store4((elem*)g.hidden + (size_t)(m0 + lr) * g.ff + n1t * 16 + 4 * lg, y);
+        for (int e = 0; e < 4; ++e) y[e] = o[e] * inv;
+        P::store4((elem*)(aT + lr * XP) + h * HD + dt * 16 + 4 * lg, y);
+        DSG_ISSUE_SLOT(2 * NKT + dt);
     }
-    if (wr) {
+#undef DSG_ISSUE_SLOT
+    DSG_LDS_BARRIER();
+    DSG_STAMP(0, 12);
+
+    // ---- (5) out_proj from the LDS rows, remaining weight k-blocks PD ahead
+    f32x4 acc[DT];
 #pragma unroll
-        for (int t = 0; t < DT; ++t) *(f32x4*)(g.X1 + (size_t)(m0 + lr) * D + (wave * DT + t) * 16 + 4 * lg) = acc[t];
+    for (int t = 0; t < DT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < KD; ++kb) {
+        if (kb + PD >= PDA && kb + PD < KD) {
+#pragma unroll
+            for (int t = 0; t < DT; ++t) bf[kb + PD][t] = wo[((size_t)(wave * DT + t) * KD + kb + PD) * 64];
+        }
+        const f32x4 af = *(const f32x4*)(aT + lr * XP + (kb * P::KB + P::E * lg) * ES);
+#pragma unroll
+        for (int t = 0; t < DT; ++t) acc[t] = P::mma(bf[kb][t], af, acc[t]);      // D[n 4lg+r][row lr]
     }
+    DSG_STAMP(0, 13);
+    mid_tail<P, DT>(g, acc, pbo, pr, pg, pbt, pb1, w1f, w1, a1, red, m0, ng, n1t, wave, lr, lg);
     DSG_STAMP(0, 7);
 }
 

@@ -129,6 +129,7 @@ struct dsg_handle {
     int latency_mode = -1;               // -1 auto (fused kernels when the batch is small), 0 never, 1 always
     int dbg_skip = 0;                    // DSG_DEBUG_SKIP bit mask: timing experiments only (results become garbage)
     bool fuse_attn = false;
+    bool fuse_attn_mid = false;          // k_attn_mid (attention inside the out_proj/LN/linear1 kernel): opt-in, DSG_FUSE_ATTN_MID=1
     int* st_tmodel = nullptr; float* st_c[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int st_cap = 0, n_run = 1;
     Sched sched;
@@ -245,6 +246,7 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     if (const char* e = getenv("DSG_LATENCY_MODE")) h->latency_mode = atoi(e);
     if (const char* e = getenv("DSG_DEBUG_SKIP")) h->dbg_skip = atoi(e);
     if (const char* e = getenv("DSG_FUSE_ATTN")) h->fuse_attn = atoi(e) != 0;
+    if (const char* e = getenv("DSG_FUSE_ATTN_MID")) h->fuse_attn_mid = atoi(e) != 0;
     *out = h;
 
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -613,6 +615,22 @@ static int launch_mid(dsg_handle* h, const MidArgs& a) {
         default: return fail(DSG_E_NOT_IMPLEMENTED, "k_mid: latent_dim / 64 must be 1, 2, 4, 6 or 8");
     }
 }
+// Attention fused into k_mid: one batch element, 4 heads (wave = head), D <= 256.  Bit-identical to k_attn + k_mid and
+// one launch less per layer, but measured on MI355X it does not pay (152.4 vs 151.3 us/step, profiles/r01_h_*): the
+// four heads' strided K / V^T fragment loads then queue on ONE CU's texture-address path (38 loads in ~6100 cycles)
+// instead of running on 24 otherwise idle CUs, which costs what the saved launch gains.  Opt-in (DSG_FUSE_ATTN_MID=1).
+static bool have_attn_mid(const dsg_handle* h, int B) {
+    return B == 1 && h->H == 4 && ((h->D == 256 && h->Tp == 96) || (h->D == 128 && h->Tp == 32));
+}
+template <class P>
+static int launch_attn_mid(dsg_handle* h, const AttnMidArgs& a) {
+    const dim3 grid(xcd_grid_x(a.mid.ff / 64), a.mid.MT);
+    if (h->D == 256 && h->Tp == 96) hipLaunchKernelGGL((k_attn_mid<P, 4, 6>), grid, dim3(256), 0, h->stream, a);
+    else if (h->D == 128 && h->Tp == 32) hipLaunchKernelGGL((k_attn_mid<P, 2, 2>), grid, dim3(256), 0, h->stream, a);
+    else return fail(DSG_E_NOT_IMPLEMENTED, "no fused attention+mid instantiation");
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 static bool use_latency_mode(const dsg_handle* h, int B) {
     if (h->latency_mode >= 0) return h->latency_mode != 0;
     return B <= 4;          // redundant recompute pays only while every launch is a latency chain
@@ -664,6 +682,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
     // k_qkv_attn is correct but, measured on MI355X (profiles/r01_c_*), its 192 KB per workgroup and 6x redundant K/V
     // GEMM make it slower (15 us) than LN+QKV followed by k_attn (6.2 + 4.6 us): opt-in only (DSG_FUSE_ATTN=1)
     const bool fuse_attn = lat && have_qkv_attn(h) && h->fuse_attn;
+    const bool attn_in_mid = lat && !fuse_attn && h->fuse_attn_mid && have_attn_mid(h, B);
     for (int l = 0; l < h->L; ++l) {
         const Layer& ly = h->layers[(skip & 64) ? 0 : l];      // 64: every layer reads layer 0's weights (L2 residency experiment)
         if (fuse_attn) {   // [LayerNorm2] + in_proj + attention per (batch, head, query tile)
@@ -686,7 +705,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                     CHK((launch_gemm<P, PRO_LN, EPI_QKV, 4, 1, 1>(h, g)));
                 }
             }
-            if (!(skip & 4)) {   // attention
+            if (!(skip & 4) && !attn_in_mid) {   // attention
                 AttnArgs a;
                 a.q = h->q; a.k = h->k; a.vt = h->vt; a.out = h->attn; a.B = B; a.H = h->H; a.ntok = ntok; a.Tp = h->Tp;
                 a.D = D;
@@ -694,11 +713,17 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
             }
         }
         if (skip & 8) {
-        } else if (lat) {      // out_proj + residual + LayerNorm1 + linear1 slice + GELU
+        } else if (lat) {      // [attention +] out_proj + residual + LayerNorm1 + linear1 slice + GELU
             MidArgs a;
             a.A = h->attn; a.R = l == 0 ? h->X0 : h->Xn; a.Wo = ly.Wo; a.bo = ly.bo; a.ln_g = ly.g1; a.ln_b = ly.be1;
             a.W1 = ly.W1; a.b1 = ly.b1; a.X1 = h->X1; a.hidden = h->hidden; a.M = M; a.MT = MT; a.ff = h->ff;
-            CHK(launch_mid<P>(h, a));
+            if (attn_in_mid) {
+                AttnMidArgs am;
+                am.mid = a; am.q = h->q; am.k = h->k; am.vt = h->vt; am.ntok = ntok; am.Tp = h->Tp;
+                CHK(launch_attn_mid<P>(h, am));
+            } else {
+                CHK(launch_mid<P>(h, a));
+            }
         } else {
             {   // out_proj + residual -> pre1
                 GemmArgs g = z;

@@ -180,6 +180,26 @@ def test_graph_equals_eager_and_deterministic(gpu):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_batch1_attention_fused_into_mid_is_bit_identical(gpu, prec, monkeypatch):
+    """The batch-1 path computes self-attention inside the out_proj/LayerNorm/linear1 kernel (k_attn_mid).  Same arithmetic
+    and rounding points as k_attn + k_mid: forward and a 30-step chain must agree bit for bit on the hardware."""
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    cfg = C.ZEGGS
+    y = synth_window_inputs(cfg, 1, window=1, seed_pose_scale=0.5)
+    x = np.random.RandomState(4243).randn(1, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+    outs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("DSG_FUSE_ATTN_MID", fused)
+        m = _model(cfg, prec, max_batch=1, latency_mode="on")
+        outs[fused] = np.asarray(m(x, np.array([999]), y)).copy()
+        d = create_gaussian_diffusion()
+        outs["c" + fused] = np.asarray(d.manual_seed(3, 2).p_sample_loop(m, x.shape, clip_denoised=False, model_kwargs={"y": y},
+                                                                         skip_timesteps=970)).copy()
+    assert np.array_equal(outs["1"], outs["0"])
+    assert np.array_equal(outs["c1"], outs["c0"])
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_throughput_kernel_set_vs_reference(gpu, golden_dir, prec):
     """latency_mode="off": the un-fused kernel set (what `auto` uses for batch > 4) against the same goldens."""
     from diffusestylegesture_amd.diffusion import create_gaussian_diffusion

@@ -25,7 +25,7 @@ m = DSGDenoiser(cfg, precision="bf16", max_batch=1, device=0, latency_mode="on")
 m.load_state_dict(sd)
 fn = m.lib.cdll.dsg_debug_stamps
 fn.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong), ctypes.c_int]
-names = {0: "k_mid", 1: "gemm PARTIAL", 2: "gemm QKV", 3: "gemm RESID (linear2)", 4: "gemm GELU", 5: "gemm OUT (head)"}
+names = {0: "k_mid / k_attn_mid", 1: "gemm PARTIAL", 2: "gemm QKV", 3: "gemm RESID (linear2)", 4: "gemm GELU", 5: "gemm OUT (head)"}
 for rep in range(3):
     d.manual_seed(1, 0).p_sample_loop(m, (1, cfg.njoints, 1, cfg.n_poses), clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=800)
     torch.cuda.synchronize()
@@ -39,4 +39,5 @@ for rep in range(3):
         if not nz:
             continue
         base = r[nz[0]]
-        print(f"  {names[k]:22s} " + " ".join(f"[{i}]+{r[i] - base}" for i in nz))
+        order = sorted(nz, key=lambda i: r[i])
+        print(f"  {names[k]:22s} " + " ".join(f"[{i}]+{r[i] - base}" for i in order))
