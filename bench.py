@@ -152,7 +152,9 @@ def main():
         # HBM-side traffic per step from the rocprofv3 PMC passes (tools/pmc_traffic.py; FETCH_SIZE doubled as the
         # MI355X guide prescribes for wide coalesced reads), measured for the headline configuration only
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "r01_g_traffic_zeggs_b1_bf16.json")
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_zeggs_b1_bf16.json")))   # newest round last
+        tf = cands[-1] if cands else ""
         if a.config == "zeggs" and a.precision == "bf16" and B == 1 and os.path.exists(tf):
             traffic = json.load(open(tf))["traffic_bytes_per_step_fetch_x2"]
         out = {
@@ -169,7 +171,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 5), "traffic": traffic,
                          "algorithmic_bytes_per_denoise_step": abytes,
-                         "note": "one denoising step = 2 + 3*L dependent kernel launches (latency mode); achieved = "
+                         "note": "one denoising step = 2 + 4*L dependent kernel launches (batch-1 latency mode); achieved = "
                                  "algorithmic bytes / HIP-event time per step on the library stream"},
         }
         if world == 1 and not a.no_cpu_baseline and a.config == "zeggs" and a.sampler == "ddpm":

@@ -822,25 +822,6 @@ static int debug_launch(dsg_handle* h, int which, int i, int B) {
             InLocArgs a; a.xs = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; a.Jp = h->Jp; a.Wp = h->Wp_in;
             a.KBtot = h->Jp / KB; a.loc = la; a.ctl_upd = nullptr; a.st = step_tables(h); a.n_tab = 1;
             DSG_LOC_DISPATCH(k_inloc, a, dim3(h->Hl, T / h->W, B + 1)); return 0; }
-        case 13: case 14: case 113: case 114: {     // 1xx = prepare (upload the argument blocks), xx = launch
-            static GemmArgs* dargs = nullptr;
-            if (!dargs) HIPCHK(hipMalloc((void**)&dargs, 16 * sizeof(GemmArgs)));
-            const bool prep = which >= 100;
-            const int w2 = which % 100;
-            GemmArgs g = z; g.M = M; g.MT = MT;
-            if (w2 == 13) {
-                g.NT = D / 16; g.KBtot = D / KB; g.Wp = ly.Wo; g.bias = ly.bo; g.A = h->attn; g.lda = D;
-                g.out = (i & 1) ? h->pre1 : h->pre2; g.ldo = D; g.R = h->X0; g.kb_per_split = g.KBtot;
-                if (prep) { HIPCHK(hipMemcpy(dargs + (i % 16), &g, sizeof(g), hipMemcpyHostToDevice)); return 0; }
-                hipLaunchKernelGGL((k_gemm_p<P, PRO_DIRECT, EPI_RESID, 4, 1, 1>), dim3(xcd_grid_x(g.NT / 4), MT), dim3(256), 0, h->stream, dargs + (i % 16));
-            } else {
-                g.NT = 3 * D / 16; g.KBtot = D / KB; g.Wp = ly.Wqkv; g.bias = ly.bqkv; g.q = h->q; g.k = h->k; g.vt = h->vt;
-                g.X = h->pre2; g.ln_g = ly.g2; g.ln_b = ly.be2; g.Xn = h->Xn; g.kb_per_split = g.KBtot;
-                if (prep) { HIPCHK(hipMemcpy(dargs + (i % 16), &g, sizeof(g), hipMemcpyHostToDevice)); return 0; }
-                hipLaunchKernelGGL((k_gemm_p<P, PRO_LN, EPI_QKV, 4, 1, 1>), dim3(xcd_grid_x(g.NT / 4), MT), dim3(256), 0, h->stream, dargs + (i % 16));
-            }
-            HIPCHK(hipGetLastError());
-            return 0; }
         default: return fail(DSG_E_INVALID, "debug_chain: unknown kernel id");
     }
 }
@@ -884,10 +865,6 @@ extern "C" int dsg_debug_chain(dsg_handle* h, int which, int n, int use_graph, i
     HIPCHK(hipSetDevice(h->cfg.device));
     auto one = [&](int i) { return h->prec == DSG_PREC_BF16 ? debug_launch<PBF16>(h, which, i, B) : debug_launch<PF32>(h, which, i, B); };
     const int G = 64;
-    if (which == 13 || which == 14) {
-        const int wp = which + 100;
-        for (int i = 0; i < 16; ++i) CHK((h->prec == DSG_PREC_BF16 ? debug_launch<PBF16>(h, wp, i, B) : debug_launch<PF32>(h, wp, i, B)));
-    }
     hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
     if (use_graph) {
         HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));

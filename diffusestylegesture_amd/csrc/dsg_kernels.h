@@ -618,10 +618,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
 
 template <class P, int PRO, int EPI, int WN, int WK, int TNW>
 __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) { gemm_body<P, PRO, EPI, WN, WK, TNW>(g); }
-// experiment: the same body with the argument block in device memory (8-byte kernarg)
-template <class P, int PRO, int EPI, int WN, int WK, int TNW>
-__global__ __launch_bounds__(256) void k_gemm_p(const GemmArgs* __restrict__ gp) { gemm_body<P, PRO, EPI, WN, WK, TNW>(*gp); }
-
 // ---------------------------------------------------------------------------------------------------------
 // k_loc: per (batch, window, local head).  h = sum_s partial_s + Cframe + TE2[t]; rotary(pos = frame);
 //        causal local attention over {previous window, own window} with q = k = v; prepend token; rotary(pos+1)

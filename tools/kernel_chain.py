@@ -14,7 +14,7 @@ from diffusestylegesture_amd.model import DSGDenoiser
 from diffusestylegesture_amd.synth import synth_state_dict, synth_window_inputs
 
 names = ["null", "oproj same-weights", "oproj cycling layers", "LN+linear1+GELU", "linear2 (K=1024)", "k_attn", "k_loc",
-         "k_in (split-K)", "pose head (LN + N=1152)", "LN+QKV", "k_mid", "k_qkv_attn", "k_inloc", "oproj args-by-pointer", "LN+QKV args-by-pointer"]
+         "k_in (split-K)", "pose head (LN + N=1152)", "LN+QKV", "k_mid", "k_qkv_attn", "k_inloc"]
 cfg = CF.ZEGGS
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 m = DSGDenoiser(cfg, precision="bf16", max_batch=B, device=0)
