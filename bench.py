@@ -55,15 +55,31 @@ def cpu_baseline(n_steps):
     d = OracleDiffusion()
     nf = sampler.philox_noise_fn(shape, 1, 0)
     sampler.p_sample_loop(d, m, shape, nf, {"y": y}, skip_timesteps=995)         # warm-up
+    # BLAS thread count: the GEMMs of one step are small (89 x 256 x 1024 at most), so all host threads is not the
+    # fastest setting; a short sweep picks the best one and `cores` reports the threads actually used
+    cores, limiter = os.cpu_count() or 1, None
+    try:
+        from threadpoolctl import threadpool_limits
+        best = None
+        for nt in sorted({1, 4, 8, 16, 32, cores}):
+            if nt > cores:
+                continue
+            with threadpool_limits(limits=nt):
+                t0 = time.perf_counter()
+                sampler.p_sample_loop(d, m, shape, nf, {"y": y}, skip_timesteps=980)
+                dt = time.perf_counter() - t0
+            if best is None or dt < best[0]:
+                best = (dt, nt)
+        cores = best[1]
+        limiter = threadpool_limits(limits=cores)
+    except Exception:
+        pass
     t0 = time.perf_counter()
     sampler.p_sample_loop(d, m, shape, nf, {"y": y}, skip_timesteps=1000 - n_steps)
     dt = time.perf_counter() - t0
+    if limiter is not None:
+        limiter.restore_original_limits()
     ms_step = 1000.0 * dt / n_steps
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count() or 1
     return {"value": round(320.0 / (4000 * ms_step / 1000.0), 3), "unit": "frames/s", "cores": int(cores),
             "kind": "port", "ms_per_denoise_step": round(ms_step, 3),
             "sample": f"{n_steps} DDPM steps of one 88-frame ZEGGS window (batch 1, fp32 numpy oracle), "

@@ -21,10 +21,16 @@ import math
 
 import numpy as np
 
-try:  # vectorised erf for GELU
-    from scipy.special import erf as _erf
+try:  # vectorised erf for GELU: torch's CPU kernel is ~10x faster than scipy's and equally exact; values only
+    import torch as _torch
+
+    def _erf(a):
+        return _torch.erf(_torch.from_numpy(np.ascontiguousarray(a))).numpy()
 except Exception:  # pragma: no cover
-    _erf = np.vectorize(math.erf)
+    try:
+        from scipy.special import erf as _erf
+    except Exception:
+        _erf = np.vectorize(math.erf)
 
 FLT_MAX = float(np.finfo(np.float32).max)
 
