@@ -145,6 +145,26 @@ def window_audio(audio, n_frames, n_poses=88, n_seed=8, sr=16000, fps=20):
     return outs, n_frames
 
 
+def load_wav_16k(path):
+    """Mono float32 waveform at 16 kHz in [-1, 1] (what `librosa.load(path, sr=16000)` returns, sample.py:346; librosa is
+    not a dependency here: scipy reads the file and resamples polyphase when the file's rate differs)."""
+    from scipy.io import wavfile
+    from scipy.signal import resample_poly
+    sr, x = wavfile.read(path)
+    if x.dtype.kind == "i":
+        x = x.astype(np.float32) / float(np.iinfo(x.dtype).max + 1)
+    elif x.dtype.kind == "u":
+        x = (x.astype(np.float32) - 128.0) / 128.0
+    else:
+        x = x.astype(np.float32)
+    if x.ndim == 2:
+        x = x.mean(axis=1)
+    if sr != 16000:
+        g = math.gcd(int(sr), 16000)
+        x = resample_poly(x, 16000 // g, int(sr) // g).astype(np.float32)
+    return x
+
+
 def denormalise(poses, mean, std):
     """sample.py:320-326: std clipped at 0.01."""
     return np.multiply(poses, np.clip(std, a_min=0.01, a_max=None)) + mean
@@ -180,7 +200,8 @@ def build_parser():
     p.add_argument('--max_len', type=int, default=0)
     # framework additions
     p.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
-    p.add_argument('--features_npy', default='', help='pre-extracted WavLM features [K, n_poses, 1024] (cached per clip)')
+    p.add_argument('--features_npy', default='', help='pre-extracted WavLM features [K, n_poses, 1024] (the per-clip cache)')
+    p.add_argument('--wavlm_path', default='./WavLM/WavLM-Large.pt', help='WavLM checkpoint (sample.py:33)')
     p.add_argument('--save_dir', default='sample_dir')
     p.add_argument('--timestep_respacing', default='')
     return p
@@ -207,14 +228,22 @@ def main(argv=None):
     diffusion = create_gaussian_diffusion(args.timestep_respacing)
     name = os.path.basename(args.audiowavlm_path or args.features_npy)
     style = style2onehot[name.split('_')[1]]                              # sample.py:378
-    if not args.features_npy:
-        raise SystemExit("WavLM feature extraction is outside this path: pass --features_npy (cached per clip)")
-    feats = np.load(args.features_npy).astype(np.float32)
+    os.makedirs(args.save_dir, exist_ok=True)
+    if args.features_npy:
+        feats = np.load(args.features_npy).astype(np.float32)
+    else:
+        # WavLM stage (PyTorch-ROCm, outside the HIP path): all windows of the clip in ONE batched forward, cached per clip
+        from .wavlm import wavlm_init
+        wav = load_wav_16k(args.audiowavlm_path)                          # librosa.load(path, sr=16000), sample.py:346
+        wins, _ = window_audio(wav, args.max_len, n_poses, ZEGGS.n_seed)
+        wavlm = wavlm_init(args.wavlm_path, device=f"cuda:{dev}")
+        feats = wavlm.clip_features(wins, n_poses).cpu().numpy()
+        np.save(os.path.join(args.save_dir, os.path.splitext(name)[0] + "_wavlm.npy"), feats)
+        del wavlm
     if args.max_len:
         feats = feats[: max(1, args.max_len // (n_poses - ZEGGS.n_seed))]
     feats_t = [torch.from_numpy(f[None]).cuda(dev) for f in feats]
     poses = generate_clip(model, diffusion, feats_t, style, seed=123456, smoothing=True)[0]
-    os.makedirs(args.save_dir, exist_ok=True)
     stem = os.path.join(args.save_dir, os.path.splitext(name)[0])
     np.save(stem + "_poses.npy", poses)
     # de-normalise (sample.py:320-326) and write the .bvh (process_zeggs_bvh.py:219) like the reference's main()

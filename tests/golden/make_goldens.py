@@ -5,6 +5,7 @@
     python tests/golden/make_goldens.py dsgplus    # BEAT-TWH-main/ (DiffuseStyleGesture+)
     python tests/golden/make_goldens.py clip       # main/mydiffusion_zeggs/sample.py inference() (G6)
     python tests/golden/make_goldens.py bvh        # main/process/process_zeggs_bvh.py pose2bvh (G7, needs G6)
+    python tests/golden/make_goldens.py wavlm      # main/mydiffusion_zeggs/WavLM (G9: small-config feature extractor)
 
 The two reference trees use the same module names, hence one process per tree.  Nothing from
 /root/reference is copied: the script imports it, feeds it seeded synthetic weights / inputs
@@ -322,6 +323,48 @@ def gen_bvh():
     np.savez_compressed(os.path.join(HERE, "g7_bvh_zeggs.npz"), **out)
 
 
+def gen_wavlm():
+    """G9: the reference's WavLM (mydiffusion_zeggs/WavLM) instantiated with two SMALL configurations that exercise both
+    architecture branches -- "large-like" (layer-norm conv extractor, pre-norm encoder, gated relative position bias:
+    the WavLM-Large topology the reference loads) and "base-like" (group-norm extractor, post-norm encoder) -- randomly
+    initialised by the reference's own init under a fixed torch seed.  Stored: the state dict (the checkpoint format the
+    build must ingest), a seeded waveform, `extract_features(wav)[0]` and the wav2wavlm interpolation to 88 frames
+    (sample.py:44-48)."""
+    sys.path[:0] = [os.path.join(REF, "main/mydiffusion_zeggs/WavLM")]
+    from WavLM import WavLM, WavLMConfig
+    import torch.nn.functional as F
+    cfgs = {
+        "large_like": dict(extractor_mode="layer_norm", encoder_layers=3, encoder_embed_dim=64, encoder_ffn_embed_dim=128,
+                           encoder_attention_heads=4, layer_norm_first=True, normalize=True, conv_bias=False,
+                           conv_feature_layers="[(32,10,5)] + [(32,3,2)] * 4 + [(32,2,2)] * 2", conv_pos=16, conv_pos_groups=4,
+                           relative_position_embedding=True, num_buckets=320, max_distance=800, gru_rel_pos=True),
+        "base_like": dict(extractor_mode="default", encoder_layers=2, encoder_embed_dim=48, encoder_ffn_embed_dim=96,
+                          encoder_attention_heads=4, layer_norm_first=False, normalize=False, conv_bias=False,
+                          conv_feature_layers="[(24,10,5)] + [(24,3,2)] * 4 + [(24,2,2)] * 2", conv_pos=16, conv_pos_groups=4,
+                          relative_position_embedding=True, num_buckets=320, max_distance=800, gru_rel_pos=True),
+    }
+    out = {}
+    for name, c in cfgs.items():
+        torch.manual_seed(1234)
+        m = WavLM(WavLMConfig(c)).eval()
+        # make the parameters the init leaves at trivial values non-trivial (biases 0, norms 1, grep_a 1)
+        g = torch.Generator().manual_seed(99)
+        for k, v in m.state_dict().items():
+            if v.dtype.is_floating_point and (k.endswith("bias") or "layer_norm" in k or "grep_a" in k or k.endswith(".2.1.weight") or k.endswith(".2.weight")):
+                v.add_(0.05 * torch.randn(v.shape, generator=g))
+        wav = torch.from_numpy(np.random.RandomState(7).randn(2, 16000 * 2 + 321).astype(np.float32) * 0.1)   # 2 windows, ~2 s
+        feat = m.extract_features(wav)[0]
+        rep = F.interpolate(feat.transpose(1, 2), size=88, align_corners=True, mode="linear").transpose(1, 2)
+        out[name + "/cfg"] = np.array(repr(c))
+        out[name + "/feat"] = feat.numpy()
+        out[name + "/rep88"] = rep.numpy()
+        for k, v in m.state_dict().items():
+            out[name + "/sd/" + k] = v.numpy()
+        print(name, feat.shape, rep.shape, sum(v.numel() for v in m.state_dict().values()), "params")
+    out["wav_seed"] = np.array(7)
+    np.savez_compressed(os.path.join(HERE, "g9_wavlm_small.npz"), **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1]
-    {"zeggs": gen_zeggs, "dsgplus": gen_dsgplus, "clip": gen_clip, "bvh": gen_bvh}[which]()
+    {"zeggs": gen_zeggs, "dsgplus": gen_dsgplus, "clip": gen_clip, "bvh": gen_bvh, "wavlm": gen_wavlm}[which]()
