@@ -15,12 +15,13 @@ from dataclasses import dataclass, asdict
 
 VARIANT_DSG = 3       # cross_local_attention3_style1 (ZEGGS)
 VARIANT_DSGPLUS = 4   # cross_local_attention4_style1 (BEAT / TWH)
+VARIANT_DSGPP = 5     # cross_local_attention5_style1 (DiffuseStyleGesture++: + y['seed_last'], BEAT-TWH mdm.py:226-264)
 
 
 @dataclass(frozen=True)
 class DSGConfig:
     name: str
-    variant: int          # 3 or 4
+    variant: int          # 3, 4 or 5
     njoints: int          # J: pose feature dim
     n_poses: int          # T: frames per denoised window
     n_seed: int           # S: seed frames
@@ -39,7 +40,11 @@ class DSGConfig:
     def audio_frames(self) -> int:
         # DSG: audio covers all T frames; DSG+ (attention4): T - S audio frames, the
         # first S "audio" rows are the per-frame seed embedding (BEAT-TWH mdm.py:188-190)
-        return self.n_poses if self.variant == VARIANT_DSG else self.n_poses - self.n_seed
+        # DSG++ (attention5): the last S rows are the embedding of y['seed_last'] as well (mdm.py:227-230; the caller
+        # drops the last S audio frames, BEAT-TWH sample.py:104)
+        if self.variant == VARIANT_DSG:
+            return self.n_poses
+        return self.n_poses - self.n_seed * (2 if self.variant == VARIANT_DSGPP else 1)
 
     @property
     def stride(self) -> int:
@@ -70,4 +75,10 @@ TINY4 = DSGConfig("tiny4", VARIANT_DSGPLUS, njoints=37, n_poses=30, n_seed=6, la
                   audio_src_dim=40, audio_dim=16, style_dim_in=3, window=15,
                   num_layers=2, num_heads=2, ff_size=128)
 
-CONFIGS = {c.name: c for c in (ZEGGS, BEAT, TWH, TINY, TINY4)}
+TINY5 = DSGConfig("tiny5", VARIANT_DSGPP, njoints=37, n_poses=30, n_seed=6, latent_dim=64,
+                  audio_src_dim=40, audio_dim=16, style_dim_in=3, window=15,
+                  num_layers=2, num_heads=2, ff_size=128)
+BEATPP = DSGConfig("beatpp", VARIANT_DSGPP, njoints=2052, n_poses=150, n_seed=30, latent_dim=384,
+                   audio_src_dim=1434, audio_dim=96, style_dim_in=2, window=15)
+
+CONFIGS = {c.name: c for c in (ZEGGS, BEAT, TWH, TINY, TINY4, TINY5, BEATPP)}

@@ -116,7 +116,8 @@ struct dsg_handle {
     float *TE = nullptr, *TE2 = nullptr, *rcos = nullptr, *rsin = nullptr, *cbase = nullptr, *zero_bias = nullptr;
     // window conditioning
     float *emb1 = nullptr, *Cf = nullptr, *enc = nullptr, *cvec = nullptr;
-    float *c_style = nullptr, *c_seed = nullptr, *c_audio = nullptr;
+    float *c_style = nullptr, *c_seed = nullptr, *c_audio = nullptr, *c_seed_last = nullptr;
+    int seed_last_B = 0;                 // batch of the last dsg_set_seed_last (variant 5)
     unsigned char* mask = nullptr; int mb = 1;
     // state / activations
     float *xs32 = nullptr, *partial = nullptr, *X0 = nullptr, *pre1 = nullptr, *pre2 = nullptr, *Xn = nullptr,
@@ -147,7 +148,14 @@ static int dalloc(dsg_handle* h, T** p, size_t n_elems, bool zero = true) {
     size_t bytes = n_elems * sizeof(T);
     if (bytes == 0) bytes = 16;
     HIPCHK(hipMalloc(&d, bytes));
-    if (zero) HIPCHK(hipMemset(d, 0, bytes));
+    // Zero-fill and WAIT for it.  hipMemset on device memory may return before the fill has run; the handle's stream is
+    // non-blocking (no implicit ordering with the null stream), so a late fill could wipe what the first kernels on the
+    // handle's stream (weight packing, conditioning) or a following synchronous copy have already written.  Seen once
+    // as a wrong TWH forward in a full `pytest -m gpu` run.  Allocation happens at create / load time only.
+    if (zero) {
+        HIPCHK(hipMemsetAsync(d, 0, bytes, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
     h->allocs.push_back(d);
     *p = (T*)d;
     return 0;
@@ -195,6 +203,10 @@ static std::map<std::string, std::vector<int64_t>> expected_tensors(const dsg_ha
         m["embed_style.bias"] = {D};
         m["embed_text.weight"] = {A, J};
         m["embed_text.bias"] = {A};
+        if (h->cfg.variant == 5) {          // DiffuseStyleGesture++ (BEAT-TWH mdm.py:85-89)
+            m["embed_text_last.weight"] = {A, J};
+            m["embed_text_last.bias"] = {A};
+        }
     }
     m["output_process.poseFinal.weight"] = {J, D};
     m["output_process.poseFinal.bias"] = {J};
@@ -206,7 +218,8 @@ static std::map<std::string, std::vector<int64_t>> expected_tensors(const dsg_ha
 
 extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     if (!c || !out) return fail(DSG_E_INVALID, "dsg_create: null argument");
-    if (c->variant != 3 && c->variant != 4) return fail(DSG_E_NOT_IMPLEMENTED, "variant must be 3 or 4");
+    if (c->variant < 3 || c->variant > 5) return fail(DSG_E_NOT_IMPLEMENTED, "variant must be 3, 4 or 5");
+    if (c->variant == 5 && c->n_poses <= 2 * c->n_seed) return fail(DSG_E_INVALID, "variant 5 needs n_poses > 2 * n_seed");
     if (c->latent_dim % 64 || c->latent_dim > 512 || c->latent_dim <= 0)
         return fail(DSG_E_INVALID, "latent_dim must be a multiple of 64, <= 512");
     if (c->variant == 3 && c->latent_dim <= 64) return fail(DSG_E_INVALID, "variant 3 needs latent_dim > 64");
@@ -238,7 +251,7 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     h->Hl = c->local_heads; h->hdl = hdl; h->ntok = ntok; h->Tp = Tp;
     h->Jp = rup(h->J, 128); h->Jq = rup(h->J, 4); h->Bmax = c->max_batch;
     h->KSin = cdiv(h->Jp, 256);
-    h->Ta = c->variant == 3 ? h->T : h->T - h->S;
+    h->Ta = c->variant == 3 ? h->T : h->T - h->S * (c->variant == 5 ? 2 : 1);
     h->n_te = c->train_steps > 0 ? c->train_steps : 1000;
     if (h->n_te > c->pe_max_len) { delete h; return fail(DSG_E_INVALID, "train_steps > pe_max_len"); }
     h->layers.resize(h->L);
@@ -282,6 +295,7 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     CHK(dalloc(h, &h->enc, (size_t)B * h->T * h->A));
     CHK(dalloc(h, &h->c_style, (size_t)B * c->style_dim_in));
     CHK(dalloc(h, &h->c_seed, (size_t)B * h->J * (h->S > 0 ? h->S : 1)));
+    if (h->cfg.variant == 5) CHK(dalloc(h, &h->c_seed_last, (size_t)B * h->J * h->S));
     CHK(dalloc(h, &h->c_audio, (size_t)B * h->Ta * h->As));
     CHK(dalloc(h, &h->mask, (size_t)B * h->T));
     CHK(dalloc(h, &h->ctr, 8));
@@ -326,7 +340,11 @@ extern "C" int dsg_load_tensor(dsg_handle* h, const char* name, const void* data
     RawT& r = h->raw[nm];
     if (!r.d) CHK(dalloc(h, &r.d, n, false));
     r.n = n; r.shape.assign(shape, shape + ndim);
-    HIPCHK(hipMemcpy(r.d, data, n * sizeof(float), is_device_ptr(data) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    const bool dev_src = is_device_ptr(data);
+    HIPCHK(hipMemcpy(r.d, data, n * sizeof(float), dev_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    // a device-to-device hipMemcpy may return before the copy has run (null stream); the packing kernels that read r.d
+    // run on the handle's non-blocking stream, which is not ordered against it
+    if (dev_src) HIPCHK(hipDeviceSynchronize());
     h->finalized = false;
     return 0;
 }
@@ -467,6 +485,19 @@ static int upload(dsg_handle* h, void* dst, const void* src, size_t bytes) {
 
 static int order_after(dsg_handle* h, void* user_stream);
 
+// y['seed_last'] of DiffuseStyleGesture++ (cross_local_attention5, BEAT-TWH-main/model/mdm.py:229): [B, J, 1, S].  It is the same
+// snippet for every window of a clip (BEAT-TWH sample.py:85-93), so it is handed over once and kept.
+extern "C" int dsg_set_seed_last(dsg_handle* h, const float* seed_last, int B, void* stream) {
+    if (!h || !seed_last) return fail(DSG_E_INVALID, "null argument");
+    if (h->cfg.variant != 5) return fail(DSG_E_INVALID, "dsg_set_seed_last is for variant 5 (cross_local_attention5) only");
+    if (B <= 0 || B > h->Bmax) return fail(DSG_E_INVALID, "batch exceeds max_batch");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    CHK(order_after(h, stream));
+    CHK(upload(h, h->c_seed_last, seed_last, (size_t)B * h->J * h->S * sizeof(float)));
+    h->seed_last_B = B;
+    return 0;
+}
+
 extern "C" int dsg_set_window_cond(dsg_handle* h, const float* style, const float* seed, const float* audio,
                                    const uint8_t* mask_local, int mask_batch, int B, int uncond, void* stream) {
     if (!h) return fail(DSG_E_INVALID, "null handle");
@@ -475,6 +506,8 @@ extern "C" int dsg_set_window_cond(dsg_handle* h, const float* style, const floa
     if (!style || !audio || (h->S > 0 && !seed)) return fail(DSG_E_INVALID, "style/seed/audio required");
     if (mask_local && !(mask_batch >= 1 && (B * h->Hl) % mask_batch == 0))
         return fail(DSG_E_INVALID, "mask_local batch must divide B*heads");
+    if (h->cfg.variant == 5 && h->seed_last_B != B)
+        return fail(DSG_E_STATE, "variant 5: call dsg_set_seed_last with the same batch before dsg_set_window_cond (y['seed_last'])");
     HIPCHK(hipSetDevice(h->cfg.device));
     CHK(order_after(h, stream));      // the caller's stream may still be producing seed / audio
     auto R = [&](const std::string& n) { return h->raw[n].d; };
@@ -513,6 +546,9 @@ extern "C" int dsg_set_window_cond(dsg_handle* h, const float* style, const floa
             CHK(launch_mm(h, h->enc + ((size_t)b * T + S) * A, A, h->c_audio + (size_t)b * h->Ta * As, As, 1,
                           R("WavEncoder.audio_feature_map.weight"), As, 1, R("WavEncoder.audio_feature_map.bias"),
                           nullptr, 0, 1, h->Ta, A, As));
+            if (h->cfg.variant == 5)    // rows S+Ta .. T-1: embed_text_last(y['seed_last'])  (BEAT-TWH mdm.py:229-230)
+                CHK(launch_mm(h, h->enc + ((size_t)b * T + S + h->Ta) * A, A, h->c_seed_last + (size_t)b * J * S, 1, S,
+                              R("embed_text_last.weight"), J, 1, R("embed_text_last.bias"), nullptr, 0, 1, S, A, J));
         }
     }
     // cvec[b] = b2 + W2b.bp + W2a.emb1[b];  Cf[b,f] = W2c.enc[b,f] + cvec[b]

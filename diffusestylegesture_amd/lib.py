@@ -44,6 +44,7 @@ SYMBOLS = {
     "dsg_finalize_weights": (_I, [_P]),
     "dsg_set_schedule": (_I, [_P, _P, _P, _I]),
     "dsg_schedule_tables": (_I, [_P, _I, _P]),
+    "dsg_set_seed_last": (_I, [_P, _P, _I, _P]),
     "dsg_set_window_cond": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "dsg_forward": (_I, [_P, _P, _P, _P, _I, _P]),
     "dsg_sample": (_I, [_P, C.POINTER(dsg_sample_args), _P, _I, _P]),

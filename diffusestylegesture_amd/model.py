@@ -100,6 +100,13 @@ class DSGDenoiser:
             raise ValueError(f"y['seed'] shape {tuple(seed.obj.shape)}")
         uncond = bool(uncond or y.get("uncond", False))
         stream = L.current_stream_ptr() if L.is_torch(y["audio"]) else None
+        if self.cfg.variant == 5:            # DiffuseStyleGesture++: y['seed_last'] (BEAT-TWH mdm.py:229)
+            if y.get("seed_last") is None:
+                raise KeyError("seed_last")  # what the reference's y['seed_last'] lookup raises
+            last = L.Buf(y["seed_last"])
+            if tuple(last.obj.shape) != (batch, self.cfg.njoints, 1, self.cfg.n_seed):
+                raise ValueError(f"y['seed_last'] shape {tuple(last.obj.shape)}")
+            self.lib.check(self.lib.cdll.dsg_set_seed_last(self.handle, last.p, batch, stream))
         self.lib.check(self.lib.cdll.dsg_set_window_cond(self.handle, style.p, seed.p, audio.p, mbuf.p, mb, batch,
                                                          int(uncond), stream))
 
@@ -133,3 +140,33 @@ class DSGDenoiser:
 
     def sync(self):
         self.lib.check(self.lib.cdll.dsg_sync(self.handle))
+
+
+class ClassifierFreeSampleModel:
+    """Classifier-free guidance wrapper, sampling only (main/model/cfg_sampler.py:8-31): two evaluations per call,
+    `out_uncond + y['scale'] * (out - out_uncond)`, the unconditional one with `y['uncond'] = True` (which zeroes the
+    style embedding -- and, for DiffuseStyleGesture, the seed-pose embedding input -- mdm.py:156-164, :180).  The
+    reference class asserts `cond_mode in ['text', 'action']` (inherited from MDM) and therefore cannot wrap the gesture
+    models at all; this one can.  A wrapped model is an opaque callable to the sampler, so `p_sample_loop` /
+    `ddim_sample_loop` take their generic path (HIP elementwise kernels for the update, one library call per evaluation)
+    instead of the single fused `dsg_sample` call."""
+
+    def __init__(self, model):
+        self.model = model
+        self.cfg, self.njoints, self.nfeats = model.cfg, model.njoints, model.nfeats
+
+    def parameters(self):
+        return self.model.parameters()
+
+    def forward(self, x, timesteps, y=None):
+        if y is None or "scale" not in y:
+            raise KeyError("scale")
+        y_uncond = dict(y)
+        y_uncond["uncond"] = True
+        out = self.model(x, timesteps, y)
+        out_uncond = self.model(x, timesteps, y_uncond)
+        scale = y["scale"]
+        scale = scale.view(-1, 1, 1, 1) if L.is_torch(scale) else np.asarray(scale, np.float32).reshape(-1, 1, 1, 1)
+        return out_uncond + scale * (out - out_uncond)
+
+    __call__ = forward

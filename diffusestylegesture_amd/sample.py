@@ -82,9 +82,12 @@ def generate_clip(model, diffusion, feats, style, seed=123456, smoothing=True, s
 
 
 def generate_clip_dsgplus(model, diffusion, feats, style, seed0, real_n_frames, seed=123456, skip_timesteps=0,
-                          sample_fn=None, stream_id=0):
+                          sample_fn=None, stream_id=0, seed_last=None):
     """DSG+ window loop (BEAT-TWH sample.py:98-192), attention4: zero-padded tail, no left audio context, GT seed for
-    window 0, no root shift, last window kept whole, first S frames dropped, crop, keep the first J/3 features."""
+    window 0, no root shift, last window kept whole, first S frames dropped, crop, keep the first J/3 features.
+    DiffuseStyleGesture++ (attention5, model.cfg.variant == 5): `feats` are still the stride-long windows; the last S
+    feature frames of every window are dropped (sample.py:104, :138) and `seed_last` [B, J, 1, S] -- the same snippet
+    for every window (sample.py:85-93) -- is passed as y['seed_last']."""
     cfg = model.cfg
     S, T, J = cfg.n_seed, cfg.n_poses, cfg.njoints
     use_torch = L.is_torch(feats[0])
@@ -107,6 +110,12 @@ def generate_clip_dsgplus(model, diffusion, feats, style, seed0, real_n_frames, 
         seedp = seed0 if c == 0 else out[-1][..., -S:]
         seedp = seedp.contiguous() if use_torch else np.ascontiguousarray(seedp)
         y = {"style": sty, "seed": seedp, "audio": feat, "mask_local": mask}
+        if cfg.variant == 5:
+            if seed_last is None:
+                raise KeyError("seed_last")
+            a = feat[:, :-S]
+            y["audio"] = a.contiguous() if use_torch else np.ascontiguousarray(a)
+            y["seed_last"] = seed_last
         s = sample_fn(model, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=skip_timesteps,
                       init_image=None, progress=False, dump_steps=None, noise=None, const_noise=False)
         if c > 0:

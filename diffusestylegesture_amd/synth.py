@@ -81,6 +81,8 @@ def synth_state_dict(cfg: DSGConfig, seed: int = 0) -> "OrderedDict[str, np.ndar
     else:
         lin("embed_style", D, cfg.style_dim_in, 1.0)
         lin("embed_text", A, J, 1.0)
+        if cfg.variant == 5:
+            lin("embed_text_last", A, J, 1.0)
     lin("output_process.poseFinal", J, D, 1.0)
     sd["rel_pos.inv_freq"] = rotary_inv_freq(D // cfg.local_heads)
     lin("input_process2", D, 2 * D + A, 1.0)
@@ -100,7 +102,11 @@ def synth_window_inputs(cfg: DSGConfig, batch: int, window: int = 0, clip0: int 
             (seed_pose_scale * np.random.RandomState(7 + clip0 + b).randn(cfg.njoints, 1, cfg.n_seed))
             for b in range(batch)]).astype(np.float32)
     mask_local = np.ones((1, cfg.n_poses), dtype=bool)
-    return {"audio": audio, "style": style, "seed": seedp, "mask_local": mask_local}
+    y = {"audio": audio, "style": style, "seed": seedp, "mask_local": mask_local}
+    if cfg.variant == 5:        # DSG++: the fixed "closing" pose snippet (BEAT-TWH sample.py:85-93)
+        y["seed_last"] = np.stack([(0.2 * np.random.RandomState(70 + clip0 + b).randn(cfg.njoints, 1, cfg.n_seed))
+                                   for b in range(batch)]).astype(np.float32)
+    return y
 
 
 def _feat(cfg: DSGConfig, s: int) -> np.ndarray:

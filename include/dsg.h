@@ -12,6 +12,9 @@
  *        GaussianDiffusion.__init__ tables                           main/diffusion/gaussian_diffusion.py:161-198
  *   dsg_set_window_cond
  *        the `y` dict of model_kwargs (style, seed, audio, mask_local) main/mydiffusion_zeggs/sample.py:227-251
+ *   dsg_set_seed_last
+ *        y['seed_last'] of DiffuseStyleGesture++ (cross_local_attention5)   BEAT-TWH-main/model/mdm.py:226-230,
+ *                                                                    BEAT-TWH-main/mydiffusion_beat_twh/sample.py:85-93
  *   dsg_forward
  *        MDM.forward(x, timesteps, y)                                main/model/mdm.py:166-358
  *                                                                    BEAT-TWH-main/model/mdm.py:134-267
@@ -96,7 +99,10 @@ int dsg_set_schedule(dsg_handle* h, const double* betas, const int64_t* timestep
  * posterior_log_variance_clipped, posterior_mean_coef1, posterior_mean_coef2 */
 int dsg_schedule_tables(const double* betas, int n, double* out);
 
-/* style [B, style_dim_in]; seed [B, J, 1, S]; audio [B, T_a, A_src] (T_a = T for variant 3, T-S for variant 4);
+/* variant 5 only: seed_last [B, J, 1, S]; kept until replaced; must precede dsg_set_window_cond with the same B */
+int dsg_set_seed_last(dsg_handle* h, const float* seed_last, int B, void* stream);
+
+/* style [B, style_dim_in]; seed [B, J, 1, S]; audio [B, T_a, A_src] (T_a = T for variant 3, T-S for variant 4, T-2S for 5);
  * mask_local uint8 [mask_batch, T] (1 = keep), mask_batch in {1, B}; uncond != 0 -> uncond_info / y['uncond'] */
 int dsg_set_window_cond(dsg_handle* h, const float* style, const float* seed, const float* audio,
                         const uint8_t* mask_local, int mask_batch, int B, int uncond, void* stream);

@@ -169,7 +169,12 @@ class MDMOracle:
                         sd["embed_text.bias"])                                    # [B, S, A]
             enc_a = _lin(audio, sd["WavEncoder.audio_feature_map.weight"],
                          sd["WavEncoder.audio_feature_map.bias"])                 # [B, T-S, A]
-            enc = np.concatenate([text, enc_a], 1)                                # [B, T, A]
+            parts = [text, enc_a]
+            if cfg.variant == 5:                                                  # BEAT-TWH mdm.py:227-230
+                last = np.asarray(y["seed_last"]).astype(dt)
+                parts.append(_lin(last[:, :, 0, :].transpose(0, 2, 1), sd["embed_text_last.weight"],
+                                  sd["embed_text_last.bias"]))                    # [B, S, A]
+            enc = np.concatenate(parts, 1)                                        # [B, T, A]
         tok = emb_1 + emb_t                                                       # [B, D]
         xf = x[:, :, 0, :].transpose(0, 2, 1)                                     # [B, T, J]
         x_ = _lin(xf, sd["input_process.poseEmbedding.weight"], sd["input_process.poseEmbedding.bias"])

@@ -97,6 +97,9 @@ def zeggs_clip(sample_window, cfg, feats, style, smoothing=True):
         seedp = np.zeros((1, J, 1, S), np.float32) if c == 0 else out[-1][..., -S:].copy()
         y = {"style": np.asarray([style], np.float32), "seed": seedp, "audio": feat,
              "mask_local": np.ones((1, T), bool)}
+        if cfg.variant == 5:
+            y["audio"] = np.ascontiguousarray(np.asarray(feat)[:, :-S])
+            y["seed_last"] = np.asarray(seed_last, np.float32)
         s = np.array(sample_window(c, y), np.float32, copy=True)
         if c > 0:
             last = out[-1][..., -S:].copy()
@@ -114,15 +117,19 @@ def zeggs_clip(sample_window, cfg, feats, style, smoothing=True):
     return seq[0, S:]
 
 
-def dsgplus_clip(sample_window, cfg, feats, style, seed0, real_n_frames):
+def dsgplus_clip(sample_window, cfg, feats, style, seed0, real_n_frames, seed_last=None):
     """DSG+ `inference()` (BEAT-TWH sample.py:98-192), attention4: no left audio context, no root shift,
-    last window kept whole, first S frames dropped, crop to real_n_frames, keep first J/3 features."""
+    last window kept whole, first S frames dropped, crop to real_n_frames, keep first J/3 features.
+    attention5 (DiffuseStyleGesture++): audio[:-S] per window (sample.py:104, :138) + y['seed_last'] (:85-93)."""
     S, T, J = cfg.n_seed, cfg.n_poses, cfg.njoints
     out = []
     for c, feat in enumerate(feats):
         seedp = np.asarray(seed0, np.float32) if c == 0 else out[-1][..., -S:].copy()
         y = {"style": np.asarray([style], np.float32), "seed": seedp, "audio": feat,
              "mask_local": np.ones((1, T), bool)}
+        if cfg.variant == 5:
+            y["audio"] = np.ascontiguousarray(np.asarray(feat)[:, :-S])
+            y["seed_last"] = np.asarray(seed_last, np.float32)
         s = np.array(sample_window(c, y), np.float32, copy=True)
         if c > 0:
             last = out[-1][..., -S:].copy()

@@ -6,6 +6,7 @@
     python tests/golden/make_goldens.py clip       # main/mydiffusion_zeggs/sample.py inference() (G6)
     python tests/golden/make_goldens.py bvh        # main/process/process_zeggs_bvh.py pose2bvh (G7, needs G6)
     python tests/golden/make_goldens.py wavlm      # main/mydiffusion_zeggs/WavLM (G9: small-config feature extractor)
+    python tests/golden/make_goldens.py dsgpp      # BEAT-TWH-main/ cross_local_attention5 (DiffuseStyleGesture++, G10)
 
 The two reference trees use the same module names, hence one process per tree.  Nothing from
 /root/reference is copied: the script imports it, feeds it seeded synthetic weights / inputs
@@ -41,8 +42,11 @@ def _to_torch_sd(sd):
 
 
 def _y_torch(y):
-    return {"style": torch.from_numpy(y["style"]), "seed": torch.from_numpy(y["seed"]),
-            "audio": torch.from_numpy(y["audio"]), "mask_local": torch.from_numpy(y["mask_local"])}
+    out = {"style": torch.from_numpy(y["style"]), "seed": torch.from_numpy(y["seed"]),
+           "audio": torch.from_numpy(y["audio"]), "mask_local": torch.from_numpy(y["mask_local"])}
+    if "seed_last" in y:
+        out["seed_last"] = torch.from_numpy(y["seed_last"])
+    return out
 
 
 class NoiseInjector:
@@ -323,6 +327,29 @@ def gen_bvh():
     np.savez_compressed(os.path.join(HERE, "g7_bvh_zeggs.npz"), **out)
 
 
+def gen_dsgpp():
+    """G10: DiffuseStyleGesture++ (cond_mode cross_local_attention5_style1: y['seed_last'] through embed_text_last,
+    BEAT-TWH-main/model/mdm.py:85-89, :226-264) at the tiny5 dims: conditional and `uncond` forward."""
+    sys.path[:0] = [REF + "/BEAT-TWH-main", REF + "/BEAT-TWH-main/model"]
+    from model.mdm import MDM
+    cfg, ts, B = C.TINY5, 500, 2
+    m = MDM(modeltype='', njoints=cfg.njoints, nfeats=1, cond_mode='cross_local_attention5_style1_sample',
+            arch='trans_enc', latent_dim=cfg.latent_dim, n_seed=cfg.n_seed, ff_size=cfg.ff_size,
+            num_layers=cfg.num_layers, num_heads=cfg.num_heads, style_dim=cfg.style_dim_in,
+            source_audio_dim=cfg.audio_src_dim, audio_feat_dim_latent=cfg.audio_dim)
+    missing, unexpected = m.load_state_dict(_to_torch_sd(synth_state_dict(cfg, WSEED)), strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    m.eval()
+    y = synth_window_inputs(cfg, B, window=3, seed_pose_scale=0.1)
+    x = np.random.RandomState(31 + B).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+    g = {"wseed": WSEED, "meta": np.array([B, 0.1, 31 + B, ts], dtype=np.float64)}
+    g["tiny5_out"] = m(torch.from_numpy(x), torch.tensor([ts] * B), y=_y_torch(y)).numpy()
+    yu = _y_torch(y); yu["uncond"] = True
+    g["tiny5_uncond"] = m(torch.from_numpy(x), torch.tensor([ts] * B), y=yu).numpy()
+    print("G10", g["tiny5_out"].shape, float(np.abs(g["tiny5_out"]).mean()))
+    np.savez_compressed(os.path.join(HERE, "g10_forward_dsgpp.npz"), **g)
+
+
 def gen_wavlm():
     """G9: the reference's WavLM (mydiffusion_zeggs/WavLM) instantiated with two SMALL configurations that exercise both
     architecture branches -- "large-like" (layer-norm conv extractor, pre-norm encoder, gated relative position bias:
@@ -367,4 +394,4 @@ def gen_wavlm():
 
 if __name__ == "__main__":
     which = sys.argv[1]
-    {"zeggs": gen_zeggs, "dsgplus": gen_dsgplus, "clip": gen_clip, "bvh": gen_bvh, "wavlm": gen_wavlm}[which]()
+    {"zeggs": gen_zeggs, "dsgplus": gen_dsgplus, "clip": gen_clip, "bvh": gen_bvh, "wavlm": gen_wavlm, "dsgpp": gen_dsgpp}[which]()

@@ -121,6 +121,19 @@ def test_batch1_attention_fused_into_mid(tiny, emu_lib, prec, monkeypatch):
     assert np.array_equal(outs["chain1"], outs["chain0"])
 
 
+def test_classifier_free_guidance_wrapper(tiny):
+    """cfg_sampler.py:23-31: uncond + scale * (cond - uncond), checked against the reference's two goldens."""
+    from diffusestylegesture_amd.model import ClassifierFreeSampleModel
+    gt, models, y, x = tiny
+    w = ClassifierFreeSampleModel(models["fp32"])
+    ts = np.array([998, 17])
+    scale = np.array([2.5, 0.5], np.float32)
+    want = gt["fwd_uncond"] + scale.reshape(-1, 1, 1, 1) * (gt["fwd_allones"] - gt["fwd_uncond"])
+    assert rel_l2(w(x, ts, dict(y, scale=scale)), want) < 2e-5
+    with pytest.raises(KeyError):
+        w(x, ts, y)
+
+
 def test_error_behaviour(tiny, emu_lib):
     gt, models, y, x = tiny
     m = models["fp32"]
@@ -163,29 +176,47 @@ def test_forward_tiny4_dsgplus(emu_lib, golden_dir):
         assert rel_l2(m(x, np.array([500, 500]), dict(y, uncond=True)), g5["tiny4_uncond"]) < TOL[prec]
 
 
-def test_dsgplus_clip_tiny4_vs_oracle(emu_lib):
-    """DSG+ window loop (ceil windows, seed hand-off, one-frame blend, crop, first third of the features)."""
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_forward_tiny5_dsgpp(emu_lib, golden_dir, prec):
+    """DiffuseStyleGesture++ (variant 5): conditioning rows = [seed embedding | audio | seed_last embedding]."""
+    g = _g(golden_dir, "g10_forward_dsgpp.npz")
+    cfg, B, ts = C.TINY5, 2, 500
+    m = DSGDenoiser(cfg, precision=prec, max_batch=2, library=emu_lib)
+    m.load_state_dict(synth_state_dict(cfg, int(g["wseed"])))
+    y = synth_window_inputs(cfg, B, window=3, seed_pose_scale=0.1)
+    x = np.random.RandomState(31 + B).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+    assert rel_l2(m(x, np.array([ts] * B), y), g["tiny5_out"]) < TOL[prec]
+    assert rel_l2(m(x, np.array([ts] * B), dict(y, uncond=True)), g["tiny5_uncond"]) < TOL[prec]
+    y_missing = {k: v for k, v in y.items() if k != "seed_last"}
+    with pytest.raises(KeyError):
+        m(x, np.array([ts] * B), y_missing)
+
+
+@pytest.mark.parametrize("cfg", [C.TINY4, C.TINY5], ids=["attention4", "attention5"])
+def test_dsgplus_clip_tiny_vs_oracle(emu_lib, cfg):
+    """DSG+ / DSG++ window loop (ceil windows, seed hand-off, one-frame blend, crop, first third of the features;
+    attention5: audio[:-S] per window and the fixed y['seed_last'])."""
     from diffusestylegesture_amd.sample import generate_clip_dsgplus
     from oracle import philox, sampler
     from oracle.mdm import MDMOracle
     from oracle.schedule import OracleDiffusion
-    cfg = C.TINY4
     sd = synth_state_dict(cfg, 9)
     m = DSGDenoiser(cfg, precision="fp32", max_batch=1, library=emu_lib)
     m.load_state_dict(sd)
     d = create_gaussian_diffusion(library=emu_lib)
     ref, od = MDMOracle(sd, cfg), OracleDiffusion()
     shape = (1, cfg.njoints, 1, cfg.n_poses)
-    feats = [synth_window_inputs(cfg, 1, window=w)["audio"] for w in range(3)]
+    feats = [synth_window_inputs(C.TINY4, 1, window=w)["audio"] for w in range(3)]      # stride-long feature windows
     seed0 = synth_window_inputs(cfg, 1, window=0, seed_pose_scale=0.2)["seed"]
+    seed_last = synth_window_inputs(cfg, 1).get("seed_last")
     real_n = 61
-    got = generate_clip_dsgplus(m, d, feats, [1, 0, 0], seed0, real_n, seed=5, skip_timesteps=996)
+    got = generate_clip_dsgplus(m, d, feats, [1, 0, 0], seed0, real_n, seed=5, skip_timesteps=996, seed_last=seed_last)
     per = 5
 
     def sample_window(c, yy):
         nf = lambda k: philox.normal_bj1t(shape, 5, c * per + k, 0)
         return sampler.p_sample_loop(od, ref, shape, nf, {"y": yy}, skip_timesteps=996)
-    want = sampler.dsgplus_clip(sample_window, cfg, feats, [1, 0, 0], seed0, real_n)
+    want = sampler.dsgplus_clip(sample_window, cfg, feats, [1, 0, 0], seed0, real_n, seed_last=seed_last)
     assert got.shape == (1, real_n, cfg.njoints // 3)
     assert rel_l2(got[0], want) < 1e-5
 

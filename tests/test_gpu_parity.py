@@ -130,6 +130,25 @@ def test_forward_dsgplus_vs_reference(gpu, golden_dir, cfg, ts):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_forward_dsgpp_attention5_vs_reference(gpu, golden_dir, prec):
+    """DiffuseStyleGesture++ (variant 5, y['seed_last']) vs the imported reference (G10); BEAT++ dims vs the oracle."""
+    g = _g(golden_dir, "g10_forward_dsgpp.npz")
+    cfg, B, ts = C.TINY5, 2, 500
+    m = _model(cfg, prec, wseed=int(g["wseed"]))
+    y = synth_window_inputs(cfg, B, window=3, seed_pose_scale=0.1)
+    x = np.random.RandomState(31 + B).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+    assert rel_l2(m(x, np.array([ts] * B), y), g["tiny5_out"]) < TOL_FWD[prec]
+    assert rel_l2(m(x, np.array([ts] * B), dict(y, uncond=True)), g["tiny5_uncond"]) < TOL_FWD[prec]
+    from oracle.mdm import MDMOracle
+    cfg = C.BEATPP
+    sd = synth_state_dict(cfg, 20240)
+    y = synth_window_inputs(cfg, 1, window=1, seed_pose_scale=0.1)
+    x = np.random.RandomState(5).randn(1, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+    mm = _model(cfg, prec, max_batch=1)
+    assert rel_l2(mm(x, np.array([700]), y), MDMOracle(sd, cfg)(x, [700], y)) < TOL_FWD[prec]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_dsgplus_chain_and_clip_vs_oracle(gpu, prec):
     """DiffuseStyleGesture+ (BEAT dims, attention4): 12-step DDPM chain and a 3-window clip (ceil windows, GT-style seed,
     one-frame blend, crop, first third of the features) against the CPU oracle with the same Philox noise."""
@@ -161,6 +180,37 @@ def test_dsgplus_chain_and_clip_vs_oracle(gpu, prec):
     want = sampler.dsgplus_clip(sample_window, cfg, feats, [1, 0], seed0, real_n)
     assert got.shape == (1, real_n, cfg.njoints // 3)
     assert rel_l2(got[0], want) < TOL_CHAIN[prec]
+
+
+def test_classifier_free_guidance_generic_loop(gpu, golden_dir):
+    """f4: the CFG wrapper (two evaluations per step) is an opaque callable, so the sampler takes its generic loop
+    (HIP elementwise update kernels); with scale 1 it must reproduce the conditional model's generic-loop result."""
+    import torch
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    from diffusestylegesture_amd.model import ClassifierFreeSampleModel
+    gt = _g(golden_dir, "gt_tiny_zeggs.npz")
+    m = _model(C.TINY, "fp32", wseed=int(gt["wseed"]))
+    y = {k: torch.from_numpy(v).cuda() for k, v in synth_window_inputs(C.TINY, 2, window=2, seed_pose_scale=0.3).items()}
+    x = torch.from_numpy(np.random.RandomState(99).randn(2, C.TINY.njoints, 1, C.TINY.n_poses).astype(np.float32)).cuda()
+    ts = torch.tensor([998, 17]).cuda()
+    w = ClassifierFreeSampleModel(m)
+    scale = torch.tensor([2.5, 0.5]).cuda()
+    want = gt["fwd_uncond"] + np.array([2.5, 0.5], np.float32).reshape(-1, 1, 1, 1) * (gt["fwd_allones"] - gt["fwd_uncond"])
+    assert rel_l2(w(x, ts, dict(y, scale=scale)).cpu().numpy(), want) < 2e-5
+    d = create_gaussian_diffusion()
+    shape = tuple(x.shape)
+
+    class Plain:                      # same evaluations through the generic loop, no guidance
+        def parameters(self):
+            return m.parameters()
+
+        def __call__(self, xx, tt, y=None):
+            return m(xx, tt, y)
+    torch.manual_seed(3)
+    a = d.p_sample_loop(w, shape, clip_denoised=False, model_kwargs={"y": dict(y, scale=torch.ones(2).cuda())}, skip_timesteps=996)
+    torch.manual_seed(3)
+    b = d.p_sample_loop(Plain(), shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=996)
+    assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
 
 
 def test_graph_equals_eager_and_deterministic(gpu):
