@@ -128,6 +128,7 @@ struct dsg_handle {
     StepCtl* ctl = nullptr;              // device-resident step control (dsg_kernels.h: StepCtl)
     int* t_arr = nullptr; unsigned* dyn = nullptr;
     int latency_mode = -1;               // -1 auto (fused kernels when the batch is small), 0 never, 1 always
+    int gemm_tnw = 0;                    // DSG_GEMM_TNW: 16-col tiles per wave in the batched GEMMs (0 = by batch size)
     int dbg_skip = 0;                    // DSG_DEBUG_SKIP bit mask: timing experiments only (results become garbage)
     bool fuse_attn = false;
     bool fuse_attn_mid = false;          // k_attn_mid (attention inside the out_proj/LN/linear1 kernel): opt-in, DSG_FUSE_ATTN_MID=1
@@ -258,6 +259,7 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     h->latency_mode = c->latency_mode == 1 ? 0 : (c->latency_mode == 2 ? 1 : -1);
     if (const char* e = getenv("DSG_LATENCY_MODE")) h->latency_mode = atoi(e);
     if (const char* e = getenv("DSG_DEBUG_SKIP")) h->dbg_skip = atoi(e);
+    if (const char* e = getenv("DSG_GEMM_TNW")) h->gemm_tnw = atoi(e);
     if (const char* e = getenv("DSG_FUSE_ATTN")) h->fuse_attn = atoi(e) != 0;
     if (const char* e = getenv("DSG_FUSE_ATTN_MID")) h->fuse_attn_mid = atoi(e) != 0;
     *out = h;
@@ -581,6 +583,26 @@ static int launch_gemm(dsg_handle* h, GemmArgs g) {
     return 0;
 }
 
+// Workgroup width of the GEMMs: 4 waves x TNW 16-col tiles.  A wider workgroup normalises its 16 rows once for more
+// columns (the LayerNorm-on-read prologue is otherwise recomputed by every n-group) and there are fewer workgroups,
+// but each one pulls TNW times more weight bytes through ONE CU's load path.  Measured on MI355X (tools/b_sweep.sh,
+// tools/b16_sweep.sh, ZEGGS bf16): TNW 2 is within noise of TNW 1 at every batch size and TNW 4 is 40 % slower at
+// batch 16 (554 vs 398 us/step), so the narrow shape stays the default; DSG_GEMM_TNW overrides it for experiments.
+static int pick_tnw(const dsg_handle* h, int NT, int M) {
+    (void)M;
+    int t = h->gemm_tnw > 0 ? h->gemm_tnw : 1;
+    while (t > 1 && NT % (4 * t)) t >>= 1;
+    return t;
+}
+template <class P, int PRO, int EPI>
+static int launch_gemm_w(dsg_handle* h, const GemmArgs& g) {
+    switch (pick_tnw(h, g.NT, g.M)) {
+        case 4: return launch_gemm<P, PRO, EPI, 4, 1, 4>(h, g);
+        case 2: return launch_gemm<P, PRO, EPI, 4, 1, 2>(h, g);
+        default: return launch_gemm<P, PRO, EPI, 4, 1, 1>(h, g);
+    }
+}
+
 template <class P, int HD, int NKT>
 static int launch_attn_t(dsg_handle* h, const AttnArgs& a) {
     const int nqt = cdiv(a.ntok, 16);
@@ -735,10 +757,10 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                 g.q = h->q; g.k = h->k; g.vt = h->vt;
                 if (l == 0) {
                     g.A = h->X0a; g.lda = D;
-                    CHK((launch_gemm<P, PRO_DIRECT, EPI_QKV, 4, 1, 1>(h, g)));
+                    CHK((launch_gemm_w<P, PRO_DIRECT, EPI_QKV>(h, g)));
                 } else {
                     g.X = h->pre2; g.ln_g = h->layers[l - 1].g2; g.ln_b = h->layers[l - 1].be2; g.Xn = h->Xn;
-                    CHK((launch_gemm<P, PRO_LN, EPI_QKV, 4, 1, 1>(h, g)));
+                    CHK((launch_gemm_w<P, PRO_LN, EPI_QKV>(h, g)));
                 }
             }
             if (!(skip & 4) && !attn_in_mid) {   // attention
@@ -765,13 +787,13 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                 GemmArgs g = z;
                 g.M = M; g.MT = MT; g.NT = D / 16; g.KBtot = D / KB; g.Wp = ly.Wo; g.bias = ly.bo;
                 g.A = h->attn; g.lda = D; g.out = h->pre1; g.ldo = D; g.R = l == 0 ? h->X0 : h->Xn;
-                CHK((launch_gemm<P, PRO_DIRECT, EPI_RESID, 4, 1, 1>(h, g)));
+                CHK((launch_gemm_w<P, PRO_DIRECT, EPI_RESID>(h, g)));
             }
             {   // LayerNorm1-on-read + linear1 + GELU -> hidden ; X1 = LN1(pre1)
                 GemmArgs g = z;
                 g.M = M; g.MT = MT; g.NT = h->ff / 16; g.KBtot = D / KB; g.Wp = ly.W1; g.bias = ly.b1;
                 g.X = h->pre1; g.ln_g = ly.g1; g.ln_b = ly.be1; g.Xn = h->X1; g.out = h->hidden; g.ldo = h->ff;
-                CHK((launch_gemm<P, PRO_LN, EPI_GELU, 4, 1, 1>(h, g)));
+                CHK((launch_gemm_w<P, PRO_LN, EPI_GELU>(h, g)));
             }
         }
         if (!(skip & 16)) {   // linear2 + residual -> pre2   (K = ff split over the 4 waves of the workgroup)
@@ -788,7 +810,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
         g.out_mode = c.out_mode; g.xs32 = h->xs32; g.xsA = h->prec == DSG_PREC_BF16 ? h->xsA : nullptr;
         g.fwd_out = h->fwd_out; g.ctl = c.use_ctr ? h->ctl : nullptr; g.st = step_tables(h); g.n_tab = h->n_run;
         g.dyn = h->dyn; g.ext_noise = c.ext_noise; g.const_noise = c.const_noise;
-        CHK((launch_gemm<P, PRO_LN, EPI_OUT, 4, 1, 1>(h, g)));
+        CHK((launch_gemm_w<P, PRO_LN, EPI_OUT>(h, g)));
     }
     return 0;
 }

@@ -134,6 +134,30 @@ def test_classifier_free_guidance_wrapper(tiny):
         w(x, ts, y)
 
 
+@pytest.mark.parametrize("tnw", ["2", "4"])
+def test_batched_gemm_wide_workgroups(tiny, emu_lib, golden_dir, tnw, monkeypatch):
+    """The batched path widens a workgroup to 4 x TNW column tiles (selected by batch size on the GPU, forced here):
+    same results as the narrow shape for every GEMM epilogue, tiny dims (TNW 2) and ZEGGS dims (TNW 4)."""
+    monkeypatch.setenv("DSG_GEMM_TNW", tnw)
+    gt, _, y, x = tiny
+    for prec in ("fp32", "bf16"):
+        m = DSGDenoiser(C.TINY, precision=prec, max_batch=2, library=emu_lib, latency_mode="off")
+        m.load_state_dict(synth_state_dict(C.TINY, int(gt["wseed"])))
+        assert rel_l2(m(x, np.array([998, 17]), dict(y, mask_local=gt["mask2"])), gt["fwd_mask2"]) < TOL[prec]
+    d = create_gaussian_diffusion(library=emu_lib)
+    s = d.manual_seed(77, 3).p_sample_loop(m, (2, C.TINY.njoints, 1, C.TINY.n_poses), clip_denoised=False,
+                                           model_kwargs={"y": y}, skip_timesteps=990)
+    assert rel_l2(s, gt["ddpm_skip990"]) < TOL["bf16"]
+    if tnw == "4":
+        g2 = _g(golden_dir, "g2_forward_zeggs.npz")
+        cfg = C.ZEGGS
+        mz = DSGDenoiser(cfg, precision="fp32", max_batch=2, library=emu_lib, latency_mode="off")
+        mz.load_state_dict(synth_state_dict(cfg, int(g2["wseed"])))
+        yz = synth_window_inputs(cfg, 2, window=1, seed_pose_scale=0.5)
+        xz = np.random.RandomState(4244).randn(2, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+        assert rel_l2(mz(xz, np.array([999, 3]), yz), g2["b2_t999_3_out"]) < TOL["fp32"]
+
+
 def test_error_behaviour(tiny, emu_lib):
     gt, models, y, x = tiny
     m = models["fp32"]
