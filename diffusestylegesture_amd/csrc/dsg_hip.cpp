@@ -128,6 +128,7 @@ struct dsg_handle {
     StepCtl* ctl = nullptr;              // device-resident step control (dsg_kernels.h: StepCtl)
     int* t_arr = nullptr; unsigned* dyn = nullptr;
     int latency_mode = -1;               // -1 auto (fused kernels when the batch is small), 0 never, 1 always
+    int gemm_tm = 0;                     // DSG_GEMM_TM: row tiles per workgroup in the GEMMs (0 = by batch size)
     int gemm_tnw = 0;                    // DSG_GEMM_TNW: 16-col tiles per wave in the batched GEMMs (0 = by batch size)
     int dbg_skip = 0;                    // DSG_DEBUG_SKIP bit mask: timing experiments only (results become garbage)
     bool fuse_attn = false;
@@ -260,6 +261,7 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     if (const char* e = getenv("DSG_LATENCY_MODE")) h->latency_mode = atoi(e);
     if (const char* e = getenv("DSG_DEBUG_SKIP")) h->dbg_skip = atoi(e);
     if (const char* e = getenv("DSG_GEMM_TNW")) h->gemm_tnw = atoi(e);
+    if (const char* e = getenv("DSG_GEMM_TM")) h->gemm_tm = atoi(e);
     if (const char* e = getenv("DSG_FUSE_ATTN")) h->fuse_attn = atoi(e) != 0;
     if (const char* e = getenv("DSG_FUSE_ATTN_MID")) h->fuse_attn_mid = atoi(e) != 0;
     *out = h;
@@ -568,7 +570,7 @@ struct StepCtx {
     int B; int out_mode; bool use_ctr; const float* ext_noise; int const_noise;
 };
 
-template <class P, int PRO, int EPI, int WN, int WK, int TNW>
+template <class P, int PRO, int EPI, int WN, int WK, int TNW, int TM = 1>
 static int launch_gemm(dsg_handle* h, GemmArgs g) {
     if (g.KS == 1) g.kb_per_split = g.KBtot;
     const int NG = g.NT / (WN * TNW);
@@ -578,7 +580,8 @@ static int launch_gemm(dsg_handle* h, GemmArgs g) {
     // EPI_PARTIAL / EPI_OUT carry one extra grid row whose first workgroup does the step bookkeeping
     const int extra = (EPI == EPI_PARTIAL || EPI == EPI_OUT) ? 1 : 0;
     g.inv_ntok = fastdiv_inv(g.ntok); g.inv_hd = fastdiv_inv(g.hd);
-    hipLaunchKernelGGL((k_gemm<P, PRO, EPI, WN, WK, TNW>), dim3(xcd_grid_x(NG), g.MT + extra, g.KS), dim3(256), 0, h->stream, g);
+    hipLaunchKernelGGL((k_gemm<P, PRO, EPI, WN, WK, TNW, TM>), dim3(xcd_grid_x(NG), cdiv(g.MT, TM) + extra, g.KS), dim3(256), 0,
+                       h->stream, g);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -588,19 +591,32 @@ static int launch_gemm(dsg_handle* h, GemmArgs g) {
 // but each one pulls TNW times more weight bytes through ONE CU's load path.  Measured on MI355X (tools/b_sweep.sh,
 // tools/b16_sweep.sh, ZEGGS bf16): TNW 2 is within noise of TNW 1 at every batch size and TNW 4 is 40 % slower at
 // batch 16 (554 vs 398 us/step), so the narrow shape stays the default; DSG_GEMM_TNW overrides it for experiments.
-static int pick_tnw(const dsg_handle* h, int NT, int M) {
-    (void)M;
+static int pick_tnw(const dsg_handle* h, int NT) {
     int t = h->gemm_tnw > 0 ? h->gemm_tnw : 1;
     while (t > 1 && NT % (4 * t)) t >>= 1;
-    return t;
+    return t > 2 ? 2 : t;
+}
+// Row tiles per workgroup (TM): 4 row tiles share one set of weight fragments, so a CU pulls 4x fewer weight bytes per
+// output row.  Measured on MI355X (tools/b16_sweep.sh, ZEGGS bf16) it LOSES at every batch size -- batch 16: 537 vs 400
+// us/step, batch 4: 352 vs 202 -- because the batched GEMMs are not bound by bytes but by how many short, independent
+// workgroups are in flight (each is LN -> 8 MFMAs -> epilogue, ~2 us; 4 of them in series per workgroup is 4x the
+// latency with 4x fewer workgroups to overlap).  The single-tile shape stays the default; DSG_GEMM_TM=4 selects this
+// one for experiments (it is covered by the emulator parity tests).
+static int pick_tm(const dsg_handle* h, int M) {
+    (void)M;
+    return h->gemm_tm >= 4 ? 4 : 1;
 }
 template <class P, int PRO, int EPI>
 static int launch_gemm_w(dsg_handle* h, const GemmArgs& g) {
-    switch (pick_tnw(h, g.NT, g.M)) {
-        case 4: return launch_gemm<P, PRO, EPI, 4, 1, 4>(h, g);
-        case 2: return launch_gemm<P, PRO, EPI, 4, 1, 2>(h, g);
-        default: return launch_gemm<P, PRO, EPI, 4, 1, 1>(h, g);
-    }
+    const int tnw = pick_tnw(h, g.NT), tm = pick_tm(h, g.M);
+    if (tm == 4) return tnw == 2 ? launch_gemm<P, PRO, EPI, 4, 1, 2, 4>(h, g) : launch_gemm<P, PRO, EPI, 4, 1, 1, 4>(h, g);
+    return tnw == 2 ? launch_gemm<P, PRO, EPI, 4, 1, 2, 1>(h, g) : launch_gemm<P, PRO, EPI, 4, 1, 1, 1>(h, g);
+}
+// linear2: K = ff split over the 4 waves of the workgroup
+template <class P>
+static int launch_gemm_k4(dsg_handle* h, const GemmArgs& g) {
+    return pick_tm(h, g.M) == 4 ? launch_gemm<P, PRO_DIRECT, EPI_RESID, 1, 4, 1, 4>(h, g)
+                                : launch_gemm<P, PRO_DIRECT, EPI_RESID, 1, 4, 1, 1>(h, g);
 }
 
 template <class P, int HD, int NKT>
@@ -800,7 +816,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
             GemmArgs g = z;
             g.M = M; g.MT = MT; g.NT = D / 16; g.KBtot = h->ff / KB; g.Wp = ly.W2; g.bias = ly.b2;
             g.A = h->hidden; g.lda = h->ff; g.out = h->pre2; g.ldo = D; g.R = h->X1;
-            CHK((launch_gemm<P, PRO_DIRECT, EPI_RESID, 1, 4, 1>(h, g)));
+            CHK(launch_gemm_k4<P>(h, g));
         }
     }
     if (!(skip & 32)) {   // final LayerNorm-on-read + pose head + sampler update

@@ -354,7 +354,9 @@ __device__ __forceinline__ void ln_rows(const GemmArgs& g, int m0, int tid, char
 }
 
 // WN x WK = 4 waves: WN waves side by side along N (TNW 16-col tiles each), WK-way split of K inside the workgroup.
-template <class P, int PRO, int EPI, int WN, int WK, int TNW>
+// TM row tiles per workgroup (batched path): the weight fragments stay in registers and are reused for TM x 16 rows, so
+// the bytes a CU pulls through its load path per output row drop TM-fold; TM = 1 is the batch-1 latency shape.
+template <class P, int PRO, int EPI, int WN, int WK, int TNW, int TM = 1>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
     typedef typename P::elem elem;
     static_assert(WN * WK == 4, "4 waves");
@@ -366,11 +368,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
     preload_kernargs(g);
     DSG_STAMP_SCALAR_WAIT(1 + EPI, 6);
     const int NG = g.NT / (WN * TNW);
-    const int ng = xcd_ngroup(), mt = blockIdx.y, ks = blockIdx.z;
+    const int ng = xcd_ngroup(), ks = blockIdx.z;
+    const int mt_first = blockIdx.y * TM;
     if constexpr (EPI == EPI_PARTIAL || EPI == EPI_OUT) {
         // step bookkeeping runs in ONE EXTRA workgroup (first block of an extra grid row), concurrently with the real
         // work and off every critical path; see StepCtl for why this is race free
-        if (mt == g.MT) {
+        if (mt_first >= g.MT) {
             if (g.ctl && blockIdx.x == 0 && ks == 0 && threadIdx.x == 0) {
                 if constexpr (EPI == EPI_PARTIAL) step_advance_B(g.ctl, g.st, g.n_tab);
                 else if (g.out_mode != OUT_FORWARD) step_advance_A(g.ctl, g.st, g.n_tab);
@@ -378,8 +381,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
             return;
         }
     }
-    if (ng >= NG) return;
-    const int m0 = mt * 16;
+    if (ng >= NG || mt_first >= g.MT) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
     const int wn = wave % WN, wk = wave / WN;
     const int lr = lane & 15, lg = lane >> 4;
@@ -393,12 +395,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
     const int kb_hi = WK > 1 ? kb_lo + kb_per_w : kb_hi_wg;
 
     // ---- main loop
-    f32x4 acc[TNW];
-#pragma unroll
-    for (int t = 0; t < TNW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const f32x4* wbase = (const f32x4*)g.Wp + lane;
-    const elem* arow = nullptr;
-    if constexpr (PRO == PRO_DIRECT) arow = (const elem*)g.A + (size_t)(m0 + lr) * g.lda + P::E * lg;
     // V tiles of the QKV projection use the un-swapped product (4 consecutive tokens per lane -> V^T rows)
     bool swapped[TNW];
 #pragma unroll
@@ -419,19 +416,30 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
         }
     };
     load_b(kb_lo);
-    // ---- epilogue operands (bias, residual, x_t, step coefficients, noise) do not depend on the main loop: fetch
-    //      them now so their latency overlaps the weight / activation fragment loads
-    f32x4 pb[TNW], pr[TNW], pz[TNW];
-    float pbs[TNW];
     int step = 0;
     float k1 = 0.f, k2 = 0.f, k3 = 0.f, k4 = 0.f, k5 = 0.f;
-    bool ovalid[TNW];
     if constexpr (EPI == EPI_OUT) {
         if (g.out_mode != OUT_FORWARD) {
             step = g.ctl->stepB;
             k1 = g.ctl->k1; k2 = g.ctl->k2; k3 = g.ctl->k3; k4 = g.ctl->k4; k5 = g.ctl->k5;
         }
     }
+#pragma unroll 1
+  for (int mi = 0; mi < TM; ++mi) {
+    const int mt = mt_first + mi;
+    if (mt >= g.MT) break;                                   // workgroup-uniform
+    const int m0 = mt * 16;
+    if (TM > 1 && mi > 0 && kb_hi - kb_lo > CH) load_b(kb_lo);     // a multi-chunk K loop has overwritten the first chunk
+    f32x4 acc[TNW];
+#pragma unroll
+    for (int t = 0; t < TNW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const elem* arow = nullptr;
+    if constexpr (PRO == PRO_DIRECT) arow = (const elem*)g.A + (size_t)(m0 + lr) * g.lda + P::E * lg;
+    // ---- epilogue operands (bias, residual, x_t, step coefficients, noise) do not depend on the main loop: fetch
+    //      them now so their latency overlaps the weight / activation fragment loads
+    f32x4 pb[TNW], pr[TNW], pz[TNW];
+    float pbs[TNW];
+    bool ovalid[TNW];
 #pragma unroll
     for (int t = 0; t < TNW; ++t) {
         const int n0 = (nt0 + t) * 16;
@@ -530,15 +538,17 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
                 *(f32x4*)(lds_red + ((((wk - 1) * WN + wn) * TNW + t) * 64 + lane) * 4) = acc[t];
         }
         DSG_LDS_BARRIER();
-        if (wk > 0) return;
+        if (wk == 0) {
 #pragma unroll
-        for (int w2 = 1; w2 < WK; ++w2)
+            for (int w2 = 1; w2 < WK; ++w2)
 #pragma unroll
-            for (int t = 0; t < TNW; ++t)
-                acc[t] += *(const f32x4*)(lds_red + ((((w2 - 1) * WN + wn) * TNW + t) * 64 + lane) * 4);
+                for (int t = 0; t < TNW; ++t)
+                    acc[t] += *(const f32x4*)(lds_red + ((((w2 - 1) * WN + wn) * TNW + t) * 64 + lane) * 4);
+        }
     }
 
-    // ---- epilogue
+    // ---- epilogue (split-K inside the workgroup: the k-slice-0 waves own it)
+    if (WK == 1 || wk == 0) {
 #pragma unroll
     for (int t = 0; t < TNW; ++t) {
         const int n0 = (nt0 + t) * 16;
@@ -613,11 +623,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
             }
         }
     }
+    }
+    if (TM > 1) DSG_LDS_BARRIER();                           // the next row tile reuses the LDS staging buffers
+  }
     DSG_STAMP(1 + EPI, 5);
 }
 
-template <class P, int PRO, int EPI, int WN, int WK, int TNW>
-__global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) { gemm_body<P, PRO, EPI, WN, WK, TNW>(g); }
+template <class P, int PRO, int EPI, int WN, int WK, int TNW, int TM = 1>
+__global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) { gemm_body<P, PRO, EPI, WN, WK, TNW, TM>(g); }
 // ---------------------------------------------------------------------------------------------------------
 // k_loc: per (batch, window, local head).  h = sum_s partial_s + Cframe + TE2[t]; rotary(pos = frame);
 //        causal local attention over {previous window, own window} with q = k = v; prepend token; rotary(pos+1)
