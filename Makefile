@@ -6,15 +6,20 @@ CSRC := diffusestylegesture_amd/csrc
 LIB := $(CSRC)/libdsg_hip.so
 EMU := tests/emu/_build/libdsg_emu.so
 
-all: $(LIB)
+all: $(LIB) $(CSRC)/dsg_kernels.hsaco
 
-$(LIB): $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h include/dsg.h
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed $(CSRC)/dsg_hip.cpp -o $@
+$(LIB): $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h $(CSRC)/dsg_aql.h include/dsg.h
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed $(CSRC)/dsg_hip.cpp -L/opt/rocm/lib -lhsa-runtime64 -o $@
+
+# the device side of the same translation unit as a bare code object: loaded through the HSA loader by the AQL
+# submission path (dsg_aql.h), which needs kernel descriptors the HIP runtime does not hand out
+$(CSRC)/dsg_kernels.hsaco: $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h include/dsg.h
+	$(HIPCC) --offload-arch=gfx950 --cuda-device-only --no-gpu-bundle-output -O3 -std=c++17 -Wno-pass-failed $(CSRC)/dsg_hip.cpp -o $@
 
 # diagnostics build: the same sources with cycle stamps at the phase boundaries of the step kernels (tools/stamps.py)
 stamps: $(CSRC)/libdsg_hip_stamps.so
 $(CSRC)/libdsg_hip_stamps.so: $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h include/dsg.h
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed -DDSG_STAMPS=1 $(CSRC)/dsg_hip.cpp -o $@
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed -DDSG_STAMPS=1 $(CSRC)/dsg_hip.cpp -L/opt/rocm/lib -lhsa-runtime64 -o $@
 
 emu: $(EMU)
 $(EMU): $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h include/dsg.h tests/emu/shim/hip/hip_runtime.h tests/emu/emu_rt.cpp
@@ -23,5 +28,5 @@ $(EMU): $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h include/ds
 	    $(CSRC)/dsg_hip.cpp tests/emu/emu_rt.cpp -o $@
 
 clean:
-	rm -f $(LIB) $(EMU)
+	rm -f $(LIB) $(EMU) $(CSRC)/dsg_kernels.hsaco
 .PHONY: all emu stamps clean

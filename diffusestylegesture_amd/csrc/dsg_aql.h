@@ -1,0 +1,218 @@
+// dsg_aql.h -- the denoising-step loop submitted as hand-written AQL packets on an own HSA user-mode queue.
+//
+// Why: at batch 1 a denoising step is 34 dependent launches and the HIP runtime's per-launch floor dominates it
+// (tools/aql_probe.cpp, profiles/r01_i_aql_probe.log, MI355X: a dependent cross-XCD kernel chain costs 2.11 us per
+// packet when the packets are written by hand -- barrier bit, agent-scope acquire/release, kernel arguments resident
+// in device memory -- against 2.9 us through hipLaunchKernelGGL; a null kernel 1.53 vs 2.45 us).  Everything a step
+// needs that changes from step to step (timestep, coefficients, noise counter) already lives in device memory
+// (StepCtl), so the 34 argument blocks are written ONCE per dsg_sample call and every step re-submits the same 34
+// packets: the host's work per step is 34 x 64-byte stores and one doorbell write.
+//
+// What the probe also established and this file relies on: the release fence must be agent scope (with release NONE a
+// consumer on another XCD reads stale data: the per-XCD L2s are not coherent with each other without the write-back),
+// system scope costs +1.8 us per packet, and kernel arguments in host memory cost 14 us per packet.
+//
+// The kernels are the SAME device code: `make` emits the device side of dsg_hip.cpp as a bare code object
+// (csrc/dsg_kernels.hsaco) next to the library; it is loaded here through the HSA loader, and a host kernel pointer is
+// mapped to its kernel descriptor through the mangled name HIP reports for it (hipKernelNameRefByPtr).  HIP appends
+// hidden arguments (grid size in blocks, ...) behind the explicit ones; hand-written packets must provide them.
+// Every wait is bounded; any failure disables the path for the handle and the HIP launch path takes over.
+#pragma once
+#ifndef DSG_EMU
+#include <dlfcn.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace dsg_aql {
+
+struct Kernel { uint64_t object = 0; uint32_t kernarg_size = 0, group = 0, priv = 0; };
+struct Launch { Kernel k; unsigned gx, gy, gz, bx, by, bz; size_t ka_off; };
+
+struct Ctx {
+    bool tried = false, ready = false, recording = false;
+    std::string err;
+    hsa_agent_t gpu{};
+    hsa_executable_t ex{};
+    hsa_queue_t* q = nullptr;
+    hsa_signal_t done{};
+    std::map<const void*, Kernel> cache;
+    std::vector<char> image;
+    char* ka_dev = nullptr; size_t ka_cap = 0;
+    std::vector<char> ka_host;
+    std::vector<Launch> plan;
+    double last_ms = 0.0;
+};
+
+inline bool hsa_ok(Ctx& c, hsa_status_t s, const char* what) {
+    if (s == HSA_STATUS_SUCCESS) return true;
+    const char* m = nullptr; hsa_status_string(s, &m);
+    c.err = std::string(what) + ": " + (m ? m : "?");
+    return false;
+}
+#define DSG_AQL_CK(c, x) do { if (!hsa_ok(c, (x), #x)) return false; } while (0)
+
+struct AgentPick { std::vector<hsa_agent_t> gpus; };
+inline hsa_status_t agent_cb(hsa_agent_t a, void* d) {
+    hsa_device_type_t t;
+    if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) == HSA_STATUS_SUCCESS && t == HSA_DEVICE_TYPE_GPU) ((AgentPick*)d)->gpus.push_back(a);
+    return HSA_STATUS_SUCCESS;
+}
+
+// one-time set-up for a handle: agent of the HIP device (matched by PCI bus/device/function), code object, queue
+inline bool init(Ctx& c, int hip_device, const void* addr_in_library) {
+    if (c.tried) return c.ready;
+    c.tried = true;
+    DSG_AQL_CK(c, hsa_init());
+    AgentPick pick;
+    DSG_AQL_CK(c, hsa_iterate_agents(agent_cb, &pick));
+    if (pick.gpus.empty()) { c.err = "no HSA GPU agent"; return false; }
+    c.gpu = pick.gpus[0];
+    if (pick.gpus.size() > 1) {
+        char bus[64] = {0};
+        unsigned dom = 0, b = 0, d = 0, f = 0;
+        if (hipDeviceGetPCIBusId(bus, sizeof bus, hip_device) != hipSuccess || sscanf(bus, "%x:%x:%x.%x", &dom, &b, &d, &f) != 4) {
+            c.err = "cannot read the PCI id of the HIP device"; return false;
+        }
+        bool found = false;
+        for (hsa_agent_t a : pick.gpus) {
+            uint32_t bdf = 0, domain = 0;
+            hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf);
+            hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &domain);
+            if (bdf == ((b << 8) | (d << 3) | f) && domain == dom) { c.gpu = a; found = true; break; }
+        }
+        if (!found) { c.err = "no HSA agent matches the HIP device's PCI id"; return false; }
+    }
+    Dl_info info;
+    if (!dladdr(addr_in_library, &info) || !info.dli_fname) { c.err = "dladdr failed"; return false; }
+    std::string path(info.dli_fname);
+    path = path.substr(0, path.find_last_of('/') + 1) + "dsg_kernels.hsaco";
+    std::ifstream f(path, std::ios::binary);
+    c.image.assign((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    if (c.image.empty()) { c.err = "cannot read " + path + " (run make)"; return false; }
+    hsa_code_object_reader_t rd;
+    DSG_AQL_CK(c, hsa_code_object_reader_create_from_memory(c.image.data(), c.image.size(), &rd));
+    DSG_AQL_CK(c, hsa_executable_create_alt(HSA_PROFILE_FULL, HSA_DEFAULT_FLOAT_ROUNDING_MODE_DEFAULT, nullptr, &c.ex));
+    DSG_AQL_CK(c, hsa_executable_load_agent_code_object(c.ex, c.gpu, rd, nullptr, nullptr));
+    DSG_AQL_CK(c, hsa_executable_freeze(c.ex, nullptr));
+    DSG_AQL_CK(c, hsa_queue_create(c.gpu, 4096, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &c.q));
+    DSG_AQL_CK(c, hsa_signal_create(1, 0, nullptr, &c.done));
+    c.ready = true;
+    return true;
+}
+
+inline bool lookup(Ctx& c, const void* host_fn, hipStream_t stream, Kernel& out) {
+    auto it = c.cache.find(host_fn);
+    if (it != c.cache.end()) { out = it->second; return true; }
+    const char* name = hipKernelNameRefByPtr(host_fn, stream);
+    if (!name) { c.err = "hipKernelNameRefByPtr returned null"; return false; }
+    const std::string kd = std::string(name) + ".kd";
+    hsa_executable_symbol_t sym;
+    DSG_AQL_CK(c, hsa_executable_get_symbol_by_name(c.ex, kd.c_str(), &c.gpu, &sym));
+    Kernel k;
+    DSG_AQL_CK(c, hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &k.object));
+    DSG_AQL_CK(c, hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &k.kernarg_size));
+    DSG_AQL_CK(c, hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_GROUP_SEGMENT_SIZE, &k.group));
+    DSG_AQL_CK(c, hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &k.priv));
+    if (k.priv != 0) { c.err = std::string(name) + " needs scratch memory, which this queue does not provide"; return false; }
+    c.cache[host_fn] = k;
+    out = k;
+    return true;
+}
+
+// one launch of the step: explicit argument struct + the hidden arguments of code object v5 behind it
+// (llvm AMDGPUUsage "Code Object V5 Kernel Argument": block counts u32 x3 at +0, group sizes u16 x3 at +12, remainders
+// u16 x3 at +18, global offsets u64 x3 at +40, grid dims u16 at +64)
+inline bool record(Ctx& c, const void* host_fn, hipStream_t stream, dim3 grid, dim3 block, const void* args, size_t size) {
+    Kernel k;
+    if (!lookup(c, host_fn, stream, k)) return false;
+    const size_t hidden = (size + 7) & ~(size_t)7;
+    const size_t need = std::max<size_t>(k.kernarg_size, hidden + 72);
+    const size_t off = (c.ka_host.size() + 255) & ~(size_t)255;
+    c.ka_host.resize(off + ((need + 255) & ~(size_t)255), 0);
+    char* p = c.ka_host.data() + off;
+    std::memcpy(p, args, size);
+    const uint32_t bc[3] = {grid.x, grid.y, grid.z};
+    const uint16_t gs[3] = {(uint16_t)block.x, (uint16_t)block.y, (uint16_t)block.z};
+    std::memcpy(p + hidden + 0, bc, sizeof bc);
+    std::memcpy(p + hidden + 12, gs, sizeof gs);
+    const uint16_t dims = 3;
+    std::memcpy(p + hidden + 64, &dims, 2);
+    c.plan.push_back(Launch{k, grid.x, grid.y, grid.z, block.x, block.y, block.z, off});
+    return true;
+}
+
+inline void begin(Ctx& c) { c.plan.clear(); c.ka_host.clear(); c.recording = true; }
+
+// argument blocks -> device memory (once per dsg_sample call)
+inline bool finish(Ctx& c) {
+    c.recording = false;
+    if (c.plan.empty()) { c.err = "empty plan"; return false; }
+    if (c.ka_host.size() > c.ka_cap) {
+        if (c.ka_dev) (void)hipFree(c.ka_dev);
+        c.ka_cap = c.ka_host.size() * 2;
+        if (hipMalloc((void**)&c.ka_dev, c.ka_cap) != hipSuccess) { c.ka_dev = nullptr; c.ka_cap = 0; c.err = "hipMalloc(kernarg)"; return false; }
+    }
+    if (hipMemcpy(c.ka_dev, c.ka_host.data(), c.ka_host.size(), hipMemcpyHostToDevice) != hipSuccess) { c.err = "hipMemcpy(kernarg)"; return false; }
+    return hipDeviceSynchronize() == hipSuccess;
+}
+
+// n_steps x plan, in order (barrier bit), agent-scope fences; the very last packet releases to system scope and carries
+// the completion signal.  Returns false on time-out (seconds) -- the caller must treat the handle's state as lost.
+inline bool run(Ctx& c, int n_steps, double timeout_s) {
+    const uint32_t mask = c.q->size - 1;
+    const size_t L = c.plan.size();
+    hsa_signal_store_relaxed(c.done, 1);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int s = 0; s < n_steps; ++s) {
+        // back-pressure: never overwrite packets the command processor has not consumed yet
+        uint64_t wr = hsa_queue_load_write_index_relaxed(c.q);
+        while (wr + L - hsa_queue_load_read_index_scacquire(c.q) > c.q->size) {
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) { c.err = "queue stalled"; return false; }
+        }
+        const uint64_t first = hsa_queue_add_write_index_relaxed(c.q, L);
+        for (size_t i = 0; i < L; ++i) {
+            const Launch& l = c.plan[i];
+            const bool last = (s == n_steps - 1) && (i == L - 1);
+            hsa_kernel_dispatch_packet_t* p = (hsa_kernel_dispatch_packet_t*)c.q->base_address + ((first + i) & mask);
+            p->setup = 3 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
+            p->workgroup_size_x = (uint16_t)l.bx; p->workgroup_size_y = (uint16_t)l.by; p->workgroup_size_z = (uint16_t)l.bz;
+            p->reserved0 = 0;
+            p->grid_size_x = l.gx * l.bx; p->grid_size_y = l.gy * l.by; p->grid_size_z = l.gz * l.bz;
+            p->private_segment_size = 0; p->group_segment_size = l.k.group;
+            p->kernel_object = l.k.object;
+            p->kernarg_address = c.ka_dev + l.ka_off;
+            p->reserved2 = 0;
+            p->completion_signal.handle = last ? c.done.handle : 0;
+            const int rel = last ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
+            const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                                               (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
+                                               (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
+            __atomic_store_n((uint16_t*)p, header, __ATOMIC_RELEASE);
+        }
+        hsa_signal_store_screlease(c.q->doorbell_signal, (hsa_signal_value_t)(first + L - 1));
+    }
+    const uint64_t budget_ns = (uint64_t)(timeout_s * 1e9);
+    const hsa_signal_value_t v = hsa_signal_wait_scacquire(c.done, HSA_SIGNAL_CONDITION_LT, 1, budget_ns, HSA_WAIT_STATE_ACTIVE);
+    c.last_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (v >= 1) { c.err = "completion signal timed out"; return false; }
+    return true;
+}
+
+inline void destroy(Ctx& c) {
+    if (c.q) hsa_queue_destroy(c.q);
+    if (c.ready) { hsa_signal_destroy(c.done); hsa_executable_destroy(c.ex); }
+    if (c.ka_dev) (void)hipFree(c.ka_dev);
+    if (c.tried) hsa_shut_down();
+    c = Ctx();
+}
+
+}  // namespace dsg_aql
+#endif  // DSG_EMU

@@ -3,6 +3,7 @@
 // See dsg_kernels.h for the kernels and the reference file:line each one replaces.
 #include "dsg_fused.h"
 #include "../../include/dsg.h"
+#include "dsg_aql.h"
 
 #include <algorithm>
 #include <cmath>
@@ -128,6 +129,13 @@ struct dsg_handle {
     StepCtl* ctl = nullptr;              // device-resident step control (dsg_kernels.h: StepCtl)
     int* t_arr = nullptr; unsigned* dyn = nullptr;
     int latency_mode = -1;               // -1 auto (fused kernels when the batch is small), 0 never, 1 always
+#ifndef DSG_EMU
+    dsg_aql::Ctx aql;                    // hand-written AQL submission of the step loop (dsg_aql.h)
+#endif
+    int aql_mode = 0;                    // DSG_AQL: 0 = HIP launches, 1 = AQL packets for the eager step loop
+    bool aql_warned = false;
+    bool aql_timing = false;             // the last dsg_sample was timed by the host clock around the AQL run
+    double aql_ms = 0.0;
     int gemm_tm = 0;                     // DSG_GEMM_TM: row tiles per workgroup in the GEMMs (0 = by batch size)
     int gemm_tnw = 0;                    // DSG_GEMM_TNW: 16-col tiles per wave in the batched GEMMs (0 = by batch size)
     int dbg_skip = 0;                    // DSG_DEBUG_SKIP bit mask: timing experiments only (results become garbage)
@@ -262,6 +270,7 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     if (const char* e = getenv("DSG_DEBUG_SKIP")) h->dbg_skip = atoi(e);
     if (const char* e = getenv("DSG_GEMM_TNW")) h->gemm_tnw = atoi(e);
     if (const char* e = getenv("DSG_GEMM_TM")) h->gemm_tm = atoi(e);
+    if (const char* e = getenv("DSG_AQL")) h->aql_mode = atoi(e);
     if (const char* e = getenv("DSG_FUSE_ATTN")) h->fuse_attn = atoi(e) != 0;
     if (const char* e = getenv("DSG_FUSE_ATTN_MID")) h->fuse_attn_mid = atoi(e) != 0;
     *out = h;
@@ -315,6 +324,9 @@ extern "C" int dsg_destroy(dsg_handle* h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto& kv : h->graphs) { (void)hipGraphExecDestroy(kv.second.exec); (void)hipGraphDestroy(kv.second.graph); }
+#ifndef DSG_EMU
+    dsg_aql::destroy(h->aql);
+#endif
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     if (h->ev_out) (void)hipEventDestroy(h->ev_out);
@@ -570,6 +582,22 @@ struct StepCtx {
     int B; int out_mode; bool use_ctr; const float* ext_noise; int const_noise;
 };
 
+// Every kernel of the denoising step goes through here: a HIP launch on the handle's stream, or -- while dsg_sample is
+// recording the step for the AQL path -- an entry of the packet plan (dsg_aql.h).
+template <auto K, class A>
+static int step_launch(dsg_handle* h, dim3 grid, dim3 block, const A& args) {
+#ifndef DSG_EMU
+    if (h->aql.recording) {
+        if (!dsg_aql::record(h->aql, (const void*)K, h->stream, grid, block, &args, sizeof(A)))
+            return fail(DSG_E_RUNTIME, "AQL plan: " + h->aql.err);
+        return 0;
+    }
+#endif
+    hipLaunchKernelGGL(K, grid, block, 0, h->stream, args);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 template <class P, int PRO, int EPI, int WN, int WK, int TNW, int TM = 1>
 static int launch_gemm(dsg_handle* h, GemmArgs g) {
     if (g.KS == 1) g.kb_per_split = g.KBtot;
@@ -580,10 +608,7 @@ static int launch_gemm(dsg_handle* h, GemmArgs g) {
     // EPI_PARTIAL / EPI_OUT carry one extra grid row whose first workgroup does the step bookkeeping
     const int extra = (EPI == EPI_PARTIAL || EPI == EPI_OUT) ? 1 : 0;
     g.inv_ntok = fastdiv_inv(g.ntok); g.inv_hd = fastdiv_inv(g.hd);
-    hipLaunchKernelGGL((k_gemm<P, PRO, EPI, WN, WK, TNW, TM>), dim3(xcd_grid_x(NG), cdiv(g.MT, TM) + extra, g.KS), dim3(256), 0,
-                       h->stream, g);
-    HIPCHK(hipGetLastError());
-    return 0;
+    return step_launch<&k_gemm<P, PRO, EPI, WN, WK, TNW, TM>>(h, dim3(xcd_grid_x(NG), cdiv(g.MT, TM) + extra, g.KS), dim3(256), g);
 }
 
 // Workgroup width of the GEMMs: 4 waves x TNW 16-col tiles.  A wider workgroup normalises its 16 rows once for more
@@ -622,9 +647,7 @@ static int launch_gemm_k4(dsg_handle* h, const GemmArgs& g) {
 template <class P, int HD, int NKT>
 static int launch_attn_t(dsg_handle* h, const AttnArgs& a) {
     const int nqt = cdiv(a.ntok, 16);
-    hipLaunchKernelGGL((k_attn<P, HD, NKT>), dim3(nqt, a.H, a.B), dim3(64), 0, h->stream, a);
-    HIPCHK(hipGetLastError());
-    return 0;
+    return step_launch<&k_attn<P, HD, NKT>>(h, dim3(nqt, a.H, a.B), dim3(64), a);
 }
 template <class P>
 static int launch_attn(dsg_handle* h, const AttnArgs& a) {
@@ -644,22 +667,19 @@ static int launch_attn(dsg_handle* h, const AttnArgs& a) {
 #define DSG_LOC_DISPATCH(KERNEL, ARGS, GRID)                                                                         \
     do {                                                                                                             \
         const int key_ = h->hdl * 100 + h->W;                                                                        \
-        if (key_ == 32 * 100 + 11) hipLaunchKernelGGL((KERNEL<P, 32, 11>), GRID, dim3(256), 0, h->stream, ARGS);     \
-        else if (key_ == 48 * 100 + 15) hipLaunchKernelGGL((KERNEL<P, 48, 15>), GRID, dim3(256), 0, h->stream, ARGS);\
-        else if (key_ == 64 * 100 + 15) hipLaunchKernelGGL((KERNEL<P, 64, 15>), GRID, dim3(256), 0, h->stream, ARGS);\
-        else if (key_ == 16 * 100 + 11) hipLaunchKernelGGL((KERNEL<P, 16, 11>), GRID, dim3(256), 0, h->stream, ARGS);\
-        else if (key_ == 8 * 100 + 15) hipLaunchKernelGGL((KERNEL<P, 8, 15>), GRID, dim3(256), 0, h->stream, ARGS);  \
+        if (key_ == 32 * 100 + 11) CHK((step_launch<&KERNEL<P, 32, 11>>(h, GRID, dim3(256), ARGS)));                 \
+        else if (key_ == 48 * 100 + 15) CHK((step_launch<&KERNEL<P, 48, 15>>(h, GRID, dim3(256), ARGS)));            \
+        else if (key_ == 64 * 100 + 15) CHK((step_launch<&KERNEL<P, 64, 15>>(h, GRID, dim3(256), ARGS)));            \
+        else if (key_ == 16 * 100 + 11) CHK((step_launch<&KERNEL<P, 16, 11>>(h, GRID, dim3(256), ARGS)));            \
+        else if (key_ == 8 * 100 + 15) CHK((step_launch<&KERNEL<P, 8, 15>>(h, GRID, dim3(256), ARGS)));              \
         else return fail(DSG_E_NOT_IMPLEMENTED, "no local-attention instantiation for (head dim, window) = (" +      \
                                                     std::to_string(h->hdl) + ", " + std::to_string(h->W) + ")");     \
-        HIPCHK(hipGetLastError());                                                                                   \
     } while (0)
 
 template <class P, int HD, int NKT, int DD>
 static int launch_qkv_attn_t(dsg_handle* h, const QkvAttnArgs& a) {
     const int nqt = cdiv(a.ntok, 16);
-    hipLaunchKernelGGL((k_qkv_attn<P, HD, NKT, DD>), dim3(nqt, a.H, a.B), dim3(256), 0, h->stream, a);
-    HIPCHK(hipGetLastError());
-    return 0;
+    return step_launch<&k_qkv_attn<P, HD, NKT, DD>>(h, dim3(nqt, a.H, a.B), dim3(256), a);
 }
 // fused LayerNorm + in_proj + attention exists for the shapes whose token block fits in LDS
 static bool have_qkv_attn(const dsg_handle* h) {
@@ -674,9 +694,7 @@ static int launch_qkv_attn(dsg_handle* h, const QkvAttnArgs& a) {
 }
 template <class P, int DT>
 static int launch_mid_t(dsg_handle* h, const MidArgs& a) {
-    hipLaunchKernelGGL((k_mid<P, DT>), dim3(xcd_grid_x(a.ff / 64), a.MT), dim3(256), 0, h->stream, a);
-    HIPCHK(hipGetLastError());
-    return 0;
+    return step_launch<&k_mid<P, DT>>(h, dim3(xcd_grid_x(a.ff / 64), a.MT), dim3(256), a);
 }
 template <class P>
 static int launch_mid(dsg_handle* h, const MidArgs& a) {
@@ -699,11 +717,9 @@ static bool have_attn_mid(const dsg_handle* h, int B) {
 template <class P>
 static int launch_attn_mid(dsg_handle* h, const AttnMidArgs& a) {
     const dim3 grid(xcd_grid_x(a.mid.ff / 64), a.mid.MT);
-    if (h->D == 256 && h->Tp == 96) hipLaunchKernelGGL((k_attn_mid<P, 4, 6>), grid, dim3(256), 0, h->stream, a);
-    else if (h->D == 128 && h->Tp == 32) hipLaunchKernelGGL((k_attn_mid<P, 2, 2>), grid, dim3(256), 0, h->stream, a);
-    else return fail(DSG_E_NOT_IMPLEMENTED, "no fused attention+mid instantiation");
-    HIPCHK(hipGetLastError());
-    return 0;
+    if (h->D == 256 && h->Tp == 96) return step_launch<&k_attn_mid<P, 4, 6>>(h, grid, dim3(256), a);
+    if (h->D == 128 && h->Tp == 32) return step_launch<&k_attn_mid<P, 2, 2>>(h, grid, dim3(256), a);
+    return fail(DSG_E_NOT_IMPLEMENTED, "no fused attention+mid instantiation");
 }
 static bool use_latency_mode(const dsg_handle* h, int B) {
     if (h->latency_mode >= 0) return h->latency_mode != 0;
@@ -1164,6 +1180,30 @@ extern "C" int dsg_sample(dsg_handle* h, const dsg_sample_args* a, float* out, i
             while (n_run - done >= spg) { HIPCHK(hipGraphLaunch(it->second.exec, h->stream)); done += spg; }
         }
     }
+    h->aql_timing = false;
+#ifndef DSG_EMU
+    // The step loop as hand-written AQL packets (dsg_aql.h): one recording pass of run_step (no launch), argument
+    // blocks to device memory, then n_run x the same packets on the handle's own HSA queue.  Any failure before the
+    // first packet falls back to the HIP launches below; a failure after submission is an error.
+    if (h->aql_mode == 1 && !dumping && done == 0 && n_run > 0) {
+        bool planned = dsg_aql::init(h->aql, h->cfg.device, (const void*)&dsg_version);
+        if (planned) {
+            dsg_aql::begin(h->aql);
+            const int rc = run_step_p(h, c);
+            planned = dsg_aql::finish(h->aql) && rc == 0;
+            h->aql.recording = false;
+        }
+        if (!planned) {
+            if (!h->aql_warned) { fprintf(stderr, "libdsg_hip: AQL path unavailable (%s); using HIP launches\n", h->aql.err.c_str()); h->aql_warned = true; }
+            h->aql_mode = 0;
+        } else {
+            HIPCHK(hipStreamSynchronize(h->stream));         // state / control block / conditioning are in place
+            if (!dsg_aql::run(h->aql, n_run, 60.0 + 0.01 * n_run)) return fail(DSG_E_RUNTIME, "AQL run: " + h->aql.err);
+            done = n_run;
+            h->aql_timing = true; h->aql_ms = h->aql.last_ms;
+        }
+    }
+#endif
     int di = 0;
     for (; done < n_run; ++done) {
         CHK(run_step_p(h, c));
@@ -1194,7 +1234,8 @@ extern "C" int dsg_last_sample_ms(dsg_handle* h, float* ms, int* n_steps) {
     if (!h || !ms) return fail(DSG_E_INVALID, "null argument");
     if (!h->timing_valid) return fail(DSG_E_STATE, "no dsg_sample has run");
     HIPCHK(hipEventSynchronize(h->ev_t1));
-    HIPCHK(hipEventElapsedTime(ms, h->ev_t0, h->ev_t1));
+    if (h->aql_timing) *ms = (float)h->aql_ms;      // AQL path: host clock from the first doorbell to the completion signal
+    else HIPCHK(hipEventElapsedTime(ms, h->ev_t0, h->ev_t1));
     if (n_steps) *n_steps = h->last_steps;
     return 0;
 }

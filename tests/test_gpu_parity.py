@@ -213,6 +213,31 @@ def test_classifier_free_guidance_generic_loop(gpu, golden_dir):
     assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_aql_step_loop_is_bit_identical_to_hip_launches(gpu, prec, monkeypatch):
+    """DSG_AQL=1 submits the step loop as hand-written AQL packets on an own HSA queue (csrc/dsg_aql.h): the same
+    kernels, arguments and order as the HIP launches, so a chain must agree bit for bit; two windows in a row check that
+    the packet plan is rebuilt per call (conditioning / noise key / skip change)."""
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    cfg = C.ZEGGS
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DSG_AQL", mode)
+        m = _model(cfg, prec, max_batch=1)
+        d = create_gaussian_diffusion()
+        res = []
+        for w, skip in ((0, 960), (1, 985)):
+            y = synth_window_inputs(cfg, 1, window=w, seed_pose_scale=0.3)
+            res.append(np.asarray(d.manual_seed(11, w).p_sample_loop(m, (1, cfg.njoints, 1, cfg.n_poses), clip_denoised=False,
+                                                                     model_kwargs={"y": y}, skip_timesteps=skip)).copy())
+        d50 = create_gaussian_diffusion("ddim50")
+        res.append(np.asarray(d50.manual_seed(12, 0).ddim_sample_loop(m, (1, cfg.njoints, 1, cfg.n_poses), clip_denoised=False,
+                                                                       model_kwargs={"y": y})).copy())
+        outs[mode] = res
+    for a, b in zip(outs["1"], outs["0"]):
+        assert np.isfinite(a).all() and np.array_equal(a, b)
+
+
 def test_graph_equals_eager_and_deterministic(gpu):
     from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
     cfg = C.ZEGGS
