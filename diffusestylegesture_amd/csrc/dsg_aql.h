@@ -49,6 +49,7 @@ struct Ctx {
     std::vector<char> ka_host;
     std::vector<Launch> plan;
     double last_ms = 0.0;
+    int acquire_scope = HSA_FENCE_SCOPE_AGENT;      // DSG_AQL_ACQUIRE=0 -> NONE (experiment)
 };
 
 inline bool hsa_ok(Ctx& c, hsa_status_t s, const char* what) {
@@ -193,7 +194,7 @@ inline bool run(Ctx& c, int n_steps, double timeout_s) {
             p->completion_signal.handle = last ? c.done.handle : 0;
             const int rel = last ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
             const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
-                                               (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
+                                               ((s == 0 && i == 0 ? HSA_FENCE_SCOPE_SYSTEM : c.acquire_scope) << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
                                                (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
             __atomic_store_n((uint16_t*)p, header, __ATOMIC_RELEASE);
         }

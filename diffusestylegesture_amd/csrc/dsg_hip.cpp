@@ -132,7 +132,7 @@ struct dsg_handle {
 #ifndef DSG_EMU
     dsg_aql::Ctx aql;                    // hand-written AQL submission of the step loop (dsg_aql.h)
 #endif
-    int aql_mode = 0;                    // DSG_AQL: 0 = HIP launches, 1 = AQL packets for the eager step loop
+    int aql_mode = 1;                    // DSG_AQL: 1 (default) = AQL packets for the eager step loop, 0 = HIP launches
     bool aql_warned = false;
     bool aql_timing = false;             // the last dsg_sample was timed by the host clock around the AQL run
     double aql_ms = 0.0;
@@ -271,6 +271,14 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     if (const char* e = getenv("DSG_GEMM_TNW")) h->gemm_tnw = atoi(e);
     if (const char* e = getenv("DSG_GEMM_TM")) h->gemm_tm = atoi(e);
     if (const char* e = getenv("DSG_AQL")) h->aql_mode = atoi(e);
+    else {
+        // under a profiler the HSA queues are intercepted and rewritten (rocprofv3 crashed on hand-written packets), so
+        // profiled runs use the HIP launches -- the same kernels, visible to the tool
+        for (const char* v : {"ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_FORCE_LOAD", "ROCPROF_COUNTER_COLLECTION", "ROCPROF_KERNEL_TRACE", "LD_PRELOAD"}) {
+            const char* val = getenv(v);
+            if (val && (strstr(val, "rocprof") || strstr(v, "ROCPROF"))) h->aql_mode = 0;
+        }
+    }
     if (const char* e = getenv("DSG_FUSE_ATTN")) h->fuse_attn = atoi(e) != 0;
     if (const char* e = getenv("DSG_FUSE_ATTN_MID")) h->fuse_attn_mid = atoi(e) != 0;
     *out = h;
@@ -1187,6 +1195,7 @@ extern "C" int dsg_sample(dsg_handle* h, const dsg_sample_args* a, float* out, i
     // first packet falls back to the HIP launches below; a failure after submission is an error.
     if (h->aql_mode == 1 && !dumping && done == 0 && n_run > 0) {
         bool planned = dsg_aql::init(h->aql, h->cfg.device, (const void*)&dsg_version);
+        if (const char* e = getenv("DSG_AQL_ACQUIRE")) h->aql.acquire_scope = atoi(e) ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE;
         if (planned) {
             dsg_aql::begin(h->aql);
             const int rc = run_step_p(h, c);

@@ -10,6 +10,8 @@ python bench.py --sampler ddim50 --batch 16 --no-cpu-baseline > $O/${TAG}_bench_
 python bench.py --config beat --steps 1 --no-cpu-baseline > $O/${TAG}_bench_beat.log 2>&1
 python bench.py --config twh --steps 1 --no-cpu-baseline > $O/${TAG}_bench_twh.log 2>&1
 python tools/step_timing.py --latency on,off --reps 3 > $O/${TAG}_step_timing.log 2>&1
+DSG_AQL=0 python tools/step_timing.py --latency on --reps 3 > $O/${TAG}_step_timing_hip_launches.log 2>&1
+timeout 100 tools/_build/aql_probe tools/_build/aql_kernels.hsaco > $O/${TAG}_aql_probe.log 2>&1
 python tools/kernel_chain.py > $O/${TAG}_kernel_chain_b1.log 2>&1
 python tools/gpu_check.py > $O/${TAG}_parity_matrix.log 2>&1
 DSG_LIB=diffusestylegesture_amd/csrc/libdsg_hip_stamps.so python tools/stamps.py > $O/${TAG}_stamps.log 2>&1
