@@ -34,7 +34,7 @@
 namespace dsg_aql {
 
 struct Kernel { uint64_t object = 0; uint32_t kernarg_size = 0, group = 0, priv = 0; };
-struct Launch { Kernel k; unsigned gx, gy, gz, bx, by, bz; size_t ka_off; };
+struct Launch { Kernel k; unsigned gx, gy, gz, bx, by, bz; size_t ka_off; bool overlap; };
 
 struct Ctx {
     bool tried = false, ready = false, recording = false;
@@ -131,7 +131,9 @@ inline bool lookup(Ctx& c, const void* host_fn, hipStream_t stream, Kernel& out)
 // one launch of the step: explicit argument struct + the hidden arguments of code object v5 behind it
 // (llvm AMDGPUUsage "Code Object V5 Kernel Argument": block counts u32 x3 at +0, group sizes u16 x3 at +12, remainders
 // u16 x3 at +18, global offsets u64 x3 at +40, grid dims u16 at +64)
-inline bool record(Ctx& c, const void* host_fn, hipStream_t stream, dim3 grid, dim3 block, const void* args, size_t size) {
+// overlap: the packet carries no barrier bit -- the kernel starts while its predecessor runs and synchronises with it
+// in-kernel (dsg_kernels.h: DepWait); everything after it is barrier'ed again, so at most two kernels are in flight
+inline bool record(Ctx& c, const void* host_fn, hipStream_t stream, dim3 grid, dim3 block, const void* args, size_t size, bool overlap = false) {
     Kernel k;
     if (!lookup(c, host_fn, stream, k)) return false;
     const size_t hidden = (size + 7) & ~(size_t)7;
@@ -146,7 +148,7 @@ inline bool record(Ctx& c, const void* host_fn, hipStream_t stream, dim3 grid, d
     std::memcpy(p + hidden + 12, gs, sizeof gs);
     const uint16_t dims = 3;
     std::memcpy(p + hidden + 64, &dims, 2);
-    c.plan.push_back(Launch{k, grid.x, grid.y, grid.z, block.x, block.y, block.z, off});
+    c.plan.push_back(Launch{k, grid.x, grid.y, grid.z, block.x, block.y, block.z, off, overlap});
     return true;
 }
 
@@ -193,7 +195,7 @@ inline bool run(Ctx& c, int n_steps, double timeout_s) {
             p->reserved2 = 0;
             p->completion_signal.handle = last ? c.done.handle : 0;
             const int rel = last ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
-            const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+            const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | ((l.overlap ? 0 : 1) << HSA_PACKET_HEADER_BARRIER) |
                                                ((s == 0 && i == 0 ? HSA_FENCE_SCOPE_SYSTEM : c.acquire_scope) << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
                                                (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
             __atomic_store_n((uint16_t*)p, header, __ATOMIC_RELEASE);

@@ -380,6 +380,7 @@ struct MidArgs {
     float* X1;              // LayerNorm1 output rows (fp32), written by hidden-slice 0
     void* hidden;           // [rows][ff] P::elem
     int M, MT, ff;
+    DepWait dep;            // overlapped launch: wait for the attention workgroups before reading A (dep.ctr null: don't)
 };
 
 // Shared tail of k_mid / k_attn_mid: acc = out_proj result tiles of this wave (D[n = 4*lg + r][row = lr]); adds bias +
@@ -493,40 +494,54 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
     f32x4 pbo[DT], pr[DT], pg[DT], pbt[DT], pb1;
     f32x4 w1f[KD <= CH ? KD : 1];
     const int n1t = ng * 4 + wave;                   // this wave's 16-col tile of the hidden layer
+    // overlapped launch (AQL path): everything that does not come from the attention kernel is requested BEFORE waiting
+    // for it -- when all of W_o fits in registers (KD <= CH) that is the whole weight set and the operands of the later
+    // phases, i.e. the load phase that bounds this kernel runs in the shadow of the attention kernel
+    constexpr bool ALLW = KD <= CH;
+    constexpr int NPRE = ALLW ? KD : PD;
 #pragma unroll
-    for (int kb = 0; kb < PD; ++kb) {
-        af[kb] = *(const f32x4*)(arow + (size_t)kb * P::KB);
+    for (int kb = 0; kb < NPRE; ++kb)
 #pragma unroll
         for (int t = 0; t < DT; ++t) bf[kb][t] = wo[((size_t)(wave * DT + t) * KD + kb) * 64];
-    }
+    auto load_operands = [&]() {
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            const int n = (wave * DT + t) * 16 + 4 * lg;
+            pbo[t] = *(const f32x4*)(g.bo + n);
+            pr[t] = *(const f32x4*)(g.R + (size_t)(m0 + lr) * D + n);
+        }
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            const int n = (wave * DT + t) * 16 + 4 * lg;
+            pg[t] = *(const f32x4*)(g.ln_g + n);
+            pbt[t] = *(const f32x4*)(g.ln_b + n);
+        }
+        if constexpr (KD <= CH) {
+#pragma unroll
+            for (int k2 = 0; k2 < KD; ++k2) w1f[k2] = w1[((size_t)n1t * KD + k2) * 64];
+        }
+        pb1 = *(const f32x4*)(g.b1 + n1t * 16 + 4 * lg);
+    };
+    if constexpr (ALLW) load_operands();
+    DSG_LOADS_ISSUED();
+    dep_wait(g.dep);
+    const bool coh = g.dep.ctr != nullptr;           // overlapped launch: the attention rows are read with agent-scope loads
+#pragma unroll
+    for (int kb = 0; kb < PD; ++kb) af[kb] = coh ? load16_agent(arow + (size_t)kb * P::KB) : *(const f32x4*)(arow + (size_t)kb * P::KB);
     f32x4 acc[DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < KD; ++kb) {
         if (kb + PD < KD) {
-            af[kb + PD] = *(const f32x4*)(arow + (size_t)(kb + PD) * P::KB);
+            af[kb + PD] = coh ? load16_agent(arow + (size_t)(kb + PD) * P::KB) : *(const f32x4*)(arow + (size_t)(kb + PD) * P::KB);
+            if constexpr (!ALLW) {
 #pragma unroll
-            for (int t = 0; t < DT; ++t) bf[kb + PD][t] = wo[((size_t)(wave * DT + t) * KD + kb + PD) * 64];
+                for (int t = 0; t < DT; ++t) bf[kb + PD][t] = wo[((size_t)(wave * DT + t) * KD + kb + PD) * 64];
+            }
         }
-        if (kb + PD == KD) {                          // all fragments requested: now the operands of the later phases
-#pragma unroll
-            for (int t = 0; t < DT; ++t) {
-                const int n = (wave * DT + t) * 16 + 4 * lg;
-                pbo[t] = *(const f32x4*)(g.bo + n);
-                pr[t] = *(const f32x4*)(g.R + (size_t)(m0 + lr) * D + n);
-            }
-#pragma unroll
-            for (int t = 0; t < DT; ++t) {
-                const int n = (wave * DT + t) * 16 + 4 * lg;
-                pg[t] = *(const f32x4*)(g.ln_g + n);
-                pbt[t] = *(const f32x4*)(g.ln_b + n);
-            }
-            if constexpr (KD <= CH) {
-#pragma unroll
-                for (int k2 = 0; k2 < KD; ++k2) w1f[k2] = w1[((size_t)n1t * KD + k2) * 64];
-            }
-            pb1 = *(const f32x4*)(g.b1 + n1t * 16 + 4 * lg);
+        if constexpr (!ALLW) {
+            if (kb + PD == KD) load_operands();       // all fragments requested: now the operands of the later phases
         }
         DSG_LOADS_ISSUED();
         if (kb == 0) DSG_STAMP(0, 1);

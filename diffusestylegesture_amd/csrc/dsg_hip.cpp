@@ -133,6 +133,9 @@ struct dsg_handle {
     dsg_aql::Ctx aql;                    // hand-written AQL submission of the step loop (dsg_aql.h)
 #endif
     int aql_mode = 1;                    // DSG_AQL: 1 (default) = AQL packets for the eager step loop, 0 = HIP launches
+    bool overlap = false;                // DSG_OVERLAP=1: (attention -> k_mid) as an overlapped, barrier-less pair (measured slower)
+    bool overlap_next = false;           // the next step_launch is such a consumer
+    unsigned* dep_ctr = nullptr;         // producer counters of the overlapped pairs (dsg_kernels.h: DepWait)
     bool aql_warned = false;
     bool aql_timing = false;             // the last dsg_sample was timed by the host clock around the AQL run
     double aql_ms = 0.0;
@@ -270,6 +273,7 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     if (const char* e = getenv("DSG_DEBUG_SKIP")) h->dbg_skip = atoi(e);
     if (const char* e = getenv("DSG_GEMM_TNW")) h->gemm_tnw = atoi(e);
     if (const char* e = getenv("DSG_GEMM_TM")) h->gemm_tm = atoi(e);
+    if (const char* e = getenv("DSG_OVERLAP")) h->overlap = atoi(e) != 0;
     if (const char* e = getenv("DSG_AQL")) h->aql_mode = atoi(e);
     else {
         // under a profiler the HSA queues are intercepted and rewritten (rocprofv3 crashed on hand-written packets), so
@@ -321,6 +325,7 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     CHK(dalloc(h, &h->mask, (size_t)B * h->T));
     CHK(dalloc(h, &h->ctr, 8));
     CHK(dalloc(h, &h->ctl, 1));
+    CHK(dalloc(h, &h->dep_ctr, 64));
     CHK(dalloc(h, &h->dyn, 8));
     CHK(dalloc(h, &h->t_arr, (size_t)B));
     // the xs32 master is read as a GEMM operand in fp32 mode: rows padded to a 16-row tile exist (allocated above)
@@ -595,11 +600,15 @@ struct StepCtx {
 template <auto K, class A>
 static int step_launch(dsg_handle* h, dim3 grid, dim3 block, const A& args) {
 #ifndef DSG_EMU
+    const bool overlap = h->overlap_next;
+    h->overlap_next = false;
     if (h->aql.recording) {
-        if (!dsg_aql::record(h->aql, (const void*)K, h->stream, grid, block, &args, sizeof(A)))
+        if (!dsg_aql::record(h->aql, (const void*)K, h->stream, grid, block, &args, sizeof(A), overlap))
             return fail(DSG_E_RUNTIME, "AQL plan: " + h->aql.err);
         return 0;
     }
+#else
+    h->overlap_next = false;
 #endif
     hipLaunchKernelGGL(K, grid, block, 0, h->stream, args);
     HIPCHK(hipGetLastError());
@@ -781,6 +790,13 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
     // GEMM make it slower (15 us) than LN+QKV followed by k_attn (6.2 + 4.6 us): opt-in only (DSG_FUSE_ATTN=1)
     const bool fuse_attn = lat && have_qkv_attn(h) && h->fuse_attn;
     const bool attn_in_mid = lat && !fuse_attn && h->fuse_attn_mid && have_attn_mid(h, B);
+    // (attention -> k_mid) as an overlapped pair: k_mid's packet carries no barrier bit, it requests W_o / W_1 / operands
+    // while the attention kernel still runs and synchronises with it in-kernel (DepWait).  Correct (bit-identical, tested)
+    // but measured SLOWER on MI355X: 158 vs 144 us/step -- the agent-scope (L2-bypassing) stores / loads of the handed-off
+    // rows and the counter round trip cost more than the command processor's barrier + fence (1.5 us) they replace; with
+    // __threadfence() instead it was 190 us (each fence writes back and invalidates the XCD's L2).  Opt-in (DSG_OVERLAP=1),
+    // sampling loop and latency kernel set only
+    const bool overlap_mid = lat && !fuse_attn && !attn_in_mid && c.use_ctr && h->overlap && !(skip & (4 | 8));
     for (int l = 0; l < h->L; ++l) {
         const Layer& ly = h->layers[(skip & 64) ? 0 : l];      // 64: every layer reads layer 0's weights (L2 residency experiment)
         if (fuse_attn) {   // [LayerNorm2] + in_proj + attention per (batch, head, query tile)
@@ -805,6 +821,8 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
             }
             if (!(skip & 4) && !attn_in_mid) {   // attention
                 AttnArgs a;
+                memset(&a, 0, sizeof(a));
+                if (overlap_mid) a.done_ctr = h->dep_ctr + 0;
                 a.q = h->q; a.k = h->k; a.vt = h->vt; a.out = h->attn; a.B = B; a.H = h->H; a.ntok = ntok; a.Tp = h->Tp;
                 a.D = D;
                 CHK(launch_attn<P>(h, a));
@@ -813,6 +831,12 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
         if (skip & 8) {
         } else if (lat) {      // [attention +] out_proj + residual + LayerNorm1 + linear1 slice + GELU
             MidArgs a;
+            memset(&a, 0, sizeof(a));
+            if (overlap_mid) {      // launched without a barrier: W_o / operands stream in while the attention kernel runs
+                a.dep.ctr = h->dep_ctr + 0; a.dep.epoch = &h->ctl->stepB; a.dep.per_step = h->L; a.dep.seq = l + 1;
+                a.dep.n_prod = (unsigned)(cdiv(ntok, 16) * h->H * B);
+                h->overlap_next = true;
+            }
             a.A = h->attn; a.R = l == 0 ? h->X0 : h->Xn; a.Wo = ly.Wo; a.bo = ly.bo; a.ln_g = ly.g1; a.ln_b = ly.be1;
             a.W1 = ly.W1; a.b1 = ly.b1; a.X1 = h->X1; a.hidden = h->hidden; a.M = M; a.MT = MT; a.ff = h->ff;
             if (attn_in_mid) {
@@ -891,7 +915,7 @@ static int debug_launch(dsg_handle* h, int which, int i, int B) {
             g.A = h->hidden; g.lda = h->ff; g.out = h->pre2; g.ldo = D; g.R = h->X1;
             return launch_gemm<P, PRO_DIRECT, EPI_RESID, 1, 4, 1>(h, g); }
         case 5: {
-            AttnArgs a; a.q = h->q; a.k = h->k; a.vt = h->vt; a.out = h->attn; a.B = B; a.H = h->H; a.ntok = ntok;
+            AttnArgs a; memset(&a, 0, sizeof(a)); a.q = h->q; a.k = h->k; a.vt = h->vt; a.out = h->attn; a.B = B; a.H = h->H; a.ntok = ntok;
             a.Tp = h->Tp; a.D = D; return launch_attn<P>(h, a); }
         case 6: DSG_LOC_DISPATCH(k_loc, la, dim3(h->Hl, T / h->W, B)); return 0;
         case 7: {
@@ -908,7 +932,7 @@ static int debug_launch(dsg_handle* h, int which, int i, int B) {
             g.q = h->q; g.k = h->k; g.vt = h->vt; g.X = h->pre2; g.ln_g = ly.g2; g.ln_b = ly.be2; g.Xn = h->Xn;
             return launch_gemm<P, PRO_LN, EPI_QKV, 4, 1, 1>(h, g); }
         case 10: {
-            MidArgs a; a.A = h->attn; a.R = h->Xn; a.Wo = ly.Wo; a.bo = ly.bo; a.ln_g = ly.g1; a.ln_b = ly.be1;
+            MidArgs a; memset(&a, 0, sizeof(a)); a.A = h->attn; a.R = h->Xn; a.Wo = ly.Wo; a.bo = ly.bo; a.ln_g = ly.g1; a.ln_b = ly.be1;
             a.W1 = ly.W1; a.b1 = ly.b1; a.X1 = h->X1; a.hidden = h->hidden; a.M = M; a.MT = MT; a.ff = h->ff;
             return launch_mid<P>(h, a); }
         case 11: {
@@ -1141,7 +1165,7 @@ extern "C" int dsg_sample(dsg_handle* h, const dsg_sample_args* a, float* out, i
             ext = h->ext_noise;
         }
     }
-    hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(64), 0, h->stream, h->ctl, h->st_tmodel);
+    hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(64), 0, h->stream, h->ctl, h->st_tmodel, h->dep_ctr, 64);
     HIPCHK(hipGetLastError());
     {
         const unsigned dyn[5] = {nk.k0, nk.k1, nk.s0, nk.s1, a->draw_base + 1u};

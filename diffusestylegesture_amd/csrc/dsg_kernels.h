@@ -79,6 +79,12 @@ struct PF32 {                       // fp32 storage, v_mfma_f32_16x16x4_f32
         return c;
     }
     static __device__ __forceinline__ void store4(elem* p, f32x4 v) { *(f32x4*)p = v; }
+    static __device__ __forceinline__ void store4_agent(elem* p, f32x4 v) {     // agent-scope (write-through) store, 2 x 8 bytes
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        const u64x2 b = __builtin_bit_cast(u64x2, v);
+        __hip_atomic_store((unsigned long long*)p, b[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((unsigned long long*)p + 1, b[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 };
 struct PBF16 {                      // bf16 storage, v_mfma_f32_16x16x32_bf16, fp32 accumulate
     typedef bf16_t elem;
@@ -94,6 +100,11 @@ struct PBF16 {                      // bf16 storage, v_mfma_f32_16x16x32_bf16, f
     static __device__ __forceinline__ void store4(elem* p, f32x4 v) {
         typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
         *(bf16x4v*)p = __builtin_convertvector(v, bf16x4v);
+    }
+    static __device__ __forceinline__ void store4_agent(elem* p, f32x4 v) {     // same values, agent-scope (write-through) store
+        typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+        __hip_atomic_store((unsigned long long*)p, __builtin_bit_cast(unsigned long long, __builtin_convertvector(v, bf16x4v)),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 };
 
@@ -221,8 +232,54 @@ __device__ __forceinline__ void step_advance_A(StepCtl* c, const StepTables& st,
     c->stepA = s;
     c->tA = st.tmodel[s < n ? s : n - 1];
 }
-__global__ void k_ctl_init(StepCtl* c, const int* tmodel) {
+__global__ void k_ctl_init(StepCtl* c, const int* tmodel, unsigned* dep_ctr, int n_ctr) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { c->stepA = 0; c->tA = tmodel[0]; c->stepB = -1; c->k1 = c->k2 = c->k3 = c->k4 = c->k5 = 0.f; }
+    if (blockIdx.x == 0 && (int)threadIdx.x < n_ctr) dep_ctr[threadIdx.x] = 0u;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// In-kernel producer -> consumer hand-off (used with the AQL submission path, dsg_aql.h): the consumer's packet carries
+// NO barrier bit, so the command processor starts it while the producer is still running; the consumer first requests
+// everything that does not depend on the producer (its weights -- the load phase that bounds k_mid), then waits here
+// until every producer workgroup has released its stores.  Counters only ever count up inside one dsg_sample call
+// (zeroed by k_ctl_init): target = (step index * launches per step + launch number in the step) * producer workgroups.
+// Run back to back (HIP launches) the wait is satisfied on the first poll.  Polling is bounded: a missing producer
+// produces a wrong result (caught by the parity tests), not a hung GPU.
+// ---------------------------------------------------------------------------------------------------------
+struct DepWait {
+    const unsigned* ctr;       // null: no waiting (forward pass / batched path)
+    const int* epoch;          // device word holding the current step index (StepCtl::stepB)
+    int per_step, seq;         // launches of the producer per step, 1-based number of this one
+    unsigned n_prod;           // workgroups per producer launch
+};
+// The handed-off data itself bypasses the non-coherent cache levels instead of being fenced: the producer writes it
+// with agent-scope (sc1, write-through) stores and the consumer reads it with agent-scope loads, so no cache-wide
+// write-back / invalidate is needed -- an in-kernel __threadfence() per wave made the step 48 us SLOWER (it writes back
+// and invalidates the XCD's whole L2, weights included).
+__device__ __forceinline__ void store8_agent(void* p, unsigned long long v) {
+    __hip_atomic_store((unsigned long long*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ f32x4 load16_agent(const void* p) {
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    u64x2 v;
+    v[0] = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v[1] = __hip_atomic_load((const unsigned long long*)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __builtin_bit_cast(f32x4, v);
+}
+// producer side: this wave's agent-scope stores have been acknowledged (vmcnt(0)) before the count goes up
+__device__ __forceinline__ void dep_signal(unsigned* ctr, bool one_lane) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0) expcnt(7) lgkmcnt(15)
+    if (one_lane) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// consumer side: called by the whole workgroup; returns when the producer's data may be read (with load16_agent)
+__device__ __forceinline__ void dep_wait(const DepWait& d) {
+    if (d.ctr == nullptr) return;
+    if (threadIdx.x == 0) {
+        const unsigned target = (unsigned)(*d.epoch * d.per_step + d.seq) * d.n_prod;
+        int spins = 0;
+        while (__hip_atomic_load(d.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_s_barrier();
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -794,6 +851,7 @@ struct AttnArgs {
     const void* q; const void* k; const void* vt;   // [B][H][Tp][hd], [B][H][Tp][hd], [B][H][hd][Tp]
     void* out;                                       // [M_pad][D] P::elem
     int B, H, ntok, Tp, D;
+    unsigned* done_ctr;                              // producer counter for the overlapped consumer (k_mid), or null
 };
 
 template <class P, int HD, int NKT>
@@ -912,9 +970,12 @@ __global__ __launch_bounds__(64) void k_attn(const AttnArgs a) {
             f32x4 y;
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = o[e] * inv;
-            P::store4((elem*)a.out + (size_t)(b * a.ntok + q) * a.D + h * HD + dt * 16 + 4 * lg, y);
+            elem* dst = (elem*)a.out + (size_t)(b * a.ntok + q) * a.D + h * HD + dt * 16 + 4 * lg;
+            if (a.done_ctr) P::store4_agent(dst, y);       // read by an overlapped consumer on other XCDs: write through
+            else P::store4(dst, y);
         }
     }
+    if (a.done_ctr) dep_signal(a.done_ctr, lane == 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -49,6 +49,14 @@ static inline void __syncthreads() { emu::syncthreads(); }
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_fence(...) ((void)0)
+#define __builtin_amdgcn_s_sleep(x) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_SEQ_CST)
+static inline void __threadfence() {}
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), __ATOMIC_SEQ_CST)
+#define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), __ATOMIC_SEQ_CST)
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 #define __builtin_amdgcn_s_barrier() emu::syncthreads()
 static inline int emu_update_dpp(int src, int ctrl) {
     // exchange across the wave, then pick the source lane the DPP control selects (row = 16 lanes)

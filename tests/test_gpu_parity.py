@@ -221,8 +221,9 @@ def test_aql_step_loop_is_bit_identical_to_hip_launches(gpu, prec, monkeypatch):
     from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
     cfg = C.ZEGGS
     outs = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("DSG_AQL", mode)
+    for mode in ("1", "0", "overlap"):
+        monkeypatch.setenv("DSG_AQL", "1" if mode == "overlap" else mode)
+        monkeypatch.setenv("DSG_OVERLAP", "1" if mode == "overlap" else "0")     # barrier-less (attention -> k_mid) pair
         m = _model(cfg, prec, max_batch=1)
         d = create_gaussian_diffusion()
         res = []
@@ -234,8 +235,8 @@ def test_aql_step_loop_is_bit_identical_to_hip_launches(gpu, prec, monkeypatch):
         res.append(np.asarray(d50.manual_seed(12, 0).ddim_sample_loop(m, (1, cfg.njoints, 1, cfg.n_poses), clip_denoised=False,
                                                                        model_kwargs={"y": y})).copy())
         outs[mode] = res
-    for a, b in zip(outs["1"], outs["0"]):
-        assert np.isfinite(a).all() and np.array_equal(a, b)
+    for a, b, c in zip(outs["1"], outs["0"], outs["overlap"]):
+        assert np.isfinite(a).all() and np.array_equal(a, b) and np.array_equal(a, c)
 
 
 def test_graph_equals_eager_and_deterministic(gpu):
