@@ -115,7 +115,7 @@ int main(int argc, char** argv) {
     CK(hsa_executable_create_alt(HSA_PROFILE_FULL, HSA_DEFAULT_FLOAT_ROUNDING_MODE_DEFAULT, nullptr, &ex));
     CK(hsa_executable_load_agent_code_object(ex, g_gpu, rd, nullptr, nullptr));
     CK(hsa_executable_freeze(ex, nullptr));
-    Kernel knull = get_kernel(ex, "k_null.kd"), kdep = get_kernel(ex, "k_dep.kd");
+    Kernel knull = get_kernel(ex, "k_null.kd"), kdep = get_kernel(ex, "k_dep.kd"), kwt = get_kernel(ex, "k_dep_wt.kd");
     printf("k_null kernarg %u B, k_dep kernarg %u B group %u priv %u\n", knull.kernarg_size, kdep.kernarg_size, kdep.group, kdep.priv);
 
     Chain c;
@@ -155,18 +155,21 @@ int main(int argc, char** argv) {
         {"dep   none/agent   barrier, kernarg device", &kdep, ka_dev, Z, A, true, NB},
         {"dep   system/system barrier, kernarg device", &kdep, ka_dev, S, S, true, NB},
         {"dep   agent/agent  barrier, kernarg device, 24 workgroups", &kdep, ka_dev, A, A, true, 24},
+        {"dep write-through stores  agent/agent", &kwt, ka_dev, A, A, true, NB},
+        {"dep write-through stores  agent/none (no release fence)", &kwt, ka_dev, A, Z, true, NB},
+        {"dep write-through stores  none/none", &kwt, ka_dev, Z, Z, true, NB},
     };
     for (const V& v : vs) {
         double best = 1e9;
         for (int r = 0; r < 4; ++r) {
-            if (v.k == &kdep) { CK(hsa_amd_memory_fill(a0, 0, NB * 8192 / 4)); CK(hsa_amd_memory_fill(a1, 0, NB * 8192 / 4)); }
+            if (v.k != &knull) { CK(hsa_amd_memory_fill(a0, 0, NB * 8192 / 4)); CK(hsa_amd_memory_fill(a1, 0, NB * 8192 / 4)); }
             const double us = c.run(*v.k, N, v.nb, v.ka, KS, v.acq, v.rel, v.bar);
             if (us < 0) { printf("%-58s : TIMEOUT\n", v.nm); return 2; }
             if (us < best) best = us;
         }
         // correctness of the dependent chain: after N launches every element written by the last launch == N
         double bad = -1;
-        if (v.k == &kdep && v.nb == NB) {
+        if (v.k != &knull && v.nb == NB) {
             std::vector<float> h(NB * 2048);
             CK(hsa_memory_copy(h.data(), (N & 1) ? a1 : a0, h.size() * 4));      // launch N-1 (odd index) wrote a0 when N even
             size_t nb = 0; for (float x : h) if (x != (float)N) ++nb;
