@@ -711,7 +711,9 @@ static int launch_qkv_attn(dsg_handle* h, const QkvAttnArgs& a) {
 }
 template <class P, int DT>
 static int launch_mid_t(dsg_handle* h, const MidArgs& a) {
-    return step_launch<&k_mid<P, DT>>(h, dim3(xcd_grid_x(a.ff / 64), a.MT), dim3(256), a);
+    const dim3 grid(xcd_grid_x(a.ff / 64), a.MT);
+    if (a.dep.ctr) return step_launch<&k_mid<P, DT, true>>(h, grid, dim3(256), a);       // overlapped launch (DSG_OVERLAP=1)
+    return step_launch<&k_mid<P, DT, false>>(h, grid, dim3(256), a);
 }
 template <class P>
 static int launch_mid(dsg_handle* h, const MidArgs& a) {
