@@ -474,6 +474,7 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
     constexpr int CH = DT >= 6 ? 4 : 8;              // fragments in flight per chunk (DT tiles each): bounded by the register file
     __shared__ __attribute__((aligned(16))) char a1[16 * XP];
     __shared__ float red[2][4][16];
+    __shared__ __attribute__((aligned(16))) float vecs[3][D];      // out_proj bias, LayerNorm1 scale / shift: one load per WORKGROUP
     DSG_STAMP(0, 0);
     preload_kernargs(g);
     DSG_STAMP_SCALAR_WAIT(0, 8);
@@ -485,6 +486,16 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
     const f32x4* wo = (const f32x4*)g.Wo + lane;
     const f32x4* w1 = (const f32x4*)g.W1 + lane;
     const elem* arow = (const elem*)g.A + (size_t)(m0 + lr) * D + P::E * lg;
+    // The three per-column vectors are the same for every wave and row tile: fetched once per workgroup (one 16-byte load
+    // by 3 D / 4 lanes) and read back from LDS, instead of 12 wave-wide loads per wave through the CU's load path, which
+    // bounds this kernel (measured: -1060 cycles per kernel without those loads).
+    constexpr int NV = (3 * D / 4 + 255) / 256;      // float4 loads per lane (1 for D <= 320, else 2)
+    f32x4 vload[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int e = min(tid + 256 * i, 3 * D / 4 - 1), vsel = e / (D / 4), vidx = e % (D / 4);      // clamped, never predicated
+        vload[i] = ((const f32x4*)(vsel == 0 ? g.bo : (vsel == 1 ? g.ln_g : g.ln_b)))[vidx];
+    }
 
     // ---- out_proj as a software pipeline.  The load phase of this kernel is bound by the CU's texture-address path
     //      (~65 x 1 KB wave loads per wave, 4 waves: measured ~90 cycles per load instruction), so the order of issue IS
@@ -509,14 +520,7 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
 #pragma unroll
         for (int t = 0; t < DT; ++t) {
             const int n = (wave * DT + t) * 16 + 4 * lg;
-            pbo[t] = *(const f32x4*)(g.bo + n);
             pr[t] = *(const f32x4*)(g.R + (size_t)(m0 + lr) * D + n);
-        }
-#pragma unroll
-        for (int t = 0; t < DT; ++t) {
-            const int n = (wave * DT + t) * 16 + 4 * lg;
-            pg[t] = *(const f32x4*)(g.ln_g + n);
-            pbt[t] = *(const f32x4*)(g.ln_b + n);
         }
         if constexpr (KD <= CH) {
 #pragma unroll
@@ -553,6 +557,17 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
         for (int t = 0; t < DT; ++t) acc[t] = P::mma(bf[kb][t], af[kb], acc[t]);      // D[n 4lg+r][row lr]
         if (kb == 0) DSG_STAMP(0, 2);
         DSG_LOADS_ISSUED();
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int e = tid + 256 * i;
+        if (e < 3 * D / 4) *(f32x4*)(&vecs[0][0] + e * 4) = vload[i];          // vecs[3][D] is contiguous: element e of the 3 D / 4 float4s
+    }
+    DSG_LDS_BARRIER();
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+        const int n = (wave * DT + t) * 16 + 4 * lg;
+        pbo[t] = *(const f32x4*)(&vecs[0][n]); pg[t] = *(const f32x4*)(&vecs[1][n]); pbt[t] = *(const f32x4*)(&vecs[2][n]);
     }
     mid_tail<P, DT>(g, acc, pbo, pr, pg, pbt, pb1, w1f, w1, a1, red, m0, ng, n1t, wave, lr, lg);
     DSG_STAMP(0, 7);
