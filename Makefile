@@ -3,18 +3,20 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 HOSTCXX ?= /opt/rocm/lib/llvm/bin/clang++
 CSRC := diffusestylegesture_amd/csrc
+# one tag for the library and the bare code object: dsg_aql.h refuses a dsg_kernels.hsaco built from other sources
+TAG := $(shell cat $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h $(CSRC)/dsg_aql.h include/dsg.h | cksum | cut -d' ' -f1)
 LIB := $(CSRC)/libdsg_hip.so
 EMU := tests/emu/_build/libdsg_emu.so
 
 all: $(LIB) $(CSRC)/dsg_kernels.hsaco
 
 $(LIB): $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h $(CSRC)/dsg_aql.h include/dsg.h
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed $(CSRC)/dsg_hip.cpp -L/opt/rocm/lib -lhsa-runtime64 -o $@
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed -DDSG_BUILD_TAG=$(TAG)u $(CSRC)/dsg_hip.cpp -L/opt/rocm/lib -lhsa-runtime64 -o $@
 
 # the device side of the same translation unit as a bare code object: loaded through the HSA loader by the AQL
 # submission path (dsg_aql.h), which needs kernel descriptors the HIP runtime does not hand out
-$(CSRC)/dsg_kernels.hsaco: $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h include/dsg.h
-	$(HIPCC) --offload-arch=gfx950 --cuda-device-only --no-gpu-bundle-output -O3 -std=c++17 -Wno-pass-failed $(CSRC)/dsg_hip.cpp -o $@
+$(CSRC)/dsg_kernels.hsaco: $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h $(CSRC)/dsg_aql.h include/dsg.h
+	$(HIPCC) --offload-arch=gfx950 --cuda-device-only --no-gpu-bundle-output -O3 -std=c++17 -Wno-pass-failed -DDSG_BUILD_TAG=$(TAG)u $(CSRC)/dsg_hip.cpp -o $@
 
 # diagnostics build: the same sources with cycle stamps at the phase boundaries of the step kernels (tools/stamps.py)
 stamps: $(CSRC)/libdsg_hip_stamps.so

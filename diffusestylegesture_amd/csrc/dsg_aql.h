@@ -103,6 +103,17 @@ inline bool init(Ctx& c, int hip_device, const void* addr_in_library) {
     DSG_AQL_CK(c, hsa_executable_create_alt(HSA_PROFILE_FULL, HSA_DEFAULT_FLOAT_ROUNDING_MODE_DEFAULT, nullptr, &c.ex));
     DSG_AQL_CK(c, hsa_executable_load_agent_code_object(c.ex, c.gpu, rd, nullptr, nullptr));
     DSG_AQL_CK(c, hsa_executable_freeze(c.ex, nullptr));
+    {   // the code object must come from the same sources as this library (same argument structs, same kernels)
+        hsa_executable_symbol_t sym;
+        uint64_t addr = 0;
+        unsigned tag = ~0u;
+        DSG_AQL_CK(c, hsa_executable_get_symbol_by_name(c.ex, "dsg_device_build_tag", &c.gpu, &sym));
+        DSG_AQL_CK(c, hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_VARIABLE_ADDRESS, &addr));
+        if (hsa_memory_copy(&tag, (const void*)addr, sizeof tag) != HSA_STATUS_SUCCESS || tag != (unsigned)DSG_BUILD_TAG) {
+            c.err = path + " was built from different sources than the library (run make)";
+            return false;
+        }
+    }
     DSG_AQL_CK(c, hsa_queue_create(c.gpu, 4096, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &c.q));
     DSG_AQL_CK(c, hsa_signal_create(1, 0, nullptr, &c.done));
     c.ready = true;

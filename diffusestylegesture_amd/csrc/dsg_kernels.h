@@ -114,6 +114,13 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // (seen in the ISA as L w L w L w ...; the LayerNorm GEMMs had 17-19 of them).  LOADS_ISSUED() additionally stops the
 // scheduler from sinking loads below the first use.
 #define DSG_LOADS_ISSUED() __builtin_amdgcn_sched_barrier(0)
+#ifndef DSG_BUILD_TAG
+#define DSG_BUILD_TAG 0u
+#endif
+// checksum of the sources this device code was built from (Makefile); the AQL path compares the tag inside
+// dsg_kernels.hsaco with the library's own before it trusts the code object with the library's argument structs
+extern "C" __device__ const unsigned dsg_device_build_tag = DSG_BUILD_TAG;
+
 // Optional cycle stamps (make stamps -> libdsg_hip_stamps.so, tools/stamps.py): wave 0 of workgroup 8 records
 // s_memtime at a few phase boundaries of the step kernels.  Compiled out of the product library.
 #ifdef DSG_STAMPS
