@@ -85,7 +85,7 @@ def test_chains_tiny(tiny, emu_lib, prec):
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_throughput_kernels_tiny(tiny, emu_lib, prec):
-    """The un-fused (batched / throughput) kernel set, which `auto` only selects for batch > 4."""
+    """The un-fused (batched / throughput) kernel set, which `auto` only selects for batch > 2."""
     gt, _, y, x = tiny
     m = DSGDenoiser(C.TINY, precision=prec, max_batch=2, library=emu_lib, latency_mode="off")
     m.load_state_dict(synth_state_dict(C.TINY, int(gt["wseed"])))

@@ -277,7 +277,7 @@ def test_batch1_attention_fused_into_mid_is_bit_identical(gpu, prec, monkeypatch
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_throughput_kernel_set_vs_reference(gpu, golden_dir, prec):
-    """latency_mode="off": the un-fused kernel set (what `auto` uses for batch > 4) against the same goldens."""
+    """latency_mode="off": the un-fused kernel set (what `auto` uses for batch > 2) against the same goldens."""
     from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
     g2, g3 = _g(golden_dir, "g2_forward_zeggs.npz"), _g(golden_dir, "g3_chains_zeggs.npz")
     cfg = C.ZEGGS
