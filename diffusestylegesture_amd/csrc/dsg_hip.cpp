@@ -638,28 +638,24 @@ static int pick_tnw(const dsg_handle* h, int NT) {
     while (t > 1 && NT % (4 * t)) t >>= 1;
     return t > 2 ? 2 : t;
 }
-// Row tiles per workgroup (TM): 4 row tiles share one set of weight fragments, so a CU pulls 4x fewer weight bytes per
-// output row.  Measured on MI355X (tools/b16_sweep.sh, ZEGGS bf16) it LOSES at every batch size -- batch 16: 537 vs 400
-// us/step, batch 4: 352 vs 202 -- because the batched GEMMs are not bound by bytes but by how many short, independent
-// workgroups are in flight (each is LN -> 8 MFMAs -> epilogue, ~2 us; 4 of them in series per workgroup is 4x the
-// latency with 4x fewer workgroups to overlap).  The single-tile shape stays the default; DSG_GEMM_TM=4 selects this
-// one for experiments (it is covered by the emulator parity tests).
+// Row tiles per workgroup (TM = 4, gemm_body_mt): measured slower than one tile per workgroup at every batch size (see the
+// comment there), so it is an experiment switch only (DSG_GEMM_TM=4; covered by the emulator parity tests).
 static int pick_tm(const dsg_handle* h, int M) {
     (void)M;
     return h->gemm_tm >= 4 ? 4 : 1;
 }
 template <class P, int PRO, int EPI>
 static int launch_gemm_w(dsg_handle* h, const GemmArgs& g) {
-    const int tnw = pick_tnw(h, g.NT), tm = pick_tm(h, g.M);
-    if (tm == 4) return tnw == 2 ? launch_gemm<P, PRO, EPI, 4, 1, 2, 4>(h, g) : launch_gemm<P, PRO, EPI, 4, 1, 1, 4>(h, g);
+    const int tnw = pick_tnw(h, g.NT);
+    // the multi-tile shape holds the whole K range in one chunk of 8 k-blocks and stages TM x 16 LayerNorm rows in LDS
+    const bool mt_ok = g.KBtot <= 8 && g.KS == 1 && (PRO != PRO_LN || g.D <= (sizeof(typename P::elem) == 2 ? 512 : 256));
+    if (pick_tm(h, g.M) == 4 && mt_ok)
+        return tnw == 2 ? launch_gemm<P, PRO, EPI, 4, 1, 2, 4>(h, g) : launch_gemm<P, PRO, EPI, 4, 1, 1, 4>(h, g);
     return tnw == 2 ? launch_gemm<P, PRO, EPI, 4, 1, 2, 1>(h, g) : launch_gemm<P, PRO, EPI, 4, 1, 1, 1>(h, g);
 }
 // linear2: K = ff split over the 4 waves of the workgroup
 template <class P>
-static int launch_gemm_k4(dsg_handle* h, const GemmArgs& g) {
-    return pick_tm(h, g.M) == 4 ? launch_gemm<P, PRO_DIRECT, EPI_RESID, 1, 4, 1, 4>(h, g)
-                                : launch_gemm<P, PRO_DIRECT, EPI_RESID, 1, 4, 1, 1>(h, g);
-}
+static int launch_gemm_k4(dsg_handle* h, const GemmArgs& g) { return launch_gemm<P, PRO_DIRECT, EPI_RESID, 1, 4, 1, 1>(h, g); }
 
 template <class P, int HD, int NKT>
 static int launch_attn_t(dsg_handle* h, const AttnArgs& a) {

@@ -417,10 +417,125 @@ __device__ __forceinline__ void ln_rows(const GemmArgs& g, int m0, int tid, char
         }
 }
 
+// Epilogue operands of one 16 x 16 output tile (bias, residual rows, x_t, noise): requested early, they do not depend on
+// the main loop
+struct TileOps { f32x4 pb, pr, pz; float pbs; bool ovalid; };
+template <class P, int EPI>
+__device__ __forceinline__ void gemm_prefetch_tile(const GemmArgs& g, int m0, int n0, int lr, int lg, int step, TileOps& o) {
+        o.pb = o.pr = o.pz = (f32x4){0.f, 0.f, 0.f, 0.f};
+        o.pbs = 0.f; o.ovalid = false;
+        if constexpr (EPI == EPI_RESID) {
+            o.pb = *(const f32x4*)(g.bias + n0 + 4 * lg);
+            o.pr = *(const f32x4*)(g.R + (size_t)(m0 + lr) * g.ldo + n0 + 4 * lg);     // rows are padded to the tile
+        } else if constexpr (EPI == EPI_GELU) {
+            o.pb = *(const f32x4*)(g.bias + n0 + 4 * lg);
+        } else if constexpr (EPI == EPI_QKV) {
+            o.pb = *(const f32x4*)(g.bias + n0 + 4 * lg);      // both forms loaded unconditionally (no branchy loads)
+            o.pbs = g.bias[n0 + lr];
+        } else if constexpr (EPI == EPI_OUT) {
+            const int m = m0 + lr, j0 = n0 + 4 * lg;
+            const int b = fdiv(m, g.inv_ntok), sx = m - b * g.ntok;
+            o.ovalid = m < g.M && sx > 0 && j0 < g.J;
+            o.pb = *(const f32x4*)(g.bias + j0);
+            {   // x_t: unconditional load from a clamped (always valid) row; unused when the lane is not `ovalid`
+                const int bc = b < g.B ? b : g.B - 1, fc = sx > 0 ? sx - 1 : 0;
+                o.pr = *(const f32x4*)(g.xs32 + ((size_t)bc * g.T + fc) * g.Jp + j0);
+            }
+            if (o.ovalid && g.out_mode != OUT_FORWARD) {
+                const int f = sx - 1;
+                const int bn = g.const_noise ? 0 : b;
+                if (g.ext_noise) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        o.pz[e] = (j0 + e < g.J)
+                                       ? g.ext_noise[(((size_t)step * g.B + bn) * g.J + j0 + e) * g.T + f] : 0.f;
+                } else {
+                    const NoiseKey nk = {g.dyn[0], g.dyn[1], g.dyn[2], g.dyn[3]};
+                    o.pz = philox_normal4((unsigned)((((size_t)bn * g.T + f) * g.Jq + j0) >> 2),
+                                           g.dyn[4] + (unsigned)step, nk);
+                }
+            }
+        }
+}
+
+template <class P, int EPI>
+__device__ __forceinline__ void gemm_epilogue_tile(const GemmArgs& g, int m0, int n0, int lr, int lg, int ks, bool swapped, const f32x4& acc,
+                                                   const TileOps& o, float k1, float k2, float k3, float k4, float k5) {
+    typedef typename P::elem elem;
+        if constexpr (EPI == EPI_PARTIAL) {
+            const int m = m0 + lr;
+            if (m < g.M) *(f32x4*)((float*)g.out + ((size_t)ks * g.MT * 16 + m) * g.ldo + n0 + 4 * lg) = acc;
+        } else if constexpr (EPI == EPI_RESID) {
+            const int m = m0 + lr, n = n0 + 4 * lg;
+            if (m < g.M) *(f32x4*)((float*)g.out + (size_t)m * g.ldo + n) = acc + o.pb + o.pr;
+        } else if constexpr (EPI == EPI_GELU) {
+            const int m = m0 + lr, n = n0 + 4 * lg;
+            if (m < g.M) {
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = gelu_erf<P>(acc[e] + o.pb[e]);
+                P::store4((elem*)g.out + (size_t)m * g.ldo + n, y);
+            }
+        } else if constexpr (EPI == EPI_QKV) {
+            const int Dm = g.H * g.hd;
+            const int which = (n0 >= Dm) + (n0 >= 2 * Dm), nn = n0 - which * Dm;
+            const int head = fdiv(nn, g.inv_hd), d0 = nn - head * g.hd;
+            if (swapped) {                    // Q or K: [B][H][Tp][hd], 4 consecutive dims of one token
+                const int m = m0 + lr;
+                if (m < g.M) {
+                    const int b = fdiv(m, g.inv_ntok), sx = m - b * g.ntok;
+                    elem* dst = (elem*)(which == 0 ? g.q : g.k) + (((size_t)b * g.H + head) * g.Tp + sx) * g.hd + d0 + 4 * lg;
+                    P::store4(dst, acc + o.pb);
+                }
+            } else {                             // V: transposed [B][H][hd][Tp], lane = one dim, 4 consecutive tokens
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int m = m0 + 4 * lg + e;
+                    if (m < g.M) {
+                        const int b = fdiv(m, g.inv_ntok), sx = m - b * g.ntok;
+                        ((elem*)g.vt)[(((size_t)b * g.H + head) * g.hd + d0 + lr) * g.Tp + sx] = P::cvt(acc[e] + o.pbs);
+                    }
+                }
+            }
+        } else if constexpr (EPI == EPI_OUT) {
+            const int m = m0 + lr, j0 = n0 + 4 * lg;
+            const int b = fdiv(m, g.inv_ntok), sx = m - b * g.ntok;
+            if (o.ovalid) {
+                const int f = sx - 1;
+                const f32x4 x0 = acc + o.pb;
+                if (g.out_mode == OUT_FORWARD) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (j0 + e < g.J) g.fwd_out[((size_t)b * g.J + j0 + e) * g.T + f] = x0[e];
+                } else {
+                    const f32x4 xt = o.pr, z = o.pz;
+                    f32x4 xn;
+                    if (g.out_mode == OUT_DDPM) {       // gaussian_diffusion.py:264-267, :557
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float mean = k1 * x0[e] + k2 * xt[e];
+                            xn[e] = mean + k3 * z[e];
+                        }
+                    } else {                            // gaussian_diffusion.py:773-791
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float eps = (k1 * xt[e] - x0[e]) / k2;
+                            const float mean = x0[e] * k3 + k4 * eps;
+                            xn[e] = mean + k5 * z[e];
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (j0 + e >= g.J) xn[e] = 0.f;
+                    *(f32x4*)(g.xs32 + ((size_t)b * g.T + f) * g.Jp + j0) = xn;
+                    if (g.xsA) P::store4((elem*)g.xsA + ((size_t)b * g.T + f) * g.Jp + j0, xn);
+                }
+            }
+        }
+}
+
 // WN x WK = 4 waves: WN waves side by side along N (TNW 16-col tiles each), WK-way split of K inside the workgroup.
-// TM row tiles per workgroup (batched path): the weight fragments stay in registers and are reused for TM x 16 rows, so
-// the bytes a CU pulls through its load path per output row drop TM-fold; TM = 1 is the batch-1 latency shape.
-template <class P, int PRO, int EPI, int WN, int WK, int TNW, int TM = 1>
+template <class P, int PRO, int EPI, int WN, int WK, int TNW>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
     typedef typename P::elem elem;
     static_assert(WN * WK == 4, "4 waves");
@@ -433,7 +548,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
     DSG_STAMP_SCALAR_WAIT(1 + EPI, 6);
     const int NG = g.NT / (WN * TNW);
     const int ng = xcd_ngroup(), ks = blockIdx.z;
-    const int mt_first = blockIdx.y * TM;
+    const int mt_first = blockIdx.y;
     if constexpr (EPI == EPI_PARTIAL || EPI == EPI_OUT) {
         // step bookkeeping runs in ONE EXTRA workgroup (first block of an extra grid row), concurrently with the real
         // work and off every critical path; see StepCtl for why this is race free
@@ -488,12 +603,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
             k1 = g.ctl->k1; k2 = g.ctl->k2; k3 = g.ctl->k3; k4 = g.ctl->k4; k5 = g.ctl->k5;
         }
     }
-#pragma unroll 1
-  for (int mi = 0; mi < TM; ++mi) {
-    const int mt = mt_first + mi;
-    if (mt >= g.MT) break;                                   // workgroup-uniform
-    const int m0 = mt * 16;
-    if (TM > 1 && mi > 0 && kb_hi - kb_lo > CH) load_b(kb_lo);     // a multi-chunk K loop has overwritten the first chunk
+    const int m0 = mt_first * 16;
     f32x4 acc[TNW];
 #pragma unroll
     for (int t = 0; t < TNW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -501,47 +611,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
     if constexpr (PRO == PRO_DIRECT) arow = (const elem*)g.A + (size_t)(m0 + lr) * g.lda + P::E * lg;
     // ---- epilogue operands (bias, residual, x_t, step coefficients, noise) do not depend on the main loop: fetch
     //      them now so their latency overlaps the weight / activation fragment loads
-    f32x4 pb[TNW], pr[TNW], pz[TNW];
-    float pbs[TNW];
-    bool ovalid[TNW];
+    TileOps ops[TNW];
 #pragma unroll
-    for (int t = 0; t < TNW; ++t) {
-        const int n0 = (nt0 + t) * 16;
-        pb[t] = pr[t] = pz[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        pbs[t] = 0.f; ovalid[t] = false;
-        if constexpr (EPI == EPI_RESID) {
-            pb[t] = *(const f32x4*)(g.bias + n0 + 4 * lg);
-            pr[t] = *(const f32x4*)(g.R + (size_t)(m0 + lr) * g.ldo + n0 + 4 * lg);     // rows are padded to the tile
-        } else if constexpr (EPI == EPI_GELU) {
-            pb[t] = *(const f32x4*)(g.bias + n0 + 4 * lg);
-        } else if constexpr (EPI == EPI_QKV) {
-            pb[t] = *(const f32x4*)(g.bias + n0 + 4 * lg);      // both forms loaded unconditionally (no branchy loads)
-            pbs[t] = g.bias[n0 + lr];
-        } else if constexpr (EPI == EPI_OUT) {
-            const int m = m0 + lr, j0 = n0 + 4 * lg;
-            const int b = fdiv(m, g.inv_ntok), sx = m - b * g.ntok;
-            ovalid[t] = m < g.M && sx > 0 && j0 < g.J;
-            pb[t] = *(const f32x4*)(g.bias + j0);
-            {   // x_t: unconditional load from a clamped (always valid) row; unused when the lane is not `ovalid`
-                const int bc = b < g.B ? b : g.B - 1, fc = sx > 0 ? sx - 1 : 0;
-                pr[t] = *(const f32x4*)(g.xs32 + ((size_t)bc * g.T + fc) * g.Jp + j0);
-            }
-            if (ovalid[t] && g.out_mode != OUT_FORWARD) {
-                const int f = sx - 1;
-                const int bn = g.const_noise ? 0 : b;
-                if (g.ext_noise) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        pz[t][e] = (j0 + e < g.J)
-                                       ? g.ext_noise[(((size_t)step * g.B + bn) * g.J + j0 + e) * g.T + f] : 0.f;
-                } else {
-                    const NoiseKey nk = {g.dyn[0], g.dyn[1], g.dyn[2], g.dyn[3]};
-                    pz[t] = philox_normal4((unsigned)((((size_t)bn * g.T + f) * g.Jq + j0) >> 2),
-                                           g.dyn[4] + (unsigned)step, nk);
-                }
-            }
-        }
-    }
+    for (int t = 0; t < TNW; ++t) gemm_prefetch_tile<P, EPI>(g, m0, (nt0 + t) * 16, lr, lg, step, ops[t]);
 
     // ---- prologue: LayerNorm-on-read (rows are owned whole: K == D)
     int pitch = 0;
@@ -614,87 +686,158 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
     // ---- epilogue (split-K inside the workgroup: the k-slice-0 waves own it)
     if (WK == 1 || wk == 0) {
 #pragma unroll
-    for (int t = 0; t < TNW; ++t) {
-        const int n0 = (nt0 + t) * 16;
-        if constexpr (EPI == EPI_PARTIAL) {
-            const int m = m0 + lr;
-            if (m < g.M) *(f32x4*)((float*)g.out + ((size_t)ks * g.MT * 16 + m) * g.ldo + n0 + 4 * lg) = acc[t];
-        } else if constexpr (EPI == EPI_RESID) {
-            const int m = m0 + lr, n = n0 + 4 * lg;
-            if (m < g.M) *(f32x4*)((float*)g.out + (size_t)m * g.ldo + n) = acc[t] + pb[t] + pr[t];
-        } else if constexpr (EPI == EPI_GELU) {
-            const int m = m0 + lr, n = n0 + 4 * lg;
-            if (m < g.M) {
-                f32x4 y;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = gelu_erf<P>(acc[t][e] + pb[t][e]);
-                P::store4((elem*)g.out + (size_t)m * g.ldo + n, y);
-            }
-        } else if constexpr (EPI == EPI_QKV) {
-            const int Dm = g.H * g.hd;
-            const int which = (n0 >= Dm) + (n0 >= 2 * Dm), nn = n0 - which * Dm;
-            const int head = fdiv(nn, g.inv_hd), d0 = nn - head * g.hd;
-            if (swapped[t]) {                    // Q or K: [B][H][Tp][hd], 4 consecutive dims of one token
-                const int m = m0 + lr;
-                if (m < g.M) {
-                    const int b = fdiv(m, g.inv_ntok), sx = m - b * g.ntok;
-                    elem* dst = (elem*)(which == 0 ? g.q : g.k) + (((size_t)b * g.H + head) * g.Tp + sx) * g.hd + d0 + 4 * lg;
-                    P::store4(dst, acc[t] + pb[t]);
-                }
-            } else {                             // V: transposed [B][H][hd][Tp], lane = one dim, 4 consecutive tokens
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int m = m0 + 4 * lg + e;
-                    if (m < g.M) {
-                        const int b = fdiv(m, g.inv_ntok), sx = m - b * g.ntok;
-                        ((elem*)g.vt)[(((size_t)b * g.H + head) * g.hd + d0 + lr) * g.Tp + sx] = P::cvt(acc[t][e] + pbs[t]);
-                    }
-                }
-            }
-        } else if constexpr (EPI == EPI_OUT) {
-            const int m = m0 + lr, j0 = n0 + 4 * lg;
-            const int b = fdiv(m, g.inv_ntok), sx = m - b * g.ntok;
-            if (ovalid[t]) {
-                const int f = sx - 1;
-                const f32x4 x0 = acc[t] + pb[t];
-                if (g.out_mode == OUT_FORWARD) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (j0 + e < g.J) g.fwd_out[((size_t)b * g.J + j0 + e) * g.T + f] = x0[e];
-                } else {
-                    const f32x4 xt = pr[t], z = pz[t];
-                    f32x4 xn;
-                    if (g.out_mode == OUT_DDPM) {       // gaussian_diffusion.py:264-267, :557
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float mean = k1 * x0[e] + k2 * xt[e];
-                            xn[e] = mean + k3 * z[e];
-                        }
-                    } else {                            // gaussian_diffusion.py:773-791
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float eps = (k1 * xt[e] - x0[e]) / k2;
-                            const float mean = x0[e] * k3 + k4 * eps;
-                            xn[e] = mean + k5 * z[e];
-                        }
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (j0 + e >= g.J) xn[e] = 0.f;
-                    *(f32x4*)(g.xs32 + ((size_t)b * g.T + f) * g.Jp + j0) = xn;
-                    if (g.xsA) P::store4((elem*)g.xsA + ((size_t)b * g.T + f) * g.Jp + j0, xn);
-                }
-            }
-        }
+    for (int t = 0; t < TNW; ++t)
+        gemm_epilogue_tile<P, EPI>(g, m0, (nt0 + t) * 16, lr, lg, ks, swapped[t], acc[t], ops[t], k1, k2, k3, k4, k5);
     }
-    }
-    if (TM > 1) DSG_LDS_BARRIER();                           // the next row tile reuses the LDS staging buffers
-  }
     DSG_STAMP(1 + EPI, 5);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Multi-tile shape of the same GEMM (experiment, DSG_GEMM_TM=4): TM row tiles per workgroup, EVERYTHING of all tiles
+// requested up front (one memory round trip per workgroup), the weight fragments loaded once and reused for TM x 16 rows,
+// all TM x TNW MFMA chains interleaved.  Correct (emulator + GPU parity) but measured SLOWER than one tile per workgroup
+// at every batch size on MI355X (tools/b16_sweep.sh: batch 16: 513 vs 380 us/step; a first version that looped over the
+// tiles serially: 537): at M = 1424 rows the 4x fewer, 4x longer workgroups quantise badly over 256 CUs (368 workgroups
+// = 2 rounds of 4 units against 5.6 rounds of 1 unit) and the LayerNorm recomputed per n-group dominates either way.
+// Constraints: 4 waves side by side (no split-K), the whole K range in one chunk of 8 k-blocks, LayerNorm rows up to
+// 512 (bf16) / 256 (fp32) wide.
+// ---------------------------------------------------------------------------------------------------------
+template <class P, int PRO, int EPI, int TNW, int TM>
+__device__ __forceinline__ void gemm_body_mt(const GemmArgs& g) {
+    typedef typename P::elem elem;
+    constexpr int ES = (int)sizeof(elem), WN = 4, CH = 8;
+    constexpr int DMAX = ES == 2 ? 512 : 256;
+    __shared__ __attribute__((aligned(16))) char lds_a[PRO == PRO_LN ? TM * 16 * (DMAX * ES + 16) : 16];
+    preload_kernargs(g);
+    const int NG = g.NT / (WN * TNW);
+    const int ng = xcd_ngroup();
+    const int mt_first = blockIdx.y * TM;
+    if constexpr (EPI == EPI_PARTIAL || EPI == EPI_OUT) {
+        if (mt_first >= g.MT) {      // extra grid row: step bookkeeping (see gemm_body)
+            if (g.ctl && blockIdx.x == 0 && threadIdx.x == 0) {
+                if constexpr (EPI == EPI_PARTIAL) step_advance_B(g.ctl, g.st, g.n_tab);
+                else if (g.out_mode != OUT_FORWARD) step_advance_A(g.ctl, g.st, g.n_tab);
+            }
+            return;
+        }
+    }
+    if (ng >= NG || mt_first >= g.MT) return;
+    const int tid = threadIdx.x, lane = tid & 63, wn = wave_id();
+    const int lr = lane & 15, lg = lane >> 4;
+    const int nt0 = (ng * WN + wn) * TNW;
+    const int kb_last = g.KBtot - 1;
+    const f32x4* wbase = (const f32x4*)g.Wp + lane;
+    bool swapped[TNW];
+#pragma unroll
+    for (int t = 0; t < TNW; ++t) swapped[t] = !(EPI == EPI_QKV && ((nt0 + t) * 16) >= 2 * (g.H * g.hd));
+    f32x4 bf[CH][TNW];
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int t = 0; t < TNW; ++t) bf[c][t] = wbase[((size_t)(nt0 + t) * g.KBtot + min(c, kb_last)) * 64];
+    int step = 0;
+    float k1 = 0.f, k2 = 0.f, k3 = 0.f, k4 = 0.f, k5 = 0.f;
+    if constexpr (EPI == EPI_OUT) {
+        if (g.out_mode != OUT_FORWARD) {
+            step = g.ctl->stepB;
+            k1 = g.ctl->k1; k2 = g.ctl->k2; k3 = g.ctl->k3; k4 = g.ctl->k4; k5 = g.ctl->k5;
+        }
+    }
+    int m0s[TM];
+    bool live[TM];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) { live[mi] = mt_first + mi < g.MT; m0s[mi] = min(mt_first + mi, g.MT - 1) * 16; }   // clamped loads, predicated stores
+    TileOps ops[TM][TNW];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int t = 0; t < TNW; ++t) gemm_prefetch_tile<P, EPI>(g, m0s[mi], (nt0 + t) * 16, lr, lg, step, ops[mi][t]);
+
+    // ---- A side: LayerNorm of TM x 16 rows into LDS (loads of all tiles first), or the activation fragments themselves
+    f32x4 af[PRO == PRO_DIRECT ? TM : 1][CH];
+    int pitch = 0;
+    if constexpr (PRO == PRO_LN) {
+        const int D = g.D, nch = D >> 6;
+        pitch = DSG_LDS_ROW_BYTES(D, ES);
+        const int row = tid >> 4, c = tid & 15;
+        f32x4 v[TM][8], gg[8], bb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int col = c * 4 + 64 * (i < nch ? i : 0);
+            gg[i] = *(const f32x4*)(g.ln_g + col);
+            bb[i] = *(const f32x4*)(g.ln_b + col);
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) v[mi][i] = *(const f32x4*)(g.X + (size_t)(m0s[mi] + row) * D + col);
+        }
+        DSG_LOADS_ISSUED();
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += (i < nch ? 1.f : 0.f) * ((v[mi][i][0] + v[mi][i][1]) + (v[mi][i][2] + v[mi][i][3]));
+            s = row16_sum(s);
+            const float mean = s / (float)D;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = v[mi][i][e] - mean; q += (i < nch ? 1.f : 0.f) * d * d; }
+            q = row16_sum(q);
+            const float rstd = 1.0f / sqrtf(q / (float)D + 1e-5f);
+            const bool wr = (g.Xn != nullptr) && ng == 0 && live[mi] && (m0s[mi] + row) < g.M;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i < nch) {
+                    f32x4 y;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = (v[mi][i][e] - mean) * rstd * gg[i][e] + bb[i][e];
+                    P::store4((elem*)(lds_a + (mi * 16 + row) * pitch) + c * 4 + 64 * i, y);
+                    if (wr) *(f32x4*)(g.Xn + (size_t)(m0s[mi] + row) * D + c * 4 + 64 * i) = y;
+                }
+        }
+        DSG_LDS_BARRIER();
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const elem* arow = (const elem*)g.A + (size_t)(m0s[mi] + lr) * g.lda + P::E * lg;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) af[mi][c] = *(const f32x4*)(arow + (size_t)min(c, kb_last) * P::KB);
+        }
+        DSG_LOADS_ISSUED();
+    }
+    f32x4 acc[TM][TNW];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int t = 0; t < TNW; ++t) acc[mi][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const bool on = c < g.KBtot;                 // wave-uniform; k-blocks past the end contribute zeros
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            f32x4 a;
+            if constexpr (PRO == PRO_DIRECT) a = af[mi][c];
+            else a = *(const f32x4*)(lds_a + (mi * 16 + lr) * pitch + (min(c, kb_last) * P::KB + P::E * lg) * ES);
+            a = on ? a : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < TNW; ++t)
+                acc[mi][t] = swapped[t] ? P::mma(bf[c][t], a, acc[mi][t]) : P::mma(a, bf[c][t], acc[mi][t]);
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+        if (live[mi]) {
+#pragma unroll
+            for (int t = 0; t < TNW; ++t)
+                gemm_epilogue_tile<P, EPI>(g, m0s[mi], (nt0 + t) * 16, lr, lg, 0, swapped[t], acc[mi][t], ops[mi][t], k1, k2, k3, k4, k5);
+        }
+}
+
 template <class P, int PRO, int EPI, int WN, int WK, int TNW, int TM = 1>
-__global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) { gemm_body<P, PRO, EPI, WN, WK, TNW, TM>(g); }
+__global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
+    if constexpr (TM == 1) gemm_body<P, PRO, EPI, WN, WK, TNW>(g);
+    else { static_assert(WN == 4 && WK == 1, "multi-tile shape: 4 waves side by side"); gemm_body_mt<P, PRO, EPI, TNW, TM>(g); }
+}
 // ---------------------------------------------------------------------------------------------------------
 // k_loc: per (batch, window, local head).  h = sum_s partial_s + Cframe + TE2[t]; rotary(pos = frame);
 //        causal local attention over {previous window, own window} with q = k = v; prepend token; rotary(pos+1)
