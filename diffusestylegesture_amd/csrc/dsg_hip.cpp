@@ -139,6 +139,7 @@ struct dsg_handle {
     bool aql_warned = false;
     bool aql_timing = false;             // the last dsg_sample was timed by the host clock around the AQL run
     double aql_ms = 0.0;
+    int gemm_lean = -1;                  // DSG_GEMM_LEAN: -1 by batch size, 0 never, 1 always (LayerNorm GEMMs compiled for 4 waves per SIMD)
     int gemm_tm = 0;                     // DSG_GEMM_TM: row tiles per workgroup in the GEMMs (0 = by batch size)
     int gemm_tnw = 0;                    // DSG_GEMM_TNW: 16-col tiles per wave in the batched GEMMs (0 = by batch size)
     int dbg_skip = 0;                    // DSG_DEBUG_SKIP bit mask: timing experiments only (results become garbage)
@@ -273,6 +274,7 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     if (const char* e = getenv("DSG_DEBUG_SKIP")) h->dbg_skip = atoi(e);
     if (const char* e = getenv("DSG_GEMM_TNW")) h->gemm_tnw = atoi(e);
     if (const char* e = getenv("DSG_GEMM_TM")) h->gemm_tm = atoi(e);
+    if (const char* e = getenv("DSG_GEMM_LEAN")) h->gemm_lean = atoi(e);
     if (const char* e = getenv("DSG_OVERLAP")) h->overlap = atoi(e) != 0;
     if (const char* e = getenv("DSG_AQL")) h->aql_mode = atoi(e);
     else {
@@ -649,6 +651,18 @@ static int launch_gemm_w(dsg_handle* h, const GemmArgs& g) {
     const int tnw = pick_tnw(h, g.NT);
     // the multi-tile shape holds the whole K range in one chunk of 8 k-blocks and stages TM x 16 LayerNorm rows in LDS
     const bool mt_ok = g.KBtot <= 8 && g.KS == 1 && (PRO != PRO_LN || g.D <= (sizeof(typename P::elem) == 2 ? 512 : 256));
+    if constexpr (PRO == PRO_LN) {      // batched path: the high-occupancy variant (DSG_GEMM_LEAN=0/1 overrides the batch rule)
+        // measured (tools/b16_lean.sh, ZEGGS bf16, un-fused set): batch 8: 250 vs 267 us/step, batch 16: 360 vs 378; neutral at 3-4
+        const bool lean = h->gemm_lean >= 0 ? h->gemm_lean != 0 : g.M >= 512;
+        if (lean && tnw == 1 && pick_tm(h, g.M) == 1) {
+            GemmArgs gl = g;
+            gl.KS = 1; gl.kb_per_split = gl.KBtot;
+            gl.inv_ntok = fastdiv_inv(gl.ntok); gl.inv_hd = fastdiv_inv(gl.hd);
+            const int extra = EPI == EPI_OUT ? 1 : 0;
+            if (gl.NT % 4) return fail(DSG_E_INVALID, "gemm: NT not divisible by the workgroup tile");
+            return step_launch<&k_gemm_lean<P, EPI>>(h, dim3(xcd_grid_x(gl.NT / 4), gl.MT + extra, 1), dim3(256), gl);
+        }
+    }
     if (pick_tm(h, g.M) == 4 && mt_ok)
         return tnw == 2 ? launch_gemm<P, PRO, EPI, 4, 1, 2, 4>(h, g) : launch_gemm<P, PRO, EPI, 4, 1, 1, 4>(h, g);
     return tnw == 2 ? launch_gemm<P, PRO, EPI, 4, 1, 2, 1>(h, g) : launch_gemm<P, PRO, EPI, 4, 1, 1, 1>(h, g);

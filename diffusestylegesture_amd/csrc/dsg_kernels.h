@@ -372,21 +372,27 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // LayerNorm of 16 rows by 256 lanes (16 lanes per row, NCH float4 chunks per lane), result to LDS in the MFMA element
 // type and kept in v[] (fp32) for the write-back.  NCH > 0: exact width, no dead work.  NCH == 0: any D <= 512 that is
 // a multiple of 64 (loads clamped to chunk 0 and weighted out, so the load phase stays branch-free).
-template <class P, int NCH>
-__device__ __forceinline__ void ln_rows(const GemmArgs& g, int m0, int tid, char* lds_a, int pitch, f32x4 (&v)[8]) {
+// LEAN (batched path): the occupancy of these kernels is what bounds the batched step (rocprofv3 SQ counters,
+// profiles/r01_k_pmc_sq_b1_b16.log: 2 waves per SIMD at ~200 VGPRs -> 2.8 rounds of workgroups at batch 16), so scale /
+// shift are fetched chunk by chunk after the statistics instead of being held for the whole row, and the normalised rows
+// are written back at once (`xn_out`) instead of staying live across the MFMA phase.
+template <class P, int NCH, bool LEAN = false>
+__device__ __forceinline__ void ln_rows(const GemmArgs& g, int m0, int tid, char* lds_a, int pitch, f32x4 (&v)[8], float* xn_out = nullptr) {
     typedef typename P::elem elem;
     constexpr int N = NCH > 0 ? NCH : 8;
     const int D = g.D;
     const int row = tid >> 4, c = tid & 15;
     const float* xr = g.X + (size_t)(m0 + row) * D;
     const int nch = NCH > 0 ? NCH : (D >> 6);
-    f32x4 gg[N], bb[N];
+    f32x4 gg[LEAN ? 1 : N], bb[LEAN ? 1 : N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const int col = c * 4 + 64 * (i < nch ? i : 0);
         v[i] = *(const f32x4*)(xr + col);
-        gg[i] = *(const f32x4*)(g.ln_g + col);
-        bb[i] = *(const f32x4*)(g.ln_b + col);
+        if constexpr (!LEAN) {
+            gg[i] = *(const f32x4*)(g.ln_g + col);
+            bb[i] = *(const f32x4*)(g.ln_b + col);
+        }
     }
     DSG_LOADS_ISSUED();
     float s = 0.f;
@@ -410,10 +416,17 @@ __device__ __forceinline__ void ln_rows(const GemmArgs& g, int m0, int tid, char
     for (int i = 0; i < N; ++i)
         if (NCH > 0 || i < nch) {
             f32x4 y;
+            if constexpr (LEAN) {
+                const f32x4 gi = *(const f32x4*)(g.ln_g + c * 4 + 64 * i), bi = *(const f32x4*)(g.ln_b + c * 4 + 64 * i);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * gg[i][e] + bb[i][e];
+                for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * gi[e] + bi[e];
+                if (xn_out) *(f32x4*)(xn_out + c * 4 + 64 * i) = y;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * gg[i][e] + bb[i][e];
+                v[i] = y;
+            }
             P::store4((elem*)(lds_a + row * pitch) + c * 4 + 64 * i, y);
-            v[i] = y;
         }
 }
 
@@ -535,7 +548,7 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmArgs& g, int m0, in
 }
 
 // WN x WK = 4 waves: WN waves side by side along N (TNW 16-col tiles each), WK-way split of K inside the workgroup.
-template <class P, int PRO, int EPI, int WN, int WK, int TNW>
+template <class P, int PRO, int EPI, int WN, int WK, int TNW, bool LEAN = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
     typedef typename P::elem elem;
     static_assert(WN * WK == 4, "4 waves");
@@ -623,10 +636,19 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
         pitch = DSG_LDS_ROW_BYTES(g.D, ES);
         wr = (g.Xn != nullptr) && ng == 0 && (m0 + (tid >> 4)) < g.M;
         const int nch = g.D >> 6;                     // D / 64 float4 chunks per thread; one straight-line copy per width
-        if (nch == 4) ln_rows<P, 4>(g, m0, tid, lds_a, pitch, v);
-        else if (nch == 6) ln_rows<P, 6>(g, m0, tid, lds_a, pitch, v);
-        else if (nch == 8) ln_rows<P, 8>(g, m0, tid, lds_a, pitch, v);
-        else ln_rows<P, 0>(g, m0, tid, lds_a, pitch, v);
+        if constexpr (LEAN) {
+            float* xn_out = wr ? g.Xn + (size_t)(m0 + (tid >> 4)) * g.D : nullptr;
+            if (nch == 4) ln_rows<P, 4, true>(g, m0, tid, lds_a, pitch, v, xn_out);
+            else if (nch == 6) ln_rows<P, 6, true>(g, m0, tid, lds_a, pitch, v, xn_out);
+            else if (nch == 8) ln_rows<P, 8, true>(g, m0, tid, lds_a, pitch, v, xn_out);
+            else ln_rows<P, 0, true>(g, m0, tid, lds_a, pitch, v, xn_out);
+            wr = false;                               // already written
+        } else {
+            if (nch == 4) ln_rows<P, 4>(g, m0, tid, lds_a, pitch, v);
+            else if (nch == 6) ln_rows<P, 6>(g, m0, tid, lds_a, pitch, v);
+            else if (nch == 8) ln_rows<P, 8>(g, m0, tid, lds_a, pitch, v);
+            else ln_rows<P, 0>(g, m0, tid, lds_a, pitch, v);
+        }
         DSG_LDS_BARRIER();
     }
     DSG_STAMP(1 + EPI, 2);
@@ -832,6 +854,10 @@ __device__ __forceinline__ void gemm_body_mt(const GemmArgs& g) {
                 gemm_epilogue_tile<P, EPI>(g, m0s[mi], (nt0 + t) * 16, lr, lg, 0, swapped[t], acc[mi][t], ops[mi][t], k1, k2, k3, k4, k5);
         }
 }
+
+// batched LayerNorm-GEMM: compiled for 3 waves per SIMD (<= 168 VGPRs; at 128 it spills to scratch), see ln_rows LEAN
+template <class P, int EPI>
+__global__ __launch_bounds__(256, 3) void k_gemm_lean(const GemmArgs g) { gemm_body<P, PRO_LN, EPI, 4, 1, 1, true>(g); }
 
 template <class P, int PRO, int EPI, int WN, int WK, int TNW, int TM = 1>
 __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
