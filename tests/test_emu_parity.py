@@ -134,13 +134,14 @@ def test_classifier_free_guidance_wrapper(tiny):
         w(x, ts, y)
 
 
-@pytest.mark.parametrize("tnw,tm", [("2", "1"), ("1", "4"), ("2", "4")])
-def test_batched_gemm_workgroup_shapes(tiny, emu_lib, golden_dir, tnw, tm, monkeypatch):
+@pytest.mark.parametrize("tnw,tm,lean", [("2", "1", "0"), ("1", "4", "0"), ("2", "4", "0"), ("1", "1", "1")])
+def test_batched_gemm_workgroup_shapes(tiny, emu_lib, golden_dir, tnw, tm, lean, monkeypatch):
     """The batched path runs 4 row tiles per workgroup (weight fragments reused; selected by batch size on the GPU, forced
     here) and can widen a workgroup to 2 column tiles per wave: same results as the batch-1 shape for every GEMM
     epilogue, at the tiny dims (ragged last row tile) and at the ZEGGS dims."""
     monkeypatch.setenv("DSG_GEMM_TNW", tnw)
     monkeypatch.setenv("DSG_GEMM_TM", tm)
+    monkeypatch.setenv("DSG_GEMM_LEAN", lean)          # "1": the high-occupancy LayerNorm GEMM the batched path uses from batch 6 up
     gt, _, y, x = tiny
     for prec in ("fp32", "bf16"):
         m = DSGDenoiser(C.TINY, precision=prec, max_batch=2, library=emu_lib, latency_mode="off")
@@ -150,7 +151,7 @@ def test_batched_gemm_workgroup_shapes(tiny, emu_lib, golden_dir, tnw, tm, monke
     s = d.manual_seed(77, 3).p_sample_loop(m, (2, C.TINY.njoints, 1, C.TINY.n_poses), clip_denoised=False,
                                            model_kwargs={"y": y}, skip_timesteps=990)
     assert rel_l2(s, gt["ddpm_skip990"]) < TOL["bf16"]
-    if tm == "4":
+    if tm == "4" or lean == "1":
         g2 = _g(golden_dir, "g2_forward_zeggs.npz")
         cfg = C.ZEGGS
         mz = DSGDenoiser(cfg, precision="fp32", max_batch=2, library=emu_lib, latency_mode="off")
