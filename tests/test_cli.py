@@ -35,3 +35,21 @@ def test_dsgplus_flags_windows_and_seed_features():
     assert np.allclose(f[0, :5, 0, :].T, gn[2:], atol=1e-6)
     assert np.allclose(f[0, 5:10, 0, :].T, (gn[1:] - gn[:-1])[1:], atol=1e-6)
     assert np.allclose(f[0, 10:, 0, :].T, gn[2:] - 2 * gn[1:-1] + gn[:-2], atol=1e-6)
+
+
+def test_bench_cpu_baseline_leg_runs_on_cpu():
+    """bench.py's cpu_baseline leg (the numpy oracle timed on the host cores) must work without a GPU and report what it used."""
+    import importlib.util
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(mod)
+        out = mod.cpu_baseline(20)
+    finally:
+        sys.argv = argv
+    assert out["kind"] == "port" and out["unit"] == "frames/s" and out["value"] > 0 and out["cores"] >= 1
+    assert "20 DDPM steps" in out["sample"]
