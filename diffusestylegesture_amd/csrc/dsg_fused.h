@@ -1,5 +1,6 @@
 // dsg_fused.h -- latency-mode kernels: the same arithmetic as dsg_kernels.h, regrouped so that one denoising step is
-// 2 + 3*L launches instead of 3 + 5*L.  At batch 1 every launch is a latency chain (kernel boundary + cold L2 +
+// 2 + 4*L dispatches (k_inloc, L x {QKV GEMM, k_attn, k_mid, linear2 GEMM}, pose head) instead of 3 + 5*L; with the opt-in
+// k_qkv_attn / k_attn_mid 2 + 3*L.  At batch 1 every launch is a latency chain (kernel boundary + dependent loads +
 // load -> MFMA -> store), so the lever is the NUMBER of dependent launches, not FLOPs: the fused kernels recompute
 // small things redundantly (K/V of a head per query tile, out_proj + LayerNorm per hidden slice, the pose embedding
 // of the previous window's frames) to avoid an all-to-all hand-off.

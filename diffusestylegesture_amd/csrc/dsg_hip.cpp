@@ -591,7 +591,7 @@ extern "C" int dsg_set_window_cond(dsg_handle* h, const float* style, const floa
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// one denoising step = 3 + 5*L launches
+// one denoising step = 3 + 5*L dispatches (un-fused set) or 2 + 4*L (latency set, batch <= 2)
 // ---------------------------------------------------------------------------------------------------------
 struct StepCtx {
     int B; int out_mode; bool use_ctr; const float* ext_noise; int const_noise;
@@ -1190,9 +1190,9 @@ extern "C" int dsg_sample(dsg_handle* h, const dsg_sample_args* a, float* out, i
     c.B = B; c.out_mode = a->mode == DSG_MODE_DDPM ? OUT_DDPM : OUT_DDIM; c.use_ctr = true; c.ext_noise = ext;
     c.const_noise = a->const_noise;
 
-    // steps_per_graph: 0 = default.  Measured on MI355X / ROCm 7.2 (profiles/r01_c_step_timing.log): stream-ordered
-    // launches with device-resident kernargs run the 26-launch step in 228 us, hipGraph replay of the same launches
-    // in 244-249 us -- so the default is eager launches and graphs stay opt-in (steps_per_graph > 0).
+    // steps_per_graph: 0 = default = no hipGraph.  Measured on MI355X / ROCm 7.2: hipGraph replay of the step is slower than
+    // stream-ordered HIP launches (180 vs 157 us; 151-163 us with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0), and both lose to the
+    // hand-written AQL submission below (139 us) -- graphs stay opt-in (steps_per_graph > 0).
     int spg = h->cfg.steps_per_graph == 0 ? -1 : h->cfg.steps_per_graph;
     const bool dumping = a->n_dump > 0 && a->dump_steps && a->dump_out;
     if (dumping || ext) spg = -1;            // rare paths run eagerly (ext pointer / dump points are per call)
