@@ -752,6 +752,7 @@ static int launch_attn_mid(dsg_handle* h, const AttnMidArgs& a) {
 }
 static bool use_latency_mode(const dsg_handle* h, int B) {
     if (h->latency_mode >= 0) return h->latency_mode != 0;
+    if (h->D > 384) return false;   // k_mid pulls all of W_o (2 D^2 bytes) through every CU: at D = 512 the un-fused set wins (TWH: 219 vs 238 us)
     return B <= 2;          // redundant recompute pays only while every launch is a latency chain (tools/b_sweep.sh: batch 3+ is
                             // as fast or faster with the un-fused set: 182 vs 187 us at batch 3, 195 vs 197 at batch 4)
 }
