@@ -553,7 +553,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
     typedef typename P::elem elem;
     static_assert(WN * WK == 4, "4 waves");
     constexpr int ES = (int)sizeof(elem);
-    __shared__ __attribute__((aligned(16))) char lds_a[PRO == PRO_LN ? 16 * (512 * 4 + 16) : 16];
+    __shared__ __attribute__((aligned(16))) char lds_a[PRO == PRO_LN ? 16 * (512 * ES + 16) : 16];     // 16 rows of up to 512 elements
     __shared__ __attribute__((aligned(16))) float lds_red[WK > 1 ? (WK - 1) * WN * TNW * 64 * 4 : 4];
 
     DSG_STAMP(1 + EPI, 0);
@@ -855,7 +855,8 @@ __device__ __forceinline__ void gemm_body_mt(const GemmArgs& g) {
         }
 }
 
-// batched LayerNorm-GEMM: compiled for 3 waves per SIMD (<= 168 VGPRs; at 128 it spills to scratch), see ln_rows LEAN
+// batched LayerNorm-GEMM: compiled for 3 waves per SIMD (<= 168 VGPRs; at 128 it spills to scratch; requesting the weights
+// only after the LayerNorm fits 5 waves per SIMD but measured slower: 370 vs 360 us/step at batch 16), see ln_rows LEAN
 template <class P, int EPI>
 __global__ __launch_bounds__(256, 3) void k_gemm_lean(const GemmArgs g) { gemm_body<P, PRO_LN, EPI, 4, 1, 1, true>(g); }
 
