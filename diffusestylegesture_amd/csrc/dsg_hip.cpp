@@ -144,7 +144,7 @@ struct dsg_handle {
     int gemm_tnw = 0;                    // DSG_GEMM_TNW: 16-col tiles per wave in the batched GEMMs (0 = by batch size)
     int dbg_skip = 0;                    // DSG_DEBUG_SKIP bit mask: timing experiments only (results become garbage)
     bool fuse_attn = false;
-    bool fuse_attn_mid = false;          // k_attn_mid (attention inside the out_proj/LN/linear1 kernel): opt-in, DSG_FUSE_ATTN_MID=1
+    bool fuse_attn_mid = true;           // k_attn_mid (attention inside the out_proj/LN/linear1 kernel) at batch 1; DSG_FUSE_ATTN_MID=0 to A/B
     int* st_tmodel = nullptr; float* st_c[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int st_cap = 0, n_run = 1;
     Sched sched;
@@ -737,9 +737,10 @@ static int launch_mid(dsg_handle* h, const MidArgs& a) {
     }
 }
 // Attention fused into k_mid: one batch element, 4 heads (wave = head), D <= 256.  Bit-identical to k_attn + k_mid and
-// one launch less per layer, but measured on MI355X it does not pay (152.4 vs 151.3 us/step, profiles/r01_h_*): the
-// four heads' strided K / V^T fragment loads then queue on ONE CU's texture-address path (38 loads in ~6100 cycles)
-// instead of running on 24 otherwise idle CUs, which costs what the saved launch gains.  Opt-in (DSG_FUSE_ATTN_MID=1).
+// one dispatch less per layer.  With HIP launches it does not pay (152.4 vs 151.3 us/step): the four heads' strided
+// K / V^T fragment loads queue on ONE CU's load path (38 loads in ~6100 cycles) instead of running on 24 otherwise idle
+// CUs, which costs what the saved launch gains.  With the AQL submission the balance tips (136.0 vs 140.8 us/step,
+// measured twice on the same box), so it is on by default; DSG_FUSE_ATTN_MID=0 selects the separate kernels.
 static bool have_attn_mid(const dsg_handle* h, int B) {
     return B == 1 && h->H == 4 && ((h->D == 256 && h->Tp == 96) || (h->D == 128 && h->Tp == 32));
 }
