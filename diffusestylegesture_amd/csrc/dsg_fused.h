@@ -638,9 +638,7 @@ __global__ __launch_bounds__(256) void k_attn_mid(const AttnMidArgs ga) {
             if constexpr (P::E == 4) {
                 vfr[dt][kb] = *(const f32x4*)(vrow + kb * 16 + 4 * lg);
             } else {
-                const f32x2 v0 = *(const f32x2*)(vrow + (2 * kb) * 16 + 4 * lg);        // 4 bf16 = 8 bytes
-                const f32x2 v1 = *(const f32x2*)(vrow + (2 * kb + 1) * 16 + 4 * lg);
-                vfr[dt][kb] = (f32x4){v0[0], v0[1], v1[0], v1[1]};
+                vfr[dt][kb] = *(const f32x4*)(vrow + kb * 32 + 8 * lg);        // pair-interleaved token order (vt_pos): 8 bf16 in one load
             }
         }
     }

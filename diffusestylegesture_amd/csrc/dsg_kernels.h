@@ -108,6 +108,16 @@ struct PBF16 {                      // bf16 storage, v_mfma_f32_16x16x32_bf16, f
     }
 };
 
+// Token order inside a V^T row.  The PV product pairs two 16-key tiles per bf16 k-block (lane (lr, lg) holds keys
+// 16*(2kb) + 4lg + r and 16*(2kb+1) + 4lg + r, the values its softmax registers already hold), so with the natural order a
+// V^T fragment is two separate 8-byte loads.  Stored pair-interleaved -- position = 32*kb + 8*lg + 4*e + r for token
+// 16*(2kb+e) + 4lg + r -- it is ONE 16-byte load per lane (half the load instructions of the attention kernels' largest
+// operand).  fp32 fragments are 4 consecutive tokens already: natural order.  Rows are padded to a multiple of 32 tokens.
+template <class P>
+__device__ __forceinline__ int vt_pos(int tok) {
+    if constexpr (P::E == 4) return tok;
+    else return (tok & ~31) | ((tok & 12) << 1) | ((tok & 16) >> 2) | (tok & 3);
+}
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // Load phases are written branch-free (clamped addresses, select afterwards): a load under a runtime predicate makes
 // hipcc place `s_waitcnt vmcnt(0)` at every join, which turns N independent loads into N serial memory round trips
@@ -506,7 +516,7 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmArgs& g, int m0, in
                     const int m = m0 + 4 * lg + e;
                     if (m < g.M) {
                         const int b = fdiv(m, g.inv_ntok), sx = m - b * g.ntok;
-                        ((elem*)g.vt)[(((size_t)b * g.H + head) * g.hd + d0 + lr) * g.Tp + sx] = P::cvt(acc[e] + o.pbs);
+                        ((elem*)g.vt)[(((size_t)b * g.H + head) * g.hd + d0 + lr) * g.Tp + vt_pos<P>(sx)] = P::cvt(acc[e] + o.pbs);
                     }
                 }
             }
@@ -1061,9 +1071,7 @@ __global__ __launch_bounds__(64) void k_attn(const AttnArgs a) {
                 if constexpr (P::E == 4) {
                     vfr[dt][kb] = *(const f32x4*)(vrow + kb * 16 + 4 * lg);
                 } else {
-                    const f32x2 v0 = *(const f32x2*)(vrow + (2 * kb) * 16 + 4 * lg);        // 4 bf16 = 8 bytes
-                    const f32x2 v1 = *(const f32x2*)(vrow + (2 * kb + 1) * 16 + 4 * lg);
-                    vfr[dt][kb] = (f32x4){v0[0], v0[1], v1[0], v1[1]};
+                    vfr[dt][kb] = *(const f32x4*)(vrow + kb * 32 + 8 * lg);        // pair-interleaved token order (vt_pos): 8 bf16 in one load
                 }
             }
         }
