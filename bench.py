@@ -187,7 +187,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 5), "traffic": traffic,
                          "algorithmic_bytes_per_denoise_step": abytes,
-                         "note": "one denoising step = 2 + 4*L dependent kernel dispatches (batch-1 latency mode), submitted as "
+                         "note": "one denoising step = 2 + 3*L dependent kernel dispatches (batch-1 latency mode), submitted as "
                                  "hand-written AQL packets on the library's own HSA queue (DSG_AQL=0: HIP launches); achieved = "
                                  "algorithmic bytes / time per step, timed from the first doorbell to the completion signal "
                                  "of the last packet (HIP events around the loop on the HIP-launch path)"},
