@@ -223,7 +223,8 @@ def test_aql_step_loop_is_bit_identical_to_hip_launches(gpu, prec, monkeypatch):
     outs = {}
     for mode in ("1", "0", "overlap"):
         monkeypatch.setenv("DSG_AQL", "1" if mode == "overlap" else mode)
-        monkeypatch.setenv("DSG_OVERLAP", "1" if mode == "overlap" else "0")     # barrier-less (attention -> k_mid) pair
+        monkeypatch.setenv("DSG_OVERLAP", "1" if mode == "overlap" else "0")     # barrier-less (attention -> k_mid) pair ...
+        monkeypatch.setenv("DSG_FUSE_ATTN_MID", "0" if mode == "overlap" else "1")   # ... which needs the separate kernels
         m = _model(cfg, prec, max_batch=1)
         d = create_gaussian_diffusion()
         res = []
