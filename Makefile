@@ -29,6 +29,19 @@ $(EMU): $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h include/ds
 	$(HOSTCXX) -O2 -g -std=c++17 -fPIC -shared -pthread -Itests/emu/shim -DDSG_EMU=1 \
 	    $(CSRC)/dsg_hip.cpp tests/emu/emu_rt.cpp -o $@
 
+# micro-probes behind the numbers in DESIGN.md s5 (tools/*.cpp; run on the GPU box, logs under profiles/)
+PROBES := xcd_probe persist_probe dep_probe icache_probe
+tools: $(addprefix tools/_build/,$(PROBES)) tools/_build/aql_probe tools/_build/aql_kernels.hsaco
+tools/_build/%: tools/%.cpp
+	mkdir -p tools/_build
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 $< -o $@
+tools/_build/aql_kernels.hsaco: tools/aql_kernels.hip
+	mkdir -p tools/_build
+	$(HIPCC) --offload-arch=gfx950 --cuda-device-only --no-gpu-bundle-output -O3 $< -o $@
+tools/_build/aql_probe: tools/aql_probe.cpp
+	mkdir -p tools/_build
+	g++ -O2 -std=c++17 -I/opt/rocm/include $< -L/opt/rocm/lib -lhsa-runtime64 -Wl,-rpath,/opt/rocm/lib -o $@
+
 clean:
 	rm -f $(LIB) $(EMU) $(CSRC)/dsg_kernels.hsaco
-.PHONY: all emu stamps clean
+.PHONY: all emu stamps tools clean
