@@ -607,6 +607,7 @@ __global__ __launch_bounds__(256) void k_attn_mid(const AttnMidArgs ga) {
     __shared__ __attribute__((aligned(16))) char aT[16 * XP];      // attention output rows (MFMA element type)
     __shared__ __attribute__((aligned(16))) char a1[16 * XP];      // LayerNorm1 output rows
     __shared__ float red[2][4][16];
+    __shared__ __attribute__((aligned(16))) float vecs[3][D];      // out_proj bias, LayerNorm1 scale / shift: one load per WORKGROUP (see k_mid)
     DSG_STAMP(0, 0);
     preload_kernargs(ga);
     const MidArgs& g = ga.mid;
@@ -654,6 +655,8 @@ __global__ __launch_bounds__(256) void k_attn_mid(const AttnMidArgs ga) {
     const int n1t = ng * 4 + wave;                   // this wave's 16-col tile of the hidden layer
     constexpr int G = PDA + 4;                       // load groups: PDA weight k-blocks, bias+residual, LN scale+shift, linear1 fragments, linear1 bias
     constexpr int S = 2 * NKT + ND;                  // slots: after each key tile of the max pass, of the exp pass, after each PV tile
+    constexpr int NV = (3 * D / 4 + 255) / 256;
+    f32x4 vload[NV];
     auto issue_group = [&](int gi) {
         if (gi < PDA) {
 #pragma unroll
@@ -662,15 +665,13 @@ __global__ __launch_bounds__(256) void k_attn_mid(const AttnMidArgs ga) {
 #pragma unroll
             for (int t = 0; t < DT; ++t) {
                 const int n = (wave * DT + t) * 16 + 4 * lg;
-                pbo[t] = *(const f32x4*)(g.bo + n);
                 pr[t] = *(const f32x4*)(g.R + (size_t)(m0 + lr) * D + n);
             }
         } else if (gi == PDA + 1) {
 #pragma unroll
-            for (int t = 0; t < DT; ++t) {
-                const int n = (wave * DT + t) * 16 + 4 * lg;
-                pg[t] = *(const f32x4*)(g.ln_g + n);
-                pbt[t] = *(const f32x4*)(g.ln_b + n);
+            for (int i = 0; i < NV; ++i) {
+                const int e = min(tid + 256 * i, 3 * D / 4 - 1), vsel = e / (D / 4), vidx = e % (D / 4);      // clamped, never predicated
+                vload[i] = ((const f32x4*)(vsel == 0 ? g.bo : (vsel == 1 ? g.ln_g : g.ln_b)))[vidx];
             }
         } else if (gi == PDA + 2) {
             if constexpr (KD <= CH) {
@@ -771,6 +772,17 @@ __global__ __launch_bounds__(256) void k_attn_mid(const AttnMidArgs ga) {
         for (int t = 0; t < DT; ++t) acc[t] = P::mma(bf[kb][t], af, acc[t]);      // D[n 4lg+r][row lr]
     }
     DSG_STAMP(0, 13);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int e = tid + 256 * i;
+        if (e < 3 * D / 4) *(f32x4*)(&vecs[0][0] + e * 4) = vload[i];
+    }
+    DSG_LDS_BARRIER();
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+        const int n = (wave * DT + t) * 16 + 4 * lg;
+        pbo[t] = *(const f32x4*)(&vecs[0][n]); pg[t] = *(const f32x4*)(&vecs[1][n]); pbt[t] = *(const f32x4*)(&vecs[2][n]);
+    }
     mid_tail<P, DT>(g, acc, pbo, pr, pg, pbt, pb1, w1f, w1, a1, red, m0, ng, n1t, wave, lr, lg);
     DSG_STAMP(0, 7);
 }
