@@ -128,10 +128,13 @@ typedef struct dsg_sample_args {
 } dsg_sample_args;
 
 /* runs num_timesteps - skip_timesteps denoising steps for the conditioning set by dsg_set_window_cond;
- * out [B,J,1,T] receives the final sample.  Asynchronous w.r.t. the host when `out` is device memory. */
+ * out [B,J,1,T] receives the final sample.  With the default AQL submission of the step loop (csrc/dsg_aql.h) the call
+ * returns when the steps have run; with HIP launches (DSG_AQL=0, or under a profiler) it only enqueues and is asynchronous
+ * w.r.t. the host when `out` is device memory. */
 int dsg_sample(dsg_handle* h, const dsg_sample_args* args, float* out, int B, void* stream);
 int dsg_sync(dsg_handle* h);
-/* GPU time (HIP events on the handle's stream) of the step loop of the last dsg_sample, and its step count */
+/* time of the step loop of the last dsg_sample (HIP events on the handle's stream; AQL path: first doorbell to the completion
+ * signal of the last packet), and its step count */
 int dsg_last_sample_ms(dsg_handle* h, float* ms, int* n_steps);
 
 /* fused sampler arithmetic on caller tensors (flat fp32 arrays of B*per_batch elements, per-batch scalars on host) */
