@@ -626,22 +626,15 @@ __global__ __launch_bounds__(256) void k_attn_mid(const AttnMidArgs ga) {
     // ---- (1) attention operand fragments
     f32x4 qf[KDH], kf[NKT][KDH], vfr[ND][NVF];
 #pragma unroll
-    for (int kb = 0; kb < KDH; ++kb) qf[kb] = *(const f32x4*)(Q + (size_t)(m0 + lr) * HD + kb * P::KB + P::E * lg);
+    for (int kb = 0; kb < KDH; ++kb) qf[kb] = *(const f32x4*)(Q + (size_t)((mt * KDH + kb) * 64 + lane) * P::E);     // fragment-major (qk_off)
 #pragma unroll
     for (int nt = 0; nt < NKT; ++nt)
 #pragma unroll
-        for (int kb = 0; kb < KDH; ++kb) kf[nt][kb] = *(const f32x4*)(K + (size_t)(nt * 16 + lr) * HD + kb * P::KB + P::E * lg);
+        for (int kb = 0; kb < KDH; ++kb) kf[nt][kb] = *(const f32x4*)(K + (size_t)((nt * KDH + kb) * 64 + lane) * P::E);
 #pragma unroll
     for (int dt = 0; dt < ND; ++dt) {
-        const elem* vrow = VT + (size_t)(dt * 16 + lr) * ga.Tp;
 #pragma unroll
-        for (int kb = 0; kb < NVF; ++kb) {
-            if constexpr (P::E == 4) {
-                vfr[dt][kb] = *(const f32x4*)(vrow + kb * 16 + 4 * lg);
-            } else {
-                vfr[dt][kb] = *(const f32x4*)(vrow + kb * 32 + 8 * lg);        // pair-interleaved token order (vt_pos): 8 bf16 in one load
-            }
-        }
+        for (int kb = 0; kb < NVF; ++kb) vfr[dt][kb] = *(const f32x4*)(VT + (size_t)((dt * NVF + kb) * 64 + lane) * P::E);       // fragment-major (vt_off)
     }
     DSG_LOADS_ISSUED();
     DSG_STAMP(0, 9);

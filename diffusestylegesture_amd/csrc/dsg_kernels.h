@@ -108,15 +108,23 @@ struct PBF16 {                      // bf16 storage, v_mfma_f32_16x16x32_bf16, f
     }
 };
 
-// Token order inside a V^T row.  The PV product pairs two 16-key tiles per bf16 k-block (lane (lr, lg) holds keys
-// 16*(2kb) + 4lg + r and 16*(2kb+1) + 4lg + r, the values its softmax registers already hold), so with the natural order a
-// V^T fragment is two separate 8-byte loads.  Stored pair-interleaved -- position = 32*kb + 8*lg + 4*e + r for token
-// 16*(2kb+e) + 4lg + r -- it is ONE 16-byte load per lane (half the load instructions of the attention kernels' largest
-// operand).  fp32 fragments are 4 consecutive tokens already: natural order.  Rows are padded to a multiple of 32 tokens.
+// Q, K and V^T of the self-attention live in HBM in MFMA-FRAGMENT order, so that every fragment a wave loads is one
+// contiguous 1 KB block (8 cache lines) instead of 16 rows x 64 B (16 half-used lines): the attention kernels' load
+// phases are bound by the CU's load path, which works per line.  Inside one (batch, head) block:
+//   Q / K : [token / 16][d / KB][lane = ((d % KB) / E) * 16 + token % 16][E]
+//   V^T   : [dim / 16][kb][lane = lg * 16 + dim % 16][E]   with the tokens of PV k-block kb held by lane group lg:
+//           fp32: token = 16 kb + 4 lg + r;  bf16: token = 16 (2 kb + e) + 4 lg + r at position 4 e + r -- the two key
+//           tiles a bf16 PV k-block pairs (the values a lane's softmax registers already hold), one 16-byte load.
+// The QKV epilogue scatters into this order (stores are off the critical path), the attention kernels read lane-linear.
 template <class P>
-__device__ __forceinline__ int vt_pos(int tok) {
-    if constexpr (P::E == 4) return tok;
-    else return (tok & ~31) | ((tok & 12) << 1) | ((tok & 16) >> 2) | (tok & 3);
+__device__ __forceinline__ int qk_off(int tok, int d, int kdh) {
+    return ((((tok >> 4) * kdh + d / P::KB) * 64 + ((d % P::KB) / P::E) * 16 + (tok & 15)) * P::E) + (d % P::E);
+}
+template <class P>
+__device__ __forceinline__ int vt_off(int dim, int tok, int nvf) {
+    const int lg = (tok & 12) >> 2, r = tok & 3;
+    if constexpr (P::E == 4) return ((((dim >> 4) * nvf + (tok >> 4)) * 64 + lg * 16 + (dim & 15)) * 4) + r;
+    else return ((((dim >> 4) * nvf + (tok >> 5)) * 64 + lg * 16 + (dim & 15)) * 8) + ((tok >> 2) & 4) + r;
 }
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // Load phases are written branch-free (clamped addresses, select afterwards): a load under a runtime predicate makes
@@ -507,7 +515,7 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmArgs& g, int m0, in
                 const int m = m0 + lr;
                 if (m < g.M) {
                     const int b = fdiv(m, g.inv_ntok), sx = m - b * g.ntok;
-                    elem* dst = (elem*)(which == 0 ? g.q : g.k) + (((size_t)b * g.H + head) * g.Tp + sx) * g.hd + d0 + 4 * lg;
+                    elem* dst = (elem*)(which == 0 ? g.q : g.k) + ((size_t)b * g.H + head) * g.Tp * g.hd + qk_off<P>(sx, d0 + 4 * lg, g.hd / P::KB);
                     P::store4(dst, acc + o.pb);
                 }
             } else {                             // V: transposed [B][H][hd][Tp], lane = one dim, 4 consecutive tokens
@@ -516,7 +524,7 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmArgs& g, int m0, in
                     const int m = m0 + 4 * lg + e;
                     if (m < g.M) {
                         const int b = fdiv(m, g.inv_ntok), sx = m - b * g.ntok;
-                        ((elem*)g.vt)[(((size_t)b * g.H + head) * g.hd + d0 + lr) * g.Tp + vt_pos<P>(sx)] = P::cvt(acc[e] + o.pbs);
+                        ((elem*)g.vt)[((size_t)b * g.H + head) * g.hd * g.Tp + vt_off<P>(d0 + lr, sx, P::E == 4 ? g.Tp / 16 : g.Tp / 32)] = P::cvt(acc[e] + o.pbs);
                     }
                 }
             }
@@ -1061,19 +1069,12 @@ __global__ __launch_bounds__(64) void k_attn(const AttnArgs a) {
     constexpr bool PRELOAD = (KD + NKT * KD + ND * NVF) * 4 <= 360;
     f32x4 qf[KD];
 #pragma unroll
-    for (int kb = 0; kb < KD; ++kb) qf[kb] = *(const f32x4*)(Q + (size_t)(qt * 16 + lr) * HD + kb * P::KB + P::E * lg);
+    for (int kb = 0; kb < KD; ++kb) qf[kb] = *(const f32x4*)(Q + (size_t)((qt * KD + kb) * 64 + lane) * P::E);       // fragment-major (qk_off)
     auto load_v = [&](f32x4 (&vfr)[ND][NVF]) {
 #pragma unroll
         for (int dt = 0; dt < ND; ++dt) {
-            const elem* vrow = VT + (size_t)(dt * 16 + lr) * a.Tp;
 #pragma unroll
-            for (int kb = 0; kb < NVF; ++kb) {
-                if constexpr (P::E == 4) {
-                    vfr[dt][kb] = *(const f32x4*)(vrow + kb * 16 + 4 * lg);
-                } else {
-                    vfr[dt][kb] = *(const f32x4*)(vrow + kb * 32 + 8 * lg);        // pair-interleaved token order (vt_pos): 8 bf16 in one load
-                }
-            }
+            for (int kb = 0; kb < NVF; ++kb) vfr[dt][kb] = *(const f32x4*)(VT + (size_t)((dt * NVF + kb) * 64 + lane) * P::E);   // fragment-major (vt_off)
         }
     };
     f32x4 vfr[ND][NVF];
@@ -1083,7 +1084,7 @@ __global__ __launch_bounds__(64) void k_attn(const AttnArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NKT; ++nt)
 #pragma unroll
-            for (int kb = 0; kb < KD; ++kb) kf[nt][kb] = *(const f32x4*)(K + (size_t)(nt * 16 + lr) * HD + kb * P::KB + P::E * lg);
+            for (int kb = 0; kb < KD; ++kb) kf[nt][kb] = *(const f32x4*)(K + (size_t)((nt * KD + kb) * 64 + lane) * P::E);
         load_v(vfr);
         DSG_LOADS_ISSUED();
 #pragma unroll
@@ -1098,7 +1099,7 @@ __global__ __launch_bounds__(64) void k_attn(const AttnArgs a) {
             s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < KD; ++kb) {
-                const f32x4 kf = *(const f32x4*)(K + (size_t)(nt * 16 + lr) * HD + kb * P::KB + P::E * lg);
+                const f32x4 kf = *(const f32x4*)(K + (size_t)((nt * KD + kb) * 64 + lane) * P::E);
                 s[nt] = P::mma(kf, qf[kb], s[nt]);
             }
         }
