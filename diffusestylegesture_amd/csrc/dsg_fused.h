@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void k_qkv_attn(const QkvAttnArgs g) {
             f32x4 y;
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = o[e] * inv;
-            P::store4((elem*)g.out + (row0 + q) * DD + h * HD + dt * 16 + 4 * lg, y);
+            P::store4((elem*)g.out + qk_off<P>((int)(row0 + q), h * HD + dt * 16 + 4 * lg, DD / P::KB), y);     // fragment-major rows
         }
     }
 }
@@ -454,7 +454,7 @@ __device__ __forceinline__ void mid_tail(const MidArgs& g, f32x4 (&acc)[DT], con
         f32x4 y;
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[e] = gelu_erf<P>(c1[e] + pb1[e]);
-        P::store4((elem*)g.hidden + (size_t)(m0 + lr) * g.ff + n1t * 16 + 4 * lg, y);
+        P::store4((elem*)g.hidden + qk_off<P>(m0 + lr, n1t * 16 + 4 * lg, g.ff / P::KB), y);       // fragment-major: linear2's A operand
     }
     if (wr) {
 #pragma unroll
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
     const f32x4* wo = (const f32x4*)g.Wo + lane;
     const f32x4* w1 = (const f32x4*)g.W1 + lane;
-    const elem* arow = (const elem*)g.A + (size_t)(m0 + lr) * D + P::E * lg;
+    const elem* arow = (const elem*)g.A + ((size_t)mt * KD * 64 + lane) * P::E;      // attention rows, fragment-major: k-block kb at + kb * 64 * E
     // The three per-column vectors are the same for every wave and row tile: fetched once per workgroup (one 16-byte load
     // by 3 D / 4 lanes) and read back from LDS, instead of 12 wave-wide loads per wave through the CU's load path, which
     // bounds this kernel (measured: -1060 cycles per kernel without those loads).
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
     constexpr int NPRE = ALLW ? KD : PD;
 #pragma unroll
     for (int kb = 0; kb < NPRE; ++kb) {
-        if constexpr (!OVL) af[kb] = *(const f32x4*)(arow + (size_t)kb * P::KB);
+        if constexpr (!OVL) af[kb] = *(const f32x4*)(arow + (size_t)kb * 64 * P::E);
 #pragma unroll
         for (int t = 0; t < DT; ++t) bf[kb][t] = wo[((size_t)(wave * DT + t) * KD + kb) * 64];
     }
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
         DSG_LOADS_ISSUED();
         dep_wait(g.dep);                              // the attention rows are read with agent-scope loads from here on
 #pragma unroll
-        for (int kb = 0; kb < PD; ++kb) af[kb] = load16_agent(arow + (size_t)kb * P::KB);
+        for (int kb = 0; kb < PD; ++kb) af[kb] = load16_agent(arow + (size_t)kb * 64 * P::E);
     }
     f32x4 acc[DT];
 #pragma unroll
@@ -542,8 +542,8 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
 #pragma unroll
     for (int kb = 0; kb < KD; ++kb) {
         if (kb + PD < KD) {
-            if constexpr (OVL) af[kb + PD] = load16_agent(arow + (size_t)(kb + PD) * P::KB);
-            else af[kb + PD] = *(const f32x4*)(arow + (size_t)(kb + PD) * P::KB);
+            if constexpr (OVL) af[kb + PD] = load16_agent(arow + (size_t)(kb + PD) * 64 * P::E);
+            else af[kb + PD] = *(const f32x4*)(arow + (size_t)(kb + PD) * 64 * P::E);
             if constexpr (!ALLW) {
 #pragma unroll
                 for (int t = 0; t < DT; ++t) bf[kb + PD][t] = wo[((size_t)(wave * DT + t) * KD + kb + PD) * 64];

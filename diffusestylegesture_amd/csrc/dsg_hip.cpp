@@ -865,20 +865,20 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
             {   // out_proj + residual -> pre1
                 GemmArgs g = z;
                 g.M = M; g.MT = MT; g.NT = D / 16; g.KBtot = D / KB; g.Wp = ly.Wo; g.bias = ly.bo;
-                g.A = h->attn; g.lda = D; g.out = h->pre1; g.ldo = D; g.R = l == 0 ? h->X0 : h->Xn;
+                g.A = h->attn; g.lda = D; g.a_frag = 1; g.out = h->pre1; g.ldo = D; g.R = l == 0 ? h->X0 : h->Xn;
                 CHK((launch_gemm_w<P, PRO_DIRECT, EPI_RESID>(h, g)));
             }
             {   // LayerNorm1-on-read + linear1 + GELU -> hidden ; X1 = LN1(pre1)
                 GemmArgs g = z;
                 g.M = M; g.MT = MT; g.NT = h->ff / 16; g.KBtot = D / KB; g.Wp = ly.W1; g.bias = ly.b1;
-                g.X = h->pre1; g.ln_g = ly.g1; g.ln_b = ly.be1; g.Xn = h->X1; g.out = h->hidden; g.ldo = h->ff;
+                g.X = h->pre1; g.ln_g = ly.g1; g.ln_b = ly.be1; g.Xn = h->X1; g.out = h->hidden; g.ldo = h->ff; g.out_frag = 1;
                 CHK((launch_gemm_w<P, PRO_LN, EPI_GELU>(h, g)));
             }
         }
         if (!(skip & 16)) {   // linear2 + residual -> pre2   (K = ff split over the 4 waves of the workgroup)
             GemmArgs g = z;
             g.M = M; g.MT = MT; g.NT = D / 16; g.KBtot = h->ff / KB; g.Wp = ly.W2; g.bias = ly.b2;
-            g.A = h->hidden; g.lda = h->ff; g.out = h->pre2; g.ldo = D; g.R = h->X1;
+            g.A = h->hidden; g.lda = h->ff; g.a_frag = 1; g.out = h->pre2; g.ldo = D; g.R = h->X1;
             CHK(launch_gemm_k4<P>(h, g));
         }
     }
@@ -919,15 +919,15 @@ static int debug_launch(dsg_handle* h, int which, int i, int B) {
         case 0: hipLaunchKernelGGL(k_ctr_inc, dim3(96), dim3(256), 0, h->stream, h->ctr); return 0;
         case 1: case 2: {
             GemmArgs g = z; g.M = M; g.MT = MT; g.NT = D / 16; g.KBtot = D / KB; g.Wp = ly.Wo; g.bias = ly.bo;
-            g.A = h->attn; g.lda = D; g.out = (i & 1) ? h->pre1 : h->pre2; g.ldo = D; g.R = h->X0;
+            g.A = h->attn; g.lda = D; g.a_frag = 1; g.out = (i & 1) ? h->pre1 : h->pre2; g.ldo = D; g.R = h->X0;
             return launch_gemm<P, PRO_DIRECT, EPI_RESID, 4, 1, 1>(h, g); }
         case 3: {
             GemmArgs g = z; g.M = M; g.MT = MT; g.NT = h->ff / 16; g.KBtot = D / KB; g.Wp = ly.W1; g.bias = ly.b1;
-            g.X = h->pre1; g.ln_g = ly.g1; g.ln_b = ly.be1; g.Xn = h->X1; g.out = h->hidden; g.ldo = h->ff;
+            g.X = h->pre1; g.ln_g = ly.g1; g.ln_b = ly.be1; g.Xn = h->X1; g.out = h->hidden; g.ldo = h->ff; g.out_frag = 1;
             return launch_gemm<P, PRO_LN, EPI_GELU, 4, 1, 1>(h, g); }
         case 4: {
             GemmArgs g = z; g.M = M; g.MT = MT; g.NT = D / 16; g.KBtot = h->ff / KB; g.Wp = ly.W2; g.bias = ly.b2;
-            g.A = h->hidden; g.lda = h->ff; g.out = h->pre2; g.ldo = D; g.R = h->X1;
+            g.A = h->hidden; g.lda = h->ff; g.a_frag = 1; g.out = h->pre2; g.ldo = D; g.R = h->X1;
             return launch_gemm<P, PRO_DIRECT, EPI_RESID, 1, 4, 1>(h, g); }
         case 5: {
             AttnArgs a; memset(&a, 0, sizeof(a)); a.q = h->q; a.k = h->k; a.vt = h->vt; a.out = h->attn; a.B = B; a.H = h->H; a.ntok = ntok;

@@ -355,6 +355,8 @@ struct GemmArgs {
     const float* ext_noise; // optional [n_steps][B][J][T] replayed noise, else null
     int B;
     int const_noise;
+    int a_frag;             // PRO_DIRECT: A is stored fragment-major ([row tile][k-block][64 lanes][16 B], qk_off) -- hidden, attention rows
+    int out_frag;           // EPI_GELU: the output goes out fragment-major (it is the next GEMM's A operand)
 };
 
 // Workgroup -> n-group with the n-group pinned to an XCD (workgroups are dealt round-robin to the 8 XCDs in linear
@@ -505,7 +507,7 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmArgs& g, int m0, in
                 f32x4 y;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] = gelu_erf<P>(acc[e] + o.pb[e]);
-                P::store4((elem*)g.out + (size_t)m * g.ldo + n, y);
+                P::store4((elem*)g.out + (g.out_frag ? (size_t)qk_off<P>(m, n, g.ldo / P::KB) : (size_t)m * g.ldo + n), y);
             }
         } else if constexpr (EPI == EPI_QKV) {
             const int Dm = g.H * g.hd;
@@ -676,7 +678,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const int kb = min(kb0 + c, kb_last);
-            if constexpr (PRO == PRO_DIRECT) af[c] = *(const f32x4*)(arow + (size_t)kb * P::KB);
+            if constexpr (PRO == PRO_DIRECT) {
+                // fragment-major A: one contiguous 1 KB block per wave load (8 cache lines instead of 16 half-used ones)
+                const elem* ap = g.a_frag ? (const elem*)g.A + ((size_t)(mt_first * g.KBtot + kb) * 64 + lane) * P::E : arow + (size_t)kb * P::KB;
+                af[c] = *(const f32x4*)ap;
+            }
             else af[c] = *(const f32x4*)(lds_a + lr * pitch + (kb * P::KB + P::E * lg) * ES);
         }
         DSG_LOADS_ISSUED();
@@ -841,7 +847,11 @@ __device__ __forceinline__ void gemm_body_mt(const GemmArgs& g) {
         for (int mi = 0; mi < TM; ++mi) {
             const elem* arow = (const elem*)g.A + (size_t)(m0s[mi] + lr) * g.lda + P::E * lg;
 #pragma unroll
-            for (int c = 0; c < CH; ++c) af[mi][c] = *(const f32x4*)(arow + (size_t)min(c, kb_last) * P::KB);
+            for (int c = 0; c < CH; ++c) {
+                const int kb = min(c, kb_last);
+                const elem* ap = g.a_frag ? (const elem*)g.A + ((size_t)((m0s[mi] >> 4) * g.KBtot + kb) * 64 + lane) * P::E : arow + (size_t)kb * P::KB;
+                af[mi][c] = *(const f32x4*)ap;
+            }
         }
         DSG_LOADS_ISSUED();
     }
@@ -1156,7 +1166,7 @@ __global__ __launch_bounds__(64) void k_attn(const AttnArgs a) {
             f32x4 y;
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = o[e] * inv;
-            elem* dst = (elem*)a.out + (size_t)(b * a.ntok + q) * a.D + h * HD + dt * 16 + 4 * lg;
+            elem* dst = (elem*)a.out + qk_off<P>(b * a.ntok + q, h * HD + dt * 16 + 4 * lg, a.D / P::KB);      // fragment-major rows (the next GEMM's A operand)
             if (a.done_ctr) P::store4_agent(dst, y);       // read by an overlapped consumer on other XCDs: write through
             else P::store4(dst, y);
         }
