@@ -10,8 +10,9 @@ EMU := tests/emu/_build/libdsg_emu.so
 
 all: $(LIB) $(CSRC)/dsg_kernels.hsaco
 
-$(LIB): $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h $(CSRC)/dsg_aql.h include/dsg.h
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed -DDSG_BUILD_TAG=$(TAG)u $(CSRC)/dsg_hip.cpp -L/opt/rocm/lib -lhsa-runtime64 -o $@
+# dsg_bvh.cpp is plain host C++ (the BVH post-processing behind the same C ABI), compiled along
+$(LIB): $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h $(CSRC)/dsg_aql.h include/dsg.h $(CSRC)/dsg_bvh.cpp
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed -DDSG_BUILD_TAG=$(TAG)u $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_bvh.cpp -L/opt/rocm/lib -lhsa-runtime64 -lpthread -o $@
 
 # the device side of the same translation unit as a bare code object: loaded through the HSA loader by the AQL
 # submission path (dsg_aql.h), which needs kernel descriptors the HIP runtime does not hand out
@@ -20,14 +21,14 @@ $(CSRC)/dsg_kernels.hsaco: $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg
 
 # diagnostics build: the same sources with cycle stamps at the phase boundaries of the step kernels (tools/stamps.py)
 stamps: $(CSRC)/libdsg_hip_stamps.so
-$(CSRC)/libdsg_hip_stamps.so: $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h include/dsg.h
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed -DDSG_STAMPS=1 $(CSRC)/dsg_hip.cpp -L/opt/rocm/lib -lhsa-runtime64 -o $@
+$(CSRC)/libdsg_hip_stamps.so: $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h include/dsg.h $(CSRC)/dsg_bvh.cpp
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed -DDSG_STAMPS=1 $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_bvh.cpp -L/opt/rocm/lib -lhsa-runtime64 -lpthread -o $@
 
 emu: $(EMU)
-$(EMU): $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h include/dsg.h tests/emu/shim/hip/hip_runtime.h tests/emu/emu_rt.cpp
+$(EMU): $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h include/dsg.h tests/emu/shim/hip/hip_runtime.h tests/emu/emu_rt.cpp $(CSRC)/dsg_bvh.cpp
 	mkdir -p tests/emu/_build
 	$(HOSTCXX) -O2 -g -std=c++17 -fPIC -shared -pthread -Itests/emu/shim -DDSG_EMU=1 \
-	    $(CSRC)/dsg_hip.cpp tests/emu/emu_rt.cpp -o $@
+	    $(CSRC)/dsg_hip.cpp tests/emu/emu_rt.cpp $(CSRC)/dsg_bvh.cpp -o $@
 
 # micro-probes behind the numbers in DESIGN.md s5 (tools/*.cpp; run on the GPU box, logs under profiles/)
 PROBES := xcd_probe persist_probe dep_probe icache_probe

@@ -1,48 +1,91 @@
 #!/usr/bin/env python3
 """Headline benchmark: gesture frames/sec, 1000-step DDPM, 320-frame ZEGGS clip (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1 without a launcher: re-executes itself under
+                                                              torch.distributed.run with N ranks, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of synthetic input = sampling ONE 320-frame clip per GPU
-(4 windows x 1000 denoising steps, batch 1 = BASELINE config[1]).  Clips are independent, so N GPUs run N clips
-(weak scaling, no collective on the data path); the finished poses are gathered to rank 0 with one RCCL gather inside
-the timed region.  Inputs (synthetic WavLM features, synthetic weights) are resident in HBM when the clock starts.
-Prints ONE JSON line on rank 0.
+A "step" is one pass of the hot path over one batch of synthetic input = sampling `--clips-per-gpu` 320-frame clips per GPU
+(4 windows x 1000 denoising steps each).  Default: 1 clip at batch 1 = BASELINE config[1].  `--clips-per-gpu 16` is the
+per-GPU share of config[3] (8 GPUs x 16 = 128 clips) in two variants:
+    --mode streams    16 sampling lanes (own HSA queue each, ONE copy of the weights), one clip per lane at batch 1,
+                      step loops interleaved by the library (dsg_sample_multi) -- "one clip per stream"
+    --mode lockstep   one batch of 16 clips advanced in lock step (the batched kernel set)
+Clips are independent, so N GPUs run N x clips-per-gpu clips (weak scaling, no collective on the data path); the finished
+poses are gathered to rank 0 with one RCCL gather inside the timed region.  Inputs (synthetic WavLM features, synthetic
+weights) are resident in HBM when the clock starts.  De-normalisation + .bvh writing (C++, rank 0) is timed separately
+(`postprocess_ms_per_clip`, `value_end_to_end`).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import platform
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")      # see diffusestylegesture_amd/__init__.py
 
-import numpy as np
-import torch
 
-
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=3, help="clips per GPU inside the timed region")
+    p.add_argument("--steps", type=int, default=3, help="passes (clips per lane / batch element) inside the timed region")
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--sampler", default="ddpm", choices=["ddpm", "ddim50"])
-    p.add_argument("--batch", type=int, default=1, help="clips advanced in lock step per GPU")
+    p.add_argument("--clips-per-gpu", type=int, default=0, help="clips in flight per GPU (default 1; 16 = config[3]'s per-GPU share)")
+    p.add_argument("--mode", default="auto", choices=["auto", "streams", "lockstep"],
+                   help="several clips per GPU: one clip per lane / HSA queue, or one lock-step batch (auto: streams)")
+    p.add_argument("--batch", type=int, default=0, help="alias: --clips-per-gpu B --mode lockstep")
     p.add_argument("--steps-per-graph", type=int, default=0)
     p.add_argument("--config", default="zeggs", choices=["zeggs", "beat", "twh"],
                    help="zeggs = headline (BASELINE config[1]); beat/twh = DiffuseStyleGesture+ dims, 1830-frame clip (config[4])")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-baseline-steps", type=int, default=400)
-    return p.parse_args()
+    p.add_argument("--no-postprocess", action="store_true")
+    p.add_argument("--cpu-baseline-steps", type=int, default=1000)
+    a = p.parse_args(argv)
+    if a.batch and not a.clips_per_gpu:
+        a.clips_per_gpu, a.mode = a.batch, "lockstep"
+    a.clips_per_gpu = a.clips_per_gpu or 1
+    if a.mode == "auto":
+        a.mode = "streams" if a.clips_per_gpu > 1 else "lockstep"
+    return a
 
 
-def cpu_baseline(n_steps):
-    """Times the CPU oracle (numpy restatement of the reference path, validated against goldens) on a bounded sample:
-    n_steps DDPM steps of one ZEGGS window, batch 1; extrapolated to 4 x 1000 steps per 320-frame clip."""
+def self_launch(a):
+    """`python bench.py --gpus N` with no launcher environment: create the N ranks (one per GPU) ourselves."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def host_cpu():
+    model = platform.processor() or ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"model": model, "nproc": os.cpu_count() or 1}
+
+
+def cpu_baseline(n_steps, one_core_steps=None):
+    """Times the CPU oracle (numpy restatement of the reference path, validated against goldens) on a bounded sample of the
+    config[0] workload: `n_steps` DDPM steps of one ZEGGS window at batch 1 (default: a whole 1000-step window, a quarter of
+    a clip), on the best BLAS thread count found by a short sweep, plus a shorter single-thread run."""
     from diffusestylegesture_amd import config as C
     from diffusestylegesture_amd.synth import synth_state_dict, synth_window_inputs
     from oracle import sampler
@@ -54,10 +97,13 @@ def cpu_baseline(n_steps):
     shape = (1, cfg.njoints, 1, cfg.n_poses)
     d = OracleDiffusion()
     nf = sampler.philox_noise_fn(shape, 1, 0)
-    sampler.p_sample_loop(d, m, shape, nf, {"y": y}, skip_timesteps=995)         # warm-up
+    run = lambda k: sampler.p_sample_loop(d, m, shape, nf, {"y": y}, skip_timesteps=1000 - k)
+    run(5)         # warm-up
     # BLAS thread count: the GEMMs of one step are small (89 x 256 x 1024 at most), so all host threads is not the
     # fastest setting; a short sweep picks the best one and `cores` reports the threads actually used
-    cores, limiter = os.cpu_count() or 1, None
+    cores = os.cpu_count() or 1
+    one_core_steps = one_core_steps if one_core_steps is not None else max(10, min(300, n_steps // 3))
+    one_core = None
     try:
         from threadpoolctl import threadpool_limits
         best = None
@@ -66,133 +112,206 @@ def cpu_baseline(n_steps):
                 continue
             with threadpool_limits(limits=nt):
                 t0 = time.perf_counter()
-                sampler.p_sample_loop(d, m, shape, nf, {"y": y}, skip_timesteps=980)
+                run(min(20, n_steps))
                 dt = time.perf_counter() - t0
             if best is None or dt < best[0]:
                 best = (dt, nt)
         cores = best[1]
-        limiter = threadpool_limits(limits=cores)
-    except Exception:
-        pass
-    t0 = time.perf_counter()
-    sampler.p_sample_loop(d, m, shape, nf, {"y": y}, skip_timesteps=1000 - n_steps)
-    dt = time.perf_counter() - t0
-    if limiter is not None:
-        limiter.restore_original_limits()
+        with threadpool_limits(limits=1):
+            t0 = time.perf_counter()
+            run(one_core_steps)
+            one_core = 1000.0 * (time.perf_counter() - t0) / one_core_steps
+        with threadpool_limits(limits=cores):
+            t0 = time.perf_counter()
+            run(n_steps)
+            dt = time.perf_counter() - t0
+    except ImportError:
+        t0 = time.perf_counter()
+        run(n_steps)
+        dt = time.perf_counter() - t0
     ms_step = 1000.0 * dt / n_steps
-    return {"value": round(320.0 / (4000 * ms_step / 1000.0), 3), "unit": "frames/s", "cores": int(cores),
-            "kind": "port", "ms_per_denoise_step": round(ms_step, 3),
-            "sample": f"{n_steps} DDPM steps of one 88-frame ZEGGS window (batch 1, fp32 numpy oracle), "
-                      f"extrapolated to 4x1000 steps per 320-frame clip"}
+    fps = lambda ms: round(320.0 / (4000 * ms / 1000.0), 3)
+    out = {"value": fps(ms_step), "unit": "frames/s", "cores": int(cores), "kind": "port",
+           "ms_per_denoise_step": round(ms_step, 3), "host": host_cpu(),
+           "sample": f"{n_steps} DDPM steps of one 88-frame ZEGGS window (batch 1, fp32 numpy oracle, {cores} BLAS threads); "
+                     f"a 320-frame clip is 4 such windows of 1000 steps"}
+    if one_core is not None:
+        out["one_core"] = {"value": fps(one_core), "ms_per_denoise_step": round(one_core, 3), "steps": one_core_steps}
+    return out
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
+    import numpy as np
+    import torch
+    emu = os.environ.get("DSG_BENCH_EMU") == "1"          # TEST INFRASTRUCTURE ONLY (tests/test_bench_launch.py): CPU emulator, gloo
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local)
+    if not emu:
+        torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")          # RCCL on ROCm
+        dist.init_process_group("gloo" if emu else "nccl")          # "nccl" = RCCL on ROCm
     from diffusestylegesture_amd import config as C
+    from diffusestylegesture_amd import lib as L
     from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
     from diffusestylegesture_amd.model import DSGDenoiser
-    from diffusestylegesture_amd.sample import generate_clip
+    from diffusestylegesture_amd.sample import generate_clip, generate_clips_streams
     from diffusestylegesture_amd.synth import synth_state_dict, synth_window_inputs
 
-    cfg = C.CONFIGS[a.config]
-    B = a.batch
-    model = DSGDenoiser(cfg, precision=a.precision, max_batch=B, device=local, steps_per_graph=a.steps_per_graph)
+    library = None
+    if emu:
+        library = L.DSGLibrary(os.path.join(ROOT, "tests", "emu", "_build", "libdsg_emu.so"))
+        cfg = C.TINY
+    else:
+        cfg = C.CONFIGS[a.config]
+    NC = a.clips_per_gpu
+    streams = a.mode == "streams" and NC > 1
+    if streams and cfg.variant != 3:
+        raise SystemExit("--mode streams drives the ZEGGS clip loop")
+    B = 1 if streams else NC
+    model = DSGDenoiser(cfg, precision=a.precision, max_batch=B, device=local, steps_per_graph=a.steps_per_graph, library=library)
     model.load_state_dict(synth_state_dict(cfg, 20240))
-    diffusion = create_gaussian_diffusion("ddim50" if a.sampler == "ddim50" else "")
+    lanes = [model] + [model.clone() for _ in range(NC - 1)] if streams else [model]
+    diffusion = create_gaussian_diffusion("ddim50" if a.sampler == "ddim50" else "", library=library)
     sample_fn = diffusion.ddim_sample_loop if a.sampler == "ddim50" else diffusion.p_sample_loop
-    if a.config == "zeggs":
-        n_windows = 4
+    skip = int(os.environ.get("DSG_BENCH_SKIP", "0")) if emu else 0
+    if cfg.variant == 3:
+        n_windows = 2 if emu else 4
         frames_per_clip = n_windows * cfg.stride                                # 320 nominal (312 emitted)
     else:
         frames_per_clip = 1830                                                  # BEAT-TWH sample.py:56, max_len=0
         n_windows = -(-frames_per_clip // cfg.stride)                           # ceil -> 16 windows
-    # synthetic per-window audio features, resident in HBM before the clock starts (clip index = rank*B + b)
-    feats = [torch.from_numpy(synth_window_inputs(cfg, B, window=w, clip0=rank * B)["audio"]).cuda(local)
-             for w in range(n_windows)]
+    # synthetic per-window audio features, resident in HBM before the clock starts (clip index = rank*NC + b)
+    to_dev = (lambda x: torch.from_numpy(x)) if emu else (lambda x: torch.from_numpy(x).cuda(local))
+    if streams:
+        feats = [[to_dev(synth_window_inputs(cfg, 1, window=w, clip0=rank * NC + c)["audio"]) for w in range(n_windows)]
+                 for c in range(NC)]
+    else:
+        feats = [to_dev(synth_window_inputs(cfg, B, window=w, clip0=rank * NC)["audio"]) for w in range(n_windows)]
+    if emu:
+        feats = [[f.numpy() for f in fl] for fl in feats] if streams else [f.numpy() for f in feats]
     style = [1] + [0] * (cfg.style_dim_in - 1)
 
-    def one_clip(i):
-        if a.config == "zeggs":
+    def one_pass(i):
+        if streams:
+            return generate_clips_streams(lanes, diffusion, feats, style, seed=123456 + i, smoothing=True, skip_timesteps=skip,
+                                          stream_ids=[rank * NC + c for c in range(NC)], ddim=a.sampler == "ddim50")
+        if cfg.variant == 3:
             return generate_clip(model, diffusion, feats, style, seed=123456 + i, smoothing=True, sample_fn=sample_fn,
-                                 stream_id=rank)
+                                 stream_id=rank, skip_timesteps=skip)
         from diffusestylegesture_amd.sample import generate_clip_dsgplus
-        seed0 = torch.from_numpy(synth_window_inputs(cfg, B, window=0, clip0=rank * B, seed_pose_scale=0.1)["seed"]).cuda(local)
+        seed0 = to_dev(synth_window_inputs(cfg, B, window=0, clip0=rank * NC, seed_pose_scale=0.1)["seed"])
         return generate_clip_dsgplus(model, diffusion, feats, style, seed0, frames_per_clip, seed=123456 + i,
                                      sample_fn=sample_fn, stream_id=rank)
 
     def sync():
-        torch.cuda.synchronize()
+        if not emu:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
+            if not emu:
+                torch.cuda.synchronize()
 
     for i in range(a.warmup):
-        one_clip(i)
+        one_pass(i)
     sync()
     step_us = []
     t0 = time.perf_counter()
     poses = None
     for i in range(a.steps):
-        poses = one_clip(a.warmup + i)
-        step_us.append(diffusion.last_step_time_us())
+        poses = one_pass(a.warmup + i)
+        if streams:       # all lanes advance one step in: (slowest lane's time) / steps
+            step_us.append(max(1000.0 * ln.last_sample_ms()[0] / max(ln.last_sample_ms()[1], 1) for ln in lanes))
+        else:
+            step_us.append(diffusion.last_step_time_us())
+    gathered = poses
     if dist is not None:        # the only exchange of the path: finished poses -> rank 0 (RCCL over xGMI)
         from diffusestylegesture_amd.parallel import gather_poses
-        gather_poses(poses, world * B, dist, dst=0, device=f"cuda:{local}")
+        gathered = gather_poses(poses, world * NC, dist, dst=0, device=None if emu else f"cuda:{local}")
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], device=f"cuda:{local}", dtype=torch.float64)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if emu else f"cuda:{local}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     if rank == 0:
-        total_frames = world * B * a.steps * frames_per_clip
-        value = total_frames / dt
-        n_denoise = diffusion.num_timesteps
+        n_clips = world * NC * a.steps
+        value = n_clips * frames_per_clip / dt
+        emitted = int(poses.shape[1])
+        n_denoise = diffusion.num_timesteps - skip
         us = float(np.mean(step_us))
-        # algorithmic bytes per denoising step (SURVEY s8d / DESIGN.md): per-step weights in the compute dtype +
-        # fp32 state I/O (x_t in, noise in, x_{t-1} out) per clip in the batch
-        # per-step weight parameters / fp32 state bytes per clip
-        wparams, sbytes = {"zeggs": (7.183e6, 1.205e6), "beat": (13.25e6, 3.694e6), "twh": (20.23e6, 4.018e6)}[a.config]
+        if not us > 0:      # no device timer (emulated test run): wall clock per denoising step
+            us = 1e6 * dt / (a.steps * n_windows * n_denoise)
+        # algorithmic work per denoising step of ONE clip (SURVEY s8d / DESIGN.md): per-step weight parameters, fp32 state
+        # bytes (x_t in, noise in, x_{t-1} out) and FLOPs
+        wparams, sbytes, gflop = {"zeggs": (7.183e6, 1.205e6, 1.3152), "beat": (13.25e6, 3.694e6, 4.183),
+                                  "twh": (20.23e6, 4.018e6, 6.311)}[a.config]
         wbytes = wparams * (2 if a.precision == "bf16" else 4)
-        abytes = wbytes + sbytes * B
-        achieved = abytes / (us * 1e-6) / 1e9
-        # HBM-side traffic per step from the rocprofv3 PMC passes (tools/pmc_traffic.py; FETCH_SIZE doubled as the
-        # MI355X guide prescribes for wide coalesced reads), measured for the headline configuration only
-        traffic = None
-        import glob
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_zeggs_b1_bf16.json")))   # newest round last
-        tf = cands[-1] if cands else ""
-        if a.config == "zeggs" and a.precision == "bf16" and B == 1 and os.path.exists(tf):
-            traffic = json.load(open(tf))["traffic_bytes_per_step_fetch_x2"]
+        abytes = wbytes + sbytes * NC           # the NC clips in flight share one pass over the weights
+        if NC >= 8:
+            # from 8 clips in flight (>= 712 token rows) the path is a dense contraction -> MFMA roofline
+            ach = gflop * NC / (us * 1e-6) / 1e3
+            peak = 2500.0 if a.precision == "bf16" else 157.3
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 5),
+                    "traffic": None, "algorithmic_gflop_per_denoise_step": gflop * NC,
+                    "note": f"{NC} clips in flight ({a.mode}): achieved = {gflop} GFLOP x {NC} clips / time in which all of them "
+                            "advance one denoising step; peak = dense MFMA " + ("bf16" if a.precision == "bf16" else "fp32")}
+        else:
+            achieved = abytes / (us * 1e-6) / 1e9
+            # HBM-side traffic per step from the rocprofv3 PMC passes (tools/pmc_traffic.py; FETCH_SIZE doubled as the
+            # MI355X guide prescribes for wide coalesced reads), measured for the headline configuration only
+            traffic, tsrc = None, None
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_zeggs_b1_bf16.json")))   # newest round last
+            if a.config == "zeggs" and a.precision == "bf16" and NC == 1 and cands:
+                traffic = json.load(open(cands[-1]))["traffic_bytes_per_step_fetch_x2"]
+                tsrc = os.path.basename(cands[-1])
+            roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": tsrc,
+                    "algorithmic_bytes_per_denoise_step": abytes,
+                    "note": "one denoising step = 2 + 3*L dependent kernel dispatches (batch-1 latency mode); achieved = "
+                            "algorithmic bytes / time per step, timed from the first doorbell to the completion signal of "
+                            "the last AQL packet (HIP events around the loop on the HIP-launch path); traffic = PMC bytes of "
+                            "the committed rocprofv3 passes (separate runs), not of this run"}
         out = {
             "metric": (f"gesture frames/sec, {'1000-step DDPM' if a.sampler == 'ddpm' else '50-step DDIM'}, "
                        + ("320-frame ZEGGS clip" if a.config == "zeggs" else f"1830-frame {a.config.upper()} clip (DSG+)")),
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1000.0 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
-            "config": {"workload": f"1xMI355X per rank, batch={B}, {frames_per_clip}-frame {a.config.upper()} clip "
-                                   f"({n_windows} windows x {n_denoise} denoising steps), {a.sampler.upper()} {a.precision}",
-                       "clips_per_gpu": B, "frames_emitted_per_clip": int(poses.shape[1]),
-                       "denoise_steps_per_window": n_denoise, "parallelism": f"clips x{world}"},
+            "vs_baseline": None, "dtype": a.precision, "data": "synthetic" + (" (EMULATED ON CPU: test run, not a measurement)" if emu else ""),
+            "config": {"workload": f"1xMI355X per rank, {NC} clip(s) in flight per GPU ({a.mode if NC > 1 else 'batch 1'}), "
+                                   f"{frames_per_clip}-frame {a.config.upper()} clip ({n_windows} windows x {n_denoise} denoising steps), "
+                                   f"{a.sampler.upper()} {a.precision}",
+                       "clips_per_gpu": NC, "mode": a.mode if NC > 1 else "batch1", "frames_nominal_per_clip": frames_per_clip,
+                       "frames_emitted_per_clip": emitted, "denoise_steps_per_window": n_denoise, "parallelism": f"clips x{world}"},
+            "value_emitted_frames": round(n_clips * emitted / dt, 2),
+            "sample_path": diffusion.last_sample_path(),
             "us_per_denoise_step": round(us, 2),
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(achieved / 8000.0, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_denoise_step": abytes,
-                         "note": "one denoising step = 2 + 3*L dependent kernel dispatches (batch-1 latency mode), submitted as "
-                                 "hand-written AQL packets on the library's own HSA queue (DSG_AQL=0: HIP launches); achieved = "
-                                 "algorithmic bytes / time per step, timed from the first doorbell to the completion signal "
-                                 "of the last packet (HIP events around the loop on the HIP-launch path)"},
+            "roofline": roof,
         }
-        if world == 1 and not a.no_cpu_baseline and a.config == "zeggs" and a.sampler == "ddpm":
+        if not a.no_postprocess and cfg.variant == 3 and not emu and gathered is not None:
+            # de-normalisation + Savitzky-Golay + .bvh text for every clip of the last pass (C++, host threads), outside the
+            # timed region as the metric defines it; value_end_to_end charges it to the job
+            from diffusestylegesture_amd.bvh import pose2bvh_batch
+            ms = np.load(os.path.join(ROOT, "diffusestylegesture_amd", "data", "zeggs_mean_std.npz"))
+            g = np.ascontiguousarray(np.asarray(gathered, np.float32))
+            with tempfile.TemporaryDirectory() as td:
+                paths = [os.path.join(td, f"clip{c:03d}.bvh") for c in range(g.shape[0])]
+                pose2bvh_batch(g, paths, smoothing=True, mean=ms["mean"], std=ms["std"])        # warm (thread start, page faults)
+                t1 = time.perf_counter()
+                pose2bvh_batch(g, paths, smoothing=True, mean=ms["mean"], std=ms["std"])
+                post = time.perf_counter() - t1
+                out["bvh_bytes_per_clip"] = os.path.getsize(paths[0])
+            out["postprocess_ms_per_clip"] = round(1000.0 * post / g.shape[0], 3)
+            out["postprocess_ms_per_pass"] = round(1000.0 * post, 3)
+            out["value_end_to_end"] = round(n_clips * frames_per_clip / (dt + post * a.steps), 2)
+        if world == 1 and not a.no_cpu_baseline and a.config == "zeggs" and a.sampler == "ddpm" and not emu:
             out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_steps)
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -81,4 +81,12 @@ TINY5 = DSGConfig("tiny5", VARIANT_DSGPP, njoints=37, n_poses=30, n_seed=6, late
 BEATPP = DSGConfig("beatpp", VARIANT_DSGPP, njoints=2052, n_poses=150, n_seed=30, latent_dim=384,
                    audio_src_dim=1434, audio_dim=96, style_dim_in=2, window=15)
 
-CONFIGS = {c.name: c for c in (ZEGGS, BEAT, TWH, TINY, TINY4, TINY5, BEATPP)}
+# BEAT-TWH-main's "DiffuseStyleGesture" (cross_local_attention3_style1_sample, BEAT-TWH-main/model/mdm.py:147-185): the ZEGGS
+# conditioning scheme at BEAT dims -- window 15, audio covers all T frames (sample.py:100-102, :132-134)
+BEAT3 = DSGConfig("beat3", VARIANT_DSG, njoints=2052, n_poses=150, n_seed=30, latent_dim=384,
+                  audio_src_dim=1434, audio_dim=96, style_dim_in=2, window=15)
+TINY3B = DSGConfig("tiny3b", VARIANT_DSG, njoints=37, n_poses=30, n_seed=6, latent_dim=384,
+                   audio_src_dim=40, audio_dim=16, style_dim_in=3, window=15,
+                   num_layers=2, num_heads=6, ff_size=128)
+
+CONFIGS = {c.name: c for c in (ZEGGS, BEAT, TWH, TINY, TINY4, TINY5, BEATPP, BEAT3, TINY3B)}

@@ -178,45 +178,84 @@ inline bool finish(Ctx& c) {
     return hipDeviceSynchronize() == hipSuccess;
 }
 
-// n_steps x plan, in order (barrier bit), agent-scope fences; the very last packet releases to system scope and carries
-// the completion signal.  Returns false on time-out (seconds) -- the caller must treat the handle's state as lost.
-inline bool run(Ctx& c, int n_steps, double timeout_s) {
+// packets of one step of `c` into its queue + doorbell; `last`: the final packet releases to system scope and carries the
+// completion signal
+inline void submit_step(Ctx& c, bool first_step, bool last_step) {
     const uint32_t mask = c.q->size - 1;
     const size_t L = c.plan.size();
+    const uint64_t first = hsa_queue_add_write_index_relaxed(c.q, L);
+    for (size_t i = 0; i < L; ++i) {
+        const Launch& l = c.plan[i];
+        const bool last = last_step && (i == L - 1);
+        hsa_kernel_dispatch_packet_t* p = (hsa_kernel_dispatch_packet_t*)c.q->base_address + ((first + i) & mask);
+        p->setup = 3 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
+        p->workgroup_size_x = (uint16_t)l.bx; p->workgroup_size_y = (uint16_t)l.by; p->workgroup_size_z = (uint16_t)l.bz;
+        p->reserved0 = 0;
+        p->grid_size_x = l.gx * l.bx; p->grid_size_y = l.gy * l.by; p->grid_size_z = l.gz * l.bz;
+        p->private_segment_size = 0; p->group_segment_size = l.k.group;
+        p->kernel_object = l.k.object;
+        p->kernarg_address = c.ka_dev + l.ka_off;
+        p->reserved2 = 0;
+        p->completion_signal.handle = last ? c.done.handle : 0;
+        const int rel = last ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
+        const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | ((l.overlap ? 0 : 1) << HSA_PACKET_HEADER_BARRIER) |
+                                           ((first_step && i == 0 ? HSA_FENCE_SCOPE_SYSTEM : c.acquire_scope) << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
+                                           (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
+        __atomic_store_n((uint16_t*)p, header, __ATOMIC_RELEASE);
+    }
+    hsa_signal_store_screlease(c.q->doorbell_signal, (hsa_signal_value_t)(first + L - 1));
+}
+// room for one more step in the queue?  (never overwrite packets the command processor has not consumed yet)
+inline bool has_room(Ctx& c) {
+    return hsa_queue_load_write_index_relaxed(c.q) + c.plan.size() - hsa_queue_load_read_index_scacquire(c.q) <= c.q->size;
+}
+
+// n_steps x plan, in order (barrier bit), agent-scope fences.  Returns false on time-out (seconds) -- the caller must treat
+// the handle's state as lost.
+inline bool run(Ctx& c, int n_steps, double timeout_s) {
     hsa_signal_store_relaxed(c.done, 1);
     const auto t0 = std::chrono::steady_clock::now();
     for (int s = 0; s < n_steps; ++s) {
-        // back-pressure: never overwrite packets the command processor has not consumed yet
-        uint64_t wr = hsa_queue_load_write_index_relaxed(c.q);
-        while (wr + L - hsa_queue_load_read_index_scacquire(c.q) > c.q->size) {
+        while (!has_room(c)) {
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) { c.err = "queue stalled"; return false; }
         }
-        const uint64_t first = hsa_queue_add_write_index_relaxed(c.q, L);
-        for (size_t i = 0; i < L; ++i) {
-            const Launch& l = c.plan[i];
-            const bool last = (s == n_steps - 1) && (i == L - 1);
-            hsa_kernel_dispatch_packet_t* p = (hsa_kernel_dispatch_packet_t*)c.q->base_address + ((first + i) & mask);
-            p->setup = 3 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
-            p->workgroup_size_x = (uint16_t)l.bx; p->workgroup_size_y = (uint16_t)l.by; p->workgroup_size_z = (uint16_t)l.bz;
-            p->reserved0 = 0;
-            p->grid_size_x = l.gx * l.bx; p->grid_size_y = l.gy * l.by; p->grid_size_z = l.gz * l.bz;
-            p->private_segment_size = 0; p->group_segment_size = l.k.group;
-            p->kernel_object = l.k.object;
-            p->kernarg_address = c.ka_dev + l.ka_off;
-            p->reserved2 = 0;
-            p->completion_signal.handle = last ? c.done.handle : 0;
-            const int rel = last ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
-            const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | ((l.overlap ? 0 : 1) << HSA_PACKET_HEADER_BARRIER) |
-                                               ((s == 0 && i == 0 ? HSA_FENCE_SCOPE_SYSTEM : c.acquire_scope) << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
-                                               (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
-            __atomic_store_n((uint16_t*)p, header, __ATOMIC_RELEASE);
-        }
-        hsa_signal_store_screlease(c.q->doorbell_signal, (hsa_signal_value_t)(first + L - 1));
+        submit_step(c, s == 0, s == n_steps - 1);
     }
     const uint64_t budget_ns = (uint64_t)(timeout_s * 1e9);
     const hsa_signal_value_t v = hsa_signal_wait_scacquire(c.done, HSA_SIGNAL_CONDITION_LT, 1, budget_ns, HSA_WAIT_STATE_ACTIVE);
     c.last_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (v >= 1) { c.err = "completion signal timed out"; return false; }
+    return true;
+}
+
+// Several lanes at once, one host thread: every lane's chain of dependent packets lives on its own queue, so the command
+// processor overlaps them; the host deals one step at a time to every lane that has room (a full queue is skipped, never
+// waited on, so one slow lane cannot starve the others).  last_ms of each lane = first doorbell of the call to ITS completion.
+inline bool run_multi(Ctx** cs, const int* n_steps, int n, double timeout_s, std::string& err) {
+    std::vector<int> next(n, 0);
+    for (int i = 0; i < n; ++i) hsa_signal_store_relaxed(cs[i]->done, 1);
+    const auto t0 = std::chrono::steady_clock::now();
+    int open = 0;
+    for (int i = 0; i < n; ++i) open += n_steps[i] > 0;
+    unsigned idle = 0;
+    while (open > 0) {
+        bool any = false;
+        for (int i = 0; i < n; ++i) {
+            if (next[i] >= n_steps[i] || !has_room(*cs[i])) continue;
+            submit_step(*cs[i], next[i] == 0, next[i] == n_steps[i] - 1);
+            if (++next[i] == n_steps[i]) --open;
+            any = true;
+        }
+        if (!any && (++idle & 1023) == 0 &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) { err = "queues stalled"; return false; }
+    }
+    for (int i = 0; i < n; ++i) {
+        if (n_steps[i] <= 0) { cs[i]->last_ms = 0.0; continue; }
+        const double left = timeout_s - std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const hsa_signal_value_t v = hsa_signal_wait_scacquire(cs[i]->done, HSA_SIGNAL_CONDITION_LT, 1, (uint64_t)(std::max(left, 1.0) * 1e9), HSA_WAIT_STATE_ACTIVE);
+        cs[i]->last_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (v >= 1) { err = cs[i]->err = "completion signal timed out"; return false; }
+    }
     return true;
 }
 

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void k_inloc(const InLocArgs g) {
     for (int i = 0; i < NSI; ++i) {
         const int idx = tid + 256 * i, q = idx >> 5, j = idx & 31, fk = f0 + j;
         const unsigned char mk = a.mask[(size_t)mrow * a.T + min(max(fk, 0), a.T - 1)];
-        keep[i] = ((int)(q < W) & (int)(j < W2) & (int)(fk >= 0) & (int)(mk != 0)) != 0;
+        keep[i] = ((int)(q < W) & (int)(j < W2) & ((int)(a.nomask != 0) | ((int)(fk >= 0) & (int)(mk != 0)))) != 0;
     }
     const int tc = min(tid, HD - 1);
     float tokv = a.emb1[(size_t)b * a.D + col0 + tc];

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -36,6 +37,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
     } while (0)
 
 extern "C" const char* dsg_last_error(void) { return g_err.c_str(); }
+void dsg_internal_set_error(const char* msg) { g_err = msg ? msg : ""; }      // for the other translation units of the library (dsg_bvh.cpp)
 extern "C" int dsg_version(void) { return DSG_VERSION; }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -100,6 +102,14 @@ struct Layer {
           *be2 = nullptr;
 };
 
+// Everything derived from the checkpoint alone (raw tensors, packed weights, tables): owned jointly by a handle and its
+// clones (dsg_clone) -- several sampling lanes of one GPU read ONE copy of the weights, which therefore stays resident in the
+// XCDs' L2 slices no matter how many clips are in flight.
+struct SharedWeights {
+    std::vector<void*> allocs;
+    ~SharedWeights() { for (void* p : allocs) (void)hipFree(p); }
+};
+
 struct dsg_handle {
     dsg_config cfg;
     int prec = 0, es = 4, kbk = 16;      // element size / k-block of the precision policy
@@ -107,7 +117,10 @@ struct dsg_handle {
     int KSin = 4;                        // split-K of the pose-embedding GEMM: one split per 256 pose features
     hipStream_t stream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
-    std::vector<void*> allocs;
+    std::vector<void*> allocs;                       // per-lane buffers (state, activations, conditioning)
+    std::shared_ptr<SharedWeights> shared;           // checkpoint-derived buffers (see SharedWeights)
+    bool alloc_shared = false;                       // dalloc target: true while loading / finalizing weights
+    bool is_clone = false;
     std::map<std::string, RawT> raw;
     bool finalized = false, cond_set = false;
     int condB = 0;
@@ -119,7 +132,11 @@ struct dsg_handle {
     float *emb1 = nullptr, *Cf = nullptr, *enc = nullptr, *cvec = nullptr;
     float *c_style = nullptr, *c_seed = nullptr, *c_audio = nullptr, *c_seed_last = nullptr;
     int seed_last_B = 0;                 // batch of the last dsg_set_seed_last (variant 5)
-    unsigned char* mask = nullptr; int mb = 1;
+    unsigned char* mask = nullptr; int mb = 1; int nomask = 0;
+    // classifier-free guidance (dsg_set_window_cond_cfg): cfgB user batch elements + their unconditional twins = condB rows
+    int cfgB = 0; float* cfg_scale = nullptr;
+    int last_path = -1;                  // submission path of the last dsg_sample: 0 HIP launches, 1 AQL packets, 2 hipGraph replay
+    bool dbg_warned = false;
     // state / activations
     float *xs32 = nullptr, *partial = nullptr, *X0 = nullptr, *pre1 = nullptr, *pre2 = nullptr, *Xn = nullptr,
           *X1 = nullptr, *fwd_out = nullptr, *io_tmp = nullptr, *io_tmp2 = nullptr, *ext_noise = nullptr;
@@ -149,8 +166,9 @@ struct dsg_handle {
     int st_cap = 0, n_run = 1;
     Sched sched;
     // graphs: key = (B, out_mode, ext_noise?, const_noise) -> exec
-    struct GKey { int B, mode, mb, cn; bool operator<(const GKey& o) const {
-        return std::tie(B, mode, mb, cn) < std::tie(o.B, o.mode, o.mb, o.cn); } };
+    // n_run is part of the key: the captured kernels carry the step-table length as an argument (n_tab)
+    struct GKey { int B, mode, mb, cn, n_run, flags; bool operator<(const GKey& o) const {
+        return std::tie(B, mode, mb, cn, n_run, flags) < std::tie(o.B, o.mode, o.mb, o.cn, o.n_run, o.flags); } };
     struct GVal { hipGraphExec_t exec; hipGraph_t graph; int steps; };
     std::map<GKey, GVal> graphs;
     float last_ms = -1.f; int last_steps = 0; bool timing_valid = false;
@@ -170,7 +188,8 @@ static int dalloc(dsg_handle* h, T** p, size_t n_elems, bool zero = true) {
         HIPCHK(hipMemsetAsync(d, 0, bytes, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
-    h->allocs.push_back(d);
+    if (h->alloc_shared) h->shared->allocs.push_back(d);
+    else h->allocs.push_back(d);
     *p = (T*)d;
     return 0;
 }
@@ -256,6 +275,7 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     HIPCHK(hipSetDevice(c->device));
 
     dsg_handle* h = new dsg_handle();
+    h->shared = std::make_shared<SharedWeights>();
     h->cfg = *c;
     h->prec = c->precision;
     h->es = h->prec == DSG_PREC_BF16 ? 2 : 4;
@@ -287,6 +307,12 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     }
     if (const char* e = getenv("DSG_FUSE_ATTN")) h->fuse_attn = atoi(e) != 0;
     if (const char* e = getenv("DSG_FUSE_ATTN_MID")) h->fuse_attn_mid = atoi(e) != 0;
+    // experiment switches that knowingly break the results are never silent
+    if (h->dbg_skip || getenv("DSG_AQL_ACQUIRE")) {
+        static bool warned = false;
+        if (!warned) fprintf(stderr, "libdsg_hip: WARNING: DSG_DEBUG_SKIP / DSG_AQL_ACQUIRE are timing experiments -- results are not valid samples\n");
+        warned = true;
+    }
     *out = h;
 
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -322,12 +348,13 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     CHK(dalloc(h, &h->enc, (size_t)B * h->T * h->A));
     CHK(dalloc(h, &h->c_style, (size_t)B * c->style_dim_in));
     CHK(dalloc(h, &h->c_seed, (size_t)B * h->J * (h->S > 0 ? h->S : 1)));
-    if (h->cfg.variant == 5) CHK(dalloc(h, &h->c_seed_last, (size_t)B * h->J * h->S));
+    if (h->cfg.variant == 5) CHK(dalloc(h, &h->c_seed_last, (size_t)B * h->J * h->S));      // (guidance: rows [B/2, B) = the twins' copy)
     CHK(dalloc(h, &h->c_audio, (size_t)B * h->Ta * h->As));
     CHK(dalloc(h, &h->mask, (size_t)B * h->T));
     CHK(dalloc(h, &h->ctr, 8));
     CHK(dalloc(h, &h->ctl, 1));
     CHK(dalloc(h, &h->dep_ctr, 64));
+    CHK(dalloc(h, &h->cfg_scale, (size_t)B));
     CHK(dalloc(h, &h->dyn, 8));
     CHK(dalloc(h, &h->t_arr, (size_t)B));
     // the xs32 master is read as a GEMM operand in fp32 mode: rows padded to a 16-row tile exist (allocated above)
@@ -352,9 +379,31 @@ extern "C" int dsg_destroy(dsg_handle* h) {
     return 0;
 }
 
+// A second sampling lane over the same weights: own stream / HSA queue, state, activations, conditioning and schedule, but
+// the checkpoint-derived buffers (packed weights, time-embedding and rotary tables) are the source's, reference counted.
+// `max_batch` <= 0 keeps the source's.
+extern "C" int dsg_clone(dsg_handle* src, int max_batch, dsg_handle** out) {
+    if (!src || !out) return fail(DSG_E_INVALID, "dsg_clone: null argument");
+    if (!src->finalized) return fail(DSG_E_STATE, "dsg_clone before dsg_finalize_weights");
+    dsg_config c = src->cfg;
+    if (max_batch > 0) c.max_batch = max_batch;
+    dsg_handle* h = nullptr;
+    CHK(dsg_create(&c, &h));
+    h->shared = src->shared;
+    h->is_clone = true;
+    h->raw = src->raw;
+    h->Wp_in = src->Wp_in; h->Wp_out = src->Wp_out; h->b_out = src->b_out; h->layers = src->layers;
+    h->TE = src->TE; h->TE2 = src->TE2; h->rcos = src->rcos; h->rsin = src->rsin; h->cbase = src->cbase;
+    h->zero_bias = src->zero_bias;
+    h->finalized = true;
+    *out = h;
+    return 0;
+}
+
 extern "C" int dsg_load_tensor(dsg_handle* h, const char* name, const void* data, const int64_t* shape, int ndim,
                                int dtype) {
     if (!h || !name || !data || !shape) return fail(DSG_E_INVALID, "dsg_load_tensor: null argument");
+    if (h->is_clone) return fail(DSG_E_STATE, "dsg_load_tensor on a clone: load the weights into the source handle");
     if (dtype != 0) return fail(DSG_E_NOT_IMPLEMENTED, "dsg_load_tensor: only float32 (dtype 0)");
     HIPCHK(hipSetDevice(h->cfg.device));
     std::string nm(name);
@@ -369,7 +418,12 @@ extern "C" int dsg_load_tensor(dsg_handle* h, const char* name, const void* data
     for (int i = 0; same && i < ndim; ++i) same = it->second[i] == shape[i];
     if (!same || n != ne) return fail(DSG_E_INVALID, "size mismatch for " + nm);
     RawT& r = h->raw[nm];
-    if (!r.d) CHK(dalloc(h, &r.d, n, false));
+    if (!r.d) {
+        h->alloc_shared = true;
+        const int rc = dalloc(h, &r.d, n, false);
+        h->alloc_shared = false;
+        CHK(rc);
+    }
     r.n = n; r.shape.assign(shape, shape + ndim);
     const bool dev_src = is_device_ptr(data);
     HIPCHK(hipMemcpy(r.d, data, n * sizeof(float), dev_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
@@ -416,8 +470,16 @@ static int padded_vec(dsg_handle* h, float** dst, const float* src, int n, int n
     return 0;
 }
 
+static int finalize_weights(dsg_handle* h);
 extern "C" int dsg_finalize_weights(dsg_handle* h) {
     if (!h) return fail(DSG_E_INVALID, "null handle");
+    if (h->is_clone) return fail(DSG_E_STATE, "dsg_finalize_weights on a clone");
+    h->alloc_shared = true;
+    const int rc = finalize_weights(h);
+    h->alloc_shared = false;
+    return rc;
+}
+static int finalize_weights(dsg_handle* h) {
     HIPCHK(hipSetDevice(h->cfg.device));
     auto exp = expected_tensors(h);
     for (auto& kv : exp)
@@ -494,14 +556,14 @@ extern "C" int dsg_set_schedule(dsg_handle* h, const double* betas, const int64_
         s.tmap[i] = (int)tmap[i];
     }
     h->sched = s;
+    // captured graphs carry the table pointers and the table length of the schedule they were captured under
+    for (auto& kv : h->graphs) { (void)hipGraphExecDestroy(kv.second.exec); (void)hipGraphDestroy(kv.second.graph); }
+    h->graphs.clear();
     if (n > h->st_cap) {
         HIPCHK(hipSetDevice(h->cfg.device));
         CHK(dalloc(h, &h->st_tmodel, (size_t)n));
         for (int k = 0; k < 5; ++k) CHK(dalloc(h, &h->st_c[k], (size_t)n));
         h->st_cap = n;
-        // graphs hold the old table pointers
-        for (auto& kv : h->graphs) { (void)hipGraphExecDestroy(kv.second.exec); (void)hipGraphDestroy(kv.second.graph); }
-        h->graphs.clear();
     }
     return 0;
 }
@@ -515,6 +577,7 @@ static int upload(dsg_handle* h, void* dst, const void* src, size_t bytes) {
 }
 
 static int order_after(dsg_handle* h, void* user_stream);
+static int order_before(dsg_handle* h, void* user_stream);
 
 // y['seed_last'] of DiffuseStyleGesture++ (cross_local_attention5, BEAT-TWH-main/model/mdm.py:229): [B, J, 1, S].  It is the same
 // snippet for every window of a clip (BEAT-TWH sample.py:85-93), so it is handed over once and kept.
@@ -526,14 +589,67 @@ extern "C" int dsg_set_seed_last(dsg_handle* h, const float* seed_last, int B, v
     CHK(order_after(h, stream));
     CHK(upload(h, h->c_seed_last, seed_last, (size_t)B * h->J * h->S * sizeof(float)));
     h->seed_last_B = B;
+    CHK(order_before(h, stream));     // the caller may release / overwrite its tensor once its stream has passed this point
     return 0;
 }
 
-extern "C" int dsg_set_window_cond(dsg_handle* h, const float* style, const float* seed, const float* audio,
-                                   const uint8_t* mask_local, int mask_batch, int B, int uncond, void* stream) {
+// conditioning of batch rows [row0, row0 + B): inputs are the caller's B elements, `uncond` selects the masked variant
+static int cond_rows(dsg_handle* h, const float* style, const float* seed, const float* audio, int row0, int B, int uncond) {
+    auto R = [&](const std::string& n) { return h->raw[n].d; };
+    const int D = h->D, J = h->J, S = h->S, A = h->A, As = h->As, T = h->T, sdi = h->cfg.style_dim_in;
+    const int W2ld = 2 * D + A;
+    const float* W2 = R("input_process2.weight");
+    float* c_style = h->c_style + (size_t)row0 * sdi;
+    float* c_seed = h->c_seed + (size_t)row0 * J * (S > 0 ? S : 1);
+    float* c_audio = h->c_audio + (size_t)row0 * h->Ta * As;
+    float* emb1 = h->emb1 + (size_t)row0 * D;
+    float* enc = h->enc + (size_t)row0 * T * A;
+    float* cvec = h->cvec + (size_t)row0 * D;
+    float* Cf = h->Cf + (size_t)row0 * T * D;
+    CHK(upload(h, c_style, style, (size_t)B * sdi * sizeof(float)));
+    if (S > 0) CHK(upload(h, c_seed, seed, (size_t)B * J * S * sizeof(float)));
+    CHK(upload(h, c_audio, audio, (size_t)B * h->Ta * As * sizeof(float)));
+    const int sdo = h->cfg.variant == 3 ? 64 : D;
+    if (uncond) {       // mask_cond(force_mask=True): zeros AFTER the style linear (mdm.py:156-159, :180)
+        hipLaunchKernelGGL(k_fill_f32, dim3(cdiv(B * D, 256)), dim3(256), 0, h->stream, emb1, 0.f, (size_t)B * D);
+        HIPCHK(hipGetLastError());
+    } else {
+        CHK(launch_mm(h, emb1, D, c_style, sdi, 1, R("embed_style.weight"), sdi, 1, R("embed_style.bias"),
+                      nullptr, 0, 1, B, sdo, sdi));
+    }
+    if (h->cfg.variant == 3) {
+        // embed_text(flattened seed) -> emb1[:, 64:]; with force_mask the seed is zeroed BEFORE the linear (bias only)
+        CHK(launch_mm(h, emb1 + 64, D, c_seed, (long long)J * S, 1, R("embed_text.weight"), (long long)J * S, 1,
+                      R("embed_text.bias"), nullptr, 0, 1, B, D - 64, uncond ? 0 : J * S));
+        CHK(launch_mm(h, enc, A, c_audio, As, 1, R("WavEncoder.audio_feature_map.weight"), As, 1,
+                      R("WavEncoder.audio_feature_map.bias"), nullptr, 0, 1, B * T, A, As));
+    } else {
+        for (int b = 0; b < B; ++b) {
+            // per-frame seed embedding: rows 0..S-1 of the "audio" block  (BEAT-TWH mdm.py:188)
+            CHK(launch_mm(h, enc + (size_t)b * T * A, A, c_seed + (size_t)b * J * S, 1, S, R("embed_text.weight"),
+                          J, 1, R("embed_text.bias"), nullptr, 0, 1, S, A, J));
+            CHK(launch_mm(h, enc + ((size_t)b * T + S) * A, A, c_audio + (size_t)b * h->Ta * As, As, 1,
+                          R("WavEncoder.audio_feature_map.weight"), As, 1, R("WavEncoder.audio_feature_map.bias"),
+                          nullptr, 0, 1, h->Ta, A, As));
+            if (h->cfg.variant == 5)    // rows S+Ta .. T-1: embed_text_last(y['seed_last'])  (BEAT-TWH mdm.py:229-230)
+                CHK(launch_mm(h, enc + ((size_t)b * T + S + h->Ta) * A, A, h->c_seed_last + (size_t)(row0 + b) * J * S, 1, S,
+                              R("embed_text_last.weight"), J, 1, R("embed_text_last.bias"), nullptr, 0, 1, S, A, J));
+        }
+    }
+    // cvec[b] = b2 + W2b.bp + W2a.emb1[b];  Cf[b,f] = W2c.enc[b,f] + cvec[b]
+    CHK(launch_mm(h, cvec, D, emb1, D, 1, W2, W2ld, 1, nullptr, h->cbase, 0, 1, B, D, D));
+    CHK(launch_mm(h, Cf, D, enc, A, 1, W2 + 2 * D, W2ld, 1, nullptr, cvec, D, T, B * T, D, A));
+    return 0;
+}
+
+// cfg_scale == nullptr: plain conditioning (`uncond` as given).  Else classifier-free guidance: rows [0, B) conditional,
+// rows [B, 2B) their unconditional twins, guidance scale per element (y['scale'], cfg_sampler.py:29-31).
+static int set_window_cond(dsg_handle* h, const float* style, const float* seed, const float* audio,
+                           const uint8_t* mask_local, int mask_batch, int B, int uncond, const float* cfg_scale, void* stream) {
     if (!h) return fail(DSG_E_INVALID, "null handle");
     if (!h->finalized) return fail(DSG_E_STATE, "dsg_set_window_cond before dsg_finalize_weights");
-    if (B <= 0 || B > h->Bmax) return fail(DSG_E_INVALID, "batch exceeds max_batch");
+    const int rows = cfg_scale ? 2 * B : B;
+    if (B <= 0 || rows > h->Bmax) return fail(DSG_E_INVALID, cfg_scale ? "classifier-free guidance needs max_batch >= 2 * batch" : "batch exceeds max_batch");
     if (!style || !audio || (h->S > 0 && !seed)) return fail(DSG_E_INVALID, "style/seed/audio required");
     if (mask_local && !(mask_batch >= 1 && (B * h->Hl) % mask_batch == 0))
         return fail(DSG_E_INVALID, "mask_local batch must divide B*heads");
@@ -541,60 +657,54 @@ extern "C" int dsg_set_window_cond(dsg_handle* h, const float* style, const floa
         return fail(DSG_E_STATE, "variant 5: call dsg_set_seed_last with the same batch before dsg_set_window_cond (y['seed_last'])");
     HIPCHK(hipSetDevice(h->cfg.device));
     CHK(order_after(h, stream));      // the caller's stream may still be producing seed / audio
-    auto R = [&](const std::string& n) { return h->raw[n].d; };
-    const int D = h->D, J = h->J, S = h->S, A = h->A, As = h->As, T = h->T, sdi = h->cfg.style_dim_in;
-    const int W2ld = 2 * D + A;
-    const float* W2 = R("input_process2.weight");
-    CHK(upload(h, h->c_style, style, (size_t)B * sdi * sizeof(float)));
-    if (S > 0) CHK(upload(h, h->c_seed, seed, (size_t)B * J * S * sizeof(float)));
-    CHK(upload(h, h->c_audio, audio, (size_t)B * h->Ta * As * sizeof(float)));
+    const int T = h->T;
     if (mask_local) {
         CHK(upload(h, h->mask, mask_local, (size_t)mask_batch * T));
         h->mb = mask_batch;
+        if (cfg_scale && mask_batch > 1) {          // the twins use the same key masks: rows [B, 2B) repeat rows [0, B)
+            if (mask_batch != B) return fail(DSG_E_NOT_IMPLEMENTED, "guidance: mask_local batch must be 1 or B");
+            CHK(upload(h, h->mask + (size_t)B * T, mask_local, (size_t)B * T));
+            h->mb = 2 * B;
+        }
+        h->nomask = 0;
     } else {
+        // `mask=None` (local_attention.py:196-210 skipped): only the causal mask applies and the look-back pads of window 0
+        // attend with key = value = -1
         HIPCHK(hipMemsetAsync(h->mask, 1, (size_t)T, h->stream));
         h->mb = 1;
+        h->nomask = 1;
     }
-    const int sdo = h->cfg.variant == 3 ? 64 : D;
-    if (uncond) {       // mask_cond(force_mask=True): zeros AFTER the style linear (mdm.py:156-159, :180)
-        hipLaunchKernelGGL(k_fill_f32, dim3(cdiv(B * D, 256)), dim3(256), 0, h->stream, h->emb1, 0.f, (size_t)B * D);
-        HIPCHK(hipGetLastError());
-    } else {
-        CHK(launch_mm(h, h->emb1, D, h->c_style, sdi, 1, R("embed_style.weight"), sdi, 1, R("embed_style.bias"),
-                      nullptr, 0, 1, B, sdo, sdi));
+    CHK(cond_rows(h, style, seed, audio, 0, B, cfg_scale ? 0 : uncond));
+    if (cfg_scale) {
+        if (h->cfg.variant == 5)      // the twins see the same closing snippet
+            HIPCHK(hipMemcpyAsync(h->c_seed_last + (size_t)B * h->J * h->S, h->c_seed_last, (size_t)B * h->J * h->S * sizeof(float),
+                                  hipMemcpyDeviceToDevice, h->stream));
+        CHK(cond_rows(h, style, seed, audio, B, B, 1));
+        CHK(upload(h, h->cfg_scale, cfg_scale, (size_t)B * sizeof(float)));
     }
-    if (h->cfg.variant == 3) {
-        // embed_text(flattened seed) -> emb1[:, 64:]; with force_mask the seed is zeroed BEFORE the linear (bias only)
-        CHK(launch_mm(h, h->emb1 + 64, D, h->c_seed, (long long)J * S, 1, R("embed_text.weight"), (long long)J * S, 1,
-                      R("embed_text.bias"), nullptr, 0, 1, B, D - 64, uncond ? 0 : J * S));
-        CHK(launch_mm(h, h->enc, A, h->c_audio, As, 1, R("WavEncoder.audio_feature_map.weight"), As, 1,
-                      R("WavEncoder.audio_feature_map.bias"), nullptr, 0, 1, B * T, A, As));
-    } else {
-        for (int b = 0; b < B; ++b) {
-            // per-frame seed embedding: rows 0..S-1 of the "audio" block  (BEAT-TWH mdm.py:188)
-            CHK(launch_mm(h, h->enc + (size_t)b * T * A, A, h->c_seed + (size_t)b * J * S, 1, S, R("embed_text.weight"),
-                          J, 1, R("embed_text.bias"), nullptr, 0, 1, S, A, J));
-            CHK(launch_mm(h, h->enc + ((size_t)b * T + S) * A, A, h->c_audio + (size_t)b * h->Ta * As, As, 1,
-                          R("WavEncoder.audio_feature_map.weight"), As, 1, R("WavEncoder.audio_feature_map.bias"),
-                          nullptr, 0, 1, h->Ta, A, As));
-            if (h->cfg.variant == 5)    // rows S+Ta .. T-1: embed_text_last(y['seed_last'])  (BEAT-TWH mdm.py:229-230)
-                CHK(launch_mm(h, h->enc + ((size_t)b * T + S + h->Ta) * A, A, h->c_seed_last + (size_t)b * J * S, 1, S,
-                              R("embed_text_last.weight"), J, 1, R("embed_text_last.bias"), nullptr, 0, 1, S, A, J));
-        }
-    }
-    // cvec[b] = b2 + W2b.bp + W2a.emb1[b];  Cf[b,f] = W2c.enc[b,f] + cvec[b]
-    CHK(launch_mm(h, h->cvec, D, h->emb1, D, 1, W2, W2ld, 1, nullptr, h->cbase, 0, 1, B, D, D));
-    CHK(launch_mm(h, h->Cf, D, h->enc, A, 1, W2 + 2 * D, W2ld, 1, nullptr, h->cvec, D, T, B * T, D, A));
+    h->cfgB = cfg_scale ? B : 0;
     h->cond_set = true;
-    h->condB = B;
+    h->condB = rows;
+    CHK(order_before(h, stream));     // uploads are enqueued copies: the caller's buffers are free once its stream passes this point
     return 0;
+}
+extern "C" int dsg_set_window_cond(dsg_handle* h, const float* style, const float* seed, const float* audio,
+                                   const uint8_t* mask_local, int mask_batch, int B, int uncond, void* stream) {
+    return set_window_cond(h, style, seed, audio, mask_local, mask_batch, B, uncond, nullptr, stream);
+}
+extern "C" int dsg_set_window_cond_cfg(dsg_handle* h, const float* style, const float* seed, const float* audio,
+                                       const uint8_t* mask_local, int mask_batch, int B, const float* scale, void* stream) {
+    if (!scale) return fail(DSG_E_INVALID, "dsg_set_window_cond_cfg: scale required (y['scale'])");
+    return set_window_cond(h, style, seed, audio, mask_local, mask_batch, B, 0, scale, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // one denoising step = 3 + 5*L dispatches (un-fused set) or 2 + 4*L (latency set, batch <= 2)
 // ---------------------------------------------------------------------------------------------------------
 struct StepCtx {
-    int B; int out_mode; bool use_ctr; const float* ext_noise; int const_noise;
+    int B;                  // batch rows the kernels run on (with guidance: conditional elements + their twins)
+    int out_mode; bool use_ctr; const float* ext_noise; int const_noise;
+    int clip_x0 = 0;        // clip_denoised=True
 };
 
 // Every kernel of the denoising step goes through here: a HIP launch on the handle's stream, or -- while dsg_sample is
@@ -781,7 +891,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
     la.partial = h->partial; la.KS = h->KSin; la.Min_pad = MTin * 16; la.Cf = h->Cf; la.TE2 = h->TE2; la.TE = h->TE;
     la.emb1 = h->emb1; la.ctl = c.use_ctr ? h->ctl : nullptr; la.t_arr = h->t_arr;
     la.rcos = h->rcos; la.rsin = h->rsin; la.mask = h->mask; la.mb = h->mb; la.inv_mask_div = fastdiv_inv((int)((long long)B * h->Hl / h->mb)); la.B = B; la.T = T; la.D = D; la.Hl = h->Hl;
-    la.hd = h->hdl; la.W = h->W; la.X0 = h->X0; la.X0a = h->X0a;
+    la.hd = h->hdl; la.W = h->W; la.X0 = h->X0; la.X0a = h->X0a; la.nomask = h->nomask;
     const int skip = h->dbg_skip;      // drop-one timing experiments: 1 in/loc, 2 QKV, 4 attention, 8 mid, 16 linear2, 32 head
     if (skip & 1) {
     } else if (lat) {          // pose embedding + local attention in one launch
@@ -850,6 +960,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
             if (overlap_mid) {      // launched without a barrier: W_o / operands stream in while the attention kernel runs
                 a.dep.ctr = h->dep_ctr + 0; a.dep.epoch = &h->ctl->stepB; a.dep.per_step = h->L; a.dep.seq = l + 1;
                 a.dep.n_prod = (unsigned)(cdiv(ntok, 16) * h->H * B);
+                a.dep.err = h->dep_ctr + 63;
                 h->overlap_next = true;
             }
             a.A = h->attn; a.R = l == 0 ? h->X0 : h->Xn; a.Wo = ly.Wo; a.bo = ly.bo; a.ln_g = ly.g1; a.ln_b = ly.be1;
@@ -888,8 +999,16 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
         g.X = h->pre2; g.ln_g = h->layers[h->L - 1].g2; g.ln_b = h->layers[h->L - 1].be2; g.Xn = nullptr;
         g.out_mode = c.out_mode; g.xs32 = h->xs32; g.xsA = h->prec == DSG_PREC_BF16 ? h->xsA : nullptr;
         g.fwd_out = h->fwd_out; g.ctl = c.use_ctr ? h->ctl : nullptr; g.st = step_tables(h); g.n_tab = h->n_run;
-        g.dyn = h->dyn; g.ext_noise = c.ext_noise; g.const_noise = c.const_noise;
-        CHK((launch_gemm_w<P, PRO_LN, EPI_OUT>(h, g)));
+        g.dyn = h->dyn; g.ext_noise = c.ext_noise; g.const_noise = c.const_noise; g.clip_x0 = c.clip_x0;
+        if (h->cfgB > 0) {      // guidance: one workgroup per CONDITIONAL row tile evaluates the twin rows as well (k_gemm_cfg)
+            g.B = h->cfgB; g.M = h->cfgB * ntok; g.MT = cdiv(g.M, 16);
+            g.cfgB = h->cfgB; g.cfg_off = h->cfgB * ntok; g.cfg_scale = h->cfg_scale;
+            g.KS = 1; g.kb_per_split = g.KBtot; g.inv_ntok = fastdiv_inv(g.ntok); g.inv_hd = fastdiv_inv(g.hd);
+            if (g.NT % 4) return fail(DSG_E_INVALID, "gemm: NT not divisible by the workgroup tile");
+            CHK((step_launch<&k_gemm_cfg<P>>(h, dim3(xcd_grid_x(g.NT / 4), g.MT + 1, 1), dim3(256), g)));
+        } else {
+            CHK((launch_gemm_w<P, PRO_LN, EPI_OUT>(h, g)));
+        }
     }
     return 0;
 }
@@ -911,7 +1030,7 @@ static int debug_launch(dsg_handle* h, int which, int i, int B) {
     la.partial = h->partial; la.KS = h->KSin; la.Min_pad = MTin * 16; la.Cf = h->Cf; la.TE2 = h->TE2; la.TE = h->TE;
     la.emb1 = h->emb1; la.ctl = nullptr; la.t_arr = h->t_arr;
     la.rcos = h->rcos; la.rsin = h->rsin; la.mask = h->mask; la.mb = h->mb; la.inv_mask_div = fastdiv_inv((int)((long long)B * h->Hl / h->mb)); la.B = B; la.T = T; la.D = D; la.Hl = h->Hl;
-    la.hd = h->hdl; la.W = h->W; la.X0 = h->X0; la.X0a = h->X0a;
+    la.hd = h->hdl; la.W = h->W; la.X0 = h->X0; la.X0a = h->X0a; la.nomask = h->nomask;
     if (which == 20) return debug_launch<P>(h, (i & 1) ? 1 : 4, i, B);                 // alternate 2 kernels
     if (which == 21) { const int seq[4] = {1, 4, 7, 9}; return debug_launch<P>(h, seq[i & 3], i, B); }   // 4 kernels
     if (which == 22) { const int seq[6] = {12, 9, 5, 10, 4, 8}; return debug_launch<P>(h, seq[i % 6], i, B); } // the step's 6 kernels
@@ -1031,6 +1150,7 @@ static int run_step_p(dsg_handle* h, const StepCtx& c) {
 static int launch_x_in(dsg_handle* h, const float* x, const float* init, int do_q, float qa, float qb, int use_philox,
                        NoiseKey nk, unsigned draw, int B) {
     XInArgs a;
+    a.dupB = h->cfgB;
     a.x = x; a.init = init; a.do_q = do_q; a.qa = qa; a.qb = qb; a.use_philox = use_philox; a.nkey = nk; a.draw = draw;
     a.B = B; a.J = h->J; a.Jp = h->Jp; a.Jq = h->Jq; a.T = h->T; a.xs32 = h->xs32;
     a.xsA = h->prec == DSG_PREC_BF16 ? h->xsA : nullptr;
@@ -1079,13 +1199,22 @@ static int from_dev(dsg_handle* h, float* dst, const float* src_dev, size_t n) {
     return 0;
 }
 
+// rows the kernels run on for a user batch of B (guidance doubles it); checks B against the conditioning
+static int rows_for(dsg_handle* h, int B, int* rows) {
+    const int want = h->cfgB > 0 ? h->cfgB : h->condB;
+    if (B != want) return fail(DSG_E_INVALID, "batch differs from the batch of dsg_set_window_cond");
+    *rows = h->condB;
+    return 0;
+}
+
 extern "C" int dsg_forward(dsg_handle* h, const float* x, const int64_t* t, float* out, int B, void* stream) {
     if (!h || !x || !t || !out) return fail(DSG_E_INVALID, "dsg_forward: null argument");
     if (!h->finalized || !h->cond_set) return fail(DSG_E_STATE, "dsg_forward before finalize / set_window_cond");
-    if (B != h->condB) return fail(DSG_E_INVALID, "batch differs from the batch of dsg_set_window_cond");
+    int rows = 0;
+    CHK(rows_for(h, B, &rows));
     HIPCHK(hipSetDevice(h->cfg.device));
     CHK(order_after(h, stream));
-    std::vector<int> tt(B);
+    std::vector<int> tt(rows);
     if (is_device_ptr(t)) {
         std::vector<int64_t> th(B);
         HIPCHK(hipMemcpy(th.data(), t, B * sizeof(int64_t), hipMemcpyDeviceToHost));
@@ -1093,16 +1222,17 @@ extern "C" int dsg_forward(dsg_handle* h, const float* x, const int64_t* t, floa
     } else {
         for (int i = 0; i < B; ++i) tt[i] = (int)t[i];
     }
+    for (int i = B; i < rows; ++i) tt[i] = tt[i - B];      // guidance: the twins share the timestep
     for (int i = 0; i < B; ++i)
         if (tt[i] < 0 || tt[i] >= h->n_te) return fail(DSG_E_INVALID, "timestep out of range");
-    HIPCHK(hipMemcpyAsync(h->t_arr, tt.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->t_arr, tt.data(), rows * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));     // tt is a stack-lifetime staging buffer
     const size_t n = (size_t)B * h->J * h->T;
     const float* xd = nullptr;
     CHK(to_dev(h, x, h->io_tmp, n, &xd));
     NoiseKey nk = {0, 0, 0, 0};
     CHK(launch_x_in(h, xd, nullptr, 0, 0.f, 0.f, 0, nk, 0, B));
-    StepCtx c; c.B = B; c.out_mode = OUT_FORWARD; c.use_ctr = false; c.ext_noise = nullptr; c.const_noise = 0;
+    StepCtx c; c.B = rows; c.out_mode = OUT_FORWARD; c.use_ctr = false; c.ext_noise = nullptr; c.const_noise = 0;
     CHK(run_step_p(h, c));
     CHK(from_dev(h, out, h->fwd_out, n));
     CHK(order_before(h, stream));
@@ -1145,10 +1275,23 @@ static int build_step_tables(dsg_handle* h, int mode, int skip, float eta, int* 
     return 0;
 }
 
-extern "C" int dsg_sample(dsg_handle* h, const dsg_sample_args* a, float* out, int B, void* stream) {
-    if (!h || !a || !out) return fail(DSG_E_INVALID, "dsg_sample: null argument");
+// ---------------------------------------------------------------------------------------------------------
+// dsg_sample = prepare (x_T, step tables, control block, [AQL packet plan]) -> step loop -> finish (x_0 out, error word).
+// dsg_sample_multi runs the step loops of several handles ("lanes": one clip each, own HSA queue, shared weights)
+// concurrently from one host thread.
+// ---------------------------------------------------------------------------------------------------------
+struct SampleJob {
+    StepCtx c;
+    int n_run = 0, B = 0, done = 0;
+    bool dumping = false, aql = false;
+    int spg = -1;
+};
+
+static int sample_prepare(dsg_handle* h, const dsg_sample_args* a, int B, void* stream, SampleJob& job) {
+    if (!h || !a) return fail(DSG_E_INVALID, "dsg_sample: null argument");
     if (!h->finalized || !h->cond_set) return fail(DSG_E_STATE, "dsg_sample before finalize / set_window_cond");
-    if (B != h->condB) return fail(DSG_E_INVALID, "batch differs from the batch of dsg_set_window_cond");
+    int rows = 0;
+    CHK(rows_for(h, B, &rows));
     if (a->mode != DSG_MODE_DDPM && a->mode != DSG_MODE_DDIM) return fail(DSG_E_INVALID, "mode");
     if (a->mode == DSG_MODE_DDIM && (a->n_dump > 0 || a->const_noise))
         return fail(DSG_E_NOT_IMPLEMENTED, "ddim_sample_loop: dump_steps / const_noise (gaussian_diffusion.py:913-916)");
@@ -1187,23 +1330,55 @@ extern "C" int dsg_sample(dsg_handle* h, const dsg_sample_args* a, float* out, i
         HIPCHK(hipMemcpyAsync(h->dyn, dyn, sizeof(dyn), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
-
-    StepCtx c;
-    c.B = B; c.out_mode = a->mode == DSG_MODE_DDPM ? OUT_DDPM : OUT_DDIM; c.use_ctr = true; c.ext_noise = ext;
-    c.const_noise = a->const_noise;
-
+    StepCtx& c = job.c;
+    c.B = rows; c.out_mode = a->mode == DSG_MODE_DDPM ? OUT_DDPM : OUT_DDIM; c.use_ctr = true; c.ext_noise = ext;
+    c.const_noise = a->const_noise; c.clip_x0 = a->clip_denoised ? 1 : 0;
+    job.n_run = n_run; job.B = B; job.done = 0;
+    job.dumping = a->n_dump > 0 && a->dump_steps && a->dump_out;
     // steps_per_graph: 0 = default = no hipGraph.  Measured on MI355X / ROCm 7.2: hipGraph replay of the step is slower than
     // stream-ordered HIP launches (180 vs 157 us; 151-163 us with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0), and both lose to the
-    // hand-written AQL submission below (139 us) -- graphs stay opt-in (steps_per_graph > 0).
-    int spg = h->cfg.steps_per_graph == 0 ? -1 : h->cfg.steps_per_graph;
-    const bool dumping = a->n_dump > 0 && a->dump_steps && a->dump_out;
-    if (dumping || ext) spg = -1;            // rare paths run eagerly (ext pointer / dump points are per call)
+    // hand-written AQL submission (139 us) -- graphs stay opt-in (steps_per_graph > 0).
+    job.spg = h->cfg.steps_per_graph == 0 ? -1 : h->cfg.steps_per_graph;
+    if (job.dumping || ext) job.spg = -1;            // rare paths run eagerly (ext pointer / dump points are per call)
+    h->aql_timing = false;
+    h->last_path = 0;
+    job.aql = false;
+#ifndef DSG_EMU
+    // The step loop as hand-written AQL packets (dsg_aql.h): one recording pass of run_step (no launch), argument
+    // blocks to device memory, then n_run x the same packets on the handle's own HSA queue.  Any failure before the
+    // first packet falls back to the HIP launches; a failure after submission is an error.
+    const bool graph_wanted = job.spg > 0 && n_run >= job.spg;
+    if (h->aql_mode == 1 && !job.dumping && !graph_wanted && n_run > 0) {
+        bool planned = dsg_aql::init(h->aql, h->cfg.device, (const void*)&dsg_version);
+        if (const char* e = getenv("DSG_AQL_ACQUIRE")) h->aql.acquire_scope = atoi(e) ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE;
+        if (planned) {
+            dsg_aql::begin(h->aql);
+            const int rc = run_step_p(h, c);
+            planned = dsg_aql::finish(h->aql) && rc == 0;
+            h->aql.recording = false;
+        }
+        if (!planned) {
+            if (!h->aql_warned) { fprintf(stderr, "libdsg_hip: AQL path unavailable (%s); using HIP launches\n", h->aql.err.c_str()); h->aql_warned = true; }
+            h->aql_mode = 0;
+        } else {
+            HIPCHK(hipStreamSynchronize(h->stream));         // state / control block / conditioning are in place
+            job.aql = true;
+        }
+    }
+#endif
     HIPCHK(hipEventRecord(h->ev_t0, h->stream));
-    int done = 0;
+    return 0;
+}
+
+// the step loop through the HIP runtime: hipGraph replays (opt-in) and / or stream-ordered launches
+static int sample_run_hip(dsg_handle* h, const dsg_sample_args* a, SampleJob& job) {
+    const int n_run = job.n_run, B = job.B, spg = job.spg;
+    const StepCtx& c = job.c;
+    const size_t n = (size_t)B * h->J * h->T;
     if (spg > 0 && n_run >= spg) {
         // everything that varies between calls (step index, coefficients, noise key, conditioning) lives in device
-        // memory, so one captured graph per (batch, sampler, mask batch, const_noise) serves every window and clip
-        dsg_handle::GKey key = {B, c.out_mode, h->mb, c.const_noise};
+        // memory, so one captured graph per (batch, sampler, mask batch, const_noise, steps, flags) serves every window and clip
+        dsg_handle::GKey key = {c.B, c.out_mode, h->mb, c.const_noise, n_run, (c.clip_x0 ? 1 : 0) | (h->cfgB ? 2 : 0) | (h->nomask ? 4 : 0)};
         auto it = h->graphs.find(key);
         bool ok = true;
         if (it == h->graphs.end()) {
@@ -1224,51 +1399,102 @@ extern "C" int dsg_sample(dsg_handle* h, const dsg_sample_args* a, float* out, i
             }
         }
         if (ok) {
-            while (n_run - done >= spg) { HIPCHK(hipGraphLaunch(it->second.exec, h->stream)); done += spg; }
+            while (n_run - job.done >= spg) { HIPCHK(hipGraphLaunch(it->second.exec, h->stream)); job.done += spg; }
+            h->last_path = 2;
         }
     }
-    h->aql_timing = false;
-#ifndef DSG_EMU
-    // The step loop as hand-written AQL packets (dsg_aql.h): one recording pass of run_step (no launch), argument
-    // blocks to device memory, then n_run x the same packets on the handle's own HSA queue.  Any failure before the
-    // first packet falls back to the HIP launches below; a failure after submission is an error.
-    if (h->aql_mode == 1 && !dumping && done == 0 && n_run > 0) {
-        bool planned = dsg_aql::init(h->aql, h->cfg.device, (const void*)&dsg_version);
-        if (const char* e = getenv("DSG_AQL_ACQUIRE")) h->aql.acquire_scope = atoi(e) ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE;
-        if (planned) {
-            dsg_aql::begin(h->aql);
-            const int rc = run_step_p(h, c);
-            planned = dsg_aql::finish(h->aql) && rc == 0;
-            h->aql.recording = false;
-        }
-        if (!planned) {
-            if (!h->aql_warned) { fprintf(stderr, "libdsg_hip: AQL path unavailable (%s); using HIP launches\n", h->aql.err.c_str()); h->aql_warned = true; }
-            h->aql_mode = 0;
-        } else {
-            HIPCHK(hipStreamSynchronize(h->stream));         // state / control block / conditioning are in place
-            if (!dsg_aql::run(h->aql, n_run, 60.0 + 0.01 * n_run)) return fail(DSG_E_RUNTIME, "AQL run: " + h->aql.err);
-            done = n_run;
-            h->aql_timing = true; h->aql_ms = h->aql.last_ms;
-        }
-    }
-#endif
     int di = 0;
-    for (; done < n_run; ++done) {
+    for (; job.done < n_run; ++job.done) {
         CHK(run_step_p(h, c));
-        if (dumping) {
-            while (di < a->n_dump && a->dump_steps[di] < done) ++di;
-            if (di < a->n_dump && a->dump_steps[di] == done) {
+        if (job.dumping) {
+            while (di < a->n_dump && a->dump_steps[di] < job.done) ++di;
+            if (di < a->n_dump && a->dump_steps[di] == job.done) {
                 CHK(launch_x_out(h, h->fwd_out, B));
                 CHK(from_dev(h, a->dump_out + (size_t)di * n, h->fwd_out, n));
                 ++di;
             }
         }
     }
+    return 0;
+}
+
+static int sample_finish(dsg_handle* h, float* out, void* stream, SampleJob& job) {
+    const size_t n = (size_t)job.B * h->J * h->T;
     HIPCHK(hipEventRecord(h->ev_t1, h->stream));
-    h->last_steps = n_run; h->timing_valid = true;
-    CHK(launch_x_out(h, h->fwd_out, B));
+    h->last_steps = job.n_run; h->timing_valid = true;
+    CHK(launch_x_out(h, h->fwd_out, job.B));
     CHK(from_dev(h, out, h->fwd_out, n));
+    if (h->overlap) {       // overlapped (barrier-less) launches: a consumer that gave up waiting raised the error word
+        unsigned err = 0;
+        HIPCHK(hipMemcpyAsync(&err, h->dep_ctr + 63, sizeof err, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (err) return fail(DSG_E_RUNTIME, "dsg_sample: an overlapped consumer kernel timed out waiting for its producer (DSG_OVERLAP); the sample is invalid");
+    }
     CHK(order_before(h, stream));
+    return 0;
+}
+
+extern "C" int dsg_sample(dsg_handle* h, const dsg_sample_args* a, float* out, int B, void* stream) {
+    if (!h || !a || !out) return fail(DSG_E_INVALID, "dsg_sample: null argument");
+    SampleJob job;
+    CHK(sample_prepare(h, a, B, stream, job));
+#ifndef DSG_EMU
+    if (job.aql) {
+        if (!dsg_aql::run(h->aql, job.n_run, 60.0 + 0.01 * job.n_run)) return fail(DSG_E_RUNTIME, "AQL run: " + h->aql.err);
+        job.done = job.n_run;
+        h->aql_timing = true; h->aql_ms = h->aql.last_ms;
+        h->last_path = 1;
+    }
+#endif
+    CHK(sample_run_hip(h, a, job));
+    return sample_finish(h, out, stream, job);
+}
+
+// n lanes (handles of ONE device, normally a handle and its clones), one independent sampling call each, advanced
+// concurrently: with the AQL submission every lane has its own HSA queue and the host thread deals the steps round-robin
+// (the queues' dependent packet chains overlap on the GPU); with HIP launches the lanes' streams are fed step by step.
+extern "C" int dsg_sample_multi(dsg_handle** hs, int n, const dsg_sample_args* args, float** outs, int B, void* stream) {
+    if (!hs || !args || !outs || n <= 0) return fail(DSG_E_INVALID, "dsg_sample_multi: bad argument");
+    for (int i = 0; i < n; ++i) {
+        if (!hs[i] || !outs[i]) return fail(DSG_E_INVALID, "dsg_sample_multi: null handle / output");
+        for (int j = 0; j < i; ++j) if (hs[j] == hs[i]) return fail(DSG_E_INVALID, "dsg_sample_multi: a handle appears twice");
+        if (hs[i]->cfg.device != hs[0]->cfg.device) return fail(DSG_E_INVALID, "dsg_sample_multi: lanes must live on one device");
+    }
+    std::vector<SampleJob> jobs(n);
+    for (int i = 0; i < n; ++i) CHK(sample_prepare(hs[i], &args[i], B, stream, jobs[i]));
+    bool all_aql = true;
+    for (int i = 0; i < n; ++i) all_aql = all_aql && jobs[i].aql;
+#ifndef DSG_EMU
+    if (all_aql) {
+        std::vector<dsg_aql::Ctx*> ctxs(n);
+        std::vector<int> steps(n);
+        double tmax = 60.0;
+        for (int i = 0; i < n; ++i) { ctxs[i] = &hs[i]->aql; steps[i] = jobs[i].n_run; tmax += 0.01 * jobs[i].n_run; }
+        std::string err;
+        if (!dsg_aql::run_multi(ctxs.data(), steps.data(), n, tmax, err)) return fail(DSG_E_RUNTIME, "AQL run: " + err);
+        for (int i = 0; i < n; ++i) {
+            jobs[i].done = jobs[i].n_run;
+            hs[i]->aql_timing = true; hs[i]->aql_ms = hs[i]->aql.last_ms; hs[i]->last_path = 1;
+        }
+    }
+#endif
+    if (!all_aql) {
+        // HIP launches: an AQL plan that was recorded for some lanes is simply not used; step s of every lane, then s + 1
+        bool plain = true;
+        for (int i = 0; i < n; ++i) plain = plain && !jobs[i].dumping && !(jobs[i].spg > 0 && jobs[i].n_run >= jobs[i].spg);
+        if (plain) {
+            int more = 1;
+            for (int s = 0; more; ++s) {
+                more = 0;
+                for (int i = 0; i < n; ++i)
+                    if (s < jobs[i].n_run) { CHK(run_step_p(hs[i], jobs[i].c)); jobs[i].done = s + 1; more = 1; }
+            }
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        CHK(sample_run_hip(hs[i], &args[i], jobs[i]));      // whatever is left (graphs, dump points); nothing after AQL
+        CHK(sample_finish(hs[i], outs[i], stream, jobs[i]));
+    }
     return 0;
 }
 
@@ -1285,6 +1511,27 @@ extern "C" int dsg_last_sample_ms(dsg_handle* h, float* ms, int* n_steps) {
     if (h->aql_timing) *ms = (float)h->aql_ms;      // AQL path: host clock from the first doorbell to the completion signal
     else HIPCHK(hipEventElapsedTime(ms, h->ev_t0, h->ev_t1));
     if (n_steps) *n_steps = h->last_steps;
+    return 0;
+}
+// how the step loop of the last dsg_sample was submitted: 0 = HIP launches, 1 = hand-written AQL packets, 2 = hipGraph replay
+extern "C" int dsg_last_sample_path(dsg_handle* h, int* path) {
+    if (!h || !path) return fail(DSG_E_INVALID, "null argument");
+    if (!h->timing_valid) return fail(DSG_E_STATE, "no dsg_sample has run");
+    *path = h->last_path;
+    return 0;
+}
+
+// the framework's noise stream as a tensor (what the fused sampler consumes for draw index `draw`): out [B, J, 1, T] device
+extern "C" int dsg_noise(float* out, int B, int J, int T, uint64_t seed, uint64_t stream_id, uint32_t draw, void* stream) {
+    if (!out || B <= 0 || J <= 0 || T <= 0) return fail(DSG_E_INVALID, "dsg_noise: bad argument");
+    if (!is_device_ptr(out)) return fail(DSG_E_INVALID, "dsg_noise writes a device tensor");
+    NoiseKey nk;
+    nk.k0 = (unsigned)(seed & 0xffffffffu); nk.k1 = (unsigned)(seed >> 32);
+    nk.s0 = (unsigned)(stream_id & 0xffffffffu); nk.s1 = (unsigned)(stream_id >> 32);
+    const int Jq = rup(J, 4);
+    const size_t n = (size_t)B * T * (Jq / 4);
+    hipLaunchKernelGGL(k_noise, dim3((int)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, out, B, J, Jq, T, nk, draw);
+    HIPCHK(hipGetLastError());
     return 0;
 }
 

@@ -268,14 +268,15 @@ __global__ void k_ctl_init(StepCtl* c, const int* tmodel, unsigned* dep_ctr, int
 // everything that does not depend on the producer (its weights -- the load phase that bounds k_mid), then waits here
 // until every producer workgroup has released its stores.  Counters only ever count up inside one dsg_sample call
 // (zeroed by k_ctl_init): target = (step index * launches per step + launch number in the step) * producer workgroups.
-// Run back to back (HIP launches) the wait is satisfied on the first poll.  Polling is bounded: a missing producer
-// produces a wrong result (caught by the parity tests), not a hung GPU.
+// Run back to back (HIP launches) the wait is satisfied on the first poll.  Polling is bounded: a missing producer does
+// not hang the GPU -- the consumer gives up, raises DepWait::err, and dsg_sample fails with DSG_E_RUNTIME.
 // ---------------------------------------------------------------------------------------------------------
 struct DepWait {
     const unsigned* ctr;       // null: no waiting (forward pass / batched path)
     const int* epoch;          // device word holding the current step index (StepCtl::stepB)
     int per_step, seq;         // launches of the producer per step, 1-based number of this one
     unsigned n_prod;           // workgroups per producer launch
+    unsigned* err;             // device error word: set to 1 when the bounded poll gives up (dsg_sample turns it into DSG_E_RUNTIME)
 };
 // The handed-off data itself bypasses the non-coherent cache levels instead of being fenced: the producer writes it
 // with agent-scope (sc1, write-through) stores and the consumer reads it with agent-scope loads, so no cache-wide
@@ -303,6 +304,7 @@ __device__ __forceinline__ void dep_wait(const DepWait& d) {
         const unsigned target = (unsigned)(*d.epoch * d.per_step + d.seq) * d.n_prod;
         int spins = 0;
         while (__hip_atomic_load(d.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+        if (spins >= (1 << 22) && d.err) __hip_atomic_store(d.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the producer never arrived
     }
     __builtin_amdgcn_s_barrier();
 }
@@ -357,6 +359,13 @@ struct GemmArgs {
     int const_noise;
     int a_frag;             // PRO_DIRECT: A is stored fragment-major ([row tile][k-block][64 lanes][16 B], qk_off) -- hidden, attention rows
     int out_frag;           // EPI_GELU: the output goes out fragment-major (it is the next GEMM's A operand)
+    // EPI_OUT, classifier-free guidance (main/model/cfg_sampler.py:8-31): the batch holds cfgB conditional elements followed
+    // by their cfgB unconditional twins (same x_t); the workgroup of a conditional row tile also evaluates the twin rows
+    // (cfg_off rows further down) and forms x0 = x0_u + scale[b] * (x0_c - x0_u) before the sampler update, which it writes to
+    // BOTH halves of the state.  cfgB == 0: off.
+    int cfgB, cfg_off;
+    const float* cfg_scale; // [cfgB]
+    int clip_x0;            // EPI_OUT: clamp x0 to [-1, 1] (clip_denoised=True, gaussian_diffusion.py:377-379)
 };
 
 // Workgroup -> n-group with the n-group pinned to an XCD (workgroups are dealt round-robin to the 8 XCDs in linear
@@ -493,7 +502,8 @@ __device__ __forceinline__ void gemm_prefetch_tile(const GemmArgs& g, int m0, in
 
 template <class P, int EPI>
 __device__ __forceinline__ void gemm_epilogue_tile(const GemmArgs& g, int m0, int n0, int lr, int lg, int ks, bool swapped, const f32x4& acc,
-                                                   const TileOps& o, float k1, float k2, float k3, float k4, float k5) {
+                                                   const TileOps& o, float k1, float k2, float k3, float k4, float k5,
+                                                   const f32x4& acc_u = (f32x4){0.f, 0.f, 0.f, 0.f}) {
     typedef typename P::elem elem;
         if constexpr (EPI == EPI_PARTIAL) {
             const int m = m0 + lr;
@@ -535,7 +545,17 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmArgs& g, int m0, in
             const int b = fdiv(m, g.inv_ntok), sx = m - b * g.ntok;
             if (o.ovalid) {
                 const int f = sx - 1;
-                const f32x4 x0 = acc + o.pb;
+                f32x4 x0 = acc + o.pb;
+                if (g.cfgB > 0) {                       // cfg_sampler.py:31: out_uncond + scale * (out - out_uncond)
+                    const f32x4 xu = acc_u + o.pb;
+                    const float sc = g.cfg_scale[b];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x0[e] = xu[e] + sc * (x0[e] - xu[e]);
+                }
+                if (g.clip_x0) {                        // gaussian_diffusion.py:377-379
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x0[e] = fminf(fmaxf(x0[e], -1.0f), 1.0f);
+                }
                 if (g.out_mode == OUT_FORWARD) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
@@ -562,14 +582,21 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmArgs& g, int m0, in
                         if (j0 + e >= g.J) xn[e] = 0.f;
                     *(f32x4*)(g.xs32 + ((size_t)b * g.T + f) * g.Jp + j0) = xn;
                     if (g.xsA) P::store4((elem*)g.xsA + ((size_t)b * g.T + f) * g.Jp + j0, xn);
+                    if (g.cfgB > 0) {                   // the unconditional twin advances with the same x_{t-1}
+                        *(f32x4*)(g.xs32 + ((size_t)(b + g.cfgB) * g.T + f) * g.Jp + j0) = xn;
+                        if (g.xsA) P::store4((elem*)g.xsA + ((size_t)(b + g.cfgB) * g.T + f) * g.Jp + j0, xn);
+                    }
                 }
             }
         }
 }
 
 // WN x WK = 4 waves: WN waves side by side along N (TNW 16-col tiles each), WK-way split of K inside the workgroup.
-template <class P, int PRO, int EPI, int WN, int WK, int TNW, bool LEAN = false>
+// CFG (EPI_OUT + PRO_LN only): two passes over the same weight fragments -- the unconditional twin rows first, then the
+// conditional rows -- combined in the epilogue (see GemmArgs::cfgB).
+template <class P, int PRO, int EPI, int WN, int WK, int TNW, bool LEAN = false, bool CFG = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
+    static_assert(!CFG || (EPI == EPI_OUT && PRO == PRO_LN && !LEAN), "guidance lives in the pose-head epilogue");
     typedef typename P::elem elem;
     static_assert(WN * WK == 4, "4 waves");
     constexpr int ES = (int)sizeof(elem);
@@ -652,22 +679,37 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
     int pitch = 0;
     f32x4 v[PRO == PRO_LN ? 8 : 1];
     bool wr = false;
+    f32x4 acc_u[CFG ? TNW : 1];
+#pragma unroll
+    for (int t = 0; t < (CFG ? TNW : 1); ++t) acc_u[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int NPASS = CFG ? 2 : 1;
+#pragma unroll
+    for (int pass = NPASS - 1; pass >= 0; --pass) {
+    const int mp = m0 + pass * (CFG ? g.cfg_off : 0);     // pass 1 (first): the unconditional twin rows
+    if constexpr (CFG) {
+        if (pass == 0) {
+#pragma unroll
+            for (int t = 0; t < TNW; ++t) { acc_u[t] = acc[t]; acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            DSG_LDS_BARRIER();                            // every wave is done with the twin rows in lds_a
+            if (kb_hi - kb_lo > CH) load_b(kb_lo);
+        }
+    }
     if constexpr (PRO == PRO_LN) {
         pitch = DSG_LDS_ROW_BYTES(g.D, ES);
-        wr = (g.Xn != nullptr) && ng == 0 && (m0 + (tid >> 4)) < g.M;
+        wr = (g.Xn != nullptr) && ng == 0 && (mp + (tid >> 4)) < g.M;
         const int nch = g.D >> 6;                     // D / 64 float4 chunks per thread; one straight-line copy per width
         if constexpr (LEAN) {
-            float* xn_out = wr ? g.Xn + (size_t)(m0 + (tid >> 4)) * g.D : nullptr;
-            if (nch == 4) ln_rows<P, 4, true>(g, m0, tid, lds_a, pitch, v, xn_out);
-            else if (nch == 6) ln_rows<P, 6, true>(g, m0, tid, lds_a, pitch, v, xn_out);
-            else if (nch == 8) ln_rows<P, 8, true>(g, m0, tid, lds_a, pitch, v, xn_out);
-            else ln_rows<P, 0, true>(g, m0, tid, lds_a, pitch, v, xn_out);
+            float* xn_out = wr ? g.Xn + (size_t)(mp + (tid >> 4)) * g.D : nullptr;
+            if (nch == 4) ln_rows<P, 4, true>(g, mp, tid, lds_a, pitch, v, xn_out);
+            else if (nch == 6) ln_rows<P, 6, true>(g, mp, tid, lds_a, pitch, v, xn_out);
+            else if (nch == 8) ln_rows<P, 8, true>(g, mp, tid, lds_a, pitch, v, xn_out);
+            else ln_rows<P, 0, true>(g, mp, tid, lds_a, pitch, v, xn_out);
             wr = false;                               // already written
         } else {
-            if (nch == 4) ln_rows<P, 4>(g, m0, tid, lds_a, pitch, v);
-            else if (nch == 6) ln_rows<P, 6>(g, m0, tid, lds_a, pitch, v);
-            else if (nch == 8) ln_rows<P, 8>(g, m0, tid, lds_a, pitch, v);
-            else ln_rows<P, 0>(g, m0, tid, lds_a, pitch, v);
+            if (nch == 4) ln_rows<P, 4>(g, mp, tid, lds_a, pitch, v);
+            else if (nch == 6) ln_rows<P, 6>(g, mp, tid, lds_a, pitch, v);
+            else if (nch == 8) ln_rows<P, 8>(g, mp, tid, lds_a, pitch, v);
+            else ln_rows<P, 0>(g, mp, tid, lds_a, pitch, v);
         }
         DSG_LDS_BARRIER();
     }
@@ -698,6 +740,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
         }
         if (kb0 + CH < kb_hi) load_b(kb0 + CH);
     }
+    }   // pass
     DSG_STAMP(1 + EPI, 4);
 
     // The normalised rows go back to global memory only now: a global store issued before the MFMA phase would sit
@@ -733,7 +776,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
     if (WK == 1 || wk == 0) {
 #pragma unroll
     for (int t = 0; t < TNW; ++t)
-        gemm_epilogue_tile<P, EPI>(g, m0, (nt0 + t) * 16, lr, lg, ks, swapped[t], acc[t], ops[t], k1, k2, k3, k4, k5);
+        gemm_epilogue_tile<P, EPI>(g, m0, (nt0 + t) * 16, lr, lg, ks, swapped[t], acc[t], ops[t], k1, k2, k3, k4, k5, acc_u[CFG ? t : 0]);
     }
     DSG_STAMP(1 + EPI, 5);
 }
@@ -888,6 +931,10 @@ __device__ __forceinline__ void gemm_body_mt(const GemmArgs& g) {
 template <class P, int EPI>
 __global__ __launch_bounds__(256, 3) void k_gemm_lean(const GemmArgs g) { gemm_body<P, PRO_LN, EPI, 4, 1, 1, true>(g); }
 
+// pose head with classifier-free guidance: conditional + unconditional rows per workgroup (GemmArgs::cfgB)
+template <class P>
+__global__ __launch_bounds__(256) void k_gemm_cfg(const GemmArgs g) { gemm_body<P, PRO_LN, EPI_OUT, 4, 1, 1, false, true>(g); }
+
 template <class P, int PRO, int EPI, int WN, int WK, int TNW, int TM = 1>
 __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
     if constexpr (TM == 1) gemm_body<P, PRO, EPI, WN, WK, TNW>(g);
@@ -910,6 +957,8 @@ struct LocArgs {
     const float* rsin;
     const unsigned char* mask;   // [mb][T] key mask (1 = keep)
     int mb;
+    int nomask;                  // `mask=None` of LocalAttention.forward (local_attention.py:196): nothing is masked but the
+                                 // causal future -- the look-back pad keys of window 0 take part with key = value = -1
     unsigned inv_mask_div;       // fastdiv_inv(B * Hl / mb): (b, head) -> mask row
     int B, T, D, Hl, hd, W;   // hd / W must match the kernel's template arguments
     float* X0;              // [M_pad][D] fp32, row = b*(T+1) + 1 + f ; row b*(T+1) = token
@@ -1015,7 +1064,7 @@ __global__ __launch_bounds__(256) void k_loc(const LocArgs a) {
     for (int i = 0; i < NSI; ++i) {
         const int idx = tid + 256 * i, q = idx >> 5, j = idx & 31, fk = f0 + j;
         const unsigned char mk = a.mask[(size_t)mrow * a.T + min(max(fk, 0), a.T - 1)];
-        keep[i] = ((int)(q < W) & (int)(j < W2) & (int)(fk >= 0) & (int)(mk != 0)) != 0;   // bitwise: keeps the load unconditional
+        keep[i] = ((int)(q < W) & (int)(j < W2) & ((int)(a.nomask != 0) | ((int)(fk >= 0) & (int)(mk != 0)))) != 0;   // bitwise: keeps the load unconditional
     }
     const int tc = min(tid, HD - 1);
     float tokv = a.emb1[(size_t)b * a.D + col0 + tc];
@@ -1186,6 +1235,7 @@ struct XInArgs {
     NoiseKey nkey; unsigned draw;
     int B, J, Jp, Jq, T;
     float* xs32; void* xsA;
+    int dupB;               // classifier-free guidance: batch element b is also written to row b + dupB (its unconditional twin)
 };
 template <class P>
 __global__ void k_x_in(const XInArgs a) {
@@ -1214,6 +1264,24 @@ __global__ void k_x_in(const XInArgs a) {
         }
         *(f32x4*)(a.xs32 + ((size_t)b * a.T + f) * a.Jp + j0) = z;
         if (a.xsA) P::store4((elem*)a.xsA + ((size_t)b * a.T + f) * a.Jp + j0, z);
+        if (a.dupB > 0) {
+            *(f32x4*)(a.xs32 + ((size_t)(b + a.dupB) * a.T + f) * a.Jp + j0) = z;
+            if (a.xsA) P::store4((elem*)a.xsA + ((size_t)(b + a.dupB) * a.T + f) * a.Jp + j0, z);
+        }
+    }
+}
+// the framework's noise stream as a tensor: out [B][J][T] (the reference's [B, J, 1, T]) = draw `draw` of (seed, stream) --
+// exactly what the fused sampler epilogue consumes for that draw index (generic sampling loop, tests)
+__global__ void k_noise(float* out, int B, int J, int Jq, int T, NoiseKey key, unsigned draw) {
+    const size_t n = (size_t)B * T * (Jq / 4);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int jq = (int)(i % (Jq / 4));
+        const size_t bf = i / (Jq / 4);
+        const int f = (int)(bf % T), b = (int)(bf / T);
+        const f32x4 z = philox_normal4((unsigned)((((size_t)b * T + f) * Jq + 4 * jq) >> 2), draw, key);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * jq + e < J) out[((size_t)b * J + 4 * jq + e) * T + f] = z[e];
     }
 }
 __global__ void k_x_out(const float* xs32, float* out, int B, int J, int Jp, int T) {

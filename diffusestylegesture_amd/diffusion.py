@@ -117,14 +117,24 @@ class DSGDiffusion:
         return self
 
     # ---- fused loops -----------------------------------------------------------------------------------------
-    def _check_unsupported(self, clip_denoised, denoised_fn, cond_fn, randomize_class, cond_fn_with_grad):
-        if clip_denoised:
-            raise NotImplementedError("clip_denoised=True is not on the sampling path (sample.py:256 passes False)")
+    def _check_unsupported(self, denoised_fn, cond_fn, randomize_class, cond_fn_with_grad):
         if denoised_fn is not None or cond_fn is not None or randomize_class or cond_fn_with_grad:
             raise NotImplementedError("denoised_fn / cond_fn / randomize_class / cond_fn_with_grad are not supported")
 
-    def _fused(self, mode, model, shape, noise, model_kwargs, skip_timesteps, init_image, dump_steps, const_noise,
-               eta, step_noise, seed, draw_base):
+    @staticmethod
+    def _library_model(model):
+        """(denoiser, guided) when the whole step loop can run inside the library: a DSGDenoiser, or the classifier-free
+        guidance wrapper around one with room for the unconditional twins."""
+        from .model import ClassifierFreeSampleModel, DSGDenoiser
+        if isinstance(model, DSGDenoiser):
+            return model, False
+        if isinstance(model, ClassifierFreeSampleModel) and isinstance(model.model, DSGDenoiser):
+            return model.model, True
+        return None, False
+
+    def _prepare(self, mode, model, guided, shape, noise, model_kwargs, skip_timesteps, init_image, dump_steps,
+                 const_noise, eta, step_noise, seed, draw_base, clip_denoised, stream_id=None):
+        """Conditioning + schedule to the library and the argument block of one dsg_sample call."""
         B = int(shape[0])
         if tuple(shape) != (B, model.njoints, model.nfeats, model.cfg.n_poses):
             raise ValueError(f"shape {tuple(shape)} does not match the denoiser ({model.njoints}, {model.nfeats}, "
@@ -133,21 +143,38 @@ class DSGDiffusion:
         if y is None:
             raise ValueError("model_kwargs['y'] is required")
         model.set_schedule(self)
-        model.set_cond(y, B)
-        n_run = self.num_timesteps - skip_timesteps
+        if guided:
+            if "scale" not in y:
+                raise KeyError("scale")
+            if model.max_batch < 2 * B:
+                raise ValueError("classifier-free guidance runs the unconditional twins in the same batch: create the "
+                                 f"DSGDenoiser with max_batch >= {2 * B}")
+            model.set_cond({k: v for k, v in y.items() if k != "scale"}, B, cfg_scale=y["scale"])
+        else:
+            model.set_cond(y, B)
         use_torch = any(L.is_torch(v) for v in (noise, init_image, y.get("audio")))
-        nb, ib, sb = L.Buf(noise), L.Buf(init_image), L.Buf(step_noise)
+        keep = (L.Buf(noise), L.Buf(init_image), L.Buf(step_noise))
         a = L.dsg_sample_args()
         a.mode, a.skip_timesteps, a.eta, a.const_noise = mode, int(skip_timesteps), float(eta), int(bool(const_noise))
-        a.init_noise, a.step_noise, a.init_image = nb.ptr, sb.ptr, ib.ptr
+        a.init_noise, a.step_noise, a.init_image = keep[0].ptr, keep[2].ptr, keep[1].ptr
         a.seed = (self._seed if seed is None else int(seed)) & (2 ** 64 - 1)
-        a.stream_id = self.stream_id
+        a.stream_id = self.stream_id if stream_id is None else int(stream_id)
         a.draw_base = self._draw if draw_base is None else int(draw_base)
+        a.clip_denoised = int(bool(clip_denoised))
         dump = None
         if dump_steps is not None:
             ds = np.ascontiguousarray(sorted(int(d) for d in dump_steps), dtype=np.int32)
             dump = np.zeros((len(ds),) + tuple(shape), dtype=np.float32)
             a.n_dump, a.dump_steps, a.dump_out = len(ds), ds.ctypes.data, dump.ctypes.data
+            keep = keep + (ds,)
+        return a, keep, dump, use_torch
+
+    def _fused(self, mode, model, guided, shape, noise, model_kwargs, skip_timesteps, init_image, dump_steps, const_noise,
+               eta, step_noise, seed, draw_base, clip_denoised):
+        B = int(shape[0])
+        a, keep, dump, use_torch = self._prepare(mode, model, guided, shape, noise, model_kwargs, skip_timesteps, init_image,
+                                                 dump_steps, const_noise, eta, step_noise, seed, draw_base, clip_denoised)
+        n_run = self.num_timesteps - skip_timesteps
         out, out_ptr = model._alloc_out(shape, use_torch)
         lib = model.lib
         lib.check(lib.cdll.dsg_sample(model.handle, C.byref(a), out_ptr, B, L.current_stream_ptr() if use_torch else None))
@@ -167,13 +194,52 @@ class DSGDiffusion:
                       model_kwargs=None, device=None, progress=False, skip_timesteps=0, init_image=None,
                       randomize_class=False, cond_fn_with_grad=False, dump_steps=None, const_noise=False,
                       *, step_noise=None, seed=None, draw_base=None):
-        self._check_unsupported(clip_denoised, denoised_fn, cond_fn, randomize_class, cond_fn_with_grad)
-        from .model import DSGDenoiser
-        if isinstance(model, DSGDenoiser):
-            return self._fused(L.MODE_DDPM, model, shape, noise, model_kwargs, skip_timesteps, init_image,
-                               dump_steps, const_noise, 0.0, step_noise, seed, draw_base)
+        self._check_unsupported(denoised_fn, cond_fn, randomize_class, cond_fn_with_grad)
+        inner, guided = self._library_model(model)
+        if inner is not None:
+            return self._fused(L.MODE_DDPM, inner, guided, shape, noise, model_kwargs, skip_timesteps, init_image,
+                               dump_steps, const_noise, 0.0, step_noise, seed, draw_base, clip_denoised)
         return self._generic_loop(False, model, shape, noise, model_kwargs, skip_timesteps, init_image, dump_steps,
-                                  const_noise, 0.0, device)
+                                  const_noise, 0.0, device, clip_denoised)
+
+    def p_sample_loop_multi(self, models, shape, model_kwargs_list, *, seeds=None, stream_ids=None, clip_denoised=False,
+                            skip_timesteps=0, init_images=None, noises=None, ddim=False, eta=0.0):
+        """`p_sample_loop` (or `ddim_sample_loop`) for SEVERAL lanes at once -- one `DSGDenoiser` per lane (a model and its
+        `clone()`s: one copy of the weights), one independent sampling problem each, advanced concurrently inside the
+        library (dsg_sample_multi: every lane owns an HSA queue; "one clip per stream").  Lane i draws from the Philox stream
+        (seeds[i], stream_ids[i]) at this object's current draw counter, which advances once for all lanes -- so lane i
+        reproduces `manual_seed(seeds[i], stream_ids[i])` + the same sequence of single-lane calls bit for bit."""
+        n = len(models)
+        if n == 0 or len(model_kwargs_list) != n:
+            raise ValueError("one model_kwargs per lane")
+        seeds = [self._seed] * n if seeds is None else list(seeds)
+        stream_ids = [self.stream_id + i for i in range(n)] if stream_ids is None else list(stream_ids)
+        B = int(shape[0])
+        args = (L.dsg_sample_args * n)()
+        outs, keeps, use_torch = [], [], False
+        for i, m in enumerate(models):
+            inner, guided = self._library_model(m)
+            if inner is None:
+                raise TypeError("p_sample_loop_multi drives library denoisers (DSGDenoiser lanes)")
+            a, keep, _, ut = self._prepare(L.MODE_DDIM if ddim else L.MODE_DDPM, inner, guided, shape,
+                                           None if noises is None else noises[i], model_kwargs_list[i], skip_timesteps,
+                                           None if init_images is None else init_images[i], None, False, eta, None,
+                                           seeds[i], None, clip_denoised, stream_id=stream_ids[i])
+            args[i] = a
+            keeps.append(keep)
+            use_torch = use_torch or ut
+            models[i] = inner
+        hs = (C.c_void_p * n)(*[m.handle for m in models])
+        optrs = (C.c_void_p * n)()
+        for i, m in enumerate(models):
+            o, p = m._alloc_out(shape, use_torch)
+            outs.append(o)
+            optrs[i] = p
+        lib = models[0].lib
+        lib.check(lib.cdll.dsg_sample_multi(hs, n, args, optrs, B, L.current_stream_ptr() if use_torch else None))
+        self._draw += 1 + (self.num_timesteps - skip_timesteps)
+        self._last_model = models[0]
+        return outs
 
     def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                          model_kwargs=None, device=None, progress=False, eta=0.0, skip_timesteps=0, init_image=None,
@@ -183,13 +249,13 @@ class DSGDiffusion:
             raise NotImplementedError()
         if const_noise:
             raise NotImplementedError()
-        self._check_unsupported(clip_denoised, denoised_fn, cond_fn, randomize_class, cond_fn_with_grad)
-        from .model import DSGDenoiser
-        if isinstance(model, DSGDenoiser):
-            return self._fused(L.MODE_DDIM, model, shape, noise, model_kwargs, skip_timesteps, init_image, None,
-                               False, eta, step_noise, seed, draw_base)
+        self._check_unsupported(denoised_fn, cond_fn, randomize_class, cond_fn_with_grad)
+        inner, guided = self._library_model(model)
+        if inner is not None:
+            return self._fused(L.MODE_DDIM, inner, guided, shape, noise, model_kwargs, skip_timesteps, init_image, None,
+                               False, eta, step_noise, seed, draw_base, clip_denoised)
         return self._generic_loop(True, model, shape, noise, model_kwargs, skip_timesteps, init_image, None, False,
-                                  eta, device)
+                                  eta, device, clip_denoised)
 
     def last_step_time_us(self):
         """GPU time per denoising step of the last fused call (HIP events inside the library)."""
@@ -200,12 +266,19 @@ class DSGDiffusion:
         m.lib.check(m.lib.cdll.dsg_last_sample_ms(m.handle, C.byref(ms), C.byref(n)))
         return 1000.0 * ms.value / max(n.value, 1)
 
+    def last_sample_path(self):
+        """"hip" / "aql" / "graph": how the library submitted the step loop of the last fused call."""
+        m = getattr(self, "_last_model", None)
+        return None if m is None else m.last_sample_path()
+
     # ---- generic loop: any callable model, fused HIP elementwise kernels for the sampler arithmetic --------------
     def _f32(self, name, idx, B):
         return np.full((B,), np.float32(getattr(self, name)[idx]), dtype=np.float32)
 
     def _generic_loop(self, ddim, model, shape, noise, model_kwargs, skip_timesteps, init_image, dump_steps,
-                      const_noise, eta, device):
+                      const_noise, eta, device, clip_denoised=False):
+        """Any callable as the denoiser.  The noise is the framework's Philox stream (dsg_noise), draw for draw the one the
+        fused loop consumes -- a wrapped model keeps seed parity with the fused path and the oracle."""
         import torch
         lib = self._lib or L.default_library()
         if device is None:
@@ -213,7 +286,16 @@ class DSGDiffusion:
         B = int(shape[0])
         per = int(np.prod(shape[1:]))
         stream = L.current_stream_ptr()
-        z = lambda: torch.randn(*shape, device=device)
+        draw0 = self._draw
+
+        def z():
+            t = torch.empty(*shape, device=device, dtype=torch.float32)
+            lib.check(lib.cdll.dsg_noise(t.data_ptr(), B, int(shape[1]) * int(shape[2]), int(shape[3]),
+                                         self._seed & (2 ** 64 - 1), self.stream_id, self._draw, stream))
+            self._draw += 1
+            return t
+        if noise is not None:
+            self._draw += 1            # the fused loop reserves the x_T draw index as well
         img = noise if noise is not None else z()
         if skip_timesteps and init_image is None:
             init_image = torch.zeros_like(img)
@@ -232,6 +314,8 @@ class DSGDiffusion:
             t = torch.full((B,), i, device=device, dtype=torch.long)
             with torch.no_grad():
                 x0 = model(img, tmap[t], **(model_kwargs or {})).contiguous().float()
+            if clip_denoised:
+                x0 = x0.clamp(-1, 1)
             eps = z()
             if const_noise:
                 eps = eps[[0]].repeat(B, 1, 1, 1)
@@ -257,6 +341,7 @@ class DSGDiffusion:
             img = out
             if dump_steps is not None and n in dump_steps:
                 dump.append(img.clone())
+        assert self._draw == draw0 + 1 + len(indices)
         return dump if dump_steps is not None else img
 
 

@@ -30,7 +30,7 @@ class dsg_sample_args(C.Structure):
         ("mode", C.c_int32), ("skip_timesteps", C.c_int32), ("eta", C.c_float), ("const_noise", C.c_int32),
         ("init_noise", C.c_void_p), ("step_noise", C.c_void_p), ("init_image", C.c_void_p),
         ("seed", C.c_uint64), ("stream_id", C.c_uint64), ("draw_base", C.c_uint32), ("n_dump", C.c_int32),
-        ("dump_steps", C.c_void_p), ("dump_out", C.c_void_p), ("reserved", C.c_int32 * 4)]
+        ("dump_steps", C.c_void_p), ("dump_out", C.c_void_p), ("clip_denoised", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 # every symbol include/dsg.h declares: name -> (restype, argtypes)
@@ -39,6 +39,7 @@ SYMBOLS = {
     "dsg_version": (_I, []),
     "dsg_last_error": (C.c_char_p, []),
     "dsg_create": (_I, [C.POINTER(dsg_config), C.POINTER(_P)]),
+    "dsg_clone": (_I, [_P, _I, C.POINTER(_P)]),
     "dsg_destroy": (_I, [_P]),
     "dsg_load_tensor": (_I, [_P, C.c_char_p, _P, C.POINTER(_I64), _I, _I]),
     "dsg_finalize_weights": (_I, [_P]),
@@ -46,10 +47,17 @@ SYMBOLS = {
     "dsg_schedule_tables": (_I, [_P, _I, _P]),
     "dsg_set_seed_last": (_I, [_P, _P, _I, _P]),
     "dsg_set_window_cond": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "dsg_set_window_cond_cfg": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "dsg_forward": (_I, [_P, _P, _P, _P, _I, _P]),
     "dsg_sample": (_I, [_P, C.POINTER(dsg_sample_args), _P, _I, _P]),
+    "dsg_sample_multi": (_I, [C.POINTER(_P), _I, C.POINTER(dsg_sample_args), C.POINTER(_P), _I, _P]),
     "dsg_sync": (_I, [_P]),
     "dsg_last_sample_ms": (_I, [_P, C.POINTER(C.c_float), C.POINTER(_I)]),
+    "dsg_last_sample_path": (_I, [_P, C.POINTER(_I)]),
+    "dsg_noise": (_I, [_P, _I, _I, _I, C.c_uint64, C.c_uint64, C.c_uint32, _P]),
+    "dsg_pose2bvh": (_I, [_P, _I, _I, _P, _P, _I, C.c_char_p]),
+    "dsg_pose2bvh_channels": (_I, [_P, _I, _I, _P, _P, _I, _P, _P]),
+    "dsg_pose2bvh_batch": (_I, [_P, _I, _I, _I, _P, _P, _I, C.POINTER(C.c_char_p)]),
     "dsg_q_sample": (_I, [_P, _P, _P, _P, _P, _I, _I64, _P]),
     "dsg_predict_xstart_from_eps": (_I, [_P, _P, _P, _P, _P, _I, _I64, _P]),
     "dsg_posterior_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I64, _P]),
@@ -79,7 +87,7 @@ class DSGLibrary:
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(self.cdll, name)          # AttributeError if the library does not export it
             fn.restype, fn.argtypes = res, args
-        if self.cdll.dsg_version() < 100:
+        if self.cdll.dsg_version() < 200:
             raise DSGError("libdsg_hip.so is older than this package")
 
     def check(self, rc: int):

@@ -17,12 +17,24 @@ from .config import DSGConfig
 
 class DSGDenoiser:
     def __init__(self, cfg: DSGConfig, precision: str = "bf16", max_batch: int = 1, device: int = 0,
-                 steps_per_graph: int = 0, library: L.DSGLibrary | None = None, latency_mode: str = "auto"):
+                 steps_per_graph: int = 0, library: L.DSGLibrary | None = None, latency_mode: str = "auto",
+                 _clone_of: "DSGDenoiser | None" = None):
         self.cfg = cfg
         self.lib = library or L.default_library()
         self.njoints, self.nfeats = cfg.njoints, 1
         self.precision = precision
         self.device_index = device
+        self.max_batch = max_batch
+        self._sched_key = None
+        self._loaded = set()
+        self._n_params = 0
+        self._source = _clone_of          # keeps the weight owner alive as long as any lane exists
+        if _clone_of is not None:
+            h = C.c_void_p()
+            self.lib.check(self.lib.cdll.dsg_clone(_clone_of.handle, max_batch, C.byref(h)))
+            self.handle = h
+            self._n_params = _clone_of._n_params
+            return
         c = L.dsg_config()
         c.variant, c.njoints, c.n_poses, c.n_seed = cfg.variant, cfg.njoints, cfg.n_poses, cfg.n_seed
         c.latent_dim, c.audio_src_dim, c.audio_dim = cfg.latent_dim, cfg.audio_src_dim, cfg.audio_dim
@@ -35,9 +47,12 @@ class DSGDenoiser:
         h = C.c_void_p()
         self.lib.check(self.lib.cdll.dsg_create(C.byref(c), C.byref(h)))
         self.handle = h
-        self.max_batch = max_batch
-        self._sched_id = None
-        self._loaded = set()
+
+    def clone(self, max_batch: int | None = None) -> "DSGDenoiser":
+        """A further sampling lane over the SAME device weights (dsg_clone): own stream / HSA queue, state, conditioning,
+        schedule.  One lane per concurrently sampled clip; `DSGDiffusion.p_sample_loop_multi` advances lanes together."""
+        return DSGDenoiser(self.cfg, self.precision, max_batch or self.max_batch, self.device_index, library=self.lib,
+                           _clone_of=self._source or self)
 
     def __del__(self):
         try:
@@ -55,18 +70,24 @@ class DSGDenoiser:
         return self
 
     def parameters(self):
+        """One placeholder tensor on the model's device, sized like the checkpoint's parameter count: the callers only ask
+        `next(model.parameters()).device` and `sum(p.numel() for p in model.parameters())` (the weights themselves live
+        repacked inside the library)."""
         import torch
         dev = torch.device(f"cuda:{self.device_index}") if torch.cuda.is_available() else torch.device("cpu")
-        yield torch.empty(0, device=dev)
+        yield torch.empty(1, device=dev).expand(self._n_params) if self._n_params else torch.empty(0, device=dev)
 
     def load_state_dict(self, state_dict, strict: bool = True):
         """Feeds every tensor to dsg_load_tensor under its checkpoint key, then repacks (dsg_finalize_weights).
         Unexpected keys raise like `load_model_wo_clip` asserts (model_util.py:11); `clip_model.*` keys are ignored
         the way the reference tolerates them as missing (model_util.py:12)."""
+        self._n_params = 0
         for name, t in state_dict.items():
             if name.startswith("clip_model."):
                 continue
             b = L.Buf(t)
+            if not (name.endswith(".pe") or name.endswith("inv_freq")):      # buffers are not parameters
+                self._n_params += int(np.prod(b.obj.shape))
             shape = tuple(int(s) for s in b.obj.shape)
             arr = (C.c_int64 * len(shape))(*shape)
             self.lib.check(self.lib.cdll.dsg_load_tensor(self.handle, name.encode(), b.p, arr, len(shape), 0))
@@ -75,17 +96,19 @@ class DSGDenoiser:
         return [], []
 
     def set_schedule(self, diffusion):
-        key = (id(diffusion), diffusion.num_timesteps)
-        if self._sched_id == key:
-            return
         betas = np.ascontiguousarray(diffusion.betas, dtype=np.float64)
         tmap = np.ascontiguousarray(diffusion.timestep_map, dtype=np.int64)
+        key = (betas.tobytes(), tmap.tobytes())          # by content: object ids are recycled
+        if self._sched_key == key:
+            return
         self.lib.check(self.lib.cdll.dsg_set_schedule(self.handle, betas.ctypes.data, tmap.ctypes.data, len(betas)))
-        self._sched_id = key
+        self._sched_key = key
 
-    def set_cond(self, y: dict, batch: int, uncond: bool = False):
+    def set_cond(self, y: dict, batch: int, uncond: bool = False, cfg_scale=None):
+        """Per-window conditioning (the `y` dict of model_kwargs).  `cfg_scale` [batch]: classifier-free guidance fused
+        into the path (dsg_set_window_cond_cfg; needs max_batch >= 2 * batch)."""
         style, seed, audio = L.Buf(y["style"]), L.Buf(y.get("seed")), L.Buf(y["audio"])
-        mask = y.get("mask_local")
+        mask = y["mask_local"]         # KeyError when absent, like the reference's y['mask_local'] (mdm.py:214); None = `mask=None`
         mb = 0
         mbuf = L.Buf(None)
         if mask is not None:
@@ -107,6 +130,15 @@ class DSGDenoiser:
             if tuple(last.obj.shape) != (batch, self.cfg.njoints, 1, self.cfg.n_seed):
                 raise ValueError(f"y['seed_last'] shape {tuple(last.obj.shape)}")
             self.lib.check(self.lib.cdll.dsg_set_seed_last(self.handle, last.p, batch, stream))
+        if cfg_scale is not None:
+            if uncond:
+                raise ValueError("guidance and y['uncond'] exclude each other")
+            sc = L.Buf(cfg_scale)
+            if int(np.prod(sc.obj.shape)) != batch:
+                raise ValueError(f"y['scale'] must have {batch} entries")
+            self.lib.check(self.lib.cdll.dsg_set_window_cond_cfg(self.handle, style.p, seed.p, audio.p, mbuf.p, mb, batch,
+                                                                 sc.p, stream))
+            return
         self.lib.check(self.lib.cdll.dsg_set_window_cond(self.handle, style.p, seed.p, audio.p, mbuf.p, mb, batch,
                                                          int(uncond), stream))
 
@@ -119,7 +151,7 @@ class DSGDenoiser:
         out = np.empty(tuple(shape), dtype=np.float32)
         return out, C.c_void_p(out.ctypes.data)
 
-    def forward(self, x, timesteps, y=None, uncond_info=False):
+    def forward(self, x, timesteps, y=None, uncond_info=False, *, cfg_scale=None):
         """x [B, njoints, nfeats, n_poses] fp32, timesteps [B] int64, y dict(style, seed, audio, mask_local)
         -> [B, njoints, nfeats, n_poses]"""
         if y is None:
@@ -130,7 +162,7 @@ class DSGDenoiser:
         if tuple(xb.obj.shape) != (B, self.njoints, self.nfeats, self.cfg.n_poses):
             raise ValueError(f"x shape {tuple(xb.obj.shape)}")
         assert tuple(tb.obj.shape) == (B,)
-        self.set_cond(y, B, uncond=uncond_info)
+        self.set_cond(y, B, uncond=uncond_info, cfg_scale=cfg_scale)
         out, optr = self._alloc_out(xb.obj.shape, use_torch)
         self.lib.check(self.lib.cdll.dsg_forward(self.handle, xb.p, tb.p, optr, B,
                                                  L.current_stream_ptr() if use_torch else None))
@@ -141,15 +173,28 @@ class DSGDenoiser:
     def sync(self):
         self.lib.check(self.lib.cdll.dsg_sync(self.handle))
 
+    def last_sample_path(self) -> str:
+        """How the step loop of the last sampling call was submitted: "hip" launches, hand-written "aql" packets, "graph"."""
+        p = C.c_int()
+        self.lib.check(self.lib.cdll.dsg_last_sample_path(self.handle, C.byref(p)))
+        return {0: "hip", 1: "aql", 2: "graph"}[p.value]
+
+    def last_sample_ms(self):
+        ms, n = C.c_float(), C.c_int()
+        self.lib.check(self.lib.cdll.dsg_last_sample_ms(self.handle, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
 
 class ClassifierFreeSampleModel:
-    """Classifier-free guidance wrapper, sampling only (main/model/cfg_sampler.py:8-31): two evaluations per call,
-    `out_uncond + y['scale'] * (out - out_uncond)`, the unconditional one with `y['uncond'] = True` (which zeroes the
-    style embedding -- and, for DiffuseStyleGesture, the seed-pose embedding input -- mdm.py:156-164, :180).  The
-    reference class asserts `cond_mode in ['text', 'action']` (inherited from MDM) and therefore cannot wrap the gesture
-    models at all; this one can.  A wrapped model is an opaque callable to the sampler, so `p_sample_loop` /
-    `ddim_sample_loop` take their generic path (HIP elementwise kernels for the update, one library call per evaluation)
-    instead of the single fused `dsg_sample` call."""
+    """Classifier-free guidance wrapper, sampling only (main/model/cfg_sampler.py:8-31): `out_uncond + y['scale'] * (out -
+    out_uncond)`, the unconditional evaluation with `y['uncond'] = True` (which zeroes the style embedding -- and, for
+    DiffuseStyleGesture, the seed-pose embedding input -- mdm.py:156-164, :180).  The reference class asserts `cond_mode in
+    ['text', 'action']` (inherited from MDM) and therefore cannot wrap the gesture models at all; this one can.
+
+    Wrapping a `DSGDenoiser` keeps everything inside the library: the conditional rows and their unconditional twins run as
+    ONE batch of 2B rows and the pose-head epilogue combines them (dsg_set_window_cond_cfg) -- in `forward` and, through
+    `DSGDiffusion.p_sample_loop` / `ddim_sample_loop`, in the fused step loop with the framework's Philox noise.  The
+    wrapped denoiser needs `max_batch >= 2 * batch`; with less, `forward` falls back to two library calls."""
 
     def __init__(self, model):
         self.model = model
@@ -161,11 +206,14 @@ class ClassifierFreeSampleModel:
     def forward(self, x, timesteps, y=None):
         if y is None or "scale" not in y:
             raise KeyError("scale")
+        scale = y["scale"]
+        B = int(x.shape[0])
+        if isinstance(self.model, DSGDenoiser) and self.model.max_batch >= 2 * B:
+            return self.model.forward(x, timesteps, {k: v for k, v in y.items() if k != "scale"}, cfg_scale=scale)
         y_uncond = dict(y)
         y_uncond["uncond"] = True
         out = self.model(x, timesteps, y)
         out_uncond = self.model(x, timesteps, y_uncond)
-        scale = y["scale"]
         scale = scale.view(-1, 1, 1, 1) if L.is_torch(scale) else np.asarray(scale, np.float32).reshape(-1, 1, 1, 1)
         return out_uncond + scale * (out - out_uncond)
 

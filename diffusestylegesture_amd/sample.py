@@ -29,48 +29,38 @@ def _xp(use_torch):
     return None
 
 
-def generate_clip(model, diffusion, feats, style, seed=123456, smoothing=True, skip_timesteps=0, sample_fn=None,
-                  stream_id=0, seed_pose=None, device=None):
-    """ZEGGS window loop (sample.py:236-296).  feats: sequence of K per-window WavLM features, each [B, T, A_src]
-    (torch cuda tensors or numpy); style: one-hot list or [B, 6] array.  Returns normalised poses
-    [B, K*stride - n_seed, J] (numpy float32) -- B independent clips advance in lock step."""
-    cfg = model.cfg
-    S, T, J = cfg.n_seed, cfg.n_poses, cfg.njoints
-    use_torch = L.is_torch(feats[0])
-    B = int(feats[0].shape[0])
-    sty = np.asarray(style, np.float32)
-    if sty.ndim == 1:
-        sty = np.repeat(sty[None], B, 0)
-    sample_fn = sample_fn or diffusion.p_sample_loop
-    diffusion.manual_seed(seed, stream_id)          # torch.manual_seed(seed) at sample.py:212
-    shape = (B, J, 1, T)
-    out = []
-    if use_torch:
+def _zeggs_window_y(cfg, feat, sty, prev, seed_pose, use_torch, mask):
+    """model_kwargs['y'] of one ZEGGS window (sample.py:227-251): seed poses = zeros / the caller's for window 0, the previous
+    window's last n_seed frames (post-stitch) afterwards."""
+    S, J = cfg.n_seed, cfg.njoints
+    B = int(feat.shape[0])
+    if prev is not None:
+        seedp = prev[..., -S:].contiguous() if use_torch else np.ascontiguousarray(prev[..., -S:])
+    elif seed_pose is not None:
+        seedp = seed_pose
+    elif use_torch:
         import torch
-        dev = feats[0].device
-        mask = torch.ones(1, T, dtype=torch.bool, device=dev)
-        sty_t = torch.from_numpy(sty).to(dev)
-        zeros_seed = torch.zeros(B, J, 1, S, device=dev)
-    for c, feat in enumerate(feats):
-        if use_torch:
-            seedp = (zeros_seed if seed_pose is None else seed_pose) if c == 0 else out[-1][..., -S:].contiguous()
-            y = {"style": sty_t, "seed": seedp, "audio": feat, "mask_local": mask}
-        else:
-            seedp = (np.zeros((B, J, 1, S), np.float32) if seed_pose is None else seed_pose) if c == 0 \
-                else np.ascontiguousarray(out[-1][..., -S:])
-            y = {"style": sty, "seed": seedp, "audio": feat, "mask_local": np.ones((1, T), bool)}
-        s = sample_fn(model, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=skip_timesteps,
-                      init_image=None, progress=False, dump_steps=None, noise=None, const_noise=False)
-        if c > 0:
-            last = out[-1][..., -S:]
-            last = last.clone() if use_torch else last.copy()
-            out[-1] = out[-1][..., :-S]
-            if smoothing:
-                delta = (s[:, 0:3, :, 0] - last[:, 0:3, :, 0])[..., None]
-                s[:, 0:3] = s[:, 0:3] - delta
-            # `for j in range(len(last_poses))` with len() == batch dim of a [1, J, 1, S] tensor: only frame 0
-            s[..., 0] = last[..., 0] * 0.5 + s[..., 0] * 0.5
-        out.append(s)
+        seedp = torch.zeros(B, J, 1, S, device=feat.device)
+    else:
+        seedp = np.zeros((B, J, 1, S), np.float32)
+    return {"style": sty, "seed": seedp, "audio": feat, "mask_local": mask}
+
+
+def _zeggs_stitch(out, s, S, smoothing, use_torch):
+    """sample.py:269-289: cut the overlap off the previous window, root-position continuity, the one-frame blend."""
+    if out:
+        last = out[-1][..., -S:]
+        last = last.clone() if use_torch else last.copy()
+        out[-1] = out[-1][..., :-S]
+        if smoothing:
+            delta = (s[:, 0:3, :, 0] - last[:, 0:3, :, 0])[..., None]
+            s[:, 0:3] = s[:, 0:3] - delta
+        # `for j in range(len(last_poses))` with len() == batch dim of a [1, J, 1, S] tensor: only frame 0
+        s[..., 0] = last[..., 0] * 0.5 + s[..., 0] * 0.5
+    out.append(s)
+
+
+def _zeggs_finish(out, S, use_torch):
     out[-1] = out[-1][..., :-S]
     if use_torch:
         import torch
@@ -81,10 +71,84 @@ def generate_clip(model, diffusion, feats, style, seed=123456, smoothing=True, s
     return np.ascontiguousarray(seq, dtype=np.float32)
 
 
+def _style_batch(style, B, use_torch, dev=None):
+    sty = np.asarray(style, np.float32)
+    if sty.ndim == 1:
+        sty = np.repeat(sty[None], B, 0)
+    if use_torch:
+        import torch
+        return torch.from_numpy(sty).to(dev)
+    return sty
+
+
+def generate_clip(model, diffusion, feats, style, seed=123456, smoothing=True, skip_timesteps=0, sample_fn=None,
+                  stream_id=0, seed_pose=None, device=None):
+    """ZEGGS window loop (sample.py:236-296).  feats: sequence of K per-window WavLM features, each [B, T, A_src]
+    (torch cuda tensors or numpy); style: one-hot list or [B, 6] array.  Returns normalised poses
+    [B, K*stride - n_seed, J] (numpy float32) -- B independent clips advance in lock step."""
+    cfg = model.cfg
+    S, T, J = cfg.n_seed, cfg.n_poses, cfg.njoints
+    use_torch = L.is_torch(feats[0])
+    B = int(feats[0].shape[0])
+    sample_fn = sample_fn or diffusion.p_sample_loop
+    diffusion.manual_seed(seed, stream_id)          # torch.manual_seed(seed) at sample.py:212
+    shape = (B, J, 1, T)
+    out = []
+    if use_torch:
+        import torch
+        mask = torch.ones(1, T, dtype=torch.bool, device=feats[0].device)
+    else:
+        mask = np.ones((1, T), bool)
+    sty = _style_batch(style, B, use_torch, feats[0].device if use_torch else None)
+    for c, feat in enumerate(feats):
+        y = _zeggs_window_y(cfg, feat, sty, out[-1] if out else None, seed_pose, use_torch, mask)
+        s = sample_fn(model, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=skip_timesteps,
+                      init_image=None, progress=False, dump_steps=None, noise=None, const_noise=False)
+        _zeggs_stitch(out, s, S, smoothing, use_torch)
+    return _zeggs_finish(out, S, use_torch)
+
+
+def generate_clips_streams(lanes, diffusion, feats_per_clip, styles, seed=123456, smoothing=True, skip_timesteps=0,
+                           stream_ids=None, ddim=False, eta=0.0):
+    """N clips of one GPU advanced concurrently, ONE CLIP PER LANE ("one clip per stream", BASELINE config[3]): `lanes` are
+    N DSGDenoiser lanes over one copy of the weights (`model.clone()`), lane i samples clip i at batch 1 on its own HSA queue
+    and the library interleaves the lanes' step loops (DSGDiffusion.p_sample_loop_multi).  Same window loop / stitching as
+    `generate_clip`; clip i uses the Philox stream (seed, stream_ids[i]) and is bit-identical to
+    `generate_clip(..., stream_id=stream_ids[i])` run alone.  feats_per_clip[i]: K per-window features [1, T, A_src].
+    Returns [N, K*stride - n_seed, J]."""
+    n = len(lanes)
+    cfg = lanes[0].cfg
+    S, T, J = cfg.n_seed, cfg.n_poses, cfg.njoints
+    K = len(feats_per_clip[0])
+    if any(len(f) != K for f in feats_per_clip) or len(feats_per_clip) != n:
+        raise ValueError("one feature list per lane, the same number of windows each")
+    use_torch = L.is_torch(feats_per_clip[0][0])
+    stream_ids = list(range(n)) if stream_ids is None else list(stream_ids)
+    diffusion.manual_seed(seed, 0)
+    shape = (1, J, 1, T)
+    dev = feats_per_clip[0][0].device if use_torch else None
+    if use_torch:
+        import torch
+        mask = torch.ones(1, T, dtype=torch.bool, device=dev)
+    else:
+        mask = np.ones((1, T), bool)
+    stys = [_style_batch(styles[i] if np.asarray(styles).ndim == 2 else styles, 1, use_torch, dev) for i in range(n)]
+    outs = [[] for _ in range(n)]
+    for c in range(K):
+        ys = [{"y": _zeggs_window_y(cfg, feats_per_clip[i][c], stys[i], outs[i][-1] if outs[i] else None, None, use_torch, mask)}
+              for i in range(n)]
+        ss = diffusion.p_sample_loop_multi(list(lanes), shape, ys, seeds=[seed] * n, stream_ids=stream_ids,
+                                           skip_timesteps=skip_timesteps, ddim=ddim, eta=eta)
+        for i in range(n):
+            _zeggs_stitch(outs[i], ss[i], S, smoothing, use_torch)
+    return np.concatenate([_zeggs_finish(o, S, use_torch) for o in outs], axis=0)
+
+
 def generate_clip_dsgplus(model, diffusion, feats, style, seed0, real_n_frames, seed=123456, skip_timesteps=0,
                           sample_fn=None, stream_id=0, seed_last=None):
     """DSG+ window loop (BEAT-TWH sample.py:98-192), attention4: zero-padded tail, no left audio context, GT seed for
     window 0, no root shift, last window kept whole, first S frames dropped, crop, keep the first J/3 features.
+    `model.cfg.variant == 3` is that tree's "DiffuseStyleGesture" (attention3 at BEAT dims): S frames of left audio context.
     DiffuseStyleGesture++ (attention5, model.cfg.variant == 5): `feats` are still the stride-long windows; the last S
     feature frames of every window are dropped (sample.py:104, :138) and `seed_last` [B, J, 1, S] -- the same snippet
     for every window (sample.py:85-93) -- is passed as y['seed_last']."""
@@ -110,6 +174,16 @@ def generate_clip_dsgplus(model, diffusion, feats, style, seed0, real_n_frames, 
         seedp = seed0 if c == 0 else out[-1][..., -S:]
         seedp = seedp.contiguous() if use_torch else np.ascontiguousarray(seedp)
         y = {"style": sty, "seed": seedp, "audio": feat, "mask_local": mask}
+        if cfg.variant == 3:
+            # name "DiffuseStyleGesture" of the BEAT-TWH tree (attention3): S frames of left context in front of the window's
+            # features -- zeros for window 0, the tail of the previous window's features afterwards (sample.py:100-102, :132-134)
+            if use_torch:
+                import torch
+                left = torch.zeros_like(feat[:, :S]) if c == 0 else feats[c - 1][:, -S:]
+                y["audio"] = torch.cat((left, feat), 1).contiguous()
+            else:
+                left = np.zeros_like(feat[:, :S]) if c == 0 else feats[c - 1][:, -S:]
+                y["audio"] = np.ascontiguousarray(np.concatenate((left, feat), 1))
         if cfg.variant == 5:
             if seed_last is None:
                 raise KeyError("seed_last")
@@ -259,8 +333,9 @@ def main(argv=None):
     from .bvh import pose2bvh
     ms = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "zeggs_mean_std.npz"))
     out_poses = denormalise(poses, ms["mean"], ms["std"])
-    pose2bvh(out_poses, stem + ".bvh", length=out_poses.shape[0], smoothing=True)
+    pose2bvh(out_poses, stem + ".bvh", length=out_poses.shape[0], smoothing=True)      # C++ writer (csrc/dsg_bvh.cpp)
     print(stem + ".bvh", out_poses.shape)
+    return stem + ".bvh"
 
 
 if __name__ == '__main__':

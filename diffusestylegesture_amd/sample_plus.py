@@ -17,7 +17,7 @@ import os
 
 import numpy as np
 
-from .config import BEAT, BEATPP, TWH
+from .config import BEAT, BEAT3, BEATPP, TWH
 from .sample import generate_clip_dsgplus
 
 
@@ -58,7 +58,8 @@ def build_parser():
     p.add_argument('--wavlm_path', type=str, default='./WavLM/WavLM-Large.pt')
     p.add_argument('--word2vector_path', type=str, default='./crawl-300d-2M.vec')
     # framework additions
-    p.add_argument('--name', default='DiffuseStyleGesture+', choices=['DiffuseStyleGesture+', 'DiffuseStyleGesture++'])
+    p.add_argument('--name', default='DiffuseStyleGesture+', choices=['DiffuseStyleGesture', 'DiffuseStyleGesture+', 'DiffuseStyleGesture++'],
+                   help="`name` of the reference's DiffuseStyleGesture.yml: attention3 / attention4 / attention5 (sample.py:297-303)")
     p.add_argument('--features_npy', required=True, help='[n_frames, audio_feature_dim] per-frame conditioning (the reference\'s textaudio)')
     p.add_argument('--seed_npy', required=True, help='[n_seed + 2, motion_dim] raw seed poses (sample.py:112-124)')
     p.add_argument('--seed_last_npy', default='', help='DiffuseStyleGesture++: raw poses of the closing snippet (sample.py:85-93)')
@@ -75,10 +76,10 @@ def main(argv=None):
     if args.wav_path or args.txt_path or args.tst_path:
         raise SystemExit("feature extraction from wav / transcript / h5 stays in the reference's pipelines: pass --features_npy")
     if args.dataset == 'BEAT':
-        cfg = BEATPP if args.name.endswith('++') else BEAT
+        cfg = {'DiffuseStyleGesture': BEAT3, 'DiffuseStyleGesture+': BEAT, 'DiffuseStyleGesture++': BEATPP}[args.name]
     elif args.dataset == 'TWH':
-        if args.name.endswith('++'):
-            raise NotImplementedError("the reference defines DiffuseStyleGesture++ for BEAT only")
+        if args.name != 'DiffuseStyleGesture+':
+            raise NotImplementedError("TWH dims are set up for DiffuseStyleGesture+ (attention4) only")
         cfg = TWH
     else:
         raise NotImplementedError(args.dataset)                               # sample.py:327
@@ -104,6 +105,7 @@ def main(argv=None):
     stem = os.path.join(args.save_dir, os.path.splitext(os.path.basename(args.features_npy))[0])
     np.save(stem + "_poses.npy", out_poses)
     print(stem + "_poses.npy", out_poses.shape)
+    return stem + "_poses.npy"
 
 
 if __name__ == '__main__':

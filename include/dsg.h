@@ -20,6 +20,15 @@
  *                                                                    BEAT-TWH-main/model/mdm.py:134-267
  *   dsg_sample
  *        GaussianDiffusion.p_sample_loop / ddim_sample_loop          main/diffusion/gaussian_diffusion.py:608-671, :889-936
+ *   dsg_set_window_cond_cfg
+ *        ClassifierFreeSampleModel.forward (y['scale'], y['uncond'])   main/model/cfg_sampler.py:8-31
+ *   dsg_clone / dsg_sample_multi
+ *        (no reference counterpart: the reference samples one clip at a time, sample.py:418 batch_size = 1; these run
+ *         several clips of one GPU concurrently over one copy of the weights -- BASELINE config[3] "one clip per stream")
+ *   dsg_noise
+ *        th.randn(*shape) / th.randn_like(x)                         main/diffusion/gaussian_diffusion.py:704, :542
+ *   dsg_pose2bvh
+ *        pose2bvh(poses, outpath, length, smoothing)                 main/process/process_zeggs_bvh.py:219-275
  *   dsg_q_sample / dsg_predict_xstart_from_eps / dsg_posterior_step / dsg_ddim_step
  *        q_sample :236-254, _predict_xstart_from_eps :400-405, q_posterior_mean_variance + p_sample :256-278/:542-557,
  *        ddim_sample :773-792   (same file)
@@ -39,7 +48,7 @@
 extern "C" {
 #endif
 
-#define DSG_VERSION 100
+#define DSG_VERSION 200
 
 enum {
     DSG_OK = 0,
@@ -84,6 +93,10 @@ int dsg_version(void);
 const char* dsg_last_error(void);
 
 int dsg_create(const dsg_config* cfg, dsg_handle** out);
+/* a further sampling lane over the SAME weights (reference counted; call after dsg_finalize_weights): own stream / HSA queue,
+ * state, conditioning and schedule.  max_batch <= 0: the source's.  One lane per concurrently sampled clip ("one clip per
+ * stream", BASELINE config[3]); see dsg_sample_multi.  Reloading weights into the source does not update existing clones. */
+int dsg_clone(dsg_handle* src, int max_batch, dsg_handle** out);
 int dsg_destroy(dsg_handle* h);
 
 /* dtype: 0 = float32.  shape/ndim are checked against the model dims. */
@@ -103,9 +116,17 @@ int dsg_schedule_tables(const double* betas, int n, double* out);
 int dsg_set_seed_last(dsg_handle* h, const float* seed_last, int B, void* stream);
 
 /* style [B, style_dim_in]; seed [B, J, 1, S]; audio [B, T_a, A_src] (T_a = T for variant 3, T-S for variant 4, T-2S for 5);
- * mask_local uint8 [mask_batch, T] (1 = keep), mask_batch in {1, B}; uncond != 0 -> uncond_info / y['uncond'] */
+ * mask_local uint8 [mask_batch, T] (1 = keep), mask_batch in {1, B}; NULL = the reference's `mask=None` (nothing masked but
+ * the causal future: the look-back pad keys of window 0 attend with value -1, local_attention.py:196);
+ * uncond != 0 -> uncond_info / y['uncond'].  The caller's buffers may be reused once `stream` has passed this call. */
 int dsg_set_window_cond(dsg_handle* h, const float* style, const float* seed, const float* audio,
                         const uint8_t* mask_local, int mask_batch, int B, int uncond, void* stream);
+/* classifier-free guidance, ClassifierFreeSampleModel.forward (main/model/cfg_sampler.py:8-31) fused into the path: the
+ * B elements and their unconditional twins (y['uncond'] = True) run as ONE batch of 2B rows (max_batch >= 2B) and the
+ * pose-head epilogue forms out_uncond + scale[b] * (out - out_uncond) before the sampler update.  scale: float[B]
+ * (y['scale']).  dsg_forward / dsg_sample are then called with the user batch B as usual. */
+int dsg_set_window_cond_cfg(dsg_handle* h, const float* style, const float* seed, const float* audio,
+                            const uint8_t* mask_local, int mask_batch, int B, const float* scale, void* stream);
 
 /* x, out: [B, J, 1, T] fp32; t: model timesteps int64[B] (each < train_steps) */
 int dsg_forward(dsg_handle* h, const float* x, const int64_t* t, float* out, int B, void* stream);
@@ -124,7 +145,8 @@ typedef struct dsg_sample_args {
     int32_t n_dump;           /* dump_steps support: number of entries in dump_steps */
     const int32_t* dump_steps;/* host int32[n_dump], ascending loop indices */
     float* dump_out;          /* [n_dump,B,J,1,T] */
-    int32_t reserved[4];
+    int32_t clip_denoised;    /* != 0: x0 clamped to [-1, 1] before the update (clip_denoised=True, gaussian_diffusion.py:377-379) */
+    int32_t reserved[3];
 } dsg_sample_args;
 
 /* runs num_timesteps - skip_timesteps denoising steps for the conditioning set by dsg_set_window_cond;
@@ -132,10 +154,34 @@ typedef struct dsg_sample_args {
  * returns when the steps have run; with HIP launches (DSG_AQL=0, or under a profiler) it only enqueues and is asynchronous
  * w.r.t. the host when `out` is device memory. */
 int dsg_sample(dsg_handle* h, const dsg_sample_args* args, float* out, int B, void* stream);
+/* n lanes (a handle and its dsg_clone()s: one device, shared weights), one independent sampling call each, run
+ * concurrently from this one host thread -- "one clip per stream": every lane owns an HSA queue, the dependent packet chains
+ * of the lanes overlap on the GPU.  args[n], outs[n]; every lane samples a batch of B.  Results are bit-identical to n
+ * separate dsg_sample calls. */
+int dsg_sample_multi(dsg_handle** lanes, int n, const dsg_sample_args* args, float** outs, int B, void* stream);
 int dsg_sync(dsg_handle* h);
 /* time of the step loop of the last dsg_sample (HIP events on the handle's stream; AQL path: first doorbell to the completion
  * signal of the last packet), and its step count */
 int dsg_last_sample_ms(dsg_handle* h, float* ms, int* n_steps);
+/* how the step loop of the last dsg_sample was submitted: 0 = HIP launches, 1 = hand-written AQL packets, 2 = hipGraph replay */
+int dsg_last_sample_path(dsg_handle* h, int* path);
+/* the framework's noise stream as a tensor: out [B, J, 1, T] (device) = draw `draw` of (seed, stream_id), i.e. exactly the
+ * noise the fused sampler uses for that draw index (x_T is draw_base, step i is draw_base + 1 + i).  Stands in for
+ * th.randn / th.randn_like of gaussian_diffusion.py:704, :542 in the generic loop. */
+int dsg_noise(float* out, int B, int J, int T, uint64_t seed, uint64_t stream_id, uint32_t draw, void* stream);
+
+/* ZEGGS pose vectors -> BVH (pose2bvh of main/process/process_zeggs_bvh.py:219-275 and what it calls; host code, no GPU).
+ * poses: host [frames, 1141], dtype 0 = float32, 1 = float64.  mean / std (float64[1141], both or neither): the sampler's
+ * normalised output is de-normalised first, `poses * clip(std, 0.01) + mean` (sample.py:320-326); NULL: poses are taken as
+ * they are.  smoothing != 0: Savitzky-Golay (15, 2) per feature (frames >= 15).  Output: `length` = frames, 3 * frames BVH
+ * frames at 60 fps, 75 joints, text identical in layout to the reference writer's.
+ * _channels: the numbers only -- offsets [75 * 3] (frame-0 positions, may be NULL) and motion [3 * frames, 228] in file order.
+ * _batch: n_clips clips of `frames` frames, one file each, formatted on several host threads. */
+int dsg_pose2bvh(const void* poses, int dtype, int frames, const double* mean, const double* std, int smoothing, const char* outpath);
+int dsg_pose2bvh_channels(const void* poses, int dtype, int frames, const double* mean, const double* std, int smoothing,
+                          double* offsets, double* motion);
+int dsg_pose2bvh_batch(const void* poses, int dtype, int n_clips, int frames, const double* mean, const double* std, int smoothing,
+                       const char* const* outpaths);
 
 /* fused sampler arithmetic on caller tensors (flat fp32 arrays of B*per_batch elements, per-batch scalars on host) */
 int dsg_q_sample(float* out, const float* x_start, const float* noise, const float* sqrt_ac, const float* sqrt_1mac,

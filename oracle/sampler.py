@@ -25,7 +25,7 @@ def _f(a, i):
 
 
 def p_sample_loop(diff: OracleDiffusion, model, shape, noise_fn, model_kwargs, skip_timesteps=0,
-                  init_image=None, noise=None, const_noise=False, dump_steps=None):
+                  init_image=None, noise=None, const_noise=False, dump_steps=None, clip_denoised=False):
     t = diff.t
     img = noise_fn(0).astype(np.float32) if noise is None else np.asarray(noise, np.float32)
     if skip_timesteps and init_image is None:
@@ -39,6 +39,8 @@ def p_sample_loop(diff: OracleDiffusion, model, shape, noise_fn, model_kwargs, s
     for n, i in enumerate(indices):
         ts = np.full((shape[0],), diff.timestep_map[i], dtype=np.int64)
         x0 = model(img, ts, **model_kwargs).astype(np.float32)
+        if clip_denoised:                               # gaussian_diffusion.py:377-379
+            x0 = np.clip(x0, np.float32(-1), np.float32(1))
         mean = _f(t["posterior_mean_coef1"], i) * x0 + _f(t["posterior_mean_coef2"], i) * img
         eps = noise_fn(1 + n).astype(np.float32)
         if const_noise:
@@ -52,7 +54,7 @@ def p_sample_loop(diff: OracleDiffusion, model, shape, noise_fn, model_kwargs, s
 
 
 def ddim_sample_loop(diff: OracleDiffusion, model, shape, noise_fn, model_kwargs, eta=0.0,
-                     skip_timesteps=0, init_image=None, noise=None):
+                     skip_timesteps=0, init_image=None, noise=None, clip_denoised=False):
     t = diff.t
     img = noise_fn(0).astype(np.float32) if noise is None else np.asarray(noise, np.float32)
     if skip_timesteps and init_image is None:
@@ -67,6 +69,8 @@ def ddim_sample_loop(diff: OracleDiffusion, model, shape, noise_fn, model_kwargs
     for n, i in enumerate(indices):
         ts = np.full((shape[0],), diff.timestep_map[i], dtype=np.int64)
         x0 = model(img, ts, **model_kwargs).astype(np.float32)
+        if clip_denoised:
+            x0 = np.clip(x0, np.float32(-1), np.float32(1))
         eps = (_f(t["sqrt_recip_alphas_cumprod"], i) * img - x0) / _f(t["sqrt_recipm1_alphas_cumprod"], i)
         ab, abp = _f(t["alphas_cumprod"], i), _f(t["alphas_cumprod_prev"], i)
         sigma = eta * np.sqrt((one - abp) / (one - ab)) * np.sqrt(one - ab / abp)
@@ -79,6 +83,21 @@ def ddim_sample_loop(diff: OracleDiffusion, model, shape, noise_fn, model_kwargs
 
 def philox_noise_fn(shape, seed, stream=0):
     return lambda d: philox.normal_bj1t(shape, seed, d, stream)
+
+
+class CFGModel:
+    """ClassifierFreeSampleModel.forward (main/model/cfg_sampler.py:19-31): two evaluations, the second with y['uncond'] =
+    True, combined as out_uncond + y['scale'].view(-1, 1, 1, 1) * (out - out_uncond)."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def __call__(self, x, timesteps, y=None):
+        yy = {k: v for k, v in y.items() if k != "scale"}
+        out = self.model(x, timesteps, yy)
+        out_uncond = self.model(x, timesteps, yy, uncond_info=True)
+        sc = np.asarray(y["scale"], np.float32).reshape(-1, 1, 1, 1)
+        return out_uncond + sc * (out - out_uncond)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -97,9 +116,6 @@ def zeggs_clip(sample_window, cfg, feats, style, smoothing=True):
         seedp = np.zeros((1, J, 1, S), np.float32) if c == 0 else out[-1][..., -S:].copy()
         y = {"style": np.asarray([style], np.float32), "seed": seedp, "audio": feat,
              "mask_local": np.ones((1, T), bool)}
-        if cfg.variant == 5:
-            y["audio"] = np.ascontiguousarray(np.asarray(feat)[:, :-S])
-            y["seed_last"] = np.asarray(seed_last, np.float32)
         s = np.array(sample_window(c, y), np.float32, copy=True)
         if c > 0:
             last = out[-1][..., -S:].copy()
@@ -120,13 +136,18 @@ def zeggs_clip(sample_window, cfg, feats, style, smoothing=True):
 def dsgplus_clip(sample_window, cfg, feats, style, seed0, real_n_frames, seed_last=None):
     """DSG+ `inference()` (BEAT-TWH sample.py:98-192), attention4: no left audio context, no root shift,
     last window kept whole, first S frames dropped, crop to real_n_frames, keep first J/3 features.
-    attention5 (DiffuseStyleGesture++): audio[:-S] per window (sample.py:104, :138) + y['seed_last'] (:85-93)."""
+    attention5 (DiffuseStyleGesture++): audio[:-S] per window (sample.py:104, :138) + y['seed_last'] (:85-93).
+    attention3 (that tree's "DiffuseStyleGesture"): S feature frames of left context -- zeros, then the previous window's
+    tail (sample.py:100-102, :132-134)."""
     S, T, J = cfg.n_seed, cfg.n_poses, cfg.njoints
     out = []
     for c, feat in enumerate(feats):
         seedp = np.asarray(seed0, np.float32) if c == 0 else out[-1][..., -S:].copy()
         y = {"style": np.asarray([style], np.float32), "seed": seedp, "audio": feat,
              "mask_local": np.ones((1, T), bool)}
+        if cfg.variant == 3:
+            left = np.zeros_like(np.asarray(feat)[:, :S]) if c == 0 else np.asarray(feats[c - 1])[:, -S:]
+            y["audio"] = np.ascontiguousarray(np.concatenate((left, np.asarray(feat)), 1))
         if cfg.variant == 5:
             y["audio"] = np.ascontiguousarray(np.asarray(feat)[:, :-S])
             y["seed_last"] = np.asarray(seed_last, np.float32)

@@ -7,6 +7,10 @@
     python tests/golden/make_goldens.py bvh        # main/process/process_zeggs_bvh.py pose2bvh (G7, needs G6)
     python tests/golden/make_goldens.py wavlm      # main/mydiffusion_zeggs/WavLM (G9: small-config feature extractor)
     python tests/golden/make_goldens.py dsgpp      # BEAT-TWH-main/ cross_local_attention5 (DiffuseStyleGesture++, G10)
+    python tests/golden/make_goldens.py dsgplus_caller   # BEAT-TWH-main/mydiffusion_beat_twh/sample.py inference() (G11)
+    python tests/golden/make_goldens.py clip1000   # G12: inference() at the full 1000 steps per window (config[1] workload)
+    python tests/golden/make_goldens.py bvh1000    # G13: the reference .bvh channels of G12
+    python tests/golden/make_goldens.py attn3beat  # G14: BEAT-TWH-main cross_local_attention3 (name "DiffuseStyleGesture")
 
 The two reference trees use the same module names, hence one process per tree.  Nothing from
 /root/reference is copied: the script imports it, feeds it seeded synthetic weights / inputs
@@ -242,9 +246,10 @@ def gen_dsgplus():
     np.savez_compressed(os.path.join(HERE, "g5_forward_dsgplus.npz"), **g5)
 
 
-def gen_clip():
+def gen_clip(skip=997, outname="g6_clip_zeggs.npz", f32=False):
     """G6: the reference's own `inference()` (window loop + stitching + de-normalisation) with a fake WavLM
-    and 3 DDPM steps per window; pose2bvh is replaced by a capture so no file is written."""
+    and 3 DDPM steps per window; pose2bvh is replaced by a capture so no file is written.
+    G12 (`clip1000`): the same at the full 1000 steps per window (skip_timesteps=0) -- the config[1] workload."""
     zdir = REF + "/main/mydiffusion_zeggs"
     os.chdir(zdir)
     for name in ("librosa", "omegaconf", "easydict"):
@@ -291,17 +296,17 @@ def gen_clip():
     with NoiseInjector(123456, stream=0) as inj:
         # one Philox stream runs through all windows like torch's global generator does (sample.py:212)
         S.inference(args, None, audio, diff.p_sample_loop, model, n_frames=320, smoothing=True,
-                    SG_filter=True, minibatch=True, skip_timesteps=997, style=style, seed=123456)
+                    SG_filter=True, minibatch=True, skip_timesteps=skip, style=style, seed=123456)
         draws = inj.draw
     mean = np.load(REF + "/ubisoft-laforge-ZeroEGGS-main/data/processed_v1/processed/mean.npz")["mean"].squeeze()
     std = np.load(REF + "/ubisoft-laforge-ZeroEGGS-main/data/processed_v1/processed/std.npz")["std"].squeeze()
-    np.savez_compressed(os.path.join(HERE, "g6_clip_zeggs.npz"), poses_denorm=captured["poses"].astype(np.float64),
-                        draws=draws, wseed=WSEED, noise_seed=123456, skip_timesteps=997)
+    np.savez_compressed(os.path.join(HERE, outname), poses_denorm=captured["poses"].astype(np.float32 if f32 else np.float64),
+                        draws=draws, wseed=WSEED, noise_seed=123456, skip_timesteps=skip)
     np.savez_compressed(os.path.join(HERE, "zeggs_mean_std.npz"), mean=mean, std=std)
     print("G6", captured["poses"].shape, draws)
 
 
-def gen_bvh():
+def gen_bvh(inname="g6_clip_zeggs.npz", outname="g7_bvh_zeggs.npz", full=True):
     """G7: the reference's own pose2bvh (Savitzky-Golay, orthogonalisation, quaternion/Euler, x3 repeat, text writer) on the
     de-normalised poses of G6; stores the hierarchy text and every motion channel value."""
     import tempfile
@@ -310,7 +315,7 @@ def gen_bvh():
     sys.path[:0] = [REF + "/main/process", REF + "/ubisoft-laforge-ZeroEGGS-main/ZEGGS"]
     os.chdir(REF + "/main/process")
     import process_zeggs_bvh as R
-    poses = np.load(os.path.join(HERE, "g6_clip_zeggs.npz"))["poses_denorm"]
+    poses = np.load(os.path.join(HERE, inname))["poses_denorm"].astype(np.float64)
     tmp = tempfile.mkdtemp()
     out = {}
     for sm in (True, False):
@@ -324,7 +329,103 @@ def gen_bvh():
                        motion_smooth=vals.astype(np.float32))
         else:
             out["motion_raw_first_last"] = np.concatenate([vals[:9], vals[-9:]]).astype(np.float32)
-    np.savez_compressed(os.path.join(HERE, "g7_bvh_zeggs.npz"), **out)
+    if not full:       # G13: only the smoothed motion channels (the header is G7's business)
+        out = {"motion_smooth": out["motion_smooth"]}
+    np.savez_compressed(os.path.join(HERE, outname), **out)
+
+
+def gen_attn3_beat():
+    """G14: BEAT-TWH-main's `cross_local_attention3_style1_sample` model (name "DiffuseStyleGesture" in that tree:
+    BEAT-TWH-main/model/mdm.py:147-185, window 15) at BEAT dims and at tiny dims, conditional + uncond forward."""
+    sys.path[:0] = [REF + "/BEAT-TWH-main", REF + "/BEAT-TWH-main/model"]
+    from model.mdm import MDM
+    g = {"wseed": WSEED}
+    for cfg, ts, B in ((C.BEAT3, 640, 1), (C.TINY3B, 500, 2)):
+        m = MDM(modeltype='', njoints=cfg.njoints, nfeats=1, cond_mode='cross_local_attention3_style1_sample',
+                arch='trans_enc', latent_dim=cfg.latent_dim, n_seed=cfg.n_seed, ff_size=cfg.ff_size,
+                num_layers=cfg.num_layers, num_heads=cfg.num_heads, style_dim=cfg.style_dim_in,
+                source_audio_dim=cfg.audio_src_dim, audio_feat_dim_latent=cfg.audio_dim)
+        missing, unexpected = m.load_state_dict(_to_torch_sd(synth_state_dict(cfg, WSEED)), strict=False)
+        assert not missing and not unexpected, (missing, unexpected)
+        m.eval()
+        y = synth_window_inputs(cfg, B, window=3, seed_pose_scale=0.1)
+        x = np.random.RandomState(31 + B).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+        out = m(torch.from_numpy(x), torch.tensor([ts] * B), y=_y_torch(y)).numpy()
+        g[cfg.name + "_out"] = out.astype(np.float32)
+        g[cfg.name + "_meta"] = np.array([B, 0.1, 31 + B, ts], dtype=np.float64)
+        if cfg.name == "tiny3b":
+            yu = _y_torch(y); yu["uncond"] = True
+            g["tiny3b_uncond"] = m(torch.from_numpy(x), torch.tensor([ts] * B), y=yu).numpy()
+        print("G14", cfg.name, out.shape, float(np.abs(out).mean()))
+    np.savez_compressed(os.path.join(HERE, "g14_forward_attn3_beat.npz"), **g)
+
+
+def gen_dsgplus_caller():
+    """G11: the reference's own DSG+ caller, `inference()` of BEAT-TWH-main/mydiffusion_beat_twh/sample.py:44-192, driven for
+    the three model names it knows (attention3 / 4 / 5) at BEAT dims with 3 DDPM steps per window (skip_timesteps=997) and
+    a 300-frame clip (3 windows, zero-padded tail).  Harness-side stand-ins only for what the image lacks and the path does
+    not need: `librosa`, `easydict`, the dataset BVH pipelines (`process_BEAT_bvh` / `process_TWH_bvh`: their pose2bvh
+    entry points become a capture of `out_poses`), and the ground-truth seed clip (`np.load` of
+    ../../BEAT_dataset/...npy returns a seeded synthetic snippet).  Mean / std are the reference's own .npy files."""
+    bdir = REF + "/BEAT-TWH-main/mydiffusion_beat_twh"
+    os.chdir(bdir)
+    captured = {}
+    for name in ("librosa", "easydict", "process_BEAT_bvh", "process_TWH_bvh"):
+        sys.modules[name] = types.ModuleType(name)
+
+    class _ED(dict):
+        __getattr__ = dict.__getitem__
+        __setattr__ = dict.__setitem__
+    sys.modules["easydict"].EasyDict = _ED
+    pb, pt = sys.modules["process_BEAT_bvh"], sys.modules["process_TWH_bvh"]
+    pb.wav2wavlm = pb.pose2bvh = None
+    pb.pose2bvh_bugfix = lambda save_dir, prefix, out_poses, pipeline=None: captured.__setitem__("poses", np.array(out_poses))
+    pt.pose2bvh = pt.wavlm_init = pt.load_metadata = None
+    sys.path[:0] = [bdir, REF + "/BEAT-TWH-main", REF + "/BEAT-TWH-main/model"]
+    import sample as S
+    S.mydevice = torch.device("cpu")
+    S.batch_size = 1
+    mean = np.load("../process/gesture_BEAT_mean_v0.npy")
+    std = np.load("../process/gesture_BEAT_std_v0.npy")
+    m = mean.shape[-1]
+    seed_raw = (mean + std * 0.5 * np.random.RandomState(4711).randn(C.BEAT.n_seed + 2, m)).astype(np.float64)
+
+    class _NP:                      # numpy as the reference module sees it: only the dataset clip is synthetic
+        def __getattr__(self, k):
+            return getattr(np, k)
+
+        @staticmethod
+        def load(path, *a, **k):
+            if "BEAT_dataset" in str(path):
+                return seed_raw.copy()
+            return np.load(path, *a, **k)
+    S.np = _NP()
+    from utils.model_util import create_gaussian_diffusion
+    from model.mdm import MDM
+    diff = create_gaussian_diffusion()
+    out = {"wseed": WSEED, "noise_seed": 123456, "skip_timesteps": 997, "real_n_frames": 300, "seed_raw": seed_raw}
+    for name, cfg, mode in (("DiffuseStyleGesture+", C.BEAT, 'cross_local_attention4_style1_sample'),
+                            ("DiffuseStyleGesture++", C.BEATPP, 'cross_local_attention5_style1_sample'),
+                            ("DiffuseStyleGesture", C.BEAT3, 'cross_local_attention3_style1_sample')):
+        model = MDM(modeltype='', njoints=cfg.njoints, nfeats=1, cond_mode=mode, arch='trans_enc', latent_dim=cfg.latent_dim,
+                    n_seed=cfg.n_seed, ff_size=cfg.ff_size, num_layers=cfg.num_layers, num_heads=cfg.num_heads,
+                    style_dim=cfg.style_dim_in, source_audio_dim=cfg.audio_src_dim, audio_feat_dim_latent=cfg.audio_dim)
+        missing, unexpected = model.load_state_dict(_to_torch_sd(synth_state_dict(cfg, WSEED)), strict=False)
+        assert not missing and not unexpected, (missing, unexpected)
+        model.eval()
+        # textaudio: 300 frames of per-frame features (the stride-long windows of the BEAT set, concatenated)
+        ta = np.concatenate([synth_window_inputs(C.BEAT, 1, window=w)["audio"][0] for w in range(3)])[:300]
+        args = _ED(n_poses=cfg.n_poses, n_seed=cfg.n_seed, audio_feature_dim=cfg.audio_src_dim, version="v0", name=name,
+                   njoints=cfg.njoints)
+        style = np.array([1.0, 0.0])
+        with NoiseInjector(123456, stream=0) as inj:
+            S.inference(args, "/tmp", "g11", torch.from_numpy(ta), diff.p_sample_loop, model, n_frames=0, smoothing=True,
+                        skip_timesteps=997, style=style, seed=123456, dataset='BEAT')
+            draws = inj.draw
+        out[name] = captured["poses"].astype(np.float64)
+        out["draws"] = draws
+        print("G11", name, captured["poses"].shape, draws, float(np.abs(captured["poses"]).mean()))
+    np.savez_compressed(os.path.join(HERE, "g11_clip_dsgplus.npz"), **out)
 
 
 def gen_dsgpp():
@@ -394,4 +495,7 @@ def gen_wavlm():
 
 if __name__ == "__main__":
     which = sys.argv[1]
-    {"zeggs": gen_zeggs, "dsgplus": gen_dsgplus, "clip": gen_clip, "bvh": gen_bvh, "wavlm": gen_wavlm, "dsgpp": gen_dsgpp}[which]()
+    {"zeggs": gen_zeggs, "dsgplus": gen_dsgplus, "clip": gen_clip, "bvh": gen_bvh, "wavlm": gen_wavlm, "dsgpp": gen_dsgpp,
+     "clip1000": lambda: gen_clip(0, "g12_clip1000_zeggs.npz", f32=True),
+     "bvh1000": lambda: gen_bvh("g12_clip1000_zeggs.npz", "g13_bvh1000_zeggs.npz", full=False),
+     "attn3beat": gen_attn3_beat, "dsgplus_caller": gen_dsgplus_caller}[which]()

@@ -1,0 +1,36 @@
+"""CPU: `python bench.py --gpus 2` must create two ranks ITSELF (no launcher environment), one per device, and report
+n_gpus 2 -- exercised with the emulated library and gloo (DSG_BENCH_EMU=1: test infrastructure, tiny dims, a few denoising
+steps); both multi-clip modes of config[3] (one clip per lane / one lock-step batch) go through the same code on one rank."""
+import json
+import os
+import subprocess
+import sys
+
+from tests.conftest import ROOT
+
+
+def _run(args, env_extra):
+    env = dict(os.environ)
+    env.update({"DSG_BENCH_EMU": "1", "DSG_BENCH_SKIP": "997", "DSG_EMU_THREADS": "2"})
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    env.update(env_extra)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]        # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_gpus2_spawns_two_ranks(emu_lib):
+    out = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--precision", "fp32", "--clips-per-gpu", "2"], {})
+    assert out["n_gpus"] == 2 and out["config"]["clips_per_gpu"] == 2 and out["config"]["mode"] == "streams"
+    assert out["config"]["parallelism"] == "clips x2" and out["value"] > 0 and out["scaling"] == "weak"
+    assert "EMULATED" in out["data"]
+
+
+def test_bench_single_rank_modes(emu_lib):
+    a = _run(["--steps", "1", "--warmup", "0", "--precision", "fp32", "--clips-per-gpu", "3", "--mode", "lockstep"], {})
+    assert a["n_gpus"] == 1 and a["config"]["mode"] == "lockstep" and a["sample_path"] == "hip"
+    b = _run(["--steps", "1", "--warmup", "0", "--precision", "fp32"], {})
+    assert b["config"]["clips_per_gpu"] == 1 and b["roofline"]["bound"] == "hbm"
+    assert b["value_emitted_frames"] < b["value"]

@@ -171,7 +171,7 @@ def test_error_behaviour(tiny, emu_lib):
     with pytest.raises(NotImplementedError):
         d.ddim_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, const_noise=True)
     with pytest.raises(NotImplementedError):
-        d.p_sample_loop(m, shape, model_kwargs={"y": y})            # clip_denoised defaults to True
+        d.p_sample_loop(m, shape, model_kwargs={"y": y}, cond_fn=lambda *a: None)       # guidance hooks are not on the path
     with pytest.raises(ValueError):
         d.p_sample_loop(m, (2, 5, 1, 22), clip_denoised=False, model_kwargs={"y": y})
     with pytest.raises(ValueError):

@@ -183,13 +183,13 @@ def test_dsgplus_chain_and_clip_vs_oracle(gpu, prec):
 
 
 def test_classifier_free_guidance_generic_loop(gpu, golden_dir):
-    """f4: the CFG wrapper (two evaluations per step) is an opaque callable, so the sampler takes its generic loop
-    (HIP elementwise update kernels); with scale 1 it must reproduce the conditional model's generic-loop result."""
+    """f4: the guidance wrapper around a DSGDenoiser runs fused (2B rows, one library call); with scale 1 it must reproduce
+    the conditional model evaluated through the generic loop (any callable + HIP elementwise update kernels)."""
     import torch
     from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
     from diffusestylegesture_amd.model import ClassifierFreeSampleModel
     gt = _g(golden_dir, "gt_tiny_zeggs.npz")
-    m = _model(C.TINY, "fp32", wseed=int(gt["wseed"]))
+    m = _model(C.TINY, "fp32", max_batch=4, wseed=int(gt["wseed"]))
     y = {k: torch.from_numpy(v).cuda() for k, v in synth_window_inputs(C.TINY, 2, window=2, seed_pose_scale=0.3).items()}
     x = torch.from_numpy(np.random.RandomState(99).randn(2, C.TINY.njoints, 1, C.TINY.n_poses).astype(np.float32)).cuda()
     ts = torch.tensor([998, 17]).cuda()
@@ -206,10 +206,9 @@ def test_classifier_free_guidance_generic_loop(gpu, golden_dir):
 
         def __call__(self, xx, tt, y=None):
             return m(xx, tt, y)
-    torch.manual_seed(3)
-    a = d.p_sample_loop(w, shape, clip_denoised=False, model_kwargs={"y": dict(y, scale=torch.ones(2).cuda())}, skip_timesteps=996)
-    torch.manual_seed(3)
-    b = d.p_sample_loop(Plain(), shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=996)
+    # guidance runs fused inside the library, the plain wrapper through the generic loop: both draw the same Philox stream
+    a = d.manual_seed(3).p_sample_loop(w, shape, clip_denoised=False, model_kwargs={"y": dict(y, scale=torch.ones(2).cuda())}, skip_timesteps=996)
+    b = d.manual_seed(3).p_sample_loop(Plain(), shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=996)
     assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
 
 
@@ -235,6 +234,7 @@ def test_aql_step_loop_is_bit_identical_to_hip_launches(gpu, prec, monkeypatch):
         d50 = create_gaussian_diffusion("ddim50")
         res.append(np.asarray(d50.manual_seed(12, 0).ddim_sample_loop(m, (1, cfg.njoints, 1, cfg.n_poses), clip_denoised=False,
                                                                        model_kwargs={"y": y})).copy())
+        assert m.last_sample_path() == ("hip" if mode == "0" else "aql"), "the comparison is void if the requested path did not run"
         outs[mode] = res
     for a, b, c in zip(outs["1"], outs["0"], outs["overlap"]):
         assert np.isfinite(a).all() and np.array_equal(a, b) and np.array_equal(a, c)
