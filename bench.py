@@ -40,6 +40,8 @@ def parse(argv=None):
     p.add_argument("--clips-per-gpu", type=int, default=0, help="clips in flight per GPU (default 1; 16 = config[3]'s per-GPU share)")
     p.add_argument("--mode", default="auto", choices=["auto", "streams", "lockstep"],
                    help="several clips per GPU: one clip per lane / HSA queue, or one lock-step batch (auto: streams)")
+    p.add_argument("--lanes", type=int, default=0, help="sampling lanes (HSA queues) per GPU; each lane advances clips-per-gpu / lanes "
+                                                       "clips in lock step (streams = one clip per lane, lockstep = 1 lane)")
     p.add_argument("--batch", type=int, default=0, help="alias: --clips-per-gpu B --mode lockstep")
     p.add_argument("--steps-per-graph", type=int, default=0)
     p.add_argument("--config", default="zeggs", choices=["zeggs", "beat", "twh"],
@@ -51,8 +53,18 @@ def parse(argv=None):
     if a.batch and not a.clips_per_gpu:
         a.clips_per_gpu, a.mode = a.batch, "lockstep"
     a.clips_per_gpu = a.clips_per_gpu or 1
-    if a.mode == "auto":
-        a.mode = "streams" if a.clips_per_gpu > 1 else "lockstep"
+    if a.lanes:
+        if a.clips_per_gpu % a.lanes:
+            p.error("--clips-per-gpu must be a multiple of --lanes")
+        a.mode = "lanes" if 1 < a.lanes < a.clips_per_gpu else ("lockstep" if a.lanes == 1 else "streams")
+    elif a.mode == "auto":
+        # the command processor overlaps one queue per compute pipe: 4 lanes, the other clips ride in the lanes' batches
+        a.lanes = min(4, a.clips_per_gpu)
+        while a.clips_per_gpu % a.lanes:
+            a.lanes -= 1
+        a.mode = "lanes" if 1 < a.lanes < a.clips_per_gpu else ("lockstep" if a.lanes == 1 else "streams")
+    else:
+        a.lanes = a.clips_per_gpu if a.mode == "streams" else 1
     return a
 
 
@@ -170,14 +182,14 @@ def main():
         cfg = C.TINY
     else:
         cfg = C.CONFIGS[a.config]
-    NC = a.clips_per_gpu
-    streams = a.mode == "streams" and NC > 1
+    NC, NL = a.clips_per_gpu, a.lanes
+    streams = NL > 1
     if streams and cfg.variant != 3:
-        raise SystemExit("--mode streams drives the ZEGGS clip loop")
-    B = 1 if streams else NC
+        raise SystemExit("sampling lanes drive the ZEGGS clip loop")
+    B = NC // NL
     model = DSGDenoiser(cfg, precision=a.precision, max_batch=B, device=local, steps_per_graph=a.steps_per_graph, library=library)
     model.load_state_dict(synth_state_dict(cfg, 20240))
-    lanes = [model] + [model.clone() for _ in range(NC - 1)] if streams else [model]
+    lanes = [model] + [model.clone() for _ in range(NL - 1)]
     diffusion = create_gaussian_diffusion("ddim50" if a.sampler == "ddim50" else "", library=library)
     sample_fn = diffusion.ddim_sample_loop if a.sampler == "ddim50" else diffusion.p_sample_loop
     skip = int(os.environ.get("DSG_BENCH_SKIP", "0")) if emu else 0
@@ -190,8 +202,8 @@ def main():
     # synthetic per-window audio features, resident in HBM before the clock starts (clip index = rank*NC + b)
     to_dev = (lambda x: torch.from_numpy(x)) if emu else (lambda x: torch.from_numpy(x).cuda(local))
     if streams:
-        feats = [[to_dev(synth_window_inputs(cfg, 1, window=w, clip0=rank * NC + c)["audio"]) for w in range(n_windows)]
-                 for c in range(NC)]
+        feats = [[to_dev(synth_window_inputs(cfg, B, window=w, clip0=rank * NC + ln * B)["audio"]) for w in range(n_windows)]
+                 for ln in range(NL)]
     else:
         feats = [to_dev(synth_window_inputs(cfg, B, window=w, clip0=rank * NC)["audio"]) for w in range(n_windows)]
     if emu:
@@ -201,7 +213,7 @@ def main():
     def one_pass(i):
         if streams:
             return generate_clips_streams(lanes, diffusion, feats, style, seed=123456 + i, smoothing=True, skip_timesteps=skip,
-                                          stream_ids=[rank * NC + c for c in range(NC)], ddim=a.sampler == "ddim50")
+                                          stream_ids=[rank * NL + ln for ln in range(NL)], ddim=a.sampler == "ddim50")
         if cfg.variant == 3:
             return generate_clip(model, diffusion, feats, style, seed=123456 + i, smoothing=True, sample_fn=sample_fn,
                                  stream_id=rank, skip_timesteps=skip)
@@ -260,7 +272,7 @@ def main():
             peak = 2500.0 if a.precision == "bf16" else 157.3
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 5),
                     "traffic": None, "algorithmic_gflop_per_denoise_step": gflop * NC,
-                    "note": f"{NC} clips in flight ({a.mode}): achieved = {gflop} GFLOP x {NC} clips / time in which all of them "
+                    "note": f"{NC} clips in flight ({NL} lane(s) x batch {B}): achieved = {gflop} GFLOP x {NC} clips / time in which all of them "
                             "advance one denoising step; peak = dense MFMA " + ("bf16" if a.precision == "bf16" else "fp32")}
         else:
             achieved = abytes / (us * 1e-6) / 1e9
@@ -285,10 +297,11 @@ def main():
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1000.0 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.precision, "data": "synthetic" + (" (EMULATED ON CPU: test run, not a measurement)" if emu else ""),
-            "config": {"workload": f"1xMI355X per rank, {NC} clip(s) in flight per GPU ({a.mode if NC > 1 else 'batch 1'}), "
+            "config": {"workload": f"1xMI355X per rank, {NC} clip(s) in flight per GPU ({f'{NL} lane(s) x batch {B}' if NC > 1 else 'batch 1'}), "
                                    f"{frames_per_clip}-frame {a.config.upper()} clip ({n_windows} windows x {n_denoise} denoising steps), "
                                    f"{a.sampler.upper()} {a.precision}",
-                       "clips_per_gpu": NC, "mode": a.mode if NC > 1 else "batch1", "frames_nominal_per_clip": frames_per_clip,
+                       "clips_per_gpu": NC, "lanes": NL, "batch_per_lane": B, "mode": a.mode if NC > 1 else "batch1",
+                       "frames_nominal_per_clip": frames_per_clip,
                        "frames_emitted_per_clip": emitted, "denoise_steps_per_window": n_denoise, "parallelism": f"clips x{world}"},
             "value_emitted_frames": round(n_clips * emitted / dt, 2),
             "sample_path": diffusion.last_sample_path(),

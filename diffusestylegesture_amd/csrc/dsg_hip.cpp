@@ -2,6 +2,7 @@
 // conditioning, the per-step launch sequence, hipGraph capture of the step loop, and the sampler entry points.
 // See dsg_kernels.h for the kernels and the reference file:line each one replaces.
 #include "dsg_fused.h"
+#include "dsg_batched.h"
 #include "../../include/dsg.h"
 #include "dsg_aql.h"
 
@@ -156,6 +157,8 @@ struct dsg_handle {
     bool aql_warned = false;
     bool aql_timing = false;             // the last dsg_sample was timed by the host clock around the AQL run
     double aql_ms = 0.0;
+    int gemm_blk = -1;                   // DSG_GEMM_BLK: -1 by batch size (block GEMMs of dsg_batched.h from 512 rows up), 0 never, 1 always
+    int gemm_blk_tnw = 0;                // DSG_GEMM_BLK_TNW: column tiles per wave in k_gemm_blk (0 = by width)
     int gemm_lean = -1;                  // DSG_GEMM_LEAN: -1 by batch size, 0 never, 1 always (LayerNorm GEMMs compiled for 4 waves per SIMD)
     int gemm_tm = 0;                     // DSG_GEMM_TM: row tiles per workgroup in the GEMMs (0 = by batch size)
     int gemm_tnw = 0;                    // DSG_GEMM_TNW: 16-col tiles per wave in the batched GEMMs (0 = by batch size)
@@ -295,6 +298,8 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     if (const char* e = getenv("DSG_GEMM_TNW")) h->gemm_tnw = atoi(e);
     if (const char* e = getenv("DSG_GEMM_TM")) h->gemm_tm = atoi(e);
     if (const char* e = getenv("DSG_GEMM_LEAN")) h->gemm_lean = atoi(e);
+    if (const char* e = getenv("DSG_GEMM_BLK")) h->gemm_blk = atoi(e);
+    if (const char* e = getenv("DSG_GEMM_BLK_TNW")) h->gemm_blk_tnw = atoi(e);
     if (const char* e = getenv("DSG_OVERLAP")) h->overlap = atoi(e) != 0;
     if (const char* e = getenv("DSG_AQL")) h->aql_mode = atoi(e);
     else {
@@ -323,7 +328,8 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
 
     const int B = h->Bmax, D = h->D;
     // row buffers carry one extra padded token block: the fused attention kernel reads Tp rows per batch element
-    const size_t Min_pad = rup(B * h->T, 16) + 16, M_pad = rup(B * ntok, 16) + Tp;
+    // (+64: the block GEMMs of dsg_batched.h read and LayerNorm whole 64-row blocks)
+    const size_t Min_pad = rup(B * h->T, 16) + 16 + 64, M_pad = rup(B * ntok, 16) + Tp + 64;
     CHK(dalloc(h, &h->xs32, (size_t)B * h->T * h->Jp + 16 * h->Jp));
     if (h->prec == DSG_PREC_BF16) CHK(dalloc_bytes(h, &h->xsA, ((size_t)Min_pad * h->Jp) * h->es));
     CHK(dalloc(h, &h->partial, (size_t)h->KSin * Min_pad * D));
@@ -756,8 +762,40 @@ static int pick_tm(const dsg_handle* h, int M) {
     (void)M;
     return h->gemm_tm >= 4 ? 4 : 1;
 }
+// Batched path: 64-row block GEMMs (dsg_batched.h).  From 512 rows up (batch 6 at ZEGGS dims) unless DSG_GEMM_BLK overrides.
+static bool use_blk(const dsg_handle* h, int M) { return h->gemm_blk >= 0 ? h->gemm_blk != 0 : M >= 512; }
+template <class P, int PRO, int EPI>
+static int launch_blk(dsg_handle* h, GemmArgs g) {
+    g.KS = 1; g.kb_per_split = g.KBtot;
+    g.inv_ntok = fastdiv_inv(g.ntok); g.inv_hd = fastdiv_inv(g.hd);
+    const int K = g.KBtot * P::KB;
+    int tnw = h->gemm_blk_tnw > 0 ? h->gemm_blk_tnw : (g.NT >= 64 ? 2 : 1);
+    if (g.NT % (4 * tnw)) tnw = 1;
+    if (g.NT % 4) return fail(DSG_E_INVALID, "gemm: NT not divisible by the workgroup tile");
+    const int extra = EPI == EPI_OUT ? 1 : 0;
+    const dim3 grid(xcd_grid_x(g.NT / (4 * tnw)), cdiv(g.MT, 4) + extra, 1);
+    if (K <= 256) {
+        if (tnw == 2) return step_launch<&k_gemm_blk<P, PRO, EPI, 256, 2>>(h, grid, dim3(256), g);
+        return step_launch<&k_gemm_blk<P, PRO, EPI, 256, 1>>(h, grid, dim3(256), g);
+    }
+    if (K > 512) return fail(DSG_E_NOT_IMPLEMENTED, "k_gemm_blk: K > 512");
+    if (tnw == 2) return step_launch<&k_gemm_blk<P, PRO, EPI, 512, 2>>(h, grid, dim3(256), g);
+    return step_launch<&k_gemm_blk<P, PRO, EPI, 512, 1>>(h, grid, dim3(256), g);
+}
+template <class P, int EPI>
+static int launch_blk_k(dsg_handle* h, GemmArgs g) {
+    if (g.KS <= 1) { g.KS = 1; g.kb_per_split = g.KBtot; }
+    g.inv_ntok = fastdiv_inv(g.ntok); g.inv_hd = fastdiv_inv(g.hd);
+    if (g.NT % 4) return fail(DSG_E_INVALID, "gemm: NT not divisible by the workgroup tile");
+    const int extra = EPI == EPI_PARTIAL ? 1 : 0;
+    return step_launch<&k_gemm_blk_k<P, EPI>>(h, dim3(xcd_grid_x(g.NT / 4), cdiv(g.MT, 4) + extra, g.KS), dim3(256), g);
+}
+
 template <class P, int PRO, int EPI>
 static int launch_gemm_w(dsg_handle* h, const GemmArgs& g) {
+    if constexpr (EPI != EPI_PARTIAL) {
+        if (use_blk(h, g.M) && g.KBtot * P::KB <= 512) return launch_blk<P, PRO, EPI>(h, g);
+    }
     const int tnw = pick_tnw(h, g.NT);
     // the multi-tile shape holds the whole K range in one chunk of 8 k-blocks and stages TM x 16 LayerNorm rows in LDS
     const bool mt_ok = g.KBtot <= 8 && g.KS == 1 && (PRO != PRO_LN || g.D <= (sizeof(typename P::elem) == 2 ? 512 : 256));
@@ -779,7 +817,10 @@ static int launch_gemm_w(dsg_handle* h, const GemmArgs& g) {
 }
 // linear2: K = ff split over the 4 waves of the workgroup
 template <class P>
-static int launch_gemm_k4(dsg_handle* h, const GemmArgs& g) { return launch_gemm<P, PRO_DIRECT, EPI_RESID, 1, 4, 1, 1>(h, g); }
+static int launch_gemm_k4(dsg_handle* h, const GemmArgs& g) {
+    if (use_blk(h, g.M)) return launch_blk_k<P, EPI_RESID>(h, g);
+    return launch_gemm<P, PRO_DIRECT, EPI_RESID, 1, 4, 1, 1>(h, g);
+}
 
 template <class P, int HD, int NKT>
 static int launch_attn_t(dsg_handle* h, const AttnArgs& a) {
@@ -907,7 +948,8 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
             g.A = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; g.lda = h->Jp;
             g.out = h->partial; g.ldo = D;
             g.ctl = c.use_ctr ? h->ctl : nullptr; g.st = step_tables(h); g.n_tab = h->n_run;
-            CHK((launch_gemm<P, PRO_DIRECT, EPI_PARTIAL, 4, 1, 1>(h, g)));
+            if (use_blk(h, g.M)) CHK((launch_blk_k<P, EPI_PARTIAL>(h, g)));
+            else CHK((launch_gemm<P, PRO_DIRECT, EPI_PARTIAL, 4, 1, 1>(h, g)));
         }
         DSG_LOC_DISPATCH(k_loc, la, dim3(h->Hl, T / h->W, B));
     }
@@ -1521,17 +1563,25 @@ extern "C" int dsg_last_sample_path(dsg_handle* h, int* path) {
     return 0;
 }
 
-// the framework's noise stream as a tensor (what the fused sampler consumes for draw index `draw`): out [B, J, 1, T] device
+// the framework's noise stream as a tensor (what the fused sampler consumes for draw index `draw`): out [B, J, 1, T], device
+// memory (written on `stream`) or host memory (generated on the device, copied back, synchronous)
 extern "C" int dsg_noise(float* out, int B, int J, int T, uint64_t seed, uint64_t stream_id, uint32_t draw, void* stream) {
     if (!out || B <= 0 || J <= 0 || T <= 0) return fail(DSG_E_INVALID, "dsg_noise: bad argument");
-    if (!is_device_ptr(out)) return fail(DSG_E_INVALID, "dsg_noise writes a device tensor");
     NoiseKey nk;
     nk.k0 = (unsigned)(seed & 0xffffffffu); nk.k1 = (unsigned)(seed >> 32);
     nk.s0 = (unsigned)(stream_id & 0xffffffffu); nk.s1 = (unsigned)(stream_id >> 32);
     const int Jq = rup(J, 4);
-    const size_t n = (size_t)B * T * (Jq / 4);
-    hipLaunchKernelGGL(k_noise, dim3((int)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, out, B, J, Jq, T, nk, draw);
+    const size_t n = (size_t)B * T * (Jq / 4), bytes = (size_t)B * J * T * sizeof(float);
+    const bool dev = is_device_ptr(out);
+    float* dst = out;
+    if (!dev) HIPCHK(hipMalloc((void**)&dst, bytes));
+    hipLaunchKernelGGL(k_noise, dim3((int)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, dst, B, J, Jq, T, nk, draw);
     HIPCHK(hipGetLastError());
+    if (!dev) {
+        HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+        HIPCHK(hipMemcpy(out, dst, bytes, hipMemcpyDeviceToHost));
+        HIPCHK(hipFree(dst));
+    }
     return 0;
 }
 

@@ -108,34 +108,38 @@ def generate_clip(model, diffusion, feats, style, seed=123456, smoothing=True, s
     return _zeggs_finish(out, S, use_torch)
 
 
-def generate_clips_streams(lanes, diffusion, feats_per_clip, styles, seed=123456, smoothing=True, skip_timesteps=0,
+def generate_clips_streams(lanes, diffusion, feats_per_lane, styles, seed=123456, smoothing=True, skip_timesteps=0,
                            stream_ids=None, ddim=False, eta=0.0):
-    """N clips of one GPU advanced concurrently, ONE CLIP PER LANE ("one clip per stream", BASELINE config[3]): `lanes` are
-    N DSGDenoiser lanes over one copy of the weights (`model.clone()`), lane i samples clip i at batch 1 on its own HSA queue
-    and the library interleaves the lanes' step loops (DSGDiffusion.p_sample_loop_multi).  Same window loop / stitching as
-    `generate_clip`; clip i uses the Philox stream (seed, stream_ids[i]) and is bit-identical to
-    `generate_clip(..., stream_id=stream_ids[i])` run alone.  feats_per_clip[i]: K per-window features [1, T, A_src].
-    Returns [N, K*stride - n_seed, J]."""
+    """Several clips of one GPU advanced concurrently on sampling LANES ("one clip per stream", BASELINE config[3]): `lanes`
+    are N DSGDenoiser lanes over one copy of the weights (`model.clone()`); lane i samples the B clips of
+    feats_per_lane[i] (K per-window features [B, T, A_src]; B = 1: one clip per lane) on its own HSA queue and the library
+    interleaves the lanes' step loops (DSGDiffusion.p_sample_loop_multi).  Same window loop / stitching as `generate_clip`;
+    lane i uses the Philox stream (seed, stream_ids[i]) and is bit-identical to `generate_clip(..., stream_id=stream_ids[i])`
+    run alone.  The command processor serves one queue per compute pipe: up to 4 lanes overlap, more than 4 share pipes and
+    block each other (measured: 4 lanes 2.7x one lane, 8 lanes slower than one) -- put the remaining clips into the lanes'
+    batches.  Returns [N * B, K*stride - n_seed, J], lane-major."""
     n = len(lanes)
     cfg = lanes[0].cfg
     S, T, J = cfg.n_seed, cfg.n_poses, cfg.njoints
-    K = len(feats_per_clip[0])
-    if any(len(f) != K for f in feats_per_clip) or len(feats_per_clip) != n:
+    K = len(feats_per_lane[0])
+    if any(len(f) != K for f in feats_per_lane) or len(feats_per_lane) != n:
         raise ValueError("one feature list per lane, the same number of windows each")
-    use_torch = L.is_torch(feats_per_clip[0][0])
+    use_torch = L.is_torch(feats_per_lane[0][0])
+    B = int(feats_per_lane[0][0].shape[0])
     stream_ids = list(range(n)) if stream_ids is None else list(stream_ids)
     diffusion.manual_seed(seed, 0)
-    shape = (1, J, 1, T)
-    dev = feats_per_clip[0][0].device if use_torch else None
+    shape = (B, J, 1, T)
+    dev = feats_per_lane[0][0].device if use_torch else None
     if use_torch:
         import torch
         mask = torch.ones(1, T, dtype=torch.bool, device=dev)
     else:
         mask = np.ones((1, T), bool)
-    stys = [_style_batch(styles[i] if np.asarray(styles).ndim == 2 else styles, 1, use_torch, dev) for i in range(n)]
+    per_lane_style = np.asarray(styles).ndim == 2 and len(styles) == n and np.asarray(styles).shape[0] == n and B == 1
+    stys = [_style_batch(styles[i] if per_lane_style else styles, B, use_torch, dev) for i in range(n)]
     outs = [[] for _ in range(n)]
     for c in range(K):
-        ys = [{"y": _zeggs_window_y(cfg, feats_per_clip[i][c], stys[i], outs[i][-1] if outs[i] else None, None, use_torch, mask)}
+        ys = [{"y": _zeggs_window_y(cfg, feats_per_lane[i][c], stys[i], outs[i][-1] if outs[i] else None, None, use_torch, mask)}
               for i in range(n)]
         ss = diffusion.p_sample_loop_multi(list(lanes), shape, ys, seeds=[seed] * n, stream_ids=stream_ids,
                                            skip_timesteps=skip_timesteps, ddim=ddim, eta=eta)

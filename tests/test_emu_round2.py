@@ -160,3 +160,46 @@ def test_attention3_beat_twh_tree(emu_lib, golden_dir, cfgname):
         m = _model(cfg, prec, emu_lib, wseed=int(g["wseed"]))
         assert rel_l2(m(x, np.array([ts] * B), y), g[cfgname + "_out"]) < TOL[prec]
         assert rel_l2(m(x, np.array([ts] * B), y, uncond_info=True), g[cfgname + "_uncond"]) < TOL[prec]
+
+
+@pytest.mark.parametrize("tnw", ["1", "2"])
+def test_block_gemms_of_the_batched_path(emu_lib, golden_dir, monkeypatch, tnw):
+    """dsg_batched.h (64-row block GEMMs, used from 512 rows up) forced on at the small test dims (DSG_GEMM_BLK=1, un-fused
+    kernel set): forward with masks / uncond, DDPM + DDIM chains, guidance, the DSG+ / DSG++ models, and ZEGGS dims at batch 2
+    -- against the same reference goldens as the latency kernels"""
+    monkeypatch.setenv("DSG_GEMM_BLK", "1")
+    monkeypatch.setenv("DSG_GEMM_BLK_TNW", tnw)
+    gt = _g(golden_dir, "gt_tiny_zeggs.npz")
+    cfg = C.TINY
+    y = synth_window_inputs(cfg, 2, window=2, seed_pose_scale=0.3)
+    x = np.random.RandomState(99).randn(2, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+    ts = np.array([998, 17])
+    shape = (2, cfg.njoints, 1, cfg.n_poses)
+    for prec in ("fp32", "bf16"):
+        m = _model(cfg, prec, emu_lib, max_batch=4, wseed=int(gt["wseed"]), latency_mode="off")
+        assert rel_l2(m(x, ts, y), gt["fwd_allones"]) < TOL[prec]
+        assert rel_l2(m(x, ts, dict(y, mask_local=gt["mask2"])), gt["fwd_mask2"]) < TOL[prec]
+        assert rel_l2(m(x, ts, y, uncond_info=True), gt["fwd_uncond"]) < TOL[prec]
+        d = create_gaussian_diffusion(library=emu_lib)
+        s = d.manual_seed(77, 3).p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=990)
+        assert rel_l2(s, gt["ddpm_skip990"]) < 3 * TOL[prec]
+        d50 = create_gaussian_diffusion("ddim50", library=emu_lib)
+        s = d50.manual_seed(77, 9).ddim_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, eta=1.0, skip_timesteps=40)
+        assert rel_l2(s, gt["ddim50_eta1_skip40"]) < 3 * TOL[prec]
+        sc = np.array([2.5, 0.5], np.float32)
+        want = gt["fwd_uncond"] + sc.reshape(-1, 1, 1, 1) * (gt["fwd_allones"] - gt["fwd_uncond"])
+        assert rel_l2(ClassifierFreeSampleModel(m)(x, ts, dict(y, scale=sc)), want) < 3 * TOL[prec]
+    g5, g10 = _g(golden_dir, "g5_forward_dsgplus.npz"), _g(golden_dir, "g10_forward_dsgpp.npz")
+    for cfg, gold in ((C.TINY4, g5["tiny4_out"]), (C.TINY5, g10["tiny5_out"])):
+        yy = synth_window_inputs(cfg, 2, window=3, seed_pose_scale=0.1)
+        xx = np.random.RandomState(33).randn(2, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+        m = _model(cfg, "fp32", emu_lib, wseed=int(g5["wseed"]), latency_mode="off")
+        assert rel_l2(m(xx, np.array([500, 500]), yy), gold) < TOL["fp32"]
+    if tnw == "2":
+        g2 = _g(golden_dir, "g2_forward_zeggs.npz")
+        cfg = C.ZEGGS
+        for prec in ("fp32", "bf16"):
+            mz = _model(cfg, prec, emu_lib, wseed=int(g2["wseed"]), latency_mode="off")
+            yz = synth_window_inputs(cfg, 2, window=1, seed_pose_scale=0.5)
+            xz = np.random.RandomState(4244).randn(2, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+            assert rel_l2(mz(xz, np.array([999, 3]), yz), g2["b2_t999_3_out"]) < TOL[prec]

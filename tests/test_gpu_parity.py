@@ -293,9 +293,10 @@ def test_throughput_kernel_set_vs_reference(gpu, golden_dir, prec):
     assert rel_l2(s, g3["ddpm25"]) < TOL_CHAIN[prec]
 
 
-def test_batch16_consistency(gpu):
+def test_batch16_consistency(gpu, monkeypatch):
     """B = 16 identical clips with shared noise: all 16 results are bit-identical (rows are independent), and they agree
-    with the B = 1 run (a different kernel set: latency mode) to rounding-order level."""
+    with the B = 1 run (a different kernel set: latency mode) to rounding-order level.  From 512 rows up the batched path
+    uses the 64-row block GEMMs (dsg_batched.h); forced on at batch 1 they must reproduce the batch-16 rows bit for bit."""
     from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
     from oracle import philox
     cfg = C.ZEGGS
@@ -313,11 +314,16 @@ def test_batch16_consistency(gpu):
     for b in range(1, B):
         assert np.array_equal(sB[b], sB[0]), f"batch element {b} differs"
     assert rel_l2(sB[0], s1[0]) < 1e-2
-    m1 = _model(cfg, "bf16", max_batch=1, latency_mode="off")
-    d.manual_seed(3, 0)
-    s1_off = d.p_sample_loop(m1, (1, cfg.njoints, 1, cfg.n_poses), noise=x1, clip_denoised=False,
-                             model_kwargs={"y": y1}, skip_timesteps=960, const_noise=True)
-    assert np.array_equal(sB[0], s1_off[0]), "same kernel set must be bit-identical across batch sizes"
+    for blk, exact in (("1", True), ("0", False)):
+        monkeypatch.setenv("DSG_GEMM_BLK", blk)
+        m1 = _model(cfg, "bf16", max_batch=1, latency_mode="off")
+        d.manual_seed(3, 0)
+        s1_off = d.p_sample_loop(m1, (1, cfg.njoints, 1, cfg.n_poses), noise=x1, clip_denoised=False,
+                                 model_kwargs={"y": y1}, skip_timesteps=960, const_noise=True)
+        if exact:
+            assert np.array_equal(sB[0], s1_off[0]), "same kernel set must be bit-identical across batch sizes"
+        else:
+            assert rel_l2(sB[0], s1_off[0]) < 1e-2      # 16 x 16 tile kernels: other k order of the split-K sums
 
 
 def test_clip_vs_reference_inference(gpu, golden_dir):
