@@ -63,12 +63,17 @@ __device__ __forceinline__ void ln_rows_blk(const GemmArgs& g, int m0, int tid, 
     }
 }
 
-// DMAX: widest row (= K) the LDS block is sized for (256 or 512); TNW: 16-column tiles per wave (1 or 2)
-template <class P, int PRO, int EPI, int DMAX, int TNW>
+// DMAX: widest row (= K) the LDS block is sized for (256 or 512); TNW: 16-column tiles per wave (1 or 2); RT: 16-row tiles
+// per workgroup (2 or 4).  Everything a workgroup needs from memory -- weight fragments, the A rows, the epilogue operands of
+// all its tiles (bias, residual rows, x_t, noise) -- is requested before the first dependent instruction: one memory round
+// trip per workgroup, like the latency kernels (a first version that fetched the epilogue operands tile by tile after the
+// MFMA loop was SLOWER than the 16 x 16 tile kernels: 407 vs 321 us per batch-16 step, profiles/r02_b_*).
+template <class P, int PRO, int EPI, int DMAX, int TNW, int RT>
 __global__ __launch_bounds__(256) void k_gemm_blk(const GemmArgs g) {
     typedef typename P::elem elem;
-    constexpr int ES = (int)sizeof(elem), RT = 4, BM = 64, CH = 8;
+    constexpr int ES = (int)sizeof(elem), BM = 16 * RT, CH = 8;
     static_assert(EPI != EPI_PARTIAL, "split-K partials come from k_gemm_blk_k");
+    static_assert(RT == 2 || RT == 4, "32- or 64-row blocks");
     __shared__ __attribute__((aligned(16))) char lds_a[BM * (DMAX * ES + 16)];
     preload_kernargs(g);
     const int NG = g.NT / (4 * TNW);
@@ -108,20 +113,26 @@ __global__ __launch_bounds__(256) void k_gemm_blk(const GemmArgs g) {
             k1 = g.ctl->k1; k2 = g.ctl->k2; k3 = g.ctl->k3; k4 = g.ctl->k4; k5 = g.ctl->k5;
         }
     }
-    // ---- stage the 64 A rows in LDS (row-major, padded pitch: conflict-free fragment reads)
+    // ---- epilogue operands of every tile of this wave (they do not depend on the main loop)
+    TileOps ops[RT][TNW];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int t = 0; t < TNW; ++t) gemm_prefetch_tile<P, EPI>(g, min(m0 + rt * 16, (g.MT - 1) * 16), (nt0 + t) * 16, lr, lg, step, ops[rt][t]);
+    // ---- stage the A rows in LDS (row-major, padded pitch: conflict-free fragment reads)
     const int K = KBtot * P::KB;
     const int pitch = K * ES + 16;
     if constexpr (PRO == PRO_LN) {
         const bool wr = g.Xn != nullptr && ng == 0;
         const int nch = g.D >> 6;
         if constexpr (DMAX <= 256) {       // one straight-line copy per row width the instantiation can see
-            if (nch == 4) ln_rows_blk<P, 4, 4>(g, m0, tid, lds_a, pitch, wr);
-            else if (nch == 2) ln_rows_blk<P, 2, 4>(g, m0, tid, lds_a, pitch, wr);
-            else if (nch == 3) ln_rows_blk<P, 3, 4>(g, m0, tid, lds_a, pitch, wr);
-            else ln_rows_blk<P, 1, 4>(g, m0, tid, lds_a, pitch, wr);
+            if (nch == 4) ln_rows_blk<P, 4, RT>(g, m0, tid, lds_a, pitch, wr);
+            else if (nch == 2) ln_rows_blk<P, 2, RT>(g, m0, tid, lds_a, pitch, wr);
+            else if (nch == 3) ln_rows_blk<P, 3, RT>(g, m0, tid, lds_a, pitch, wr);
+            else ln_rows_blk<P, 1, RT>(g, m0, tid, lds_a, pitch, wr);
         } else {
 #pragma unroll 1
-            for (int half = 0; half < 2; ++half) {
+            for (int half = 0; half < RT / 2; ++half) {
                 if (nch == 8) ln_rows_blk<P, 8, 2>(g, m0 + 32 * half, tid, lds_a + 32 * half * pitch, pitch, wr);
                 else if (nch == 6) ln_rows_blk<P, 6, 2>(g, m0 + 32 * half, tid, lds_a + 32 * half * pitch, pitch, wr);
                 else if (nch == 5) ln_rows_blk<P, 5, 2>(g, m0 + 32 * half, tid, lds_a + 32 * half * pitch, pitch, wr);
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(256) void k_gemm_blk(const GemmArgs g) {
         }
     }
     DSG_LDS_BARRIER();
-    // ---- main loop: one weight fragment (per column tile) feeds the 4 row tiles
+    // ---- main loop: one weight fragment (per column tile) feeds the RT row tiles
     f32x4 acc[RT][TNW];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -184,27 +195,30 @@ __global__ __launch_bounds__(256) void k_gemm_blk(const GemmArgs g) {
         }
         if (kb0 + CH < KBtot) load_b(kb0 + CH);
     }
-    // ---- epilogue, tile by tile (operands fetched per tile: the block is throughput-, not latency-bound)
+    // ---- epilogue
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         const int mt = m0 + rt * 16;
         if (mt >= g.MT * 16) continue;                      // wave-uniform: row tiles past the end of the batch
 #pragma unroll
-        for (int t = 0; t < TNW; ++t) {
-            TileOps o;
-            gemm_prefetch_tile<P, EPI>(g, mt, (nt0 + t) * 16, lr, lg, step, o);
-            gemm_epilogue_tile<P, EPI>(g, mt, (nt0 + t) * 16, lr, lg, 0, swapped[t], acc[rt][t], o, k1, k2, k3, k4, k5);
-        }
+        for (int t = 0; t < TNW; ++t)
+            gemm_epilogue_tile<P, EPI>(g, mt, (nt0 + t) * 16, lr, lg, 0, swapped[t], acc[rt][t], ops[rt][t], k1, k2, k3, k4, k5);
     }
 }
 
-// Large-K block GEMM: the 4 waves split the k-blocks of this workgroup's K range (blockIdx.z of g.KS splits, EPI_PARTIAL)
-template <class P, int EPI>
+// Large-K block GEMM (linear2: K = ff; pose embedding: K = J): a 32 x 32 output block per workgroup, the 4 waves split
+// the k-blocks of the workgroup's K range (blockIdx.z of g.KS splits for EPI_PARTIAL) and every wave requests ALL fragments
+// of its share -- 2 A + 2 B per k-block, up to KPW k-blocks -- before its first MFMA: a round trip to data another XCD
+// produced costs 1.5-2 us at these sizes, so the kernel makes exactly one (a first version with 64 x 64 blocks that streamed
+// its K range in four chunks took 10 us for linear2 against 7.8 us for the 16 x 16 tile kernel; profiles/r02_c_*).  Each
+// fragment pair feeds 4 MFMAs (the 16 x 16 kernel: 1), halving the bytes pulled through L2 per output.  The 4 partial blocks
+// are reduced through LDS in a fixed order; wave w finishes tile (w >> 1, w & 1).
+template <class P, int EPI, int KPW>
 __global__ __launch_bounds__(256) void k_gemm_blk_k(const GemmArgs g) {
     typedef typename P::elem elem;
-    constexpr int RT = 4, CT = 4, BM = 64, CH = 2;
+    constexpr int RT = 2, CT = 2;
     static_assert(EPI == EPI_RESID || EPI == EPI_PARTIAL, "direct A operand, fp32 output");
-    __shared__ __attribute__((aligned(16))) float red[4][RT * CT][64][4];      // 64 KB: every wave's partial 64 x 64 block
+    __shared__ __attribute__((aligned(16))) float red[4][RT * CT][64][4];      // every wave's partial 32 x 32 block
     preload_kernargs(g);
     const int NG = g.NT / CT;
     const int ng = xcd_ngroup(), mb = blockIdx.y, ks = blockIdx.z;
@@ -217,17 +231,25 @@ __global__ __launch_bounds__(256) void k_gemm_blk_k(const GemmArgs g) {
     }
     if (ng >= NG || mb >= MB) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
-    const int m0 = mb * BM, nt0 = ng * CT;
+    const int m0 = mb * 16 * RT, nt0 = ng * CT;
     const int KBtot = g.KBtot, kb_last = KBtot - 1;
     const int kb_lo_wg = ks * g.kb_per_split, kb_hi_wg = min(kb_lo_wg + g.kb_per_split, KBtot);
     const int per = (kb_hi_wg - kb_lo_wg + 3) >> 2;
     const int kb_lo = min(kb_lo_wg + wave * per, kb_hi_wg), kb_hi = min(kb_lo + per, kb_hi_wg);
     const f32x4* wbase = (const f32x4*)g.Wp + lane;
     const int mt_last = g.MT - 1;
-    f32x4 af[CH][RT], bf[CH][CT];
-    auto load = [&](int kb0) {
+    f32x4 acc[RT][CT];
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int t = 0; t < CT; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // this wave finishes tile (wave >> 1, wave & 1): its bias / residual operands travel with the fragments
+    TileOps ops;
+    gemm_prefetch_tile<P, EPI>(g, min(m0 + (wave >> 1) * 16, mt_last * 16), (nt0 + (wave & 1)) * 16, lr, lg, 0, ops);
+    for (int kb0 = kb_lo; kb0 < kb_hi; kb0 += KPW) {       // one pass when the wave's share fits (the sizes of the path)
+        f32x4 af[KPW][RT], bf[KPW][CT];
+#pragma unroll
+        for (int c = 0; c < KPW; ++c) {
             const int kb = min(kb0 + c, kb_last);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
@@ -239,52 +261,31 @@ __global__ __launch_bounds__(256) void k_gemm_blk_k(const GemmArgs g) {
 #pragma unroll
             for (int t = 0; t < CT; ++t) bf[c][t] = wbase[((size_t)(nt0 + t) * KBtot + kb) * 64];
         }
-    };
-    f32x4 acc[RT][CT];
+        DSG_LOADS_ISSUED();
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int t = 0; t < CT; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    load(kb_lo);
-    for (int kb0 = kb_lo; kb0 < kb_hi; kb0 += CH) {
-        f32x4 a2[CH][RT], b2[CH][CT];
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) a2[c][rt] = af[c][rt];
-#pragma unroll
-            for (int t = 0; t < CT; ++t) b2[c][t] = bf[c][t];
-        }
-        if (kb0 + CH < kb_hi) load(kb0 + CH);               // next chunk in flight under this chunk's MFMAs
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
+        for (int c = 0; c < KPW; ++c) {
             const bool live = kb0 + c < kb_hi;
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                const f32x4 a = live ? a2[c][rt] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                const f32x4 a = live ? af[c][rt] : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int t = 0; t < CT; ++t) acc[rt][t] = P::mma(b2[c][t], a, acc[rt][t]);      // D[col 4lg+r][row lr]
+                for (int t = 0; t < CT; ++t) acc[rt][t] = P::mma(bf[c][t], a, acc[rt][t]);      // D[col 4lg+r][row lr]
             }
         }
     }
-    // ---- reduce the 4 K ranges through LDS in a fixed order; wave w finishes row tile w
+    // ---- reduce the 4 K ranges through LDS in a fixed order
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int t = 0; t < CT; ++t) *(f32x4*)&red[wave][rt * CT + t][lane][0] = acc[rt][t];
     DSG_LDS_BARRIER();
-    const int rt = wave;
+    const int rt = wave >> 1, t = wave & 1;
     const int mt = m0 + rt * 16;
     if (mt >= g.MT * 16) return;
+    f32x4 sum = *(const f32x4*)&red[0][rt * CT + t][lane][0];
 #pragma unroll
-    for (int t = 0; t < CT; ++t) {
-        f32x4 sum = *(const f32x4*)&red[0][rt * CT + t][lane][0];
-#pragma unroll
-        for (int w2 = 1; w2 < 4; ++w2) sum += *(const f32x4*)&red[w2][rt * CT + t][lane][0];
-        TileOps o;
-        gemm_prefetch_tile<P, EPI>(g, mt, (nt0 + t) * 16, lr, lg, 0, o);
-        gemm_epilogue_tile<P, EPI>(g, mt, (nt0 + t) * 16, lr, lg, ks, true, sum, o, 0.f, 0.f, 0.f, 0.f, 0.f);
-    }
+    for (int w2 = 1; w2 < 4; ++w2) sum += *(const f32x4*)&red[w2][rt * CT + t][lane][0];
+    gemm_epilogue_tile<P, EPI>(g, mt, (nt0 + t) * 16, lr, lg, ks, true, sum, ops, 0.f, 0.f, 0.f, 0.f, 0.f);
 }
 
 }  // namespace dsg

@@ -780,4 +780,119 @@ __global__ __launch_bounds__(256) void k_attn_mid(const AttnMidArgs ga) {
     DSG_STAMP(0, 7);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Embedded-space state (batch <= 2 sampling loop).  The denoiser only ever sees x_t through the pose embedding
+// E(x_t) = Wfold . x_t (Wfold = input_process2[:, D:2D] . poseEmbedding, [D x J]), and the sampler update is linear in
+// (x0, x_t, z):  x_{t-1} = a x0 + b x_t + c z  (DDPM: posterior mean + sigma z, gaussian_diffusion.py:264-267, :557; DDIM:
+// :773-791 rearranged).  So the loop carries E(x_t) [T x D] instead of x_t [T x J]:
+//     E(x_{t-1}) = a (W_io . h + b_io) + b E(x_t) + c E(z),      W_io = Wfold . W_out [D x D],  b_io = Wfold . b_out
+// which takes both J-wide GEMMs off the critical path of a step: the pose embedding (K = J = 1141) disappears from the first
+// kernel of the step (k_loc_e = the local-attention kernel reading E(x_t) directly) and the pose head shrinks from N = J to
+// N = D (EPI_ESTEP).  E(z) = Wfold . z needs a K = J GEMM on fresh noise every step, but depends on nothing: k_enoise runs
+// beside the step's first kernel (AQL packet without the barrier bit) on CUs that kernel leaves idle.  The last step of DDPM /
+// DDIM has a = 1, b = c = 0, i.e. x_0 = W_out . h + b_out: one ordinary pose-head launch after the loop produces the sample.
+// Rounding: identical operands to the reference order except that x_t is never rounded to the GEMM type (its embedding is
+// carried in fp32) and W_io is rounded once -- fp32 mode agrees with the pose-space loop to ~1e-6, bf16 mode stays within the
+// stated 3e-2 (tests/test_gpu_parity.py run both against the same goldens).  Not used with dump_steps, replayed noise,
+// const_noise, clip_denoised (non-linear in x0) or guidance: those take the pose-space loop.
+// ---------------------------------------------------------------------------------------------------------
+struct LocEArgs {
+    LocArgs loc;            // partial = E(x_t) rows, KS = 1
+    StepCtl* ctl_upd;       // first kernel of a step: an extra grid slice advances the B side of the step control
+    StepTables st; int n_tab;
+};
+template <class P, int HD, int W>
+__global__ __launch_bounds__(256) void k_loc_e(const LocEArgs g) {
+    preload_kernargs(g);
+    if (blockIdx.z == gridDim.z - 1) {
+        if (g.ctl_upd && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) step_advance_B(g.ctl_upd, g.st, g.n_tab);
+        return;
+    }
+    loc_body<P, HD, W>(g.loc, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// E(z) partial sums: workgroup (ks, mt) = 16 frames x one K range of the noise; all D output columns.  The noise of the range
+// is generated ONCE (Philox, the draw the pose-space epilogue would use for this step), staged in LDS in the GEMM element
+// type, and multiplied with the Wfold fragments, which were requested before the first Philox round.
+struct ENoiseArgs {
+    const void* Wp;         // packed Wfold [D/16][KBtot][64][16 B]
+    int KBtot, kb_per_split, KS;
+    float* ez;              // [KS][ez_rows][D]
+    int ez_rows;
+    const StepCtl* ctl;     // step index = ctl->stepA (stable for the whole step)
+    const unsigned* dyn;    // {seed lo, seed hi, stream lo, stream hi, draw index of step 0}
+    int B, T, J, Jq, D;
+};
+template <class P, int DT>      // DT = D / 64: 16-column tiles per wave
+__global__ __launch_bounds__(256) void k_enoise(const ENoiseArgs g) {
+    typedef typename P::elem elem;
+    constexpr int ES = (int)sizeof(elem), KMAX = 12;          // k-blocks per split the fragment registers are sized for
+    __shared__ __attribute__((aligned(16))) char za[16 * (KMAX * P::KB * ES + 16)];
+    preload_kernargs(g);
+    const int ks = blockIdx.x, mt = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
+    const int kb_lo = ks * g.kb_per_split, nkb = min(g.kb_per_split, g.KBtot - kb_lo);
+    const int kb_last = g.KBtot - 1;
+    const f32x4* wbase = (const f32x4*)g.Wp + lane;
+    // ---- Wfold fragments of this wave's column tiles for the whole K range: in flight during the Philox rounds
+    constexpr int CHK = DT >= 6 ? 2 : (DT >= 4 ? 3 : 6);      // k-blocks per pass (register budget: CHK * DT fragments)
+    f32x4 bf[CHK][DT];
+    auto load_b = [&](int c0) {
+#pragma unroll
+        for (int c = 0; c < CHK; ++c) {
+            const int kb = min(kb_lo + c0 + c, kb_last);
+#pragma unroll
+            for (int t = 0; t < DT; ++t) bf[c][t] = wbase[((size_t)(wave * DT + t) * g.KBtot + kb) * 64];
+        }
+    };
+    load_b(0);
+    const int step = g.ctl->stepA;
+    const NoiseKey nk = {g.dyn[0], g.dyn[1], g.dyn[2], g.dyn[3]};
+    const unsigned draw = g.dyn[4] + (unsigned)step;
+    // ---- noise of 16 frames x this K range -> LDS
+    const int pitch = nkb * P::KB * ES + 16;
+    const int qpr = nkb * P::KB / 4;                          // quads per row
+    for (int e = tid; e < 16 * qpr; e += 256) {
+        const int r = e / qpr, qi = e - r * qpr;
+        const int m = mt * 16 + r, j0 = kb_lo * P::KB + 4 * qi;
+        f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (m < g.B * g.T && j0 < g.J) {
+            z = philox_normal4((unsigned)(((size_t)m * g.Jq + j0) >> 2), draw, nk);      // m = b * T + f
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (j0 + q >= g.J) z[q] = 0.f;
+        }
+        P::store4((elem*)(za + r * pitch) + 4 * qi, z);
+    }
+    DSG_LDS_BARRIER();
+    f32x4 acc[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < nkb; c0 += CHK) {
+#pragma unroll
+        for (int c = 0; c < CHK; ++c) {
+            const bool live = c0 + c < nkb;
+            f32x4 a = *(const f32x4*)(za + lr * pitch + (min(c0 + c, nkb - 1) * P::KB + P::E * lg) * ES);
+            a = live ? a : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < DT; ++t) acc[t] = P::mma(bf[c][t], a, acc[t]);      // D[col 4lg+r][row lr]
+        }
+        if (c0 + CHK < nkb) load_b(c0 + CHK);
+    }
+    const int m = mt * 16 + lr;
+    if (m < g.B * g.T) {
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+            *(f32x4*)(g.ez + ((size_t)ks * g.ez_rows + m) * g.D + (wave * DT + t) * 16 + 4 * lg) = acc[t];
+    }
+}
+
+// once per window: E(x_T) = sum of the split-K partials of the pose-embedding GEMM
+__global__ void k_sum_partials(float* out, const float* partial, int KS, size_t stride, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int s2 = 0; s2 < KS; ++s2) v += partial[(size_t)s2 * stride + i];
+        out[i] = v;
+    }
+}
+
 }  // namespace dsg

@@ -136,6 +136,11 @@ struct dsg_handle {
     unsigned char* mask = nullptr; int mb = 1; int nomask = 0;
     // classifier-free guidance (dsg_set_window_cond_cfg): cfgB user batch elements + their unconditional twins = condB rows
     int cfgB = 0; float* cfg_scale = nullptr;
+    // embedded-space state (dsg_fused.h): E(x_t), E(z) partial sums, W_io = Wfold . W_out, b_io = Wfold . b_out
+    float *epose = nullptr, *ez = nullptr, *b_io = nullptr; void* W_io = nullptr;
+    int ez_ks = 0, ez_rows = 0;
+    int ecarry = -1;                     // DSG_ECARRY: -1 auto (on in the latency kernel set), 0 off
+    bool emode = false;                  // the current dsg_sample runs the embedded-space loop
     int last_path = -1;                  // submission path of the last dsg_sample: 0 HIP launches, 1 AQL packets, 2 hipGraph replay
     bool dbg_warned = false;
     // state / activations
@@ -158,7 +163,12 @@ struct dsg_handle {
     bool aql_timing = false;             // the last dsg_sample was timed by the host clock around the AQL run
     double aql_ms = 0.0;
     int gemm_blk = -1;                   // DSG_GEMM_BLK: -1 by batch size (block GEMMs of dsg_batched.h from 512 rows up), 0 never, 1 always
-    int gemm_blk_tnw = 0;                // DSG_GEMM_BLK_TNW: column tiles per wave in k_gemm_blk (0 = by width)
+    int gemm_blk_tnw = 0;                // DSG_GEMM_BLK_TNW: column tiles per wave in k_gemm_blk (default 1)
+    int gemm_blk_rt = 0;                 // DSG_GEMM_BLK_RT: 16-row tiles per workgroup in k_gemm_blk: 2 (default) or 4
+    int gemm_blk_mask = 1 | 4 | 32;      // DSG_GEMM_BLK_MASK: which GEMMs of the batched step use the block kernels: 1 QKV, 2 out_proj,
+                                         // 4 linear1, 8 linear2, 16 pose head, 32 pose embedding.  Measured per GEMM in the real
+                                         // batch-16 step (profiles/r02_c_blk_sweep.log): QKV -13 us, linear1 -7, embedding -9.5 per
+                                         // step; out_proj +4 and the pose head +3.5 (few, long workgroups) stay on the 16 x 16 kernels
     int gemm_lean = -1;                  // DSG_GEMM_LEAN: -1 by batch size, 0 never, 1 always (LayerNorm GEMMs compiled for 4 waves per SIMD)
     int gemm_tm = 0;                     // DSG_GEMM_TM: row tiles per workgroup in the GEMMs (0 = by batch size)
     int gemm_tnw = 0;                    // DSG_GEMM_TNW: 16-col tiles per wave in the batched GEMMs (0 = by batch size)
@@ -298,8 +308,11 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     if (const char* e = getenv("DSG_GEMM_TNW")) h->gemm_tnw = atoi(e);
     if (const char* e = getenv("DSG_GEMM_TM")) h->gemm_tm = atoi(e);
     if (const char* e = getenv("DSG_GEMM_LEAN")) h->gemm_lean = atoi(e);
+    if (const char* e = getenv("DSG_ECARRY")) h->ecarry = atoi(e);
     if (const char* e = getenv("DSG_GEMM_BLK")) h->gemm_blk = atoi(e);
     if (const char* e = getenv("DSG_GEMM_BLK_TNW")) h->gemm_blk_tnw = atoi(e);
+    if (const char* e = getenv("DSG_GEMM_BLK_RT")) h->gemm_blk_rt = atoi(e);
+    if (const char* e = getenv("DSG_GEMM_BLK_MASK")) h->gemm_blk_mask = atoi(e);
     if (const char* e = getenv("DSG_OVERLAP")) h->overlap = atoi(e) != 0;
     if (const char* e = getenv("DSG_AQL")) h->aql_mode = atoi(e);
     else {
@@ -361,6 +374,9 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     CHK(dalloc(h, &h->ctl, 1));
     CHK(dalloc(h, &h->dep_ctr, 64));
     CHK(dalloc(h, &h->cfg_scale, (size_t)B));
+    h->ez_ks = DSG_EZ_MAXKS; h->ez_rows = (int)Min_pad;
+    CHK(dalloc(h, &h->epose, Min_pad * D));
+    CHK(dalloc(h, &h->ez, (size_t)h->ez_ks * Min_pad * D));
     CHK(dalloc(h, &h->dyn, 8));
     CHK(dalloc(h, &h->t_arr, (size_t)B));
     // the xs32 master is read as a GEMM operand in fp32 mode: rows padded to a 16-row tile exist (allocated above)
@@ -400,7 +416,7 @@ extern "C" int dsg_clone(dsg_handle* src, int max_batch, dsg_handle** out) {
     h->raw = src->raw;
     h->Wp_in = src->Wp_in; h->Wp_out = src->Wp_out; h->b_out = src->b_out; h->layers = src->layers;
     h->TE = src->TE; h->TE2 = src->TE2; h->rcos = src->rcos; h->rsin = src->rsin; h->cbase = src->cbase;
-    h->zero_bias = src->zero_bias;
+    h->zero_bias = src->zero_bias; h->W_io = src->W_io; h->b_io = src->b_io;
     h->finalized = true;
     *out = h;
     return 0;
@@ -514,6 +530,14 @@ static int finalize_weights(dsg_handle* h) {
     CHK(launch_mm(h, h->cbase, D, R("input_process.poseEmbedding.bias"), 0, 1, W2 + D, W2ld, 1,
                   R("input_process2.bias"), nullptr, 0, 1, 1, D, D, 0));
     CHK(pack(h, &h->Wp_in, Wfold, J, D, J, D, h->Jp));
+    {   // embedded-space state: W_io[d][k] = sum_j Wfold[d][j] W_out[j][k],  b_io[d] = sum_j Wfold[d][j] b_out[j]
+        float* Wio = nullptr;
+        CHK(dalloc(h, &Wio, (size_t)D * D));
+        CHK(launch_mm(h, Wio, D, Wfold, J, 1, R("output_process.poseFinal.weight"), 1, D, nullptr, nullptr, 0, 1, D, D, J, 0));
+        CHK(pack(h, &h->W_io, Wio, D, D, D, D, D));
+        CHK(dalloc(h, &h->b_io, (size_t)D));
+        CHK(launch_mm(h, h->b_io, D, R("output_process.poseFinal.bias"), 0, 1, Wfold, J, 1, nullptr, nullptr, 0, 1, 1, D, J, 0));
+    }
     CHK(dalloc(h, &h->zero_bias, (size_t)std::max(D, h->Jp)));
     for (int i = 0; i < L; ++i) {
         const std::string p = "seqTransEncoder.layers." + std::to_string(i) + ".";
@@ -711,6 +735,8 @@ struct StepCtx {
     int B;                  // batch rows the kernels run on (with guidance: conditional elements + their twins)
     int out_mode; bool use_ctr; const float* ext_noise; int const_noise;
     int clip_x0 = 0;        // clip_denoised=True
+    bool emode = false;     // embedded-space state (dsg_fused.h): k_loc_e + k_enoise ... EPI_ESTEP instead of k_inloc ... EPI_OUT
+    bool only_head = false; // just the pose head on the final-layer rows already in place (the sample after an embedded-space loop)
 };
 
 // Every kernel of the denoising step goes through here: a HIP launch on the handle's stream, or -- while dsg_sample is
@@ -741,7 +767,7 @@ static int launch_gemm(dsg_handle* h, GemmArgs g) {
     if (WK > 1 && (g.KS != 1 || g.KBtot % WK)) return fail(DSG_E_INVALID, "gemm: k-blocks not divisible by the wave split");
     if (g.KS < 1 || g.kb_per_split * g.KS < g.KBtot) return fail(DSG_E_INVALID, "gemm: split-K does not cover K");
     // EPI_PARTIAL / EPI_OUT carry one extra grid row whose first workgroup does the step bookkeeping
-    const int extra = (EPI == EPI_PARTIAL || EPI == EPI_OUT) ? 1 : 0;
+    const int extra = (EPI == EPI_PARTIAL || EPI == EPI_OUT || EPI == EPI_ESTEP) ? 1 : 0;
     g.inv_ntok = fastdiv_inv(g.ntok); g.inv_hd = fastdiv_inv(g.hd);
     return step_launch<&k_gemm<P, PRO, EPI, WN, WK, TNW, TM>>(h, dim3(xcd_grid_x(NG), cdiv(g.MT, TM) + extra, g.KS), dim3(256), g);
 }
@@ -763,38 +789,51 @@ static int pick_tm(const dsg_handle* h, int M) {
     return h->gemm_tm >= 4 ? 4 : 1;
 }
 // Batched path: 64-row block GEMMs (dsg_batched.h).  From 512 rows up (batch 6 at ZEGGS dims) unless DSG_GEMM_BLK overrides.
-static bool use_blk(const dsg_handle* h, int M) { return h->gemm_blk >= 0 ? h->gemm_blk != 0 : M >= 512; }
+static bool use_blk(const dsg_handle* h, int M, int which) {
+    return (h->gemm_blk_mask & which) && (h->gemm_blk >= 0 ? h->gemm_blk != 0 : M >= 512);
+}
+template <class P, int PRO, int EPI, int DMAX>
+static int launch_blk_d(dsg_handle* h, const GemmArgs& g, int tnw, int rt) {
+    const int extra = EPI == EPI_OUT ? 1 : 0;
+    const dim3 grid(xcd_grid_x(g.NT / (4 * tnw)), cdiv(g.MT, rt) + extra, 1);
+    if (rt == 2) {
+        if (tnw == 2) return step_launch<&k_gemm_blk<P, PRO, EPI, DMAX, 2, 2>>(h, grid, dim3(256), g);
+        return step_launch<&k_gemm_blk<P, PRO, EPI, DMAX, 1, 2>>(h, grid, dim3(256), g);
+    }
+    if (tnw == 2) return step_launch<&k_gemm_blk<P, PRO, EPI, DMAX, 2, 4>>(h, grid, dim3(256), g);
+    return step_launch<&k_gemm_blk<P, PRO, EPI, DMAX, 1, 4>>(h, grid, dim3(256), g);
+}
 template <class P, int PRO, int EPI>
 static int launch_blk(dsg_handle* h, GemmArgs g) {
     g.KS = 1; g.kb_per_split = g.KBtot;
     g.inv_ntok = fastdiv_inv(g.ntok); g.inv_hd = fastdiv_inv(g.hd);
     const int K = g.KBtot * P::KB;
-    int tnw = h->gemm_blk_tnw > 0 ? h->gemm_blk_tnw : (g.NT >= 64 ? 2 : 1);
+    int tnw = h->gemm_blk_tnw > 0 ? h->gemm_blk_tnw : 1;
     if (g.NT % (4 * tnw)) tnw = 1;
     if (g.NT % 4) return fail(DSG_E_INVALID, "gemm: NT not divisible by the workgroup tile");
-    const int extra = EPI == EPI_OUT ? 1 : 0;
-    const dim3 grid(xcd_grid_x(g.NT / (4 * tnw)), cdiv(g.MT, 4) + extra, 1);
-    if (K <= 256) {
-        if (tnw == 2) return step_launch<&k_gemm_blk<P, PRO, EPI, 256, 2>>(h, grid, dim3(256), g);
-        return step_launch<&k_gemm_blk<P, PRO, EPI, 256, 1>>(h, grid, dim3(256), g);
-    }
+    const int rt = h->gemm_blk_rt == 4 ? 4 : 2;
+    if (K <= 256) return launch_blk_d<P, PRO, EPI, 256>(h, g, tnw, rt);
     if (K > 512) return fail(DSG_E_NOT_IMPLEMENTED, "k_gemm_blk: K > 512");
-    if (tnw == 2) return step_launch<&k_gemm_blk<P, PRO, EPI, 512, 2>>(h, grid, dim3(256), g);
-    return step_launch<&k_gemm_blk<P, PRO, EPI, 512, 1>>(h, grid, dim3(256), g);
+    return launch_blk_d<P, PRO, EPI, 512>(h, g, tnw, rt);
 }
 template <class P, int EPI>
 static int launch_blk_k(dsg_handle* h, GemmArgs g) {
     if (g.KS <= 1) { g.KS = 1; g.kb_per_split = g.KBtot; }
     g.inv_ntok = fastdiv_inv(g.ntok); g.inv_hd = fastdiv_inv(g.hd);
-    if (g.NT % 4) return fail(DSG_E_INVALID, "gemm: NT not divisible by the workgroup tile");
+    if (g.NT % 2) return fail(DSG_E_INVALID, "gemm: NT not divisible by the workgroup tile");
     const int extra = EPI == EPI_PARTIAL ? 1 : 0;
-    return step_launch<&k_gemm_blk_k<P, EPI>>(h, dim3(xcd_grid_x(g.NT / 4), cdiv(g.MT, 4) + extra, g.KS), dim3(256), g);
+    const dim3 grid(xcd_grid_x(g.NT / 2), cdiv(g.MT, 2) + extra, g.KS);
+    // k-blocks per wave in one pass: 8 when the wave's share of the K range is that long (linear2 at ff = 1024 in bf16), else 4
+    const int per = cdiv(std::min(g.kb_per_split, g.KBtot), 4);
+    if (per > 4) return step_launch<&k_gemm_blk_k<P, EPI, 8>>(h, grid, dim3(256), g);
+    return step_launch<&k_gemm_blk_k<P, EPI, 4>>(h, grid, dim3(256), g);
 }
 
 template <class P, int PRO, int EPI>
 static int launch_gemm_w(dsg_handle* h, const GemmArgs& g) {
     if constexpr (EPI != EPI_PARTIAL) {
-        if (use_blk(h, g.M) && g.KBtot * P::KB <= 512) return launch_blk<P, PRO, EPI>(h, g);
+        constexpr int which = EPI == EPI_QKV ? 1 : (EPI == EPI_RESID ? 2 : (EPI == EPI_GELU ? 4 : 16));
+        if (use_blk(h, g.M, which) && g.KBtot * P::KB <= 512) return launch_blk<P, PRO, EPI>(h, g);
     }
     const int tnw = pick_tnw(h, g.NT);
     // the multi-tile shape holds the whole K range in one chunk of 8 k-blocks and stages TM x 16 LayerNorm rows in LDS
@@ -818,7 +857,7 @@ static int launch_gemm_w(dsg_handle* h, const GemmArgs& g) {
 // linear2: K = ff split over the 4 waves of the workgroup
 template <class P>
 static int launch_gemm_k4(dsg_handle* h, const GemmArgs& g) {
-    if (use_blk(h, g.M)) return launch_blk_k<P, EPI_RESID>(h, g);
+    if (use_blk(h, g.M, 8)) return launch_blk_k<P, EPI_RESID>(h, g);
     return launch_gemm<P, PRO_DIRECT, EPI_RESID, 1, 4, 1, 1>(h, g);
 }
 
@@ -933,8 +972,26 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
     la.emb1 = h->emb1; la.ctl = c.use_ctr ? h->ctl : nullptr; la.t_arr = h->t_arr;
     la.rcos = h->rcos; la.rsin = h->rsin; la.mask = h->mask; la.mb = h->mb; la.inv_mask_div = fastdiv_inv((int)((long long)B * h->Hl / h->mb)); la.B = B; la.T = T; la.D = D; la.Hl = h->Hl;
     la.hd = h->hdl; la.W = h->W; la.X0 = h->X0; la.X0a = h->X0a; la.nomask = h->nomask;
-    const int skip = h->dbg_skip;      // drop-one timing experiments: 1 in/loc, 2 QKV, 4 attention, 8 mid, 16 linear2, 32 head
+    // drop-one timing experiments: 1 in/loc, 2 QKV, 4 attention, 8 mid, 16 linear2, 32 head
+    const int skip = c.only_head ? (1 | 2 | 4 | 8 | 16) : h->dbg_skip;
     if (skip & 1) {
+    } else if (c.emode) {      // embedded-space state: local attention straight from E(x_t); E(z) beside it
+        LocEArgs a;
+        a.loc = la; a.loc.partial = h->epose; a.loc.KS = 1; a.loc.Min_pad = 0;
+        a.ctl_upd = h->ctl; a.st = step_tables(h); a.n_tab = h->n_run;
+        DSG_LOC_DISPATCH(k_loc_e, a, dim3(h->Hl, T / h->W, B + 1));
+        ENoiseArgs e;
+        e.Wp = h->Wp_in; e.KBtot = h->Jp / KB; e.KS = h->ez_ks; e.kb_per_split = cdiv(e.KBtot, e.KS);
+        e.ez = h->ez; e.ez_rows = h->ez_rows; e.ctl = h->ctl; e.dyn = h->dyn; e.B = B; e.T = T; e.J = h->J; e.Jq = h->Jq; e.D = D;
+        h->overlap_next = true;        // AQL: no barrier bit -- it runs beside k_loc_e (it depends on nothing of this step)
+        const dim3 eg(e.KS, MTin, 1);
+        switch (D / 64) {
+            case 1: CHK((step_launch<&k_enoise<P, 1>>(h, eg, dim3(256), e))); break;
+            case 2: CHK((step_launch<&k_enoise<P, 2>>(h, eg, dim3(256), e))); break;
+            case 4: CHK((step_launch<&k_enoise<P, 4>>(h, eg, dim3(256), e))); break;
+            case 6: CHK((step_launch<&k_enoise<P, 6>>(h, eg, dim3(256), e))); break;
+            default: return fail(DSG_E_NOT_IMPLEMENTED, "embedded-space state: latent_dim / 64 must be 1, 2, 4 or 6");
+        }
     } else if (lat) {          // pose embedding + local attention in one launch
         InLocArgs a;
         a.xs = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; a.Jp = h->Jp; a.Wp = h->Wp_in; a.KBtot = h->Jp / KB;
@@ -948,7 +1005,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
             g.A = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; g.lda = h->Jp;
             g.out = h->partial; g.ldo = D;
             g.ctl = c.use_ctr ? h->ctl : nullptr; g.st = step_tables(h); g.n_tab = h->n_run;
-            if (use_blk(h, g.M)) CHK((launch_blk_k<P, EPI_PARTIAL>(h, g)));
+            if (use_blk(h, g.M, 32)) CHK((launch_blk_k<P, EPI_PARTIAL>(h, g)));
             else CHK((launch_gemm<P, PRO_DIRECT, EPI_PARTIAL, 4, 1, 1>(h, g)));
         }
         DSG_LOC_DISPATCH(k_loc, la, dim3(h->Hl, T / h->W, B));
@@ -967,12 +1024,14 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
     for (int l = 0; l < h->L; ++l) {
         const Layer& ly = h->layers[(skip & 64) ? 0 : l];      // 64: every layer reads layer 0's weights (L2 residency experiment)
         if (fuse_attn) {   // [LayerNorm2] + in_proj + attention per (batch, head, query tile)
-            QkvAttnArgs a;
-            memset(&a, 0, sizeof(a));
-            if (l == 0) a.Xa = h->X0a;
-            else { a.X = h->pre2; a.ln_g = h->layers[l - 1].g2; a.ln_b = h->layers[l - 1].be2; a.Xn = h->Xn; }
-            a.Wp = ly.Wqkv; a.bias = ly.bqkv; a.out = h->attn; a.B = B; a.H = h->H; a.ntok = ntok;
-            CHK(launch_qkv_attn<P>(h, a));
+            if (!(skip & 2)) {
+                QkvAttnArgs a;
+                memset(&a, 0, sizeof(a));
+                if (l == 0) a.Xa = h->X0a;
+                else { a.X = h->pre2; a.ln_g = h->layers[l - 1].g2; a.ln_b = h->layers[l - 1].be2; a.Xn = h->Xn; }
+                a.Wp = ly.Wqkv; a.bias = ly.bqkv; a.out = h->attn; a.B = B; a.H = h->H; a.ntok = ntok;
+                CHK(launch_qkv_attn<P>(h, a));
+            }
         } else {
             if (!(skip & 2)) {   // QKV projection (LayerNorm2 of the previous layer applied on read)
                 GemmArgs g = z;
@@ -1035,7 +1094,14 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
             CHK(launch_gemm_k4<P>(h, g));
         }
     }
-    if (!(skip & 32)) {   // final LayerNorm-on-read + pose head + sampler update
+    if (!(skip & 32) && c.emode) {   // final LayerNorm-on-read + W_io + sampler update in embedded space
+        GemmArgs g = z;
+        g.M = M; g.MT = MT; g.NT = D / 16; g.KBtot = D / KB; g.Wp = h->W_io; g.bias = h->b_io;
+        g.X = h->pre2; g.ln_g = h->layers[h->L - 1].g2; g.ln_b = h->layers[h->L - 1].be2; g.Xn = nullptr;
+        g.ctl = h->ctl; g.st = step_tables(h); g.n_tab = h->n_run;
+        g.epose = h->epose; g.ez = h->ez; g.ez_ks = h->ez_ks; g.ez_rows = h->ez_rows;
+        CHK((launch_gemm<P, PRO_LN, EPI_ESTEP, 4, 1, 1>(h, g)));
+    } else if (!(skip & 32)) {   // final LayerNorm-on-read + pose head + sampler update
         GemmArgs g = z;
         g.M = M; g.MT = MT; g.NT = h->Jp / 16; g.KBtot = D / KB; g.Wp = h->Wp_out; g.bias = h->b_out;
         g.X = h->pre2; g.ln_g = h->layers[h->L - 1].g2; g.ln_b = h->layers[h->L - 1].be2; g.Xn = nullptr;
@@ -1282,7 +1348,7 @@ extern "C" int dsg_forward(dsg_handle* h, const float* x, const int64_t* t, floa
 }
 
 // per-step coefficient tables in execution order (gaussian_diffusion.py:1617 `.float()` of the float64 tables)
-static int build_step_tables(dsg_handle* h, int mode, int skip, float eta, int* n_run_out) {
+static int build_step_tables(dsg_handle* h, int mode, int skip, float eta, bool emode, int* n_run_out) {
     const Sched& s = h->sched;
     if (s.n == 0) return fail(DSG_E_STATE, "dsg_sample before dsg_set_schedule");
     if (skip < 0 || skip >= s.n) return fail(DSG_E_INVALID, "skip_timesteps out of range");
@@ -1306,6 +1372,15 @@ static int build_step_tables(dsg_handle* h, int mode, int skip, float eta, int* 
             c[2][i] = sqrtf(abp);
             c[3][i] = sqrtf(1.f - abp - sigma * sigma);
             c[4][i] = nz * sigma;
+        }
+    }
+    if (emode) {      // x_{t-1} = a x0 + b x_t + c z, the three coefficients of the embedded-space update (EPI_ESTEP)
+        if (mode == DSG_MODE_DDIM) {
+            // x0 sqrt(abar_prev) + dir (sqrt_recip x_t - x0) / sqrt_recipm1 + nz sigma z   (gaussian_diffusion.py:773-791)
+            for (int i = 0; i < n_run; ++i) {
+                const float k1 = c[0][i], k2 = c[1][i], k3 = c[2][i], k4 = c[3][i], k5 = c[4][i];
+                c[0][i] = k3 - k4 / k2; c[1][i] = k4 * k1 / k2; c[2][i] = k5; c[3][i] = 0.f; c[4][i] = 0.f;
+            }
         }
     }
     HIPCHK(hipMemcpyAsync(h->st_tmodel, tm.data(), n_run * sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -1339,8 +1414,14 @@ static int sample_prepare(dsg_handle* h, const dsg_sample_args* a, int B, void* 
         return fail(DSG_E_NOT_IMPLEMENTED, "ddim_sample_loop: dump_steps / const_noise (gaussian_diffusion.py:913-916)");
     HIPCHK(hipSetDevice(h->cfg.device));
     CHK(order_after(h, stream));
+    // embedded-space state (dsg_fused.h): whenever the update is linear in (x0, x_t, z) and nobody needs x_t itself
+    const bool dumping_ = a->n_dump > 0 && a->dump_steps && a->dump_out;
+    const int kb_in = h->Jp / h->kbk;
+    h->emode = h->ecarry != 0 && use_latency_mode(h, rows) && !dumping_ && !a->step_noise && !a->const_noise && !a->clip_denoised &&
+               h->cfgB == 0 && h->D <= 384 && (h->D / 64 == 1 || h->D / 64 == 2 || h->D / 64 == 4 || h->D / 64 == 6) &&
+               cdiv(kb_in, h->ez_ks) <= 12 && !(h->dbg_skip & 1);
     int n_run = 0;
-    CHK(build_step_tables(h, a->mode, a->skip_timesteps, a->eta, &n_run));
+    CHK(build_step_tables(h, a->mode, a->skip_timesteps, a->eta, h->emode, &n_run));
     const size_t n = (size_t)B * h->J * h->T;
     NoiseKey nk;
     nk.k0 = (unsigned)(a->seed & 0xffffffffu); nk.k1 = (unsigned)(a->seed >> 32);
@@ -1365,6 +1446,22 @@ static int sample_prepare(dsg_handle* h, const dsg_sample_args* a, int B, void* 
             ext = h->ext_noise;
         }
     }
+    if (h->emode) {      // E(x_T) = Wfold . x_T: the pose-embedding GEMM once per window, its split-K partials summed
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        const int Min = rows * h->T, MTin = cdiv(Min, 16);
+        g.B = rows; g.ntok = h->ntok; g.Tp = h->Tp; g.H = h->H; g.hd = h->hd; g.T = h->T; g.J = h->J; g.Jp = h->Jp; g.Jq = h->Jq; g.D = h->D;
+        g.M = Min; g.MT = MTin; g.NT = h->D / 16; g.KBtot = kb_in; g.KS = h->KSin; g.Wp = h->Wp_in;
+        g.kb_per_split = cdiv(g.KBtot, g.KS);
+        g.A = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; g.lda = h->Jp;
+        g.out = h->partial; g.ldo = h->D;
+        if (h->prec == DSG_PREC_BF16) CHK((launch_gemm<PBF16, PRO_DIRECT, EPI_PARTIAL, 4, 1, 1>(h, g)));
+        else CHK((launch_gemm<PF32, PRO_DIRECT, EPI_PARTIAL, 4, 1, 1>(h, g)));
+        const size_t ne = (size_t)Min * h->D;
+        hipLaunchKernelGGL(k_sum_partials, dim3((int)std::min<size_t>((ne + 255) / 256, 1024)), dim3(256), 0, h->stream, h->epose, h->partial,
+                           h->KSin, (size_t)MTin * 16 * h->D, ne);
+        HIPCHK(hipGetLastError());
+    }
     hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(64), 0, h->stream, h->ctl, h->st_tmodel, h->dep_ctr, 64);
     HIPCHK(hipGetLastError());
     {
@@ -1374,7 +1471,7 @@ static int sample_prepare(dsg_handle* h, const dsg_sample_args* a, int B, void* 
     }
     StepCtx& c = job.c;
     c.B = rows; c.out_mode = a->mode == DSG_MODE_DDPM ? OUT_DDPM : OUT_DDIM; c.use_ctr = true; c.ext_noise = ext;
-    c.const_noise = a->const_noise; c.clip_x0 = a->clip_denoised ? 1 : 0;
+    c.const_noise = a->const_noise; c.clip_x0 = a->clip_denoised ? 1 : 0; c.emode = h->emode;
     job.n_run = n_run; job.B = B; job.done = 0;
     job.dumping = a->n_dump > 0 && a->dump_steps && a->dump_out;
     // steps_per_graph: 0 = default = no hipGraph.  Measured on MI355X / ROCm 7.2: hipGraph replay of the step is slower than
@@ -1462,9 +1559,16 @@ static int sample_run_hip(dsg_handle* h, const dsg_sample_args* a, SampleJob& jo
 
 static int sample_finish(dsg_handle* h, float* out, void* stream, SampleJob& job) {
     const size_t n = (size_t)job.B * h->J * h->T;
+    if (job.c.emode) {
+        // the last step of DDPM / DDIM is x_0 = x0-prediction (posterior_mean_coef1[0] = 1, coef2[0] = 0, no noise at t = 0;
+        // DDIM: abar_prev = 1): one pose-head launch on the last step's final-layer rows gives the sample in the caller's layout
+        StepCtx f = job.c;
+        f.emode = false; f.out_mode = OUT_FORWARD; f.use_ctr = false; f.only_head = true;
+        CHK(run_step_p(h, f));
+    }
     HIPCHK(hipEventRecord(h->ev_t1, h->stream));
     h->last_steps = job.n_run; h->timing_valid = true;
-    CHK(launch_x_out(h, h->fwd_out, job.B));
+    if (!job.c.emode) CHK(launch_x_out(h, h->fwd_out, job.B));
     CHK(from_dev(h, out, h->fwd_out, n));
     if (h->overlap) {       // overlapped (barrier-less) launches: a consumer that gave up waiting raised the error word
         unsigned err = 0;

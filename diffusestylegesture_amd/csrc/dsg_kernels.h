@@ -36,6 +36,7 @@ typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short bf16_t;
 
 #define DSG_FLT_MAX 3.402823466e+38f
+#define DSG_EZ_MAXKS 6          // K splits of the noise embedding (k_enoise), summed on read by the EPI_ESTEP epilogue
 
 // ---------------------------------------------------------------------------------------------------------
 // precision policies
@@ -313,7 +314,7 @@ __device__ __forceinline__ void dep_wait(const DepWait& d) {
 // GEMM  (skinny-M, weight-stationary-per-XCD):  Out[m][n] = sum_k Act[m][k] * W[n][k]  (+ epilogue)
 // ---------------------------------------------------------------------------------------------------------
 enum { PRO_DIRECT = 0, PRO_LN = 1 };
-enum { EPI_PARTIAL = 0, EPI_QKV = 1, EPI_RESID = 2, EPI_GELU = 3, EPI_OUT = 4 };
+enum { EPI_PARTIAL = 0, EPI_QKV = 1, EPI_RESID = 2, EPI_GELU = 3, EPI_OUT = 4, EPI_ESTEP = 5 };
 enum { OUT_FORWARD = 0, OUT_DDPM = 1, OUT_DDIM = 2 };
 
 struct GemmArgs {
@@ -366,6 +367,13 @@ struct GemmArgs {
     int cfgB, cfg_off;
     const float* cfg_scale; // [cfgB]
     int clip_x0;            // EPI_OUT: clamp x0 to [-1, 1] (clip_denoised=True, gaussian_diffusion.py:377-379)
+    // EPI_ESTEP: the sampler update carried in EMBEDDED space (dsg_fused.h: "embedded-space state").  epose [B*T][D] fp32 holds
+    // E(x_t) = Wfold . x_t; this GEMM multiplies the final LayerNorm rows with W_io = Wfold . W_out, so acc + bias = E(x0), and
+    // the update E(x_{t-1}) = k1 E(x0) + k2 E(x_t) + k3 E(z) is written back in place.  ez: ez_ks partial sums of E(z)
+    // ([ez_ks][ez_rows][D], k_enoise) added on read.
+    float* epose;
+    const float* ez;
+    int ez_ks, ez_rows;
 };
 
 // Workgroup -> n-group with the n-group pinned to an XCD (workgroups are dealt round-robin to the 8 XCDs in linear
@@ -474,6 +482,21 @@ __device__ __forceinline__ void gemm_prefetch_tile(const GemmArgs& g, int m0, in
         } else if constexpr (EPI == EPI_QKV) {
             o.pb = *(const f32x4*)(g.bias + n0 + 4 * lg);      // both forms loaded unconditionally (no branchy loads)
             o.pbs = g.bias[n0 + lr];
+        } else if constexpr (EPI == EPI_ESTEP) {
+            const int m = m0 + lr, n = n0 + 4 * lg;
+            const int b = fdiv(m, g.inv_ntok), sx = m - b * g.ntok;
+            o.ovalid = m < g.M && sx > 0;
+            o.pb = *(const f32x4*)(g.bias + n);
+            const int bc = b < g.B ? b : g.B - 1, fc = sx > 0 ? sx - 1 : 0;      // clamped row: unconditional loads
+            const size_t row = (size_t)bc * g.T + fc;
+            o.pr = *(const f32x4*)(g.epose + row * g.D + n);
+#pragma unroll
+            for (int s2 = 0; s2 < DSG_EZ_MAXKS; ++s2) {      // branch-free: clamped slice, weighted out
+                const float wgt = s2 < g.ez_ks ? 1.f : 0.f;
+                const f32x4 zz = *(const f32x4*)(g.ez + ((size_t)min(s2, g.ez_ks - 1) * g.ez_rows + row) * g.D + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o.pz[e] += wgt * zz[e];
+            }
         } else if constexpr (EPI == EPI_OUT) {
             const int m = m0 + lr, j0 = n0 + 4 * lg;
             const int b = fdiv(m, g.inv_ntok), sx = m - b * g.ntok;
@@ -539,6 +562,16 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmArgs& g, int m0, in
                         ((elem*)g.vt)[((size_t)b * g.H + head) * g.hd * g.Tp + vt_off<P>(d0 + lr, sx, P::E == 4 ? g.Tp / 16 : g.Tp / 32)] = P::cvt(acc[e] + o.pbs);
                     }
                 }
+            }
+        } else if constexpr (EPI == EPI_ESTEP) {
+            const int m = m0 + lr, n = n0 + 4 * lg;
+            const int b = fdiv(m, g.inv_ntok), sx = m - b * g.ntok;
+            if (o.ovalid) {
+                const f32x4 e0 = acc + o.pb;
+                f32x4 en;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) en[e] = (k1 * e0[e] + k2 * o.pr[e]) + k3 * o.pz[e];
+                *(f32x4*)(g.epose + ((size_t)b * g.T + (sx - 1)) * g.D + n) = en;
             }
         } else if constexpr (EPI == EPI_OUT) {
             const int m = m0 + lr, j0 = n0 + 4 * lg;
@@ -609,13 +642,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
     const int NG = g.NT / (WN * TNW);
     const int ng = xcd_ngroup(), ks = blockIdx.z;
     const int mt_first = blockIdx.y;
-    if constexpr (EPI == EPI_PARTIAL || EPI == EPI_OUT) {
+    if constexpr (EPI == EPI_PARTIAL || EPI == EPI_OUT || EPI == EPI_ESTEP) {
         // step bookkeeping runs in ONE EXTRA workgroup (first block of an extra grid row), concurrently with the real
         // work and off every critical path; see StepCtl for why this is race free
         if (mt_first >= g.MT) {
             if (g.ctl && blockIdx.x == 0 && ks == 0 && threadIdx.x == 0) {
                 if constexpr (EPI == EPI_PARTIAL) step_advance_B(g.ctl, g.st, g.n_tab);
-                else if (g.out_mode != OUT_FORWARD) step_advance_A(g.ctl, g.st, g.n_tab);
+                else if (EPI == EPI_ESTEP || g.out_mode != OUT_FORWARD) step_advance_A(g.ctl, g.st, g.n_tab);
             }
             return;
         }
@@ -663,6 +696,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
             k1 = g.ctl->k1; k2 = g.ctl->k2; k3 = g.ctl->k3; k4 = g.ctl->k4; k5 = g.ctl->k5;
         }
     }
+    if constexpr (EPI == EPI_ESTEP) { k1 = g.ctl->k1; k2 = g.ctl->k2; k3 = g.ctl->k3; }
     const int m0 = mt_first * 16;
     f32x4 acc[TNW];
 #pragma unroll
@@ -1021,14 +1055,12 @@ __device__ __forceinline__ void local_attn_tail(const LocArgs& a, float (&rot)[2
 }
 
 template <class P, int HD, int W>
-__global__ __launch_bounds__(256) void k_loc(const LocArgs a) {
+__device__ __forceinline__ void loc_body(const LocArgs& a, int h, int w, int b) {
     typedef typename P::elem elem;
     constexpr int W2 = 2 * W, half = HD / 2, NP1 = W2 * half, NPI = (NP1 + 255) / 256;
     constexpr int NSI = (W * 32 + 255) / 256, NP2 = W * half, NPO = (NP2 + 255) / 256, MAXKS = 9;
     __shared__ float rot[W2][HD + 1];
     __shared__ float sc[W][W2 + 2];
-    preload_kernargs(a);
-    const int h = blockIdx.x, w = blockIdx.y, b = blockIdx.z;            // grid (local heads, windows, batch)
     const int tid = threadIdx.x;
     const int* tp = a.ctl ? &a.ctl->tA : a.t_arr + b;      // select the ADDRESS, then one unconditional load
     const int t = *tp;
@@ -1093,6 +1125,12 @@ __global__ __launch_bounds__(256) void k_loc(const LocArgs a) {
     }
     DSG_LDS_BARRIER();
     local_attn_tail<P, HD, W>(a, rot, sc, b, w, h, keep, c2, s2);
+}
+
+template <class P, int HD, int W>
+__global__ __launch_bounds__(256) void k_loc(const LocArgs a) {
+    preload_kernargs(a);
+    loc_body<P, HD, W>(a, blockIdx.x, blockIdx.y, blockIdx.z);          // grid (local heads, windows, batch)
 }
 
 // ---------------------------------------------------------------------------------------------------------

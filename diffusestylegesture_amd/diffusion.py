@@ -302,10 +302,10 @@ class DSGDiffusion:
         indices = list(range(self.num_timesteps - skip_timesteps))[::-1]
         if init_image is not None:
             out = torch.empty_like(img)
-            lib.check(lib.cdll.dsg_q_sample(out.data_ptr(), init_image.contiguous().data_ptr(),
-                                            img.contiguous().data_ptr(),
-                                            self._f32("sqrt_alphas_cumprod", indices[0], B).ctypes.data,
-                                            self._f32("sqrt_one_minus_alphas_cumprod", indices[0], B).ctypes.data,
+            init_c, img_c = init_image.contiguous(), img.contiguous()
+            # (host coefficient arrays are bound to names: a temporary's `.ctypes.data` dangles once the expression is done)
+            qa, qb = self._f32("sqrt_alphas_cumprod", indices[0], B), self._f32("sqrt_one_minus_alphas_cumprod", indices[0], B)
+            lib.check(lib.cdll.dsg_q_sample(out.data_ptr(), init_c.data_ptr(), img_c.data_ptr(), qa.ctypes.data, qb.ctypes.data,
                                             B, per, stream))
             img = out
         tmap = torch.tensor(self.timestep_map, device=device, dtype=torch.long)
@@ -324,11 +324,10 @@ class DSGDiffusion:
             img = img.contiguous()
             if not ddim:
                 sig = nz * np.exp(np.float32(0.5) * np.float32(self.posterior_log_variance_clipped[i]))
-                lib.check(lib.cdll.dsg_posterior_step(
-                    out.data_ptr(), x0.data_ptr(), img.data_ptr(), eps.data_ptr(),
-                    self._f32("posterior_mean_coef1", i, B).ctypes.data,
-                    self._f32("posterior_mean_coef2", i, B).ctypes.data,
-                    np.full((B,), sig, np.float32).ctypes.data, B, per, stream))
+                c1, c2 = self._f32("posterior_mean_coef1", i, B), self._f32("posterior_mean_coef2", i, B)
+                c3 = np.full((B,), sig, np.float32)
+                lib.check(lib.cdll.dsg_posterior_step(out.data_ptr(), x0.data_ptr(), img.data_ptr(), eps.data_ptr(),
+                                                      c1.ctypes.data, c2.ctypes.data, c3.ctypes.data, B, per, stream))
             else:
                 ab, abp = np.float32(self.alphas_cumprod[i]), np.float32(self.alphas_cumprod_prev[i])
                 one = np.float32(1)
@@ -336,8 +335,9 @@ class DSGDiffusion:
                 coef = np.tile(np.array([np.float32(self.sqrt_recip_alphas_cumprod[i]),
                                          np.float32(self.sqrt_recipm1_alphas_cumprod[i]), np.sqrt(abp),
                                          np.sqrt(one - abp - sigma * sigma), nz * sigma], np.float32), (B, 1))
+                coef = np.ascontiguousarray(coef)
                 lib.check(lib.cdll.dsg_ddim_step(out.data_ptr(), x0.data_ptr(), img.data_ptr(), eps.data_ptr(),
-                                                 np.ascontiguousarray(coef).ctypes.data, B, per, stream))
+                                                 coef.ctypes.data, B, per, stream))
             img = out
             if dump_steps is not None and n in dump_steps:
                 dump.append(img.clone())

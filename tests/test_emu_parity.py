@@ -80,7 +80,9 @@ def test_chains_tiny(tiny, emu_lib, prec):
     x_T = philox.normal_bj1t(shape, 77, 0, 3)
     s1 = d.manual_seed(77, 3).p_sample_loop(m, shape, clip_denoised=False, model_kwargs=mk, skip_timesteps=994)
     s2 = d.p_sample_loop(m, shape, noise=x_T, clip_denoised=False, model_kwargs=mk, skip_timesteps=994, step_noise=ext)
-    assert rel_l2(s2, s1) < 1e-5
+    # (replayed noise runs the pose-space loop, the Philox run the embedded-space loop: same arithmetic in another rounding
+    # order -- 1e-6 apart in fp32, two independent bf16 approximations otherwise)
+    assert rel_l2(s2, s1) < (1e-5 if prec == "fp32" else 2e-2)
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])

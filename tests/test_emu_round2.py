@@ -168,6 +168,8 @@ def test_block_gemms_of_the_batched_path(emu_lib, golden_dir, monkeypatch, tnw):
     kernel set): forward with masks / uncond, DDPM + DDIM chains, guidance, the DSG+ / DSG++ models, and ZEGGS dims at batch 2
     -- against the same reference goldens as the latency kernels"""
     monkeypatch.setenv("DSG_GEMM_BLK", "1")
+    monkeypatch.setenv("DSG_GEMM_BLK_MASK", "127")          # every GEMM of the step, not only the ones the default mask selects
+    monkeypatch.setenv("DSG_GEMM_BLK_RT", "4" if tnw == "2" else "2")
     monkeypatch.setenv("DSG_GEMM_BLK_TNW", tnw)
     gt = _g(golden_dir, "gt_tiny_zeggs.npz")
     cfg = C.TINY
