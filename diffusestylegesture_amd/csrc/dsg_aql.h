@@ -50,6 +50,7 @@ struct Ctx {
     std::vector<Launch> plan;
     double last_ms = 0.0;
     int acquire_scope = HSA_FENCE_SCOPE_AGENT;      // DSG_AQL_ACQUIRE=0 -> NONE (experiment)
+    int overlap_acquire_scope = HSA_FENCE_SCOPE_AGENT;      // acquire scope of the packets WITHOUT barrier bit (DSG_OVL_ACQUIRE=0 -> NONE)
 };
 
 inline bool hsa_ok(Ctx& c, hsa_status_t s, const char* what) {
@@ -199,7 +200,7 @@ inline void submit_step(Ctx& c, bool first_step, bool last_step) {
         p->completion_signal.handle = last ? c.done.handle : 0;
         const int rel = last ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
         const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | ((l.overlap ? 0 : 1) << HSA_PACKET_HEADER_BARRIER) |
-                                           ((first_step && i == 0 ? HSA_FENCE_SCOPE_SYSTEM : c.acquire_scope) << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
+                                           ((first_step && i == 0 ? HSA_FENCE_SCOPE_SYSTEM : (l.overlap ? c.overlap_acquire_scope : c.acquire_scope)) << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
                                            (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
         __atomic_store_n((uint16_t*)p, header, __ATOMIC_RELEASE);
     }

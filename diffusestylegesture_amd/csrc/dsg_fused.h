@@ -793,8 +793,13 @@ __global__ __launch_bounds__(256) void k_attn_mid(const AttnMidArgs ga) {
 // DDIM has a = 1, b = c = 0, i.e. x_0 = W_out . h + b_out: one ordinary pose-head launch after the loop produces the sample.
 // Rounding: identical operands to the reference order except that x_t is never rounded to the GEMM type (its embedding is
 // carried in fp32) and W_io is rounded once -- fp32 mode agrees with the pose-space loop to ~1e-6, bf16 mode stays within the
-// stated 3e-2 (tests/test_gpu_parity.py run both against the same goldens).  Not used with dump_steps, replayed noise,
-// const_noise, clip_denoised (non-linear in x0) or guidance: those take the pose-space loop.
+// stated 3e-2 (the parity tests run it against the same goldens).  Not used with dump_steps, replayed noise, const_noise,
+// clip_denoised (non-linear in x0) or guidance: those take the pose-space loop.
+// STATUS: opt-in (DSG_ECARRY=1).  Measured on MI355X (profiles/r02_f_*, r02_h_*): the step's first + last kernel get 2.7 us
+// shorter (111.5 vs 114.2 us/step with the noise embedding left out), but E(z) costs 4-5 us per step however it is scheduled --
+// as a packet without barrier bit behind the step's first kernel or behind the layer-0 attention kernel, with 6 or 18 K
+// splits, 256- or 1024-thread workgroups, with or without an acquire fence: 115.9-118.7 us/step against 113.1-115.7 for the
+// pose-space loop on the same boxes.  The command processor handles the extra packet and its fences in line with the chain.
 // ---------------------------------------------------------------------------------------------------------
 struct LocEArgs {
     LocArgs loc;            // partial = E(x_t) rows, KS = 1
@@ -823,19 +828,23 @@ struct ENoiseArgs {
     const unsigned* dyn;    // {seed lo, seed hi, stream lo, stream hi, draw index of step 0}
     int B, T, J, Jq, D;
 };
+// Many small workgroups: the Philox rounds are the long part (one quad = ~350 instructions) and the kernel has to be over
+// before the kernel it runs beside is, so K is split 18 ways -- at the ZEGGS sizes 2 k-blocks = one quad per lane -- and the
+// 18 partial sums are added by the consumer's operand prefetch.  (6 splits with 3 quads per lane, or 1024-thread workgroups,
+// ran 5-6 us and showed up in the step time: profiles/r02_f_ecarry_ab.log.)
 template <class P, int DT>      // DT = D / 64: 16-column tiles per wave
 __global__ __launch_bounds__(256) void k_enoise(const ENoiseArgs g) {
     typedef typename P::elem elem;
-    constexpr int ES = (int)sizeof(elem), KMAX = 12;          // k-blocks per split the fragment registers are sized for
+    constexpr int ES = (int)sizeof(elem), KMAX = 8;           // k-blocks per split the LDS tile is sized for
     __shared__ __attribute__((aligned(16))) char za[16 * (KMAX * P::KB * ES + 16)];
     preload_kernargs(g);
     const int ks = blockIdx.x, mt = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
-    const int kb_lo = ks * g.kb_per_split, nkb = min(g.kb_per_split, g.KBtot - kb_lo);
+    const int kb_lo = min(ks * g.kb_per_split, g.KBtot), nkb = min(g.kb_per_split, g.KBtot - kb_lo);
     const int kb_last = g.KBtot - 1;
     const f32x4* wbase = (const f32x4*)g.Wp + lane;
-    // ---- Wfold fragments of this wave's column tiles for the whole K range: in flight during the Philox rounds
-    constexpr int CHK = DT >= 6 ? 2 : (DT >= 4 ? 3 : 6);      // k-blocks per pass (register budget: CHK * DT fragments)
+    // ---- Wfold fragments of this wave's column tiles: in flight during the Philox rounds
+    constexpr int CHK = DT >= 6 ? 2 : 4;                      // k-blocks per pass (register budget: CHK * DT fragments)
     f32x4 bf[CHK][DT];
     auto load_b = [&](int c0) {
 #pragma unroll
@@ -846,11 +855,12 @@ __global__ __launch_bounds__(256) void k_enoise(const ENoiseArgs g) {
         }
     };
     load_b(0);
-    const int step = g.ctl->stepA;
+    // (agent-scope load: this kernel's packet may carry no acquire fence, and the word was rewritten by the previous step)
+    const int step = __hip_atomic_load(&g.ctl->stepA, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const NoiseKey nk = {g.dyn[0], g.dyn[1], g.dyn[2], g.dyn[3]};
     const unsigned draw = g.dyn[4] + (unsigned)step;
     // ---- noise of 16 frames x this K range -> LDS
-    const int pitch = nkb * P::KB * ES + 16;
+    const int pitch = KMAX * P::KB * ES + 16;
     const int qpr = nkb * P::KB / 4;                          // quads per row
     for (int e = tid; e < 16 * qpr; e += 256) {
         const int r = e / qpr, qi = e - r * qpr;
@@ -871,7 +881,7 @@ __global__ __launch_bounds__(256) void k_enoise(const ENoiseArgs g) {
 #pragma unroll
         for (int c = 0; c < CHK; ++c) {
             const bool live = c0 + c < nkb;
-            f32x4 a = *(const f32x4*)(za + lr * pitch + (min(c0 + c, nkb - 1) * P::KB + P::E * lg) * ES);
+            f32x4 a = *(const f32x4*)(za + lr * pitch + (min(c0 + c, max(nkb - 1, 0)) * P::KB + P::E * lg) * ES);
             a = live ? a : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < DT; ++t) acc[t] = P::mma(bf[c][t], a, acc[t]);      // D[col 4lg+r][row lr]
@@ -879,7 +889,7 @@ __global__ __launch_bounds__(256) void k_enoise(const ENoiseArgs g) {
         if (c0 + CHK < nkb) load_b(c0 + CHK);
     }
     const int m = mt * 16 + lr;
-    if (m < g.B * g.T) {
+    if (m < g.B * g.T) {       // (a split past the end of K writes zeros: the consumer sums all KS slices)
 #pragma unroll
         for (int t = 0; t < DT; ++t)
             *(f32x4*)(g.ez + ((size_t)ks * g.ez_rows + m) * g.D + (wave * DT + t) * 16 + 4 * lg) = acc[t];

@@ -139,7 +139,9 @@ struct dsg_handle {
     // embedded-space state (dsg_fused.h): E(x_t), E(z) partial sums, W_io = Wfold . W_out, b_io = Wfold . b_out
     float *epose = nullptr, *ez = nullptr, *b_io = nullptr; void* W_io = nullptr;
     int ez_ks = 0, ez_rows = 0;
-    int ecarry = -1;                     // DSG_ECARRY: -1 auto (on in the latency kernel set), 0 off
+    int ecarry = 0;                      // DSG_ECARRY=1: embedded-space state in the latency kernel set.  OFF by default: measured 2 us per
+                                         // step SLOWER than the pose-space loop (117.3 vs 115.0 us, profiles/r02_h_*) -- the first and last
+                                         // kernel of the step get 2.7 us shorter, but the noise embedding beside the step costs more
     bool emode = false;                  // the current dsg_sample runs the embedded-space loop
     int last_path = -1;                  // submission path of the last dsg_sample: 0 HIP launches, 1 AQL packets, 2 hipGraph replay
     bool dbg_warned = false;
@@ -162,10 +164,13 @@ struct dsg_handle {
     bool aql_warned = false;
     bool aql_timing = false;             // the last dsg_sample was timed by the host clock around the AQL run
     double aql_ms = 0.0;
-    int gemm_blk = -1;                   // DSG_GEMM_BLK: -1 by batch size (block GEMMs of dsg_batched.h from 512 rows up), 0 never, 1 always
+    int gemm_blk = -1;                   // DSG_GEMM_BLK: -1 by size (block GEMMs of dsg_batched.h), 0 never, 1 always
+    int lanes_now = 1;                   // lanes advanced together by the current dsg_sample_multi call (1: dsg_sample)
+    int gemm_tp_mask = 1 | 4 | 16;       // DSG_GEMM_TP_MASK: which GEMMs take k_gemm_tp (bits as DSG_GEMM_BLK_MASK)
+    int gemm_tp = 0;                     // DSG_GEMM_TP=1: k_gemm_tp (BM x 128 blocks) for the GEMMs of DSG_GEMM_TP_MASK (experiment: slower)
     int gemm_blk_tnw = 0;                // DSG_GEMM_BLK_TNW: column tiles per wave in k_gemm_blk (default 1)
     int gemm_blk_rt = 0;                 // DSG_GEMM_BLK_RT: 16-row tiles per workgroup in k_gemm_blk: 2 (default) or 4
-    int gemm_blk_mask = 1 | 4 | 32;      // DSG_GEMM_BLK_MASK: which GEMMs of the batched step use the block kernels: 1 QKV, 2 out_proj,
+    int gemm_blk_mask = 1 | 4 | 8 | 32;      // DSG_GEMM_BLK_MASK: which GEMMs of the batched step use the block kernels: 1 QKV, 2 out_proj,
                                          // 4 linear1, 8 linear2, 16 pose head, 32 pose embedding.  Measured per GEMM in the real
                                          // batch-16 step (profiles/r02_c_blk_sweep.log): QKV -13 us, linear1 -7, embedding -9.5 per
                                          // step; out_proj +4 and the pose head +3.5 (few, long workgroups) stay on the 16 x 16 kernels
@@ -310,6 +315,8 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     if (const char* e = getenv("DSG_GEMM_LEAN")) h->gemm_lean = atoi(e);
     if (const char* e = getenv("DSG_ECARRY")) h->ecarry = atoi(e);
     if (const char* e = getenv("DSG_GEMM_BLK")) h->gemm_blk = atoi(e);
+    if (const char* e = getenv("DSG_GEMM_TP")) h->gemm_tp = atoi(e);
+    if (const char* e = getenv("DSG_GEMM_TP_MASK")) h->gemm_tp_mask = atoi(e);
     if (const char* e = getenv("DSG_GEMM_BLK_TNW")) h->gemm_blk_tnw = atoi(e);
     if (const char* e = getenv("DSG_GEMM_BLK_RT")) h->gemm_blk_rt = atoi(e);
     if (const char* e = getenv("DSG_GEMM_BLK_MASK")) h->gemm_blk_mask = atoi(e);
@@ -342,7 +349,7 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     const int B = h->Bmax, D = h->D;
     // row buffers carry one extra padded token block: the fused attention kernel reads Tp rows per batch element
     // (+64: the block GEMMs of dsg_batched.h read and LayerNorm whole 64-row blocks)
-    const size_t Min_pad = rup(B * h->T, 16) + 16 + 64, M_pad = rup(B * ntok, 16) + Tp + 64;
+    const size_t Min_pad = rup(B * h->T, 16) + 16 + 128, M_pad = rup(B * ntok, 16) + Tp + 128;
     CHK(dalloc(h, &h->xs32, (size_t)B * h->T * h->Jp + 16 * h->Jp));
     if (h->prec == DSG_PREC_BF16) CHK(dalloc_bytes(h, &h->xsA, ((size_t)Min_pad * h->Jp) * h->es));
     CHK(dalloc(h, &h->partial, (size_t)h->KSin * Min_pad * D));
@@ -467,6 +474,11 @@ static int launch_mm(dsg_handle* h, float* C, int ldc, const float* A, long long
     a.add = add; a.sadd = sadd; a.add_div = add_div < 1 ? 1 : add_div; a.M = M; a.N = N; a.K = K; a.act = act;
     const size_t n = (size_t)M * N;
     if (n == 0) return 0;
+    if (K >= 512 && n <= 65536) {       // long reductions, few outputs: a workgroup per output (k_mm_longk)
+        hipLaunchKernelGGL(k_mm_longk, dim3((int)std::min<size_t>(n, 16384)), dim3(256), 0, h->stream, a);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     const int grid = (int)std::min<size_t>((n + 127) / 128, 4096);
     hipLaunchKernelGGL(k_mm_naive, dim3(grid), dim3(128), 0, h->stream, a);
     HIPCHK(hipGetLastError());
@@ -790,7 +802,13 @@ static int pick_tm(const dsg_handle* h, int M) {
 }
 // Batched path: 64-row block GEMMs (dsg_batched.h).  From 512 rows up (batch 6 at ZEGGS dims) unless DSG_GEMM_BLK overrides.
 static bool use_blk(const dsg_handle* h, int M, int which) {
-    return (h->gemm_blk_mask & which) && (h->gemm_blk >= 0 ? h->gemm_blk != 0 : M >= 512);
+    // One lane: from ~1000 rows (batch 12 at ZEGGS dims) -- at 712 rows (batch 8) the 16 x 16 tile kernels still win (227 vs
+    // 235 us/step): a single chain is latency-bound and prefers many short workgroups.  Several lanes at once are
+    // throughput-bound (their kernels share the CUs), and the blocks' smaller footprint wins from ~300 rows per lane
+    // (4 lanes x batch 4: 4691 vs 4400 frames/s, x batch 8: 6835 vs 5722, x batch 16: 8243 vs 6447; profiles/r02_i_*)
+    if (!(h->gemm_blk_mask & which)) return false;
+    if (h->gemm_blk >= 0) return h->gemm_blk != 0;
+    return M >= (h->lanes_now > 1 ? 300 : 1000);
 }
 template <class P, int PRO, int EPI, int DMAX>
 static int launch_blk_d(dsg_handle* h, const GemmArgs& g, int tnw, int rt) {
@@ -802,6 +820,22 @@ static int launch_blk_d(dsg_handle* h, const GemmArgs& g, int tnw, int rt) {
     }
     if (tnw == 2) return step_launch<&k_gemm_blk<P, PRO, EPI, DMAX, 2, 4>>(h, grid, dim3(256), g);
     return step_launch<&k_gemm_blk<P, PRO, EPI, DMAX, 1, 4>>(h, grid, dim3(256), g);
+}
+// large batches: BM x 128 blocks (k_gemm_tp)
+// OFF unless DSG_GEMM_TP=1: measured SLOWER than the 32-row blocks at every size tried (batch 64: QKV 31.8 vs 23.9 us, linear1
+// 25.5 vs 23.0, pose head 70.7 vs 55.2; profiles/r02_k_b64_kernel_stats_tp.csv) -- see the note at k_gemm_tp
+static bool use_tp(const dsg_handle* h, int M) { (void)M; return h->gemm_tp > 0; }
+template <class P, int PRO, int EPI>
+static int launch_tp(dsg_handle* h, GemmArgs g) {
+    g.KS = 1; g.kb_per_split = g.KBtot;
+    g.inv_ntok = fastdiv_inv(g.ntok); g.inv_hd = fastdiv_inv(g.hd);
+    const int K = g.KBtot * P::KB;
+    constexpr int BM = sizeof(typename P::elem) == 2 ? 128 : 64;        // fp32 rows are twice as wide in LDS
+    const int extra = EPI == EPI_OUT ? 1 : 0;
+    const dim3 grid(xcd_grid_x(cdiv(g.NT, 8)), cdiv(g.MT * 16, BM) + extra, 1);
+    if (K <= 256) return step_launch<&k_gemm_tp<P, PRO, EPI, 256, BM>>(h, grid, dim3(256), g);
+    if (K > 512) return fail(DSG_E_NOT_IMPLEMENTED, "k_gemm_tp: K > 512");
+    return step_launch<&k_gemm_tp<P, PRO, EPI, 512, BM>>(h, grid, dim3(256), g);
 }
 template <class P, int PRO, int EPI>
 static int launch_blk(dsg_handle* h, GemmArgs g) {
@@ -833,6 +867,7 @@ template <class P, int PRO, int EPI>
 static int launch_gemm_w(dsg_handle* h, const GemmArgs& g) {
     if constexpr (EPI != EPI_PARTIAL) {
         constexpr int which = EPI == EPI_QKV ? 1 : (EPI == EPI_RESID ? 2 : (EPI == EPI_GELU ? 4 : 16));
+        if (use_tp(h, g.M) && g.KBtot * P::KB <= 512 && g.NT % 4 == 0 && (h->gemm_tp_mask & which)) return launch_tp<P, PRO, EPI>(h, g);
         if (use_blk(h, g.M, which) && g.KBtot * P::KB <= 512) return launch_blk<P, PRO, EPI>(h, g);
     }
     const int tnw = pick_tnw(h, g.NT);
@@ -980,18 +1015,6 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
         a.loc = la; a.loc.partial = h->epose; a.loc.KS = 1; a.loc.Min_pad = 0;
         a.ctl_upd = h->ctl; a.st = step_tables(h); a.n_tab = h->n_run;
         DSG_LOC_DISPATCH(k_loc_e, a, dim3(h->Hl, T / h->W, B + 1));
-        ENoiseArgs e;
-        e.Wp = h->Wp_in; e.KBtot = h->Jp / KB; e.KS = h->ez_ks; e.kb_per_split = cdiv(e.KBtot, e.KS);
-        e.ez = h->ez; e.ez_rows = h->ez_rows; e.ctl = h->ctl; e.dyn = h->dyn; e.B = B; e.T = T; e.J = h->J; e.Jq = h->Jq; e.D = D;
-        h->overlap_next = true;        // AQL: no barrier bit -- it runs beside k_loc_e (it depends on nothing of this step)
-        const dim3 eg(e.KS, MTin, 1);
-        switch (D / 64) {
-            case 1: CHK((step_launch<&k_enoise<P, 1>>(h, eg, dim3(256), e))); break;
-            case 2: CHK((step_launch<&k_enoise<P, 2>>(h, eg, dim3(256), e))); break;
-            case 4: CHK((step_launch<&k_enoise<P, 4>>(h, eg, dim3(256), e))); break;
-            case 6: CHK((step_launch<&k_enoise<P, 6>>(h, eg, dim3(256), e))); break;
-            default: return fail(DSG_E_NOT_IMPLEMENTED, "embedded-space state: latent_dim / 64 must be 1, 2, 4 or 6");
-        }
     } else if (lat) {          // pose embedding + local attention in one launch
         InLocArgs a;
         a.xs = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; a.Jp = h->Jp; a.Wp = h->Wp_in; a.KBtot = h->Jp / KB;
@@ -1085,6 +1108,24 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                 g.M = M; g.MT = MT; g.NT = h->ff / 16; g.KBtot = D / KB; g.Wp = ly.W1; g.bias = ly.b1;
                 g.X = h->pre1; g.ln_g = ly.g1; g.ln_b = ly.be1; g.Xn = h->X1; g.out = h->hidden; g.ldo = h->ff; g.out_frag = 1;
                 CHK((launch_gemm_w<P, PRO_LN, EPI_GELU>(h, g)));
+            }
+        }
+        if (c.emode && l == 0 && !c.only_head && h->ecarry != 2) {       // (DSG_ECARRY=2: timing experiment without the noise embedding)
+            // E(z) of this step (k_enoise): depends on nothing of the step and is needed only by its last kernel, so its AQL
+            // packet carries no barrier bit and sits behind the longest kernel of the step -- it runs on the CUs the layer-0
+            // attention / mid kernel leaves idle and is done before that kernel is (placed behind the step's FIRST kernel it
+            // delayed the QKV projection: 117.0 vs 116.2 us/step, profiles/r02_d_*)
+            ENoiseArgs e;
+            e.Wp = h->Wp_in; e.KBtot = h->Jp / KB; e.KS = h->ez_ks; e.kb_per_split = cdiv(e.KBtot, e.KS);
+            e.ez = h->ez; e.ez_rows = h->ez_rows; e.ctl = h->ctl; e.dyn = h->dyn; e.B = B; e.T = T; e.J = h->J; e.Jq = h->Jq; e.D = D;
+            h->overlap_next = true;
+            const dim3 eg(e.KS, MTin, 1);
+            switch (D / 64) {
+                case 1: CHK((step_launch<&k_enoise<P, 1>>(h, eg, dim3(256), e))); break;
+                case 2: CHK((step_launch<&k_enoise<P, 2>>(h, eg, dim3(256), e))); break;
+                case 4: CHK((step_launch<&k_enoise<P, 4>>(h, eg, dim3(256), e))); break;
+                case 6: CHK((step_launch<&k_enoise<P, 6>>(h, eg, dim3(256), e))); break;
+                default: return fail(DSG_E_NOT_IMPLEMENTED, "embedded-space state: latent_dim / 64 must be 1, 2, 4 or 6");
             }
         }
         if (!(skip & 16)) {   // linear2 + residual -> pre2   (K = ff split over the 4 waves of the workgroup)
@@ -1417,9 +1458,9 @@ static int sample_prepare(dsg_handle* h, const dsg_sample_args* a, int B, void* 
     // embedded-space state (dsg_fused.h): whenever the update is linear in (x0, x_t, z) and nobody needs x_t itself
     const bool dumping_ = a->n_dump > 0 && a->dump_steps && a->dump_out;
     const int kb_in = h->Jp / h->kbk;
-    h->emode = h->ecarry != 0 && use_latency_mode(h, rows) && !dumping_ && !a->step_noise && !a->const_noise && !a->clip_denoised &&
+    h->emode = h->ecarry > 0 && use_latency_mode(h, rows) && !dumping_ && !a->step_noise && !a->const_noise && !a->clip_denoised &&
                h->cfgB == 0 && h->D <= 384 && (h->D / 64 == 1 || h->D / 64 == 2 || h->D / 64 == 4 || h->D / 64 == 6) &&
-               cdiv(kb_in, h->ez_ks) <= 12 && !(h->dbg_skip & 1);
+               cdiv(kb_in, h->ez_ks) <= 8 && !(h->dbg_skip & 1);
     int n_run = 0;
     CHK(build_step_tables(h, a->mode, a->skip_timesteps, a->eta, h->emode, &n_run));
     const size_t n = (size_t)B * h->J * h->T;
@@ -1490,6 +1531,7 @@ static int sample_prepare(dsg_handle* h, const dsg_sample_args* a, int B, void* 
     if (h->aql_mode == 1 && !job.dumping && !graph_wanted && n_run > 0) {
         bool planned = dsg_aql::init(h->aql, h->cfg.device, (const void*)&dsg_version);
         if (const char* e = getenv("DSG_AQL_ACQUIRE")) h->aql.acquire_scope = atoi(e) ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE;
+        if (const char* e = getenv("DSG_OVL_ACQUIRE")) h->aql.overlap_acquire_scope = atoi(e) ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE;
         if (planned) {
             dsg_aql::begin(h->aql);
             const int rc = run_step_p(h, c);
@@ -1606,7 +1648,13 @@ extern "C" int dsg_sample_multi(dsg_handle** hs, int n, const dsg_sample_args* a
         for (int j = 0; j < i; ++j) if (hs[j] == hs[i]) return fail(DSG_E_INVALID, "dsg_sample_multi: a handle appears twice");
         if (hs[i]->cfg.device != hs[0]->cfg.device) return fail(DSG_E_INVALID, "dsg_sample_multi: lanes must live on one device");
     }
+    if (n > 16) return fail(DSG_E_INVALID, "dsg_sample_multi: at most 16 lanes (more than 4 already share the command processor's pipes)");
     std::vector<SampleJob> jobs(n);
+    struct LaneScope {      // the kernel-shape rules see how many lanes run together, for the duration of this call
+        dsg_handle** hs; int n;
+        LaneScope(dsg_handle** h, int k) : hs(h), n(k) { for (int i = 0; i < n; ++i) hs[i]->lanes_now = n; }
+        ~LaneScope() { for (int i = 0; i < n; ++i) hs[i]->lanes_now = 1; }
+    } scope(hs, n);
     for (int i = 0; i < n; ++i) CHK(sample_prepare(hs[i], &args[i], B, stream, jobs[i]));
     bool all_aql = true;
     for (int i = 0; i < n; ++i) all_aql = all_aql && jobs[i].aql;

@@ -36,7 +36,7 @@ typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short bf16_t;
 
 #define DSG_FLT_MAX 3.402823466e+38f
-#define DSG_EZ_MAXKS 6          // K splits of the noise embedding (k_enoise), summed on read by the EPI_ESTEP epilogue
+#define DSG_EZ_MAXKS 18         // K splits of the noise embedding (k_enoise), summed on read by the EPI_ESTEP epilogue
 
 // ---------------------------------------------------------------------------------------------------------
 // precision policies
@@ -1381,6 +1381,35 @@ __global__ void k_mm_naive(const MMArgs a) {
         float v = (float)acc;
         if (a.act == 1) v = v / (1.0f + expf(-v));
         a.C[(size_t)m * a.ldc + nn] = v;
+    }
+}
+// the same product for LONG reductions (the seed-pose embedding: K = J * n_seed = 9128): one workgroup per output element, the
+// 256 lanes stride over k, double accumulation, fixed-order tree reduction -- the one-thread-per-output kernel above needs
+// 1.4 ms for that GEMV, which was most of the per-window host-side gap (2 ms per 115 ms window)
+__global__ __launch_bounds__(256) void k_mm_longk(const MMArgs a) {
+    __shared__ double red[256];
+    const size_t n = (size_t)a.M * a.N;
+    for (size_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const int nn = (int)(i % a.N), m = (int)(i / a.N);
+        const float* pa = a.A + (long long)m * a.sam;
+        const float* pb = a.Bm + (long long)nn * a.sbn;
+        double acc = 0.0;
+        for (int k = threadIdx.x; k < a.K; k += 256) acc += (double)pa[(long long)k * a.sak] * (double)pb[(long long)k * a.sbk];
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int s2 = 128; s2 > 0; s2 >>= 1) {
+            if ((int)threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            double r = red[0];
+            if (a.bias) r += (double)a.bias[nn];
+            if (a.add) r += (double)a.add[(long long)(m / a.add_div) * a.sadd + nn];
+            float v = (float)r;
+            if (a.act == 1) v = v / (1.0f + expf(-v));
+            a.C[(size_t)m * a.ldc + nn] = v;
+        }
+        __syncthreads();
     }
 }
 // pack W[N][K] fp32 (row pitch ldw, column offset folded into the pointer) into MFMA fragment order

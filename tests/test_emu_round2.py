@@ -162,11 +162,15 @@ def test_attention3_beat_twh_tree(emu_lib, golden_dir, cfgname):
         assert rel_l2(m(x, np.array([ts] * B), y, uncond_info=True), g[cfgname + "_uncond"]) < TOL[prec]
 
 
-@pytest.mark.parametrize("tnw", ["1", "2"])
+@pytest.mark.parametrize("tnw", ["1", "2", "tp"])
 def test_block_gemms_of_the_batched_path(emu_lib, golden_dir, monkeypatch, tnw):
     """dsg_batched.h (64-row block GEMMs, used from 512 rows up) forced on at the small test dims (DSG_GEMM_BLK=1, un-fused
     kernel set): forward with masks / uncond, DDPM + DDIM chains, guidance, the DSG+ / DSG++ models, and ZEGGS dims at batch 2
     -- against the same reference goldens as the latency kernels"""
+    if tnw == "tp":                                          # k_gemm_tp: the BM x 128 blocks used from ~2000 rows up
+        monkeypatch.setenv("DSG_GEMM_TP", "1")
+        monkeypatch.setenv("DSG_GEMM_TP_MASK", "127")
+        tnw = "2"
     monkeypatch.setenv("DSG_GEMM_BLK", "1")
     monkeypatch.setenv("DSG_GEMM_BLK_MASK", "127")          # every GEMM of the step, not only the ones the default mask selects
     monkeypatch.setenv("DSG_GEMM_BLK_RT", "4" if tnw == "2" else "2")
@@ -205,3 +209,24 @@ def test_block_gemms_of_the_batched_path(emu_lib, golden_dir, monkeypatch, tnw):
             yz = synth_window_inputs(cfg, 2, window=1, seed_pose_scale=0.5)
             xz = np.random.RandomState(4244).randn(2, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
             assert rel_l2(mz(xz, np.array([999, 3]), yz), g2["b2_t999_3_out"]) < TOL[prec]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_embedded_space_state_option(emu_lib, golden_dir, monkeypatch, prec):
+    """DSG_ECARRY=1 (opt-in, measured slower on the hardware): the loop carries E(x_t) = Wfold . x_t instead of x_t, the noise
+    enters through its embedding, the pose head runs once after the loop -- same goldens, DDPM and DDIM, start from an image"""
+    monkeypatch.setenv("DSG_ECARRY", "1")
+    gt = _g(golden_dir, "gt_tiny_zeggs.npz")
+    cfg = C.TINY
+    m = _model(cfg, prec, emu_lib, wseed=int(gt["wseed"]))
+    y = synth_window_inputs(cfg, 2, window=2, seed_pose_scale=0.3)
+    shape = (2, cfg.njoints, 1, cfg.n_poses)
+    d, d50 = create_gaussian_diffusion(library=emu_lib), create_gaussian_diffusion("ddim50", library=emu_lib)
+    tol = 3 * TOL[prec]
+    assert rel_l2(d.manual_seed(77, 3).p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=990), gt["ddpm_skip990"]) < tol
+    init = np.random.RandomState(5).randn(*shape).astype(np.float32)
+    assert rel_l2(d.manual_seed(77, 4).p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=992, init_image=init),
+                  gt["ddpm_init_skip992"]) < tol
+    assert rel_l2(d50.manual_seed(77, 9).ddim_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, eta=1.0, skip_timesteps=40),
+                  gt["ddim50_eta1_skip40"]) < tol
+    assert rel_l2(d.manual_seed(77, 10).p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=800), gt["ddpm200_tiny"]) < tol
