@@ -7,10 +7,13 @@
 
 A "step" is one pass of the hot path over one batch of synthetic input = sampling `--clips-per-gpu` 320-frame clips per GPU
 (4 windows x 1000 denoising steps each).  Default: 1 clip at batch 1 = BASELINE config[1].  `--clips-per-gpu 16` is the
-per-GPU share of config[3] (8 GPUs x 16 = 128 clips) in two variants:
-    --mode streams    16 sampling lanes (own HSA queue each, ONE copy of the weights), one clip per lane at batch 1,
-                      step loops interleaved by the library (dsg_sample_multi) -- "one clip per stream"
-    --mode lockstep   one batch of 16 clips advanced in lock step (the batched kernel set)
+per-GPU share of config[3] (8 GPUs x 16 = 128 clips); how the clips of a GPU are arranged:
+    (default)         4 sampling lanes (own HSA queue each, ONE copy of the weights) x 4 clips per lane in lock step, the
+                      lanes' step loops interleaved by the library (dsg_sample_multi) -- the fastest arrangement measured
+    --lanes L         L lanes x clips-per-gpu / L clips each
+    --mode streams    one clip per lane ("one clip per stream"): beyond 4 lanes the queues share hardware pipes and the
+                      rate collapses -- kept for the measurement
+    --mode lockstep   one batch of all clips advanced in lock step (the batched kernel set)
 Clips are independent, so N GPUs run N x clips-per-gpu clips (weak scaling, no collective on the data path); the finished
 poses are gathered to rank 0 with one RCCL gather inside the timed region.  Inputs (synthetic WavLM features, synthetic
 weights) are resident in HBM when the clock starts.  De-normalisation + .bvh writing (C++, rank 0) is timed separately
@@ -59,7 +62,8 @@ def parse(argv=None):
         a.mode = "lanes" if 1 < a.lanes < a.clips_per_gpu else ("lockstep" if a.lanes == 1 else "streams")
     elif a.mode == "auto":
         # the command processor overlaps one queue per compute pipe: 4 lanes, the other clips ride in the lanes' batches
-        a.lanes = min(4, a.clips_per_gpu)
+        # (DDIM-50: the step loops are 20x shorter and the per-window host work of 4 lanes shows -- one lock-step batch)
+        a.lanes = 1 if a.sampler == "ddim50" else min(4, a.clips_per_gpu)
         while a.clips_per_gpu % a.lanes:
             a.lanes -= 1
         a.mode = "lanes" if 1 < a.lanes < a.clips_per_gpu else ("lockstep" if a.lanes == 1 else "streams")

@@ -182,6 +182,7 @@ struct dsg_handle {
     bool fuse_attn_mid = true;           // k_attn_mid (attention inside the out_proj/LN/linear1 kernel) at batch 1; DSG_FUSE_ATTN_MID=0 to A/B
     int* st_tmodel = nullptr; float* st_c[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int st_cap = 0, n_run = 1;
+    bool st_valid = false, st_emode = false; int st_mode = -1, st_skip = -1; float st_eta = 0.f;      // what the device tables hold
     Sched sched;
     // graphs: key = (B, out_mode, ext_noise?, const_noise) -> exec
     // n_run is part of the key: the captured kernels carry the step-table length as an argument (n_tab)
@@ -598,6 +599,7 @@ extern "C" int dsg_set_schedule(dsg_handle* h, const double* betas, const int64_
         s.tmap[i] = (int)tmap[i];
     }
     h->sched = s;
+    h->st_valid = false;
     // captured graphs carry the table pointers and the table length of the schedule they were captured under
     for (auto& kv : h->graphs) { (void)hipGraphExecDestroy(kv.second.exec); (void)hipGraphDestroy(kv.second.graph); }
     h->graphs.clear();
@@ -1394,6 +1396,11 @@ static int build_step_tables(dsg_handle* h, int mode, int skip, float eta, bool 
     if (s.n == 0) return fail(DSG_E_STATE, "dsg_sample before dsg_set_schedule");
     if (skip < 0 || skip >= s.n) return fail(DSG_E_INVALID, "skip_timesteps out of range");
     const int n_run = s.n - skip;
+    // every window of a clip asks for the same tables: they stay on the device until schedule / mode / skip / eta change
+    if (h->st_valid && h->st_mode == mode && h->st_skip == skip && h->st_eta == eta && h->st_emode == emode) {
+        *n_run_out = n_run; h->n_run = n_run;
+        return 0;
+    }
     std::vector<int> tm(n_run);
     std::vector<float> c[5];
     for (auto& v : c) v.assign(n_run, 0.f);
@@ -1430,6 +1437,7 @@ static int build_step_tables(dsg_handle* h, int mode, int skip, float eta, bool 
     HIPCHK(hipStreamSynchronize(h->stream));
     *n_run_out = n_run;
     h->n_run = n_run;
+    h->st_valid = true; h->st_mode = mode; h->st_skip = skip; h->st_eta = eta; h->st_emode = emode;
     return 0;
 }
 

@@ -40,10 +40,12 @@ def _model(cfg, prec, max_batch=1, wseed=20240, spg=0, latency_mode="auto"):
 # N1: "outputs match the reference .bvh frames within a stated L2 tolerance on identical seeds" -- the whole config[1]
 # workload (4 windows x 1000 steps) through de-normalisation and the BVH writer, against the reference's inference() +
 # pose2bvh driven with the same Philox noise (G12 poses, G13 .bvh channels).
-#   stated tolerance, fp32 kernels: rel-L2 <= 1e-3 on de-normalised poses; BVH rotations max <= 0.5 deg, positions <= 0.05 cm
-#   stated tolerance, bf16 kernels: rel-L2 <= 3e-2 on NORMALISED poses (the per-window bound, windows are chained);
-#                                   BVH rotation channels median <= 0.5 deg, 99th percentile <= 8 deg; root position <= 2 cm
-# (measured values are printed and recorded in DESIGN.md / profiles/)
+#   stated tolerance, fp32 kernels: rel-L2 <= 1e-5 on de-normalised poses; BVH rotations max <= 2e-3 deg, root position <= 1e-3 cm
+#       (measured on MI355X: 2.0e-7; 1.1e-4 deg; 2.7e-5 cm)
+#   stated tolerance, bf16 kernels: rel-L2 <= 3e-2 on NORMALISED poses (the per-window bound; windows are chained);
+#       BVH rotation channels max <= 3 deg, median <= 0.1 deg; root position <= 1 cm
+#       (measured: 9.3e-3; max 0.72 / p99 0.26 / median 0.011 deg; 0.32 cm)
+# (the measured values are printed by the test and recorded in DESIGN.md s2 / profiles/)
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_full_clip_1000_steps_bvh_parity(gpu, golden_dir, tmp_path, prec):
@@ -76,9 +78,9 @@ def test_full_clip_1000_steps_bvh_parity(gpu, golden_dir, tmp_path, prec):
                  pos_max_cm=dpos.max(), pos_median_cm=np.median(dpos))
     print(f"N1 {prec}: " + " ".join(f"{k}={v:.3e}" for k, v in stats.items()))
     if prec == "fp32":
-        assert e_den < 1e-3 and drot.max() < 0.5 and dpos.max() < 0.05, stats
+        assert e_den < 1e-5 and drot.max() < 2e-3 and dpos.max() < 1e-3, stats
     else:
-        assert e_norm < 3e-2 and np.median(drot) < 0.5 and np.percentile(drot, 99) < 8.0 and dpos.max() < 2.0, stats
+        assert e_norm < 3e-2 and drot.max() < 3.0 and np.median(drot) < 0.1 and dpos.max() < 1.0, stats
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
