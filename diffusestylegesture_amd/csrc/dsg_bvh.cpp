@@ -195,16 +195,22 @@ void dfs(int i, const std::vector<std::vector<int>>& kids, std::vector<int>& seq
     seq.push_back(i);
     for (int k : kids[i]) dfs(k, kids, seq);
 }
-const std::vector<int>& joint_sequence(std::vector<std::vector<int>>* kids_out = nullptr) {
-    static std::vector<std::vector<int>> kids;
-    static std::vector<int> seq;
-    if (seq.empty()) {
+// children lists and the depth-first joint order of the file; built once (function-local static: initialisation is
+// thread-safe -- the batch writer enters here from many threads at once)
+struct Skeleton {
+    std::vector<std::vector<int>> kids;
+    std::vector<int> seq;
+    Skeleton() {
         kids.assign(NJ, {});
         for (int j = 1; j < NJ; ++j) kids[PARENTS[j]].push_back(j);
         dfs(0, kids, seq);
     }
-    if (kids_out) *kids_out = kids;
-    return seq;
+};
+const Skeleton& skeleton() { static const Skeleton s; return s; }
+const std::vector<int>& joint_sequence(std::vector<std::vector<int>>* kids_out = nullptr) {
+    const Skeleton& s = skeleton();
+    if (kids_out) *kids_out = s.kids;
+    return s.seq;
 }
 
 // offsets [NJ*3], motion [3*frames][NCH] in file order (root: 3 positions + 3 rotations, then 3 rotations per joint in DFS order)

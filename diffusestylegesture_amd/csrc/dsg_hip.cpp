@@ -150,6 +150,8 @@ struct dsg_handle {
           *X1 = nullptr, *fwd_out = nullptr, *io_tmp = nullptr, *io_tmp2 = nullptr, *ext_noise = nullptr;
     size_t ext_noise_cap = 0;
     void *xsA = nullptr, *X0a = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *attn = nullptr, *hidden = nullptr;
+    void* X1a = nullptr;                 // LayerNorm1 rows in the GEMM type, fragment-major (k_attn_op -> linear1)
+    int attn_op = -1;                    // DSG_ATTN_OP: -1 auto (batched kernel set, shapes with an instantiation), 0 never
     int* ctr = nullptr;                  // scratch counter for diagnostics
     StepCtl* ctl = nullptr;              // device-resident step control (dsg_kernels.h: StepCtl)
     int* t_arr = nullptr; unsigned* dyn = nullptr;
@@ -315,6 +317,7 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     if (const char* e = getenv("DSG_GEMM_TM")) h->gemm_tm = atoi(e);
     if (const char* e = getenv("DSG_GEMM_LEAN")) h->gemm_lean = atoi(e);
     if (const char* e = getenv("DSG_ECARRY")) h->ecarry = atoi(e);
+    if (const char* e = getenv("DSG_ATTN_OP")) h->attn_op = atoi(e);
     if (const char* e = getenv("DSG_GEMM_BLK")) h->gemm_blk = atoi(e);
     if (const char* e = getenv("DSG_GEMM_TP")) h->gemm_tp = atoi(e);
     if (const char* e = getenv("DSG_GEMM_TP_MASK")) h->gemm_tp_mask = atoi(e);
@@ -361,6 +364,7 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     CHK(dalloc(h, &h->Xn, M_pad * D));
     CHK(dalloc(h, &h->X1, M_pad * D));
     CHK(dalloc_bytes(h, &h->attn, M_pad * D * h->es));
+    CHK(dalloc_bytes(h, &h->X1a, M_pad * D * h->es));
     CHK(dalloc_bytes(h, &h->hidden, M_pad * (size_t)h->ff * h->es));
     const size_t qkv_elems = (size_t)B * h->H * Tp * hd;
     CHK(dalloc_bytes(h, &h->q, qkv_elems * h->es));
@@ -1039,6 +1043,10 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
     // GEMM make it slower (15 us) than LN+QKV followed by k_attn (6.2 + 4.6 us): opt-in only (DSG_FUSE_ATTN=1)
     const bool fuse_attn = lat && have_qkv_attn(h) && h->fuse_attn;
     const bool attn_in_mid = lat && !fuse_attn && h->fuse_attn_mid && have_attn_mid(h, B);
+    // batched kernel set: attention fused with out_proj + LayerNorm1 (k_attn_op) where an instantiation exists
+    // (bf16 only: in fp32 W_o is 16 k-blocks x DT tiles per wave and does not fit the register file next to the attention)
+    const bool attn_op = sizeof(typename P::elem) == 2 && !lat && !fuse_attn && h->attn_op != 0 && h->H == 4 && ((D == 256 && h->Tp == 96) || (D == 128 && h->Tp == 32)) &&
+                         (h->attn_op > 0 || M >= 256);
     // (attention -> k_mid) as an overlapped pair: k_mid's packet carries no barrier bit, it requests W_o / W_1 / operands
     // while the attention kernel still runs and synchronises with it in-kernel (DepWait).  Correct (bit-identical, tested)
     // but measured SLOWER on MI355X: 158 vs 144 us/step -- the agent-scope (L2-bypassing) stores / loads of the handed-off
@@ -1070,7 +1078,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                     CHK((launch_gemm_w<P, PRO_LN, EPI_QKV>(h, g)));
                 }
             }
-            if (!(skip & 4) && !attn_in_mid) {   // attention
+            if (!(skip & 4) && !attn_in_mid && !attn_op) {   // attention
                 AttnArgs a;
                 memset(&a, 0, sizeof(a));
                 if (overlap_mid) a.done_ctr = h->dep_ctr + 0;
@@ -1097,6 +1105,25 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                 CHK(launch_attn_mid<P>(h, am));
             } else {
                 CHK(launch_mid<P>(h, a));
+            }
+        } else if (attn_op) {
+            // attention + out_proj + residual + LayerNorm1 in one kernel per (query tile, batch element); linear1 reads the
+            // normalised rows in the GEMM type
+            if (!(skip & 4)) {
+                AttnOpArgs a;
+                a.q = h->q; a.k = h->k; a.vt = h->vt; a.R = l == 0 ? h->X0 : h->Xn; a.Wo = ly.Wo; a.bo = ly.bo; a.ln_g = ly.g1; a.ln_b = ly.be1;
+                a.X1 = h->X1; a.X1a = h->X1a; a.B = B; a.ntok = ntok; a.Tp = h->Tp;
+                const dim3 grid(cdiv(ntok, 16), B);
+                if constexpr (sizeof(typename P::elem) == 2) {
+                    if (D == 256 && h->Tp == 96) CHK((step_launch<&k_attn_op<P, 4, 6>>(h, grid, dim3(256), a)));
+                    else CHK((step_launch<&k_attn_op<P, 2, 2>>(h, grid, dim3(256), a)));
+                }
+            }
+            {   // linear1 + GELU -> hidden
+                GemmArgs g = z;
+                g.M = M; g.MT = MT; g.NT = h->ff / 16; g.KBtot = D / KB; g.Wp = ly.W1; g.bias = ly.b1;
+                g.A = h->X1a; g.lda = D; g.a_frag = 1; g.out = h->hidden; g.ldo = h->ff; g.out_frag = 1;
+                CHK((launch_gemm_w<P, PRO_DIRECT, EPI_GELU>(h, g)));
             }
         } else {
             {   // out_proj + residual -> pre1

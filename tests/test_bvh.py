@@ -93,3 +93,26 @@ def test_fixed_point_formatter_edge_values(tmp_path, hip_lib_path):
         bvh.pose2bvh(poses, p, 1, False)
         first = open(p).read().split("MOTION\n")[1].split("\n")[2].split()[0]
         assert first == "%f" % v, (v, first)
+
+
+def test_batch_writer_first_call_from_many_threads(tmp_path, hip_lib_path):
+    """the batch writer's worker threads all reach the lazily built skeleton tables at once in a fresh process (a thread-unsafe
+    lazy initialisation there crashed `bench.py --clips-per-gpu 16` about every second run)"""
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    code = (
+        "import numpy as np, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from diffusestylegesture_amd import bvh\n"
+        "rs = np.random.RandomState(0)\n"
+        "p = rs.randn(32, 40, 1141).astype(np.float32)\n"
+        "p[..., 3] += 3.0\n"
+        f"paths = [{str(tmp_path)!r} + '/c%d.bvh' % i for i in range(32)]\n"
+        "bvh.pose2bvh_batch(p, paths, smoothing=True)\n"
+        f"bvh.pose2bvh(p[7], {str(tmp_path)!r} + '/one.bvh', 40, True)\n"
+        f"assert open(paths[7]).read() == open({str(tmp_path)!r} + '/one.bvh').read()\n"
+        "print('ok')\n")
+    for _ in range(6):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and "ok" in r.stdout, (r.returncode, r.stderr[-500:])

@@ -296,7 +296,8 @@ def test_throughput_kernel_set_vs_reference(gpu, golden_dir, prec):
 def test_batch16_consistency(gpu, monkeypatch):
     """B = 16 identical clips with shared noise: all 16 results are bit-identical (rows are independent), and they agree
     with the B = 1 run (a different kernel set: latency mode) to rounding-order level.  From 512 rows up the batched path
-    uses the 64-row block GEMMs (dsg_batched.h); forced on at batch 1 they must reproduce the batch-16 rows bit for bit."""
+    uses the 32-row block GEMMs (dsg_batched.h) and k_attn_op; forced on at batch 1 they must reproduce the batch-16 rows
+    bit for bit."""
     from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
     from oracle import philox
     cfg = C.ZEGGS
@@ -316,6 +317,7 @@ def test_batch16_consistency(gpu, monkeypatch):
     assert rel_l2(sB[0], s1[0]) < 1e-2
     for blk, exact in (("1", True), ("0", False)):
         monkeypatch.setenv("DSG_GEMM_BLK", blk)
+        monkeypatch.setenv("DSG_ATTN_OP", blk)           # batch 16 also fuses attention + out_proj + LayerNorm1 (k_attn_op)
         m1 = _model(cfg, "bf16", max_batch=1, latency_mode="off")
         d.manual_seed(3, 0)
         s1_off = d.p_sample_loop(m1, (1, cfg.njoints, 1, cfg.n_poses), noise=x1, clip_denoised=False,
