@@ -17,7 +17,8 @@ $(LIB): $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h $(CSRC)/ds
 # the device side of the same translation unit as a bare code object: loaded through the HSA loader by the AQL
 # submission path (dsg_aql.h), which needs kernel descriptors the HIP runtime does not hand out
 $(CSRC)/dsg_kernels.hsaco: $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h $(CSRC)/dsg_batched.h $(CSRC)/dsg_aql.h include/dsg.h
-	$(HIPCC) --offload-arch=gfx950 --cuda-device-only --no-gpu-bundle-output -O3 -std=c++17 -Wno-pass-failed -DDSG_BUILD_TAG=$(TAG)u $(CSRC)/dsg_hip.cpp -o $@
+	$(HIPCC) --offload-arch=gfx950 --cuda-device-only --no-gpu-bundle-output -O3 -std=c++17 -Wno-pass-failed -DDSG_BUILD_TAG=$(TAG)u \
+	    -Rpass-analysis=kernel-resource-usage $(CSRC)/dsg_hip.cpp -o $@ 2> $(CSRC)/dsg_kernels.resources.txt || (cat $(CSRC)/dsg_kernels.resources.txt >&2; exit 1)
 
 # diagnostics build: the same sources with cycle stamps at the phase boundaries of the step kernels (tools/stamps.py)
 stamps: $(CSRC)/libdsg_hip_stamps.so
@@ -44,5 +45,5 @@ tools/_build/aql_probe: tools/aql_probe.cpp
 	g++ -O2 -std=c++17 -I/opt/rocm/include $< -L/opt/rocm/lib -lhsa-runtime64 -Wl,-rpath,/opt/rocm/lib -o $@
 
 clean:
-	rm -f $(LIB) $(EMU) $(CSRC)/dsg_kernels.hsaco
+	rm -f $(LIB) $(EMU) $(CSRC)/dsg_kernels.hsaco $(CSRC)/dsg_kernels.resources.txt
 .PHONY: all emu stamps tools clean

@@ -74,21 +74,29 @@ def test_window_audio_split():
     assert wins[1][0] == 72 * 800 and wins[1][8 * 800] == 80 * 800
 
 
-def test_no_kernel_spills_to_scratch():
+def test_no_kernel_spills_to_scratch(hip_lib_path):
     """Every gfx950 kernel must fit the register file: a spilling instantiation is slow, and on hardware the two
-    spilling shapes seen during bring-up (fp32 attention <128,10>, k_mid<8>) also produced wrong results."""
+    spilling shapes seen during bring-up (fp32 attention <128,10>, k_mid<8>) also produced wrong results.  The register
+    report is written by `make` next to the code object it describes (csrc/dsg_kernels.resources.txt, hipcc
+    -Rpass-analysis=kernel-resource-usage of the same compile); it is regenerated here when it is missing or stale."""
     import shutil
     import subprocess
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        pytest.skip("hipcc not available")
-    src = os.path.join(ROOT, "diffusestylegesture_amd", "csrc", "dsg_hip.cpp")
-    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-pass-failed", "--cuda-device-only",
-                          "-c", src, "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"],
-                         capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    names = re.findall(r"Function Name: (\S+)", out.stderr)
-    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
+    csrc = os.path.join(ROOT, "diffusestylegesture_amd", "csrc")
+    rep = os.path.join(csrc, "dsg_kernels.resources.txt")
+    srcs = [os.path.join(csrc, f) for f in ("dsg_hip.cpp", "dsg_kernels.h", "dsg_fused.h", "dsg_batched.h", "dsg_aql.h")]
+    if not os.path.exists(rep) or os.path.getmtime(rep) < max(os.path.getmtime(f) for f in srcs):
+        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        if not os.path.exists(hipcc):
+            pytest.skip("hipcc not available")
+        out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-pass-failed", "--cuda-device-only",
+                              "-c", srcs[0], "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"],
+                             capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        text = out.stderr
+    else:
+        text = open(rep).read()
+    names = re.findall(r"Function Name: (\S+)", text)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", text)]
     assert len(names) == len(scratch) and len(names) > 40
     bad = [(n, s) for n, s in zip(names, scratch) if s != 0]
     assert not bad, bad
