@@ -171,6 +171,7 @@ struct dsg_handle {
     int gemm_tp_mask = 1 | 4 | 16;       // DSG_GEMM_TP_MASK: which GEMMs take k_gemm_tp (bits as DSG_GEMM_BLK_MASK)
     int gemm_tp = 0;                     // DSG_GEMM_TP=1: k_gemm_tp (BM x 128 blocks) for the GEMMs of DSG_GEMM_TP_MASK (experiment: slower)
     int gemm_blk_tnw = 0;                // DSG_GEMM_BLK_TNW: column tiles per wave in k_gemm_blk (default 1)
+    int kin_ks = 0;                      // DSG_KIN_KS: workgroup split-K of the pose embedding on the block path (default 2)
     int gemm_blk_rt = 0;                 // DSG_GEMM_BLK_RT: 16-row tiles per workgroup in k_gemm_blk: 2 (default) or 4
     int gemm_blk_mask = 1 | 4 | 8 | 32;      // DSG_GEMM_BLK_MASK: which GEMMs of the batched step use the block kernels: 1 QKV, 2 out_proj,
                                          // 4 linear1, 8 linear2, 16 pose head, 32 pose embedding.  Measured per GEMM in the real
@@ -323,6 +324,7 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     if (const char* e = getenv("DSG_GEMM_TP_MASK")) h->gemm_tp_mask = atoi(e);
     if (const char* e = getenv("DSG_GEMM_BLK_TNW")) h->gemm_blk_tnw = atoi(e);
     if (const char* e = getenv("DSG_GEMM_BLK_RT")) h->gemm_blk_rt = atoi(e);
+    if (const char* e = getenv("DSG_KIN_KS")) h->kin_ks = atoi(e);
     if (const char* e = getenv("DSG_GEMM_BLK_MASK")) h->gemm_blk_mask = atoi(e);
     if (const char* e = getenv("DSG_OVERLAP")) h->overlap = atoi(e) != 0;
     if (const char* e = getenv("DSG_AQL")) h->aql_mode = atoi(e);
@@ -479,7 +481,7 @@ static int launch_mm(dsg_handle* h, float* C, int ldc, const float* A, long long
     a.add = add; a.sadd = sadd; a.add_div = add_div < 1 ? 1 : add_div; a.M = M; a.N = N; a.K = K; a.act = act;
     const size_t n = (size_t)M * N;
     if (n == 0) return 0;
-    if (K >= 512 && n <= 65536) {       // long reductions, few outputs: a workgroup per output (k_mm_longk)
+    if (K >= 512 && n <= (1u << 20)) {  // long reductions: a workgroup per output (k_mm_longk); the big set-up tables stay on k_mm_naive
         hipLaunchKernelGGL(k_mm_longk, dim3((int)std::min<size_t>(n, 16384)), dim3(256), 0, h->stream, a);
         HIPCHK(hipGetLastError());
         return 0;
@@ -1009,7 +1011,11 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
     const bool lat = use_latency_mode(h, B);
     LocArgs la;
     memset(&la, 0, sizeof(la));
-    la.partial = h->partial; la.KS = h->KSin; la.Min_pad = MTin * 16; la.Cf = h->Cf; la.TE2 = h->TE2; la.TE = h->TE;
+    // split-K of the pose-embedding GEMM across workgroups: one split per 256 pose features for the 16 x 16 tile kernel; the
+    // block kernel splits K over its 4 waves already, so 2 workgroup splits keep a wave's share at <= 8 k-blocks (one batch of
+    // loads) without fragmenting the work 5 ways (DSG_KIN_KS overrides)
+    const int ks_in = use_blk(h, Min, 32) ? std::min(h->KSin, h->kin_ks > 0 ? h->kin_ks : 2) : h->KSin;
+    la.partial = h->partial; la.KS = ks_in; la.Min_pad = MTin * 16; la.Cf = h->Cf; la.TE2 = h->TE2; la.TE = h->TE;
     la.emb1 = h->emb1; la.ctl = c.use_ctr ? h->ctl : nullptr; la.t_arr = h->t_arr;
     la.rcos = h->rcos; la.rsin = h->rsin; la.mask = h->mask; la.mb = h->mb; la.inv_mask_div = fastdiv_inv((int)((long long)B * h->Hl / h->mb)); la.B = B; la.T = T; la.D = D; la.Hl = h->Hl;
     la.hd = h->hdl; la.W = h->W; la.X0 = h->X0; la.X0a = h->X0a; la.nomask = h->nomask;
@@ -1029,7 +1035,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
     } else {
         {   // k_in: partial[s] = xs[:, chunk s] . Wfold[:, chunk s]^T
             GemmArgs g = z;
-            g.M = Min; g.MT = MTin; g.NT = D / 16; g.KBtot = h->Jp / KB; g.KS = h->KSin; g.Wp = h->Wp_in;
+            g.M = Min; g.MT = MTin; g.NT = D / 16; g.KBtot = h->Jp / KB; g.KS = ks_in; g.Wp = h->Wp_in;
             g.kb_per_split = cdiv(g.KBtot, g.KS);
             g.A = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; g.lda = h->Jp;
             g.out = h->partial; g.ldo = D;

@@ -209,6 +209,7 @@ class DSGDiffusion:
         library (dsg_sample_multi: every lane owns an HSA queue; "one clip per stream").  Lane i draws from the Philox stream
         (seeds[i], stream_ids[i]) at this object's current draw counter, which advances once for all lanes -- so lane i
         reproduces `manual_seed(seeds[i], stream_ids[i])` + the same sequence of single-lane calls bit for bit."""
+        models = list(models)
         n = len(models)
         if n == 0 or len(model_kwargs_list) != n:
             raise ValueError("one model_kwargs per lane")

@@ -206,7 +206,7 @@ def test_block_gemms_of_the_batched_path(emu_lib, golden_dir, monkeypatch, tnw):
     if zeggs_too:
         g2 = _g(golden_dir, "g2_forward_zeggs.npz")
         cfg = C.ZEGGS
-        for prec in ("fp32", "bf16"):
+        for prec in ("bf16",):           # (fp32 at these dims: test_emu_parity.py::test_batched_gemm_workgroup_shapes)
             mz = _model(cfg, prec, emu_lib, wseed=int(g2["wseed"]), latency_mode="off")
             yz = synth_window_inputs(cfg, 2, window=1, seed_pose_scale=0.5)
             xz = np.random.RandomState(4244).randn(2, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
