@@ -51,6 +51,7 @@ struct Ctx {
     double last_ms = 0.0;
     int acquire_scope = HSA_FENCE_SCOPE_AGENT;      // DSG_AQL_ACQUIRE=0 -> NONE (experiment)
     int overlap_acquire_scope = HSA_FENCE_SCOPE_AGENT;      // acquire scope of the packets WITHOUT barrier bit (DSG_OVL_ACQUIRE=0 -> NONE)
+    bool pinned = false;    // the plan holds XCD-pinned kernels (dsg_kernels.h): no fences between the packets of the loop
 };
 
 inline bool hsa_ok(Ctx& c, hsa_status_t s, const char* what) {
@@ -164,7 +165,7 @@ inline bool record(Ctx& c, const void* host_fn, hipStream_t stream, dim3 grid, d
     return true;
 }
 
-inline void begin(Ctx& c) { c.plan.clear(); c.ka_host.clear(); c.recording = true; }
+inline void begin(Ctx& c) { c.plan.clear(); c.ka_host.clear(); c.recording = true; c.pinned = false; }
 
 // argument blocks -> device memory (once per dsg_sample call)
 inline bool finish(Ctx& c) {
@@ -198,9 +199,13 @@ inline void submit_step(Ctx& c, bool first_step, bool last_step) {
         p->kernarg_address = c.ka_dev + l.ka_off;
         p->reserved2 = 0;
         p->completion_signal.handle = last ? c.done.handle : 0;
-        const int rel = last ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
+        // pinned plan: what a lane reads was written on its own XCD and is read past the L1 (sc1), so only the first packet
+        // acquires (everything the set-up kernels wrote) and only the last one releases (the samples)
+        const int mid_scope = c.pinned ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT;
+        const int rel = last ? HSA_FENCE_SCOPE_SYSTEM : mid_scope;
+        const int acq = first_step && i == 0 ? HSA_FENCE_SCOPE_SYSTEM : (c.pinned ? HSA_FENCE_SCOPE_NONE : (l.overlap ? c.overlap_acquire_scope : c.acquire_scope));
         const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | ((l.overlap ? 0 : 1) << HSA_PACKET_HEADER_BARRIER) |
-                                           ((first_step && i == 0 ? HSA_FENCE_SCOPE_SYSTEM : (l.overlap ? c.overlap_acquire_scope : c.acquire_scope)) << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
+                                           (acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
                                            (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
         __atomic_store_n((uint16_t*)p, header, __ATOMIC_RELEASE);
     }

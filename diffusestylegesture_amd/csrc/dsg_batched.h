@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_gemm_blk(const GemmArgs g) {
     __shared__ __attribute__((aligned(16))) char lds_a[BM * (DMAX * ES + 16)];
     preload_kernargs(g);
     const int NG = g.NT / (4 * TNW);
-    const int ng = xcd_ngroup(), mb = blockIdx.y;
+    const int ng = xcd_ngroup<P>(), mb = blockIdx.y;
     const int MB = (g.MT + RT - 1) / RT;
     if constexpr (EPI == EPI_OUT) {
         if (mb >= MB) {      // extra grid row: step bookkeeping (see gemm_body)
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void k_gemm_blk_k(const GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float red[4][RT * CT][64][4];      // every wave's partial 32 x 32 block
     preload_kernargs(g);
     const int NG = g.NT / CT;
-    const int ng = xcd_ngroup(), mb = blockIdx.y, ks = blockIdx.z;
+    const int ng = xcd_ngroup<P>(), mb = blockIdx.y, ks = blockIdx.z;
     const int MB = (g.MT + RT - 1) / RT;
     if constexpr (EPI == EPI_PARTIAL) {
         if (mb >= MB) {      // extra grid row: step bookkeeping (see gemm_body)
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void k_gemm_tp(const GemmArgs g) {
     __shared__ __attribute__((aligned(16))) char lds_a[BM * (DMAX * ES + 16)];
     preload_kernargs(g);
     const int NGT = (g.NT + 7) / 8;                  // 128-column groups (the last one may be partial)
-    const int ng = xcd_ngroup(), mb = blockIdx.y;
+    const int ng = xcd_ngroup<P>(), mb = blockIdx.y;
     const int MB = (g.MT * 16 + BM - 1) / BM;
     if constexpr (EPI == EPI_OUT) {
         if (mb >= MB) {      // extra grid row: step bookkeeping (see gemm_body)

@@ -31,12 +31,13 @@ struct InLocArgs {
 };
 
 template <class P, int HD, int W>
-__global__ __launch_bounds__(256) void k_inloc(const InLocArgs g) {
+__device__ __forceinline__ void inloc_body(const InLocArgs& g) {
     typedef typename P::elem elem;
+    constexpr int ES = (int)sizeof(elem);
     preload_kernargs(g);
     const LocArgs& a = g.loc;
     if (blockIdx.z == gridDim.z - 1) {      // an EXTRA grid slice: its first workgroup does the step bookkeeping (see StepCtl), off the critical path
-        if (g.ctl_upd && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) step_advance_B(g.ctl_upd, g.st, g.n_tab);
+        if (g.ctl_upd && vbx<P>() == 0 && blockIdx.y == 0 && threadIdx.x == 0) step_advance_B<P>(g.ctl_upd, g.st, g.n_tab);
         return;
     }
     constexpr int W2 = 2 * W, half = HD / 2, NP1 = W2 * half, NPI = (NP1 + 255) / 256;
@@ -45,11 +46,11 @@ __global__ __launch_bounds__(256) void k_inloc(const InLocArgs g) {
     __shared__ __attribute__((aligned(16))) float red[4][2][NL][64][4];      // per-wave partial accumulators
     __shared__ float rot[W2][HD + 1];
     __shared__ float sc[W][W2 + 2];
-    const int h = blockIdx.x, w = blockIdx.y, b = blockIdx.z;            // grid (local heads, windows, batch [+1 bookkeeping])
+    const int h = vbx<P>(), w = blockIdx.y, b = blockIdx.z;            // grid (local heads, windows, batch [+1 bookkeeping])
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
     const int col0 = h * HD, ntok = a.T + 1, f0 = (w - 1) * W;
     const int* tp = a.ctl ? &a.ctl->tA : a.t_arr + b;      // select the ADDRESS, then one unconditional load
-    const int t = *tp;
+    const int t = ldw<P>(tp);
 
     // ---- (1) window constants, rotary tables and the key mask: issued first, unconditionally (clamped indices)
     float lo[NPI], hi[NPI], c1[NPI], s1[NPI];
@@ -89,12 +90,12 @@ __global__ __launch_bounds__(256) void k_inloc(const InLocArgs g) {
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NL; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const elem* arow[2];
+    size_t arow[2];                                  // element offsets into g.xs
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         int f = f0 + mt * 16 + lr;
         f = f < 0 ? 0 : (f > a.T - 1 ? a.T - 1 : f);          // rows outside the window pair are computed and ignored
-        arow[mt] = (const elem*)g.xs + ((size_t)b * a.T + f) * g.Jp + P::E * lg;
+        arow[mt] = ((size_t)b * a.T + f) * g.Jp + P::E * lg;
     }
     const f32x4* wbase = (const f32x4*)g.Wp + lane;
     constexpr int CH = 9;
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void k_inloc(const InLocArgs g) {
         for (int c = 0; c < CH; ++c) {
             const int kb = min(kb0 + c, kb_last);                  // clamped, never predicated
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) af[c][mt] = *(const f32x4*)(arow[mt] + (size_t)kb * P::KB);
+            for (int mt = 0; mt < 2; ++mt) af[c][mt] = lda16<P>(g.xs, (arow[mt] + (size_t)kb * P::KB) * ES);
 #pragma unroll
             for (int nt = 0; nt < NL; ++nt) bf[c][nt] = wbase[((size_t)(ntile0 + nt) * g.KBtot + kb) * 64];
         }
@@ -164,6 +165,8 @@ __global__ __launch_bounds__(256) void k_inloc(const InLocArgs g) {
     DSG_LDS_BARRIER();
     local_attn_tail<P, HD, W>(a, rot, sc, b, w, h, keep, c2, s2);
 }
+template <class P, int HD, int W>
+__global__ __launch_bounds__(256) void k_inloc(const InLocArgs g) { inloc_body<P, HD, W>(g); }
 
 // ---------------------------------------------------------------------------------------------------------
 // k_qkv_attn
@@ -480,7 +483,7 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
     preload_kernargs(g);
     DSG_STAMP_SCALAR_WAIT(0, 8);
     const int NGH = g.ff / 64;
-    const int ng = xcd_ngroup(), mt = blockIdx.y;
+    const int ng = xcd_ngroup<P>(), mt = blockIdx.y;
     if (ng >= NGH) return;
     const int m0 = mt * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
@@ -590,7 +593,7 @@ struct AttnMidArgs {
 };
 
 template <class P, int DT, int NKT>      // D = 64 DT, H = 4, hd = 16 DT, Tp = 16 NKT
-__global__ __launch_bounds__(256) void k_attn_mid(const AttnMidArgs ga) {
+__device__ __forceinline__ void attn_mid_body(const AttnMidArgs& ga) {
     typedef typename P::elem elem;
     constexpr int ES = (int)sizeof(elem);
     constexpr int D = DT * 64, HD = DT * 16;
@@ -612,29 +615,27 @@ __global__ __launch_bounds__(256) void k_attn_mid(const AttnMidArgs ga) {
     preload_kernargs(ga);
     const MidArgs& g = ga.mid;
     const int NGH = g.ff / 64;
-    const int ng = xcd_ngroup(), mt = blockIdx.y;
+    const int ng = xcd_ngroup<P>(), mt = blockIdx.y;
     if (ng >= NGH) return;
     const int m0 = mt * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
     const f32x4* wo = (const f32x4*)g.Wo + lane;
     const f32x4* w1 = (const f32x4*)g.W1 + lane;
     const int h = wave;                              // head of this wave
-    const elem* Q = (const elem*)ga.q + (size_t)h * ga.Tp * HD;
-    const elem* K = (const elem*)ga.k + (size_t)h * ga.Tp * HD;
-    const elem* VT = (const elem*)ga.vt + (size_t)h * HD * ga.Tp;
+    const size_t Q = (size_t)h * ga.Tp * HD, K = Q, VT = (size_t)h * HD * ga.Tp;      // element offsets of this head in q / k / vt
 
     // ---- (1) attention operand fragments
     f32x4 qf[KDH], kf[NKT][KDH], vfr[ND][NVF];
 #pragma unroll
-    for (int kb = 0; kb < KDH; ++kb) qf[kb] = *(const f32x4*)(Q + (size_t)((mt * KDH + kb) * 64 + lane) * P::E);     // fragment-major (qk_off)
+    for (int kb = 0; kb < KDH; ++kb) qf[kb] = lda16<P>(ga.q, (Q + (size_t)((mt * KDH + kb) * 64 + lane) * P::E) * ES);     // fragment-major (qk_off)
 #pragma unroll
     for (int nt = 0; nt < NKT; ++nt)
 #pragma unroll
-        for (int kb = 0; kb < KDH; ++kb) kf[nt][kb] = *(const f32x4*)(K + (size_t)((nt * KDH + kb) * 64 + lane) * P::E);
+        for (int kb = 0; kb < KDH; ++kb) kf[nt][kb] = lda16<P>(ga.k, (K + (size_t)((nt * KDH + kb) * 64 + lane) * P::E) * ES);
 #pragma unroll
     for (int dt = 0; dt < ND; ++dt) {
 #pragma unroll
-        for (int kb = 0; kb < NVF; ++kb) vfr[dt][kb] = *(const f32x4*)(VT + (size_t)((dt * NVF + kb) * 64 + lane) * P::E);       // fragment-major (vt_off)
+        for (int kb = 0; kb < NVF; ++kb) vfr[dt][kb] = lda16<P>(ga.vt, (VT + (size_t)((dt * NVF + kb) * 64 + lane) * P::E) * ES);       // fragment-major (vt_off)
     }
     DSG_LOADS_ISSUED();
     DSG_STAMP(0, 9);
@@ -658,7 +659,7 @@ __global__ __launch_bounds__(256) void k_attn_mid(const AttnMidArgs ga) {
 #pragma unroll
             for (int t = 0; t < DT; ++t) {
                 const int n = (wave * DT + t) * 16 + 4 * lg;
-                pr[t] = *(const f32x4*)(g.R + (size_t)(m0 + lr) * D + n);
+                pr[t] = lda16<P>(g.R, ((size_t)(m0 + lr) * D + n) * sizeof(float));
             }
         } else if (gi == PDA + 1) {
 #pragma unroll
@@ -778,6 +779,47 @@ __global__ __launch_bounds__(256) void k_attn_mid(const AttnMidArgs ga) {
     }
     mid_tail<P, DT>(g, acc, pbo, pr, pg, pbt, pb1, w1f, w1, a1, red, m0, ng, n1t, wave, lr, lg);
     DSG_STAMP(0, 7);
+}
+template <class P, int DT, int NKT>
+__global__ __launch_bounds__(256) void k_attn_mid(const AttnMidArgs ga) { attn_mid_body<P, DT, NKT>(ga); }
+
+// ---------------------------------------------------------------------------------------------------------
+// XCD-pinned lanes (dsg_kernels.h): the batch-1 step kernels for up to 8 lanes per dispatch.  a[lane] holds what the
+// lane's own launch would have received as kernel arguments.
+// ---------------------------------------------------------------------------------------------------------
+// the lanes' arguments travel in the kernel-argument segment itself (scalar loads, like any kernel's arguments)
+template <class T> struct PinTab { T a[8]; int nl; int pad; unsigned* err; };
+__device__ __forceinline__ void pin_check_xcd(unsigned* err) {
+#ifndef DSG_EMU
+    // HW_REG_XCC_ID (id 20), bits 3:0
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+    if (threadIdx.x == 0 && (xcc & 7u) != (blockIdx.x & 7u) && err) __hip_atomic_store(err, 1u + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    (void)err;
+#endif
+}
+// (the LayerNorm GEMMs in their 3-waves-per-SIMD form, ln_rows LEAN: a lane has 32 CUs for its 72-108 workgroups)
+template <int PRO, int EPI, int WN, int WK, int TNW>
+__global__ __launch_bounds__(256, PRO == PRO_LN ? 3 : 1) void k_gemm_x(const PinTab<GemmArgs> t) {
+    const int lane = blockIdx.x & 7;
+    if (lane >= t.nl) return;
+    gemm_body<PBF16X, PRO, EPI, WN, WK, TNW, PRO == PRO_LN>(t.a[lane]);
+    pin_drain<PBF16X>();
+}
+template <int HD, int W>
+__global__ __launch_bounds__(256) void k_inloc_x(const PinTab<InLocArgs> t) {
+    const int lane = blockIdx.x & 7;
+    if (lane >= t.nl) return;
+    pin_check_xcd(t.err);
+    inloc_body<PBF16X, HD, W>(t.a[lane]);
+    pin_drain<PBF16X>();
+}
+template <int DT, int NKT>
+__global__ __launch_bounds__(256, 2) void k_attn_mid_x(const PinTab<AttnMidArgs> t) {
+    const int lane = blockIdx.x & 7;
+    if (lane >= t.nl) return;
+    attn_mid_body<PBF16X, DT, NKT>(t.a[lane]);
+    pin_drain<PBF16X>();
 }
 
 // ---------------------------------------------------------------------------------------------------------

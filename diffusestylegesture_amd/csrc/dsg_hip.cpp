@@ -111,6 +111,15 @@ struct SharedWeights {
     ~SharedWeights() { for (void* p : allocs) (void)hipFree(p); }
 };
 
+// one launch of a lane's step, recorded for the pinned submission: the pinned twin of the kernel + the lane's arguments
+struct PinLaunch {
+    const void* fnx;        // pinned kernel (host pointer)
+    void (*launch)(hipStream_t, dim3, dim3, const void* tab);
+    dim3 grid, block;       // the lane's own grid
+    size_t tab_size, nl_off, err_off;      // layout of the pinned kernel's argument struct (PinTab<Args>)
+    std::vector<char> args;
+};
+
 struct dsg_handle {
     dsg_config cfg;
     int prec = 0, es = 4, kbk = 16;      // element size / k-block of the precision policy
@@ -159,6 +168,12 @@ struct dsg_handle {
 #ifndef DSG_EMU
     dsg_aql::Ctx aql;                    // hand-written AQL submission of the step loop (dsg_aql.h)
 #endif
+    // XCD-pinned lanes (dsg_kernels.h): the batch-1 step of up to 8 handles in shared dispatches, lane l on XCD l, no fences
+    // between the packets of the loop.  DSG_PIN: 1 (default) when the AQL path is available, 0 never, 2 also through HIP launches
+    // (no fence to save there -- for the emulator tests)
+    int pin_mode = 1;
+    bool pin_rec = false, pin_unsupported = false;   // run_step is being recorded into pin_plan
+    std::vector<PinLaunch> pin_plan;
     int aql_mode = 1;                    // DSG_AQL: 1 (default) = AQL packets for the eager step loop, 0 = HIP launches
     bool overlap = false;                // DSG_OVERLAP=1: (attention -> k_mid) as an overlapped, barrier-less pair (measured slower)
     bool overlap_next = false;           // the next step_launch is such a consumer
@@ -325,6 +340,7 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     if (const char* e = getenv("DSG_GEMM_BLK_TNW")) h->gemm_blk_tnw = atoi(e);
     if (const char* e = getenv("DSG_GEMM_BLK_RT")) h->gemm_blk_rt = atoi(e);
     if (const char* e = getenv("DSG_KIN_KS")) h->kin_ks = atoi(e);
+    if (const char* e = getenv("DSG_PIN")) h->pin_mode = atoi(e);
     if (const char* e = getenv("DSG_GEMM_BLK_MASK")) h->gemm_blk_mask = atoi(e);
     if (const char* e = getenv("DSG_OVERLAP")) h->overlap = atoi(e) != 0;
     if (const char* e = getenv("DSG_AQL")) h->aql_mode = atoi(e);
@@ -759,10 +775,47 @@ struct StepCtx {
     bool only_head = false; // just the pose head on the final-layer rows already in place (the sample after an embedded-space loop)
 };
 
+// kernel -> its XCD-pinned twin (dsg_fused.h): only the batch-1 bf16 kernel set has one
+template <auto K> struct PinOf { static constexpr bool have = false; };
+#define DSG_PIN_PAIR(K, KX, ARGS)                                                                                       \
+    template <> struct PinOf<&K> {                                                                                      \
+        static constexpr bool have = true;                                                                              \
+        typedef PinTab<ARGS> Tab;                                                                                       \
+        static const void* fnx() { return (const void*)&KX; }                                                           \
+        static void launch(hipStream_t st, dim3 grid, dim3 block, const void* tab) {                                    \
+            hipLaunchKernelGGL((KX), grid, block, 0, st, *(const Tab*)tab);                                             \
+        }                                                                                                               \
+    }
+#define DSG_COMMA ,
+DSG_PIN_PAIR(k_gemm<PBF16 DSG_COMMA PRO_DIRECT DSG_COMMA EPI_QKV DSG_COMMA 4 DSG_COMMA 1 DSG_COMMA 1 DSG_COMMA 1>, k_gemm_x<PRO_DIRECT DSG_COMMA EPI_QKV DSG_COMMA 4 DSG_COMMA 1 DSG_COMMA 1>, GemmArgs);
+DSG_PIN_PAIR(k_gemm<PBF16 DSG_COMMA PRO_LN DSG_COMMA EPI_QKV DSG_COMMA 4 DSG_COMMA 1 DSG_COMMA 1 DSG_COMMA 1>, k_gemm_x<PRO_LN DSG_COMMA EPI_QKV DSG_COMMA 4 DSG_COMMA 1 DSG_COMMA 1>, GemmArgs);
+DSG_PIN_PAIR(k_gemm<PBF16 DSG_COMMA PRO_DIRECT DSG_COMMA EPI_RESID DSG_COMMA 1 DSG_COMMA 4 DSG_COMMA 1 DSG_COMMA 1>, k_gemm_x<PRO_DIRECT DSG_COMMA EPI_RESID DSG_COMMA 1 DSG_COMMA 4 DSG_COMMA 1>, GemmArgs);
+DSG_PIN_PAIR(k_gemm<PBF16 DSG_COMMA PRO_LN DSG_COMMA EPI_OUT DSG_COMMA 4 DSG_COMMA 1 DSG_COMMA 1 DSG_COMMA 1>, k_gemm_x<PRO_LN DSG_COMMA EPI_OUT DSG_COMMA 4 DSG_COMMA 1 DSG_COMMA 1>, GemmArgs);
+DSG_PIN_PAIR(k_inloc<PBF16 DSG_COMMA 32 DSG_COMMA 11>, k_inloc_x<32 DSG_COMMA 11>, InLocArgs);
+DSG_PIN_PAIR(k_inloc<PBF16 DSG_COMMA 16 DSG_COMMA 11>, k_inloc_x<16 DSG_COMMA 11>, InLocArgs);
+DSG_PIN_PAIR(k_attn_mid<PBF16 DSG_COMMA 4 DSG_COMMA 6>, k_attn_mid_x<4 DSG_COMMA 6>, AttnMidArgs);
+DSG_PIN_PAIR(k_attn_mid<PBF16 DSG_COMMA 2 DSG_COMMA 2>, k_attn_mid_x<2 DSG_COMMA 2>, AttnMidArgs);
+#undef DSG_COMMA
+
 // Every kernel of the denoising step goes through here: a HIP launch on the handle's stream, or -- while dsg_sample is
-// recording the step for the AQL path -- an entry of the packet plan (dsg_aql.h).
+// recording the step for the AQL path -- an entry of the packet plan (dsg_aql.h), or an entry of the pinned plan.
 template <auto K, class A>
 static int step_launch(dsg_handle* h, dim3 grid, dim3 block, const A& args) {
+    if (h->pin_rec) {
+        h->overlap_next = false;
+        if constexpr (PinOf<K>::have) {
+            PinLaunch l;
+            typedef typename PinOf<K>::Tab Tab;
+            static_assert(sizeof(Tab) <= 4096 && sizeof(((Tab*)nullptr)->a[0]) == sizeof(A), "pinned argument table");
+            l.fnx = PinOf<K>::fnx(); l.launch = &PinOf<K>::launch; l.grid = grid; l.block = block;
+            l.tab_size = sizeof(Tab); l.nl_off = offsetof(Tab, nl); l.err_off = offsetof(Tab, err);
+            l.args.assign((const char*)&args, (const char*)&args + sizeof(A));
+            h->pin_plan.push_back(std::move(l));
+        } else {
+            h->pin_unsupported = true;
+        }
+        return 0;
+    }
 #ifndef DSG_EMU
     const bool overlap = h->overlap_next;
     h->overlap_next = false;
@@ -1482,11 +1535,13 @@ static int build_step_tables(dsg_handle* h, int mode, int skip, float eta, bool 
 struct SampleJob {
     StepCtx c;
     int n_run = 0, B = 0, done = 0;
-    bool dumping = false, aql = false;
+    bool dumping = false, aql = false, pin = false;
     int spg = -1;
 };
 
-static int sample_prepare(dsg_handle* h, const dsg_sample_args* a, int B, void* stream, SampleJob& job) {
+static bool g_pin_broken = false;      // the XCD placement check failed once in this process: pinned lanes stay off
+
+static int sample_prepare(dsg_handle* h, const dsg_sample_args* a, int B, void* stream, SampleJob& job, bool want_pin = false) {
     if (!h || !a) return fail(DSG_E_INVALID, "dsg_sample: null argument");
     if (!h->finalized || !h->cond_set) return fail(DSG_E_STATE, "dsg_sample before finalize / set_window_cond");
     int rows = 0;
@@ -1564,12 +1619,29 @@ static int sample_prepare(dsg_handle* h, const dsg_sample_args* a, int B, void* 
     h->aql_timing = false;
     h->last_path = 0;
     job.aql = false;
+    job.pin = false;
+    {
+        // XCD-pinned lanes: record the step as (pinned kernel, this lane's arguments); the caller merges the lanes' plans
+        bool pin_ok = want_pin && !g_pin_broken && h->pin_mode != 0 && h->prec == DSG_PREC_BF16 && rows == 1 && !job.dumping &&
+                      !(job.spg > 0 && n_run >= job.spg) && n_run > 0 && !h->emode && !h->overlap && h->dbg_skip == 0;
+#ifndef DSG_EMU
+        if (pin_ok && h->pin_mode == 1) pin_ok = h->aql_mode == 1 && dsg_aql::init(h->aql, h->cfg.device, (const void*)&dsg_version);
+#else
+        if (pin_ok && h->pin_mode == 1) pin_ok = false;
+#endif
+        if (pin_ok) {
+            h->pin_plan.clear(); h->pin_unsupported = false; h->pin_rec = true;
+            const int rc = run_step_p(h, c);
+            h->pin_rec = false;
+            job.pin = rc == 0 && !h->pin_unsupported && !h->pin_plan.empty();
+        }
+    }
 #ifndef DSG_EMU
     // The step loop as hand-written AQL packets (dsg_aql.h): one recording pass of run_step (no launch), argument
     // blocks to device memory, then n_run x the same packets on the handle's own HSA queue.  Any failure before the
     // first packet falls back to the HIP launches; a failure after submission is an error.
     const bool graph_wanted = job.spg > 0 && n_run >= job.spg;
-    if (h->aql_mode == 1 && !job.dumping && !graph_wanted && n_run > 0) {
+    if (!job.pin && h->aql_mode == 1 && !job.dumping && !graph_wanted && n_run > 0) {
         bool planned = dsg_aql::init(h->aql, h->cfg.device, (const void*)&dsg_version);
         if (const char* e = getenv("DSG_AQL_ACQUIRE")) h->aql.acquire_scope = atoi(e) ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE;
         if (const char* e = getenv("DSG_OVL_ACQUIRE")) h->aql.overlap_acquire_scope = atoi(e) ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE;
@@ -1663,25 +1735,130 @@ static int sample_finish(dsg_handle* h, float* out, void* stream, SampleJob& job
     return 0;
 }
 
+// The step loop of n prepared batch-1 lanes as XCD-pinned dispatches: groups of 8 lanes, one packet chain (one HSA queue)
+// per group, led by the group's first handle.  retry = true: the placement check failed -- nothing of the result may be used,
+// the caller prepares again and runs the fenced path.
+static int run_pinned(dsg_handle** hs, int n, std::vector<SampleJob>& jobs, bool& retry) {
+    retry = false;
+    const size_t L = hs[0]->pin_plan.size();
+    for (int i = 0; i < n; ++i) {
+        const auto& pl = hs[i]->pin_plan;
+        if (pl.size() != L || jobs[i].n_run != jobs[0].n_run) return fail(DSG_E_STATE, "pinned lanes: the lanes' steps differ");
+        for (size_t k = 0; k < L; ++k)
+            if (pl[k].fnx != hs[0]->pin_plan[k].fnx || pl[k].args.size() != hs[0]->pin_plan[k].args.size() || pl[k].grid.x != hs[0]->pin_plan[k].grid.x ||
+                pl[k].grid.y != hs[0]->pin_plan[k].grid.y || pl[k].grid.z != hs[0]->pin_plan[k].grid.z)
+                return fail(DSG_E_STATE, "pinned lanes: the lanes' steps differ");
+    }
+    const int n_run = jobs[0].n_run, G = cdiv(n, 8);
+    bool use_aql = false;
+#ifndef DSG_EMU
+    use_aql = true;
+    for (int g = 0; g < G; ++g) use_aql = use_aql && hs[8 * g]->aql_mode == 1 && dsg_aql::init(hs[8 * g]->aql, hs[8 * g]->cfg.device, (const void*)&dsg_version);
+#endif
+    // argument structs of the pinned kernels, per group: the lanes' own arguments side by side + lane count + error word
+    std::vector<std::vector<std::vector<char>>> tabs(G, std::vector<std::vector<char>>(L));
+    for (int g = 0; g < G; ++g) {
+        dsg_handle* ld = hs[8 * g];
+        const int nl = std::min(8, n - 8 * g);
+        unsigned* errw = ld->dep_ctr + 62;
+        for (size_t k = 0; k < L; ++k) {
+            const PinLaunch& pl = ld->pin_plan[k];
+            std::vector<char>& t = tabs[g][k];
+            t.assign(pl.tab_size, 0);
+            for (int l = 0; l < nl; ++l) {
+                const auto& a = hs[8 * g + l]->pin_plan[k].args;
+                std::memcpy(t.data() + (size_t)l * a.size(), a.data(), a.size());
+            }
+            std::memcpy(t.data() + pl.nl_off, &nl, sizeof nl);
+            std::memcpy(t.data() + pl.err_off, &errw, sizeof errw);
+        }
+#ifndef DSG_EMU
+        if (use_aql) {
+            dsg_aql::Ctx& c = ld->aql;
+            dsg_aql::begin(c);
+            bool ok = true;
+            for (size_t k = 0; k < L && ok; ++k) {
+                const PinLaunch& pl = ld->pin_plan[k];
+                ok = dsg_aql::record(c, pl.fnx, ld->stream, dim3(pl.grid.x * 8, pl.grid.y, pl.grid.z), pl.block, tabs[g][k].data(), tabs[g][k].size());
+            }
+            ok = dsg_aql::finish(c) && ok;
+            c.recording = false;
+            c.pinned = true;
+            if (!ok) return fail(DSG_E_RUNTIME, "pinned lanes: AQL plan: " + c.err);
+        }
+#endif
+    }
+#ifndef DSG_EMU
+    if (use_aql) {
+        std::vector<dsg_aql::Ctx*> ctxs(G);
+        std::vector<int> steps(G, n_run);
+        for (int g = 0; g < G; ++g) ctxs[g] = &hs[8 * g]->aql;
+        std::string err;
+        const bool ok = dsg_aql::run_multi(ctxs.data(), steps.data(), G, 60.0 + 0.01 * n_run * G, err);
+        for (int g = 0; g < G; ++g) ctxs[g]->pinned = false;
+        if (!ok) return fail(DSG_E_RUNTIME, "AQL run (pinned lanes): " + err);
+    }
+#endif
+    if (!use_aql) {
+        for (int sidx = 0; sidx < n_run; ++sidx)
+            for (int g = 0; g < G; ++g) {
+                dsg_handle* ld = hs[8 * g];
+                for (size_t k = 0; k < L; ++k) {
+                    const PinLaunch& pl = ld->pin_plan[k];
+                    pl.launch(ld->stream, dim3(pl.grid.x * 8, pl.grid.y, pl.grid.z), pl.block, tabs[g][k].data());
+                    HIPCHK(hipGetLastError());
+                }
+            }
+        for (int g = 0; g < G; ++g) HIPCHK(hipStreamSynchronize(hs[8 * g]->stream));
+    }
+    for (int g = 0; g < G; ++g) {
+        dsg_handle* ld = hs[8 * g];
+        unsigned err = 0;
+        HIPCHK(hipMemcpyAsync(&err, ld->dep_ctr + 62, sizeof err, hipMemcpyDeviceToHost, ld->stream));
+        HIPCHK(hipStreamSynchronize(ld->stream));
+        if (err) {
+            fprintf(stderr, "libdsg_hip: XCD placement check failed (lane on XCC %u); pinned lanes disabled, using the fenced submission\n", err - 1u);
+            g_pin_broken = true;
+            retry = true;
+            return 0;
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        jobs[i].done = jobs[i].n_run;
+        hs[i]->last_path = use_aql ? 3 : 4;
+#ifndef DSG_EMU
+        if (use_aql) { hs[i]->aql_timing = true; hs[i]->aql_ms = hs[8 * (i / 8)]->aql.last_ms; }
+#endif
+    }
+    return 0;
+}
+
 extern "C" int dsg_sample(dsg_handle* h, const dsg_sample_args* a, float* out, int B, void* stream) {
     if (!h || !a || !out) return fail(DSG_E_INVALID, "dsg_sample: null argument");
-    SampleJob job;
-    CHK(sample_prepare(h, a, B, stream, job));
+    std::vector<SampleJob> job(1);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        CHK(sample_prepare(h, a, B, stream, job[0], attempt == 0));
+        if (!job[0].pin) break;
+        bool retry = false;
+        CHK(run_pinned(&h, 1, job, retry));
+        if (!retry) break;
+    }
 #ifndef DSG_EMU
-    if (job.aql) {
-        if (!dsg_aql::run(h->aql, job.n_run, 60.0 + 0.01 * job.n_run)) return fail(DSG_E_RUNTIME, "AQL run: " + h->aql.err);
-        job.done = job.n_run;
+    if (job[0].aql) {
+        if (!dsg_aql::run(h->aql, job[0].n_run, 60.0 + 0.01 * job[0].n_run)) return fail(DSG_E_RUNTIME, "AQL run: " + h->aql.err);
+        job[0].done = job[0].n_run;
         h->aql_timing = true; h->aql_ms = h->aql.last_ms;
         h->last_path = 1;
     }
 #endif
-    CHK(sample_run_hip(h, a, job));
-    return sample_finish(h, out, stream, job);
+    CHK(sample_run_hip(h, a, job[0]));
+    return sample_finish(h, out, stream, job[0]);
 }
 
 // n lanes (handles of ONE device, normally a handle and its clones), one independent sampling call each, advanced
-// concurrently: with the AQL submission every lane has its own HSA queue and the host thread deals the steps round-robin
-// (the queues' dependent packet chains overlap on the GPU); with HIP launches the lanes' streams are fed step by step.
+// concurrently.  Batch-1 bf16 lanes run XCD-pinned (run_pinned: 8 lanes per packet chain, up to 64 lanes); otherwise, with
+// the AQL submission, every lane has its own HSA queue and the host thread deals the steps round-robin (the queues' dependent
+// packet chains overlap on the GPU); with HIP launches the lanes' streams are fed step by step.
 extern "C" int dsg_sample_multi(dsg_handle** hs, int n, const dsg_sample_args* args, float** outs, int B, void* stream) {
     if (!hs || !args || !outs || n <= 0) return fail(DSG_E_INVALID, "dsg_sample_multi: bad argument");
     for (int i = 0; i < n; ++i) {
@@ -1689,18 +1866,36 @@ extern "C" int dsg_sample_multi(dsg_handle** hs, int n, const dsg_sample_args* a
         for (int j = 0; j < i; ++j) if (hs[j] == hs[i]) return fail(DSG_E_INVALID, "dsg_sample_multi: a handle appears twice");
         if (hs[i]->cfg.device != hs[0]->cfg.device) return fail(DSG_E_INVALID, "dsg_sample_multi: lanes must live on one device");
     }
-    if (n > 16) return fail(DSG_E_INVALID, "dsg_sample_multi: at most 16 lanes (more than 4 already share the command processor's pipes)");
+    if (n > 64) return fail(DSG_E_INVALID, "dsg_sample_multi: at most 64 lanes");
     std::vector<SampleJob> jobs(n);
     struct LaneScope {      // the kernel-shape rules see how many lanes run together, for the duration of this call
         dsg_handle** hs; int n;
         LaneScope(dsg_handle** h, int k) : hs(h), n(k) { for (int i = 0; i < n; ++i) hs[i]->lanes_now = n; }
         ~LaneScope() { for (int i = 0; i < n; ++i) hs[i]->lanes_now = 1; }
     } scope(hs, n);
-    for (int i = 0; i < n; ++i) CHK(sample_prepare(hs[i], &args[i], B, stream, jobs[i]));
     bool all_aql = true;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        for (int i = 0; i < n; ++i) CHK(sample_prepare(hs[i], &args[i], B, stream, jobs[i], attempt == 0));
+        bool all_pin = true;
+        for (int i = 0; i < n; ++i) all_pin = all_pin && jobs[i].pin && jobs[i].n_run == jobs[0].n_run;
+        if (!all_pin) {
+            bool any_pin = false;
+            for (int i = 0; i < n; ++i) any_pin = any_pin || jobs[i].pin;
+            if (any_pin) {      // mixed lanes: everybody takes the fenced path
+                for (int i = 0; i < n; ++i) CHK(sample_prepare(hs[i], &args[i], B, stream, jobs[i], false));
+            }
+            break;
+        }
+        bool retry = false;
+        CHK(run_pinned(hs, n, jobs, retry));
+        if (!retry) break;
+    }
+    bool pinned_done = true;
+    for (int i = 0; i < n; ++i) pinned_done = pinned_done && jobs[i].pin && jobs[i].done == jobs[i].n_run;
+    if (!pinned_done && n > 16) return fail(DSG_E_INVALID, "dsg_sample_multi: more than 16 lanes need the pinned submission (batch 1, bf16, AQL path)");
     for (int i = 0; i < n; ++i) all_aql = all_aql && jobs[i].aql;
 #ifndef DSG_EMU
-    if (all_aql) {
+    if (!pinned_done && all_aql) {
         std::vector<dsg_aql::Ctx*> ctxs(n);
         std::vector<int> steps(n);
         double tmax = 60.0;
@@ -1713,7 +1908,7 @@ extern "C" int dsg_sample_multi(dsg_handle** hs, int n, const dsg_sample_args* a
         }
     }
 #endif
-    if (!all_aql) {
+    if (!pinned_done && !all_aql) {
         // HIP launches: an AQL plan that was recorded for some lanes is simply not used; step s of every lane, then s + 1
         bool plain = true;
         for (int i = 0; i < n; ++i) plain = plain && !jobs[i].dumping && !(jobs[i].spg > 0 && jobs[i].n_run >= jobs[i].spg);

@@ -67,6 +67,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 struct PF32 {                       // fp32 storage, v_mfma_f32_16x16x4_f32
     typedef float elem;
+    static constexpr bool PIN = false;
     static constexpr int E = 4;     // elements per 16-byte fragment
     static constexpr int KB = 16;   // k-values per k-block (4 lane groups x E)
     static __device__ __forceinline__ elem cvt(float f) { return f; }
@@ -89,6 +90,7 @@ struct PF32 {                       // fp32 storage, v_mfma_f32_16x16x4_f32
 };
 struct PBF16 {                      // bf16 storage, v_mfma_f32_16x16x32_bf16, fp32 accumulate
     typedef bf16_t elem;
+    static constexpr bool PIN = false;
     static constexpr int E = 8;
     static constexpr int KB = 32;
     static __device__ __forceinline__ elem cvt(float f) { return f2bf(f); }
@@ -108,6 +110,48 @@ struct PBF16 {                      // bf16 storage, v_mfma_f32_16x16x32_bf16, f
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 };
+
+// ---------------------------------------------------------------------------------------------------------
+// XCD-pinned lanes (dsg_hip.cpp: "pinned lanes"): up to 8 independent batch-1 sampling calls ("lanes") share every dispatch
+// of the step, lane = blockIdx.x & 7.  Workgroups are dealt round-robin to the 8 XCDs in linear launch order and the
+// x extent of these grids is a multiple of 8, so lane l runs on XCD l and NOTHING a lane reads during the loop was written
+// on another XCD: its activations are handed from kernel to kernel through that XCD's L2, the dispatch packets carry no
+// acquire / release fence (no L2 write-back / invalidate per kernel boundary), and a dependent load is an L2 hit instead of
+// a round trip through memory.  What the missing acquire no longer does is invalidate the CUs' vector L1 and scalar caches,
+// so every load of data that CHANGES during the loop (activations, state, step control) bypasses them (sc1: served by the
+// L2); weights, tables and conditioning are constant during the loop and stay plain loads.  The placement is an observed
+// property, not a promise, so one kernel per step compares HW_REG_XCC_ID with its lane and raises an error word that makes
+// the host fall back to the fenced submission.
+// The kernels are the SAME bodies, instantiated for a policy with PIN = true.
+// ---------------------------------------------------------------------------------------------------------
+struct PBF16X : PBF16 { static constexpr bool PIN = true; };
+constexpr int DSG_PIN_SH = 3;                       // 8 lanes per dispatch
+template <class P> __device__ __forceinline__ int vbx() {      // blockIdx.x of the lane's own grid
+    if constexpr (P::PIN) return (int)(blockIdx.x >> DSG_PIN_SH); else return (int)blockIdx.x;
+}
+// 16 bytes at base + off of data another kernel of the loop wrote (off < 4 GB)
+template <class P> __device__ __forceinline__ f32x4 lda16(const void* base, size_t off) {
+#ifndef DSG_EMU
+    if constexpr (P::PIN) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xffffffff, 0x00020000);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(unsigned)off, 0, 16);      // aux 16 = sc1
+        return __builtin_bit_cast(f32x4, v);
+    }
+#endif
+    return *(const f32x4*)((const char*)base + off);
+}
+template <class P> __device__ __forceinline__ int ldw(const int* p) {      // one word of the step control
+#ifndef DSG_EMU
+    if constexpr (P::PIN) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    return *p;
+}
+template <class P> __device__ __forceinline__ float ldwf(const float* p) { return __builtin_bit_cast(float, ldw<P>((const int*)p)); }
+// end of a pinned kernel: this wave's stores have reached the L2 before the wave retires (the packet releases nothing)
+template <class P> __device__ __forceinline__ void pin_drain() {
+    if constexpr (P::PIN) __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0)
+}
 
 // Q, K and V^T of the self-attention live in HBM in MFMA-FRAGMENT order, so that every fragment a wave loads is one
 // contiguous 1 KB block (8 cache lines) instead of 16 rows x 64 B (16 half-used lines): the attention kernels' load
@@ -247,14 +291,16 @@ struct StepTables {            // execution-ordered, one entry per step that wil
     const float* c5;           //                                    | DDIM: nonzero * sigma
 };
 
+template <class P = PF32>
 __device__ __forceinline__ void step_advance_B(StepCtl* c, const StepTables& st, int n) {
-    const int s = c->stepB + 1, i = s < n ? s : n - 1;
+    const int s = ldw<P>(&c->stepB) + 1, i = s < n ? s : n - 1;
     const float a1 = st.c1[i], a2 = st.c2[i], a3 = st.c3[i], a4 = st.c4[i], a5 = st.c5[i];   // loads first, then stores
     c->stepB = s;
     c->k1 = a1; c->k2 = a2; c->k3 = a3; c->k4 = a4; c->k5 = a5;
 }
+template <class P = PF32>
 __device__ __forceinline__ void step_advance_A(StepCtl* c, const StepTables& st, int n) {
-    const int s = c->stepA + 1;
+    const int s = ldw<P>(&c->stepA) + 1;
     c->stepA = s;
     c->tA = st.tmodel[s < n ? s : n - 1];
 }
@@ -381,7 +427,7 @@ struct GemmArgs {
 // the same XCD's L2 and stays resident there across the 1000 steps.  Row tile / k-split come from blockIdx.y / .z --
 // the hardware hands them over for free, whereas decomposing a flat id costs integer divisions (~40 instructions
 // each, and at one wave per SIMD every instruction is ~2 ns of critical path).
-__device__ __forceinline__ int xcd_ngroup() { return (int)(blockIdx.x & 7) + 8 * (int)(blockIdx.x >> 3); }
+template <class P> __device__ __forceinline__ int xcd_ngroup() { const int x = vbx<P>(); return (x & 7) + 8 * (x >> 3); }
 __host__ __device__ inline int xcd_grid_x(int NG) { return 8 * ((NG + 7) / 8); }
 
 // x / d for 0 <= x, x * d < 2^32, as one v_mul_hi_u32: inv = ceil(2^32 / d) (host: fastdiv_inv; d == 1 -> inv 0)
@@ -419,13 +465,13 @@ __device__ __forceinline__ void ln_rows(const GemmArgs& g, int m0, int tid, char
     constexpr int N = NCH > 0 ? NCH : 8;
     const int D = g.D;
     const int row = tid >> 4, c = tid & 15;
-    const float* xr = g.X + (size_t)(m0 + row) * D;
+    const size_t xr = (size_t)(m0 + row) * D;        // element offset of the row in g.X
     const int nch = NCH > 0 ? NCH : (D >> 6);
     f32x4 gg[LEAN ? 1 : N], bb[LEAN ? 1 : N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const int col = c * 4 + 64 * (i < nch ? i : 0);
-        v[i] = *(const f32x4*)(xr + col);
+        v[i] = lda16<P>(g.X, (xr + col) * sizeof(float));
         if constexpr (!LEAN) {
             gg[i] = *(const f32x4*)(g.ln_g + col);
             bb[i] = *(const f32x4*)(g.ln_b + col);
@@ -476,7 +522,7 @@ __device__ __forceinline__ void gemm_prefetch_tile(const GemmArgs& g, int m0, in
         o.pbs = 0.f; o.ovalid = false;
         if constexpr (EPI == EPI_RESID) {
             o.pb = *(const f32x4*)(g.bias + n0 + 4 * lg);
-            o.pr = *(const f32x4*)(g.R + (size_t)(m0 + lr) * g.ldo + n0 + 4 * lg);     // rows are padded to the tile
+            o.pr = lda16<P>(g.R, ((size_t)(m0 + lr) * g.ldo + n0 + 4 * lg) * sizeof(float));     // rows are padded to the tile
         } else if constexpr (EPI == EPI_GELU) {
             o.pb = *(const f32x4*)(g.bias + n0 + 4 * lg);
         } else if constexpr (EPI == EPI_QKV) {
@@ -504,7 +550,7 @@ __device__ __forceinline__ void gemm_prefetch_tile(const GemmArgs& g, int m0, in
             o.pb = *(const f32x4*)(g.bias + j0);
             {   // x_t: unconditional load from a clamped (always valid) row; unused when the lane is not `ovalid`
                 const int bc = b < g.B ? b : g.B - 1, fc = sx > 0 ? sx - 1 : 0;
-                o.pr = *(const f32x4*)(g.xs32 + ((size_t)bc * g.T + fc) * g.Jp + j0);
+                o.pr = lda16<P>(g.xs32, (((size_t)bc * g.T + fc) * g.Jp + j0) * sizeof(float));
             }
             if (o.ovalid && g.out_mode != OUT_FORWARD) {
                 const int f = sx - 1;
@@ -640,15 +686,15 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
     preload_kernargs(g);
     DSG_STAMP_SCALAR_WAIT(1 + EPI, 6);
     const int NG = g.NT / (WN * TNW);
-    const int ng = xcd_ngroup(), ks = blockIdx.z;
+    const int ng = xcd_ngroup<P>(), ks = blockIdx.z;
     const int mt_first = blockIdx.y;
     if constexpr (EPI == EPI_PARTIAL || EPI == EPI_OUT || EPI == EPI_ESTEP) {
         // step bookkeeping runs in ONE EXTRA workgroup (first block of an extra grid row), concurrently with the real
         // work and off every critical path; see StepCtl for why this is race free
         if (mt_first >= g.MT) {
-            if (g.ctl && blockIdx.x == 0 && ks == 0 && threadIdx.x == 0) {
-                if constexpr (EPI == EPI_PARTIAL) step_advance_B(g.ctl, g.st, g.n_tab);
-                else if (EPI == EPI_ESTEP || g.out_mode != OUT_FORWARD) step_advance_A(g.ctl, g.st, g.n_tab);
+            if (g.ctl && vbx<P>() == 0 && ks == 0 && threadIdx.x == 0) {
+                if constexpr (EPI == EPI_PARTIAL) step_advance_B<P>(g.ctl, g.st, g.n_tab);
+                else if (EPI == EPI_ESTEP || g.out_mode != OUT_FORWARD) step_advance_A<P>(g.ctl, g.st, g.n_tab);
             }
             return;
         }
@@ -692,8 +738,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
     float k1 = 0.f, k2 = 0.f, k3 = 0.f, k4 = 0.f, k5 = 0.f;
     if constexpr (EPI == EPI_OUT) {
         if (g.out_mode != OUT_FORWARD) {
-            step = g.ctl->stepB;
-            k1 = g.ctl->k1; k2 = g.ctl->k2; k3 = g.ctl->k3; k4 = g.ctl->k4; k5 = g.ctl->k5;
+            step = ldw<P>(&g.ctl->stepB);
+            k1 = ldwf<P>(&g.ctl->k1); k2 = ldwf<P>(&g.ctl->k2); k3 = ldwf<P>(&g.ctl->k3); k4 = ldwf<P>(&g.ctl->k4); k5 = ldwf<P>(&g.ctl->k5);
         }
     }
     if constexpr (EPI == EPI_ESTEP) { k1 = g.ctl->k1; k2 = g.ctl->k2; k3 = g.ctl->k3; }
@@ -701,8 +747,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
     f32x4 acc[TNW];
 #pragma unroll
     for (int t = 0; t < TNW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const elem* arow = nullptr;
-    if constexpr (PRO == PRO_DIRECT) arow = (const elem*)g.A + (size_t)(m0 + lr) * g.lda + P::E * lg;
+    size_t arow_off = 0;                             // element offset of this lane's row-major A fragment
+    if constexpr (PRO == PRO_DIRECT) arow_off = (size_t)(m0 + lr) * g.lda + P::E * lg;
     // ---- epilogue operands (bias, residual, x_t, step coefficients, noise) do not depend on the main loop: fetch
     //      them now so their latency overlaps the weight / activation fragment loads
     TileOps ops[TNW];
@@ -756,8 +802,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
             const int kb = min(kb0 + c, kb_last);
             if constexpr (PRO == PRO_DIRECT) {
                 // fragment-major A: one contiguous 1 KB block per wave load (8 cache lines instead of 16 half-used ones)
-                const elem* ap = g.a_frag ? (const elem*)g.A + ((size_t)(mt_first * g.KBtot + kb) * 64 + lane) * P::E : arow + (size_t)kb * P::KB;
-                af[c] = *(const f32x4*)ap;
+                const size_t ao = g.a_frag ? ((size_t)(mt_first * g.KBtot + kb) * 64 + lane) * P::E : arow_off + (size_t)kb * P::KB;
+                af[c] = lda16<P>(g.A, ao * ES);
             }
             else af[c] = *(const f32x4*)(lds_a + lr * pitch + (kb * P::KB + P::E * lg) * ES);
         }
@@ -833,7 +879,7 @@ __device__ __forceinline__ void gemm_body_mt(const GemmArgs& g) {
     __shared__ __attribute__((aligned(16))) char lds_a[PRO == PRO_LN ? TM * 16 * (DMAX * ES + 16) : 16];
     preload_kernargs(g);
     const int NG = g.NT / (WN * TNW);
-    const int ng = xcd_ngroup();
+    const int ng = xcd_ngroup<P>();
     const int mt_first = blockIdx.y * TM;
     if constexpr (EPI == EPI_PARTIAL || EPI == EPI_OUT) {
         if (mt_first >= g.MT) {      // extra grid row: step bookkeeping (see gemm_body)
@@ -862,8 +908,8 @@ __device__ __forceinline__ void gemm_body_mt(const GemmArgs& g) {
     float k1 = 0.f, k2 = 0.f, k3 = 0.f, k4 = 0.f, k5 = 0.f;
     if constexpr (EPI == EPI_OUT) {
         if (g.out_mode != OUT_FORWARD) {
-            step = g.ctl->stepB;
-            k1 = g.ctl->k1; k2 = g.ctl->k2; k3 = g.ctl->k3; k4 = g.ctl->k4; k5 = g.ctl->k5;
+            step = ldw<P>(&g.ctl->stepB);
+            k1 = ldwf<P>(&g.ctl->k1); k2 = ldwf<P>(&g.ctl->k2); k3 = ldwf<P>(&g.ctl->k3); k4 = ldwf<P>(&g.ctl->k4); k5 = ldwf<P>(&g.ctl->k5);
         }
     }
     int m0s[TM];

@@ -174,10 +174,12 @@ class DSGDenoiser:
         self.lib.check(self.lib.cdll.dsg_sync(self.handle))
 
     def last_sample_path(self) -> str:
-        """How the step loop of the last sampling call was submitted: "hip" launches, hand-written "aql" packets, "graph"."""
+        """How the step loop of the last sampling call was submitted: "hip" launches, hand-written "aql" packets, "graph"
+        replays, "aql-pinned" (XCD-pinned lanes: shared dispatches without fences) or "hip-pinned" (the pinned kernels through
+        HIP launches: DSG_PIN=2, tests)."""
         p = C.c_int()
         self.lib.check(self.lib.cdll.dsg_last_sample_path(self.handle, C.byref(p)))
-        return {0: "hip", 1: "aql", 2: "graph"}[p.value]
+        return {0: "hip", 1: "aql", 2: "graph", 3: "aql-pinned", 4: "hip-pinned"}[p.value]
 
     def last_sample_ms(self):
         ms, n = C.c_float(), C.c_int()

@@ -163,7 +163,9 @@ int dsg_sync(dsg_handle* h);
 /* time of the step loop of the last dsg_sample (HIP events on the handle's stream; AQL path: first doorbell to the completion
  * signal of the last packet), and its step count */
 int dsg_last_sample_ms(dsg_handle* h, float* ms, int* n_steps);
-/* how the step loop of the last dsg_sample was submitted: 0 = HIP launches, 1 = hand-written AQL packets, 2 = hipGraph replay */
+/* how the step loop of the last dsg_sample was submitted: 0 = HIP launches, 1 = hand-written AQL packets, 2 = hipGraph replay,
+ * 3 = AQL packets of XCD-pinned lanes (batch 1, bf16: up to 8 handles per dispatch, lane l on XCD l, no fences between the
+ * packets of the loop), 4 = the pinned kernels through HIP launches (DSG_PIN=2; tests) */
 int dsg_last_sample_path(dsg_handle* h, int* path);
 /* the framework's noise stream as a tensor: out [B, J, 1, T] (device) = draw `draw` of (seed, stream_id), i.e. exactly the
  * noise the fused sampler uses for that draw index (x_T is draw_base, step i is draw_base + 1 + i).  Stands in for

@@ -233,3 +233,37 @@ def test_embedded_space_state_option(emu_lib, golden_dir, monkeypatch, prec):
                   gt["ddim50_eta1_skip40"]) < tol
     assert rel_l2(d.manual_seed(77, 10).p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=960)[0],
                   d.manual_seed(77, 10).p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=960)[0]) == 0.0
+
+
+def test_xcd_pinned_lanes(emu_lib, monkeypatch):
+    """XCD-pinned lanes (dsg_kernels.h): batch-1 bf16 lanes share every dispatch of the step, lane = blockIdx.x & 7, arguments
+    from a per-lane table.  Same arithmetic as a lane's own launches: bit-identical samples, for 1, 3 and 10 lanes (two packet
+    chains), with DDPM and DDIM, and the single-call path (dsg_sample) takes it too.  (The emulator has no caches: what the
+    missing fences would break is covered by the GPU twin of this test.)"""
+    cfg = C.TINY
+    shape = (1, cfg.njoints, 1, cfg.n_poses)
+    monkeypatch.setenv("DSG_PIN", "0")
+    m0 = _model(cfg, "bf16", emu_lib, max_batch=1)
+    d = create_gaussian_diffusion(library=emu_lib)
+    ys = [{"y": synth_window_inputs(cfg, 1, window=w % 4, clip0=w, seed_pose_scale=0.2)} for w in range(10)]
+    want = [d.manual_seed(5 + i, i).p_sample_loop(m0, shape, clip_denoised=False, model_kwargs=ys[i], skip_timesteps=994) for i in range(10)]
+    assert m0.last_sample_path() == "hip"
+    monkeypatch.setenv("DSG_PIN", "2")
+    m = _model(cfg, "bf16", emu_lib, max_batch=1)
+    lanes = [m] + [m.clone() for _ in range(9)]
+    for n in (1, 3, 10):
+        got = d.manual_seed(0, 0).p_sample_loop_multi(lanes[:n], shape, ys[:n], seeds=[5 + i for i in range(n)], stream_ids=list(range(n)), skip_timesteps=994)
+        assert all(l.last_sample_path() == "hip-pinned" for l in lanes[:n])
+        for i in range(n):
+            assert np.array_equal(got[i], want[i]), (n, i)
+    one = d.manual_seed(7, 2).p_sample_loop(m, shape, clip_denoised=False, model_kwargs=ys[2], skip_timesteps=994)
+    assert m.last_sample_path() == "hip-pinned" and np.array_equal(one, want[2])
+    dd = create_gaussian_diffusion(library=emu_lib, timestep_respacing="ddim5")
+    w2 = dd.manual_seed(3, 1).ddim_sample_loop(m0, shape, clip_denoised=False, model_kwargs=ys[1])
+    g2 = dd.manual_seed(3, 1).ddim_sample_loop(m, shape, clip_denoised=False, model_kwargs=ys[1])
+    assert m.last_sample_path() == "hip-pinned" and np.array_equal(g2, w2)
+    # fp32 handles and batches > 1 keep their own launches
+    mf = _model(cfg, "fp32", emu_lib, max_batch=2)
+    d.manual_seed(1, 0).p_sample_loop(mf, (2,) + shape[1:], clip_denoised=False,
+                                      model_kwargs={"y": synth_window_inputs(cfg, 2, window=0)}, skip_timesteps=997)
+    assert mf.last_sample_path() == "hip"
