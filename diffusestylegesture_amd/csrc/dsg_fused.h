@@ -793,7 +793,8 @@ __device__ __forceinline__ void pin_check_xcd(unsigned* err) {
 #ifndef DSG_EMU
     // HW_REG_XCC_ID (id 20), bits 3:0
     const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
-    if (threadIdx.x == 0 && (xcc & 7u) != (blockIdx.x & 7u) && err) __hip_atomic_store(err, 1u + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0 && (xcc & 7u) != (blockIdx.x & 7u) && err)
+        __hip_atomic_store(err, 0x80000000u | (blockIdx.z << 24) | (blockIdx.y << 16) | (blockIdx.x << 4) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
     (void)err;
 #endif

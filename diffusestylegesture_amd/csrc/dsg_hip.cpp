@@ -169,9 +169,14 @@ struct dsg_handle {
     dsg_aql::Ctx aql;                    // hand-written AQL submission of the step loop (dsg_aql.h)
 #endif
     // XCD-pinned lanes (dsg_kernels.h): the batch-1 step of up to 8 handles in shared dispatches, lane l on XCD l, no fences
-    // between the packets of the loop.  DSG_PIN: 1 (default) when the AQL path is available, 0 never, 2 also through HIP launches
-    // (no fence to save there -- for the emulator tests)
-    int pin_mode = 1;
+    // between the packets of the loop.  DSG_PIN: 0 (default) never, 1 when the AQL path is available, 2 also through HIP launches
+    // (no fence to save there -- for the emulator tests).  OFF by default -- measured on MI355X (profiles/r02_n_pinned_lanes.log):
+    // bit-identical to the fenced submission, but a lane then has ONE XCD's 32 CUs for kernels shaped for 256: 203 us/step for
+    // one lane against 115 fenced (the same kernels behind agent fences: 217, so the fences themselves are 0.5 us per packet);
+    // 8 lanes 243 us/step = 2.9 k frames/s, the same as 4 fenced lanes x 2 clips; 16 lanes (two packet chains) 2.0 k.  And once
+    // a grid exceeds what an XCD can hold, the dispatcher no longer deals workgroup i to XCD i % 8 (seen: the last workgroups of
+    // a 1024-workgroup k_inloc_x) -- the in-kernel placement check then sends the call to the fenced path.
+    int pin_mode = 0;
     bool pin_rec = false, pin_unsupported = false;   // run_step is being recorded into pin_plan
     std::vector<PinLaunch> pin_plan;
     int aql_mode = 1;                    // DSG_AQL: 1 (default) = AQL packets for the eager step loop, 0 = HIP launches
@@ -1783,7 +1788,7 @@ static int run_pinned(dsg_handle** hs, int n, std::vector<SampleJob>& jobs, bool
             }
             ok = dsg_aql::finish(c) && ok;
             c.recording = false;
-            c.pinned = true;
+            c.pinned = getenv("DSG_PIN_FENCED") == nullptr;      // (DSG_PIN_FENCED: the pinned kernels behind agent-scope fences, to price the fences alone)
             if (!ok) return fail(DSG_E_RUNTIME, "pinned lanes: AQL plan: " + c.err);
         }
 #endif
@@ -1816,8 +1821,9 @@ static int run_pinned(dsg_handle** hs, int n, std::vector<SampleJob>& jobs, bool
         unsigned err = 0;
         HIPCHK(hipMemcpyAsync(&err, ld->dep_ctr + 62, sizeof err, hipMemcpyDeviceToHost, ld->stream));
         HIPCHK(hipStreamSynchronize(ld->stream));
-        if (err) {
-            fprintf(stderr, "libdsg_hip: XCD placement check failed (lane on XCC %u); pinned lanes disabled, using the fenced submission\n", err - 1u);
+        if (err && !getenv("DSG_PIN_NOCHECK")) {      // (DSG_PIN_NOCHECK: placement experiments)
+            fprintf(stderr, "libdsg_hip: XCD placement check failed (workgroup (%u, %u, %u) on XCC %u); pinned lanes disabled, using the fenced submission\n",
+                    (err >> 4) & 0xfffu, (err >> 16) & 0xffu, (err >> 24) & 0x7fu, err & 0xfu);
             g_pin_broken = true;
             retry = true;
             return 0;

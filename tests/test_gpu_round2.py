@@ -337,3 +337,28 @@ def test_command_lines_end_to_end(gpu, tmp_path):
             argv += ["--seed_last_npy", str(tmp_path / "seed.npy")]
         res = np.load(sample_plus.main(argv))
         assert res.shape == (200, c.njoints // 3) and np.isfinite(res).all()
+
+
+@pytest.mark.gpu
+def test_xcd_pinned_lane_equals_fenced_submission(monkeypatch):
+    """DSG_PIN=1 (opt-in): the batch-1 step as XCD-pinned dispatches -- no acquire / release between the packets of the loop,
+    loop-written data read past the L1 -- gives the fenced submission's sample bit for bit (a stale read would not), over two
+    consecutive windows; the path is reported as such."""
+    from diffusestylegesture_amd.model import DSGDenoiser
+    from diffusestylegesture_amd.synth import synth_state_dict, synth_window_inputs
+    cfg = C.ZEGGS
+    shape = (1, cfg.njoints, 1, cfg.n_poses)
+    d = create_gaussian_diffusion()
+    monkeypatch.setenv("DSG_PIN", "0")
+    m0 = DSGDenoiser(cfg, precision="bf16", max_batch=1)
+    m0.load_state_dict(synth_state_dict(cfg, 1))
+    monkeypatch.setenv("DSG_PIN", "1")
+    m = DSGDenoiser(cfg, precision="bf16", max_batch=1)
+    m.load_state_dict(synth_state_dict(cfg, 1))
+    for w in range(2):
+        y = {"y": synth_window_inputs(cfg, 1, window=w, seed_pose_scale=0.2)}
+        want = d.manual_seed(11, w).p_sample_loop(m0, shape, clip_denoised=False, model_kwargs=y, skip_timesteps=700)
+        assert m0.last_sample_path() == "aql"
+        got = d.manual_seed(11, w).p_sample_loop(m, shape, clip_denoised=False, model_kwargs=y, skip_timesteps=700)
+        assert m.last_sample_path() == "aql-pinned"
+        assert np.array_equal(np.asarray(got), np.asarray(want))
