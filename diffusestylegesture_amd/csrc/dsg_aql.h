@@ -51,7 +51,8 @@ struct Ctx {
     double last_ms = 0.0;
     int acquire_scope = HSA_FENCE_SCOPE_AGENT;      // DSG_AQL_ACQUIRE=0 -> NONE (experiment)
     int overlap_acquire_scope = HSA_FENCE_SCOPE_AGENT;      // acquire scope of the packets WITHOUT barrier bit (DSG_OVL_ACQUIRE=0 -> NONE)
-    bool pinned = false;    // the plan holds XCD-pinned kernels (dsg_kernels.h): no fences between the packets of the loop
+    bool nofence = false;   // no acquire / release between the packets of the loop: everything the loop writes is coherent without
+                            // cache maintenance (uncached buffers, dsg_hip.cpp uc_mode; or XCD-pinned lanes, dsg_kernels.h)
 };
 
 inline bool hsa_ok(Ctx& c, hsa_status_t s, const char* what) {
@@ -165,7 +166,7 @@ inline bool record(Ctx& c, const void* host_fn, hipStream_t stream, dim3 grid, d
     return true;
 }
 
-inline void begin(Ctx& c) { c.plan.clear(); c.ka_host.clear(); c.recording = true; c.pinned = false; }
+inline void begin(Ctx& c) { c.plan.clear(); c.ka_host.clear(); c.recording = true; c.nofence = false; }
 
 // argument blocks -> device memory (once per dsg_sample call)
 inline bool finish(Ctx& c) {
@@ -199,11 +200,12 @@ inline void submit_step(Ctx& c, bool first_step, bool last_step) {
         p->kernarg_address = c.ka_dev + l.ka_off;
         p->reserved2 = 0;
         p->completion_signal.handle = last ? c.done.handle : 0;
-        // pinned plan: what a lane reads was written on its own XCD and is read past the L1 (sc1), so only the first packet
-        // acquires (everything the set-up kernels wrote) and only the last one releases (the samples)
-        const int mid_scope = c.pinned ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT;
+        // fence-free plan: only the first packet acquires (everything the set-up kernels wrote) and only the last one releases
+        // (the samples); a kernel's stores have been acknowledged when its waves end (s_endpgm waits for them) and the barrier
+        // bit orders the packets
+        const int mid_scope = c.nofence ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT;
         const int rel = last ? HSA_FENCE_SCOPE_SYSTEM : mid_scope;
-        const int acq = first_step && i == 0 ? HSA_FENCE_SCOPE_SYSTEM : (c.pinned ? HSA_FENCE_SCOPE_NONE : (l.overlap ? c.overlap_acquire_scope : c.acquire_scope));
+        const int acq = first_step && i == 0 ? HSA_FENCE_SCOPE_SYSTEM : (c.nofence ? HSA_FENCE_SCOPE_NONE : (l.overlap ? c.overlap_acquire_scope : c.acquire_scope));
         const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | ((l.overlap ? 0 : 1) << HSA_PACKET_HEADER_BARRIER) |
                                            (acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
                                            (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));

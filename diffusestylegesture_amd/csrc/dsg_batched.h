@@ -109,8 +109,8 @@ __global__ __launch_bounds__(256) void k_gemm_blk(const GemmArgs g) {
     float k1 = 0.f, k2 = 0.f, k3 = 0.f, k4 = 0.f, k5 = 0.f;
     if constexpr (EPI == EPI_OUT) {
         if (g.out_mode != OUT_FORWARD) {
-            step = g.ctl->stepB;
-            k1 = g.ctl->k1; k2 = g.ctl->k2; k3 = g.ctl->k3; k4 = g.ctl->k4; k5 = g.ctl->k5;
+            step = ldw<P>(&g.ctl->stepB);
+            k1 = ldwf<P>(&g.ctl->k1); k2 = ldwf<P>(&g.ctl->k2); k3 = ldwf<P>(&g.ctl->k3); k4 = ldwf<P>(&g.ctl->k4); k5 = ldwf<P>(&g.ctl->k5);
         }
     }
     // ---- epilogue operands of every tile of this wave (they do not depend on the main loop)
@@ -338,8 +338,8 @@ __global__ __launch_bounds__(256) void k_gemm_tp(const GemmArgs g) {
     float k1 = 0.f, k2 = 0.f, k3 = 0.f, k4 = 0.f, k5 = 0.f;
     if constexpr (EPI == EPI_OUT) {
         if (g.out_mode != OUT_FORWARD) {
-            step = g.ctl->stepB;
-            k1 = g.ctl->k1; k2 = g.ctl->k2; k3 = g.ctl->k3; k4 = g.ctl->k4; k5 = g.ctl->k5;
+            step = ldw<P>(&g.ctl->stepB);
+            k1 = ldwf<P>(&g.ctl->k1); k2 = ldwf<P>(&g.ctl->k2); k3 = ldwf<P>(&g.ctl->k3); k4 = ldwf<P>(&g.ctl->k4); k5 = ldwf<P>(&g.ctl->k5);
         }
     }
     // ---- stage the BM A rows in LDS

@@ -177,6 +177,16 @@ struct dsg_handle {
     // a grid exceeds what an XCD can hold, the dispatcher no longer deals workgroup i to XCD i % 8 (seen: the last workgroups of
     // a 1024-workgroup k_inloc_x) -- the in-kernel placement check then sends the call to the fenced path.
     int pin_mode = 0;
+    // Fence-free step loop (DSG_UC, default 1): every buffer the loop WRITES (state, activations, step control) lives in
+    // uncached device memory (MTYPE UC: neither the CUs' L1 nor the XCDs' L2 hold its lines, so a kernel on any XCD reads what
+    // the previous kernel wrote without cache maintenance), the step control is read with vector loads (never through the
+    // scalar cache), and the AQL packets of the loop carry NO acquire / release fence (first packet acquires, last releases).
+    // Weights, tables and conditioning stay in cached memory -- nothing writes them during the loop.  Measured on MI355X
+    // (profiles/r02_q_*): the fences are worth ~6 us per batch-1 step, the uncached buffers cost ~3 (117 us with uncached buffers
+    // behind the usual fences, DSG_UC=2): 111.0 vs 114.2 us/step, bit-identical samples; 16 clips in 4 lanes: 5628 vs 5120 frames/s.
+    // DSG_UC=0: cached buffers, agent-scope fences.  HIP launches / hipGraph keep the runtime's own fences either way.
+    int uc_mode = 1;
+    bool alloc_uc = false;               // dalloc target: a loop-written buffer
     bool pin_rec = false, pin_unsupported = false;   // run_step is being recorded into pin_plan
     std::vector<PinLaunch> pin_plan;
     int aql_mode = 1;                    // DSG_AQL: 1 (default) = AQL packets for the eager step loop, 0 = HIP launches
@@ -221,7 +231,16 @@ static int dalloc(dsg_handle* h, T** p, size_t n_elems, bool zero = true) {
     void* d = nullptr;
     size_t bytes = n_elems * sizeof(T);
     if (bytes == 0) bytes = 16;
-    HIPCHK(hipMalloc(&d, bytes));
+#ifndef DSG_EMU
+    if (h->uc_mode && h->alloc_uc && !h->alloc_shared) {
+        if (hipExtMallocWithFlags(&d, bytes, hipDeviceMallocUncached) != hipSuccess) {      // no uncached memory here: fenced packets
+            (void)hipGetLastError();
+            d = nullptr;
+            h->uc_mode = 0;
+        }
+    }
+#endif
+    if (!d) HIPCHK(hipMalloc(&d, bytes));
     // Zero-fill and WAIT for it.  hipMemset on device memory may return before the fill has run; the handle's stream is
     // non-blocking (no implicit ordering with the null stream), so a late fill could wipe what the first kernels on the
     // handle's stream (weight packing, conditioning) or a following synchronous copy have already written.  Seen once
@@ -346,6 +365,10 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     if (const char* e = getenv("DSG_GEMM_BLK_RT")) h->gemm_blk_rt = atoi(e);
     if (const char* e = getenv("DSG_KIN_KS")) h->kin_ks = atoi(e);
     if (const char* e = getenv("DSG_PIN")) h->pin_mode = atoi(e);
+    // large batches re-read their activations from the L2 often enough that the uncached buffers cost what the fences save
+    // (64 clips in 4 lanes x 16: 9667 vs 9680 frames/s): cached + fenced from batch 32
+    if (c->max_batch > 16) h->uc_mode = 0;
+    if (const char* e = getenv("DSG_UC")) h->uc_mode = atoi(e);
     if (const char* e = getenv("DSG_GEMM_BLK_MASK")) h->gemm_blk_mask = atoi(e);
     if (const char* e = getenv("DSG_OVERLAP")) h->overlap = atoi(e) != 0;
     if (const char* e = getenv("DSG_AQL")) h->aql_mode = atoi(e);
@@ -377,6 +400,7 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     // row buffers carry one extra padded token block: the fused attention kernel reads Tp rows per batch element
     // (+64: the block GEMMs of dsg_batched.h read and LayerNorm whole 64-row blocks)
     const size_t Min_pad = rup(B * h->T, 16) + 16 + 128, M_pad = rup(B * ntok, 16) + Tp + 128;
+    h->alloc_uc = true;                  // ---- written by the kernels of the step loop
     CHK(dalloc(h, &h->xs32, (size_t)B * h->T * h->Jp + 16 * h->Jp));
     if (h->prec == DSG_PREC_BF16) CHK(dalloc_bytes(h, &h->xsA, ((size_t)Min_pad * h->Jp) * h->es));
     CHK(dalloc(h, &h->partial, (size_t)h->KSin * Min_pad * D));
@@ -393,6 +417,12 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     CHK(dalloc_bytes(h, &h->q, qkv_elems * h->es));
     CHK(dalloc_bytes(h, &h->k, qkv_elems * h->es));
     CHK(dalloc_bytes(h, &h->vt, qkv_elems * h->es));
+    CHK(dalloc(h, &h->ctl, 1));
+    CHK(dalloc(h, &h->dep_ctr, 64));
+    h->ez_ks = DSG_EZ_MAXKS; h->ez_rows = (int)Min_pad;
+    CHK(dalloc(h, &h->epose, Min_pad * D));
+    CHK(dalloc(h, &h->ez, (size_t)h->ez_ks * Min_pad * D));
+    h->alloc_uc = false;                 // ---- inputs / outputs / conditioning: constant while the loop runs
     CHK(dalloc(h, &h->fwd_out, (size_t)B * h->J * h->T));
     CHK(dalloc(h, &h->io_tmp, (size_t)B * h->J * h->T));
     CHK(dalloc(h, &h->io_tmp2, (size_t)B * h->J * h->T));
@@ -406,12 +436,7 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     CHK(dalloc(h, &h->c_audio, (size_t)B * h->Ta * h->As));
     CHK(dalloc(h, &h->mask, (size_t)B * h->T));
     CHK(dalloc(h, &h->ctr, 8));
-    CHK(dalloc(h, &h->ctl, 1));
-    CHK(dalloc(h, &h->dep_ctr, 64));
     CHK(dalloc(h, &h->cfg_scale, (size_t)B));
-    h->ez_ks = DSG_EZ_MAXKS; h->ez_rows = (int)Min_pad;
-    CHK(dalloc(h, &h->epose, Min_pad * D));
-    CHK(dalloc(h, &h->ez, (size_t)h->ez_ks * Min_pad * D));
     CHK(dalloc(h, &h->dyn, 8));
     CHK(dalloc(h, &h->t_arr, (size_t)B));
     // the xs32 master is read as a GEMM operand in fp32 mode: rows padded to a 16-row tile exist (allocated above)
@@ -1655,6 +1680,9 @@ static int sample_prepare(dsg_handle* h, const dsg_sample_args* a, int B, void* 
             const int rc = run_step_p(h, c);
             planned = dsg_aql::finish(h->aql) && rc == 0;
             h->aql.recording = false;
+            // fence-free packets (see uc_mode; 2: uncached buffers behind the usual fences); the overlapped-launch experiment
+            // synchronises through cached counters and keeps the fences
+            h->aql.nofence = h->uc_mode == 1 && !h->overlap;
         }
         if (!planned) {
             if (!h->aql_warned) { fprintf(stderr, "libdsg_hip: AQL path unavailable (%s); using HIP launches\n", h->aql.err.c_str()); h->aql_warned = true; }
@@ -1788,7 +1816,7 @@ static int run_pinned(dsg_handle** hs, int n, std::vector<SampleJob>& jobs, bool
             }
             ok = dsg_aql::finish(c) && ok;
             c.recording = false;
-            c.pinned = getenv("DSG_PIN_FENCED") == nullptr;      // (DSG_PIN_FENCED: the pinned kernels behind agent-scope fences, to price the fences alone)
+            c.nofence = getenv("DSG_PIN_FENCED") == nullptr;      // (DSG_PIN_FENCED: the pinned kernels behind agent-scope fences, to price the fences alone)
             if (!ok) return fail(DSG_E_RUNTIME, "pinned lanes: AQL plan: " + c.err);
         }
 #endif
@@ -1800,7 +1828,7 @@ static int run_pinned(dsg_handle** hs, int n, std::vector<SampleJob>& jobs, bool
         for (int g = 0; g < G; ++g) ctxs[g] = &hs[8 * g]->aql;
         std::string err;
         const bool ok = dsg_aql::run_multi(ctxs.data(), steps.data(), G, 60.0 + 0.01 * n_run * G, err);
-        for (int g = 0; g < G; ++g) ctxs[g]->pinned = false;
+        for (int g = 0; g < G; ++g) ctxs[g]->nofence = false;
         if (!ok) return fail(DSG_E_RUNTIME, "AQL run (pinned lanes): " + err);
     }
 #endif

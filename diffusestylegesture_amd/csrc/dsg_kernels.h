@@ -141,11 +141,12 @@ template <class P> __device__ __forceinline__ f32x4 lda16(const void* base, size
 #endif
     return *(const f32x4*)((const char*)base + off);
 }
-template <class P> __device__ __forceinline__ int ldw(const int* p) {      // one word of the step control
+template <class P> __device__ __forceinline__ int ldw(const int* p) {      // one word of the step control: never through the scalar cache
 #ifndef DSG_EMU
-    if constexpr (P::PIN) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
     return *p;
+#endif
 }
 template <class P> __device__ __forceinline__ float ldwf(const float* p) { return __builtin_bit_cast(float, ldw<P>((const int*)p)); }
 // end of a pinned kernel: this wave's stores have reached the L2 before the wave retires (the packet releases nothing)
@@ -600,6 +601,16 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmArgs& g, int m0, in
                     P::store4(dst, acc + o.pb);
                 }
             } else {                             // V: transposed [B][H][hd][Tp], lane = one dim, 4 consecutive tokens
+                // the 4 tokens of a lane are adjacent in the fragment order when they start a group of 4 inside one batch element
+                // (always at batch 1): one 8- / 16-byte store instead of 4 element stores (the buffer is uncached memory)
+                const int mq = m0 + 4 * lg;
+                const int bq = fdiv(mq, g.inv_ntok), sq = mq - bq * g.ntok;
+                if ((sq & 3) == 0 && sq + 3 < g.ntok && mq + 3 < g.M) {
+                    f32x4 y;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = acc[e] + o.pbs;
+                    P::store4((elem*)g.vt + ((size_t)bq * g.H + head) * g.hd * g.Tp + vt_off<P>(d0 + lr, sq, P::E == 4 ? g.Tp / 16 : g.Tp / 32), y);
+                } else
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int m = m0 + 4 * lg + e;
@@ -742,7 +753,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
             k1 = ldwf<P>(&g.ctl->k1); k2 = ldwf<P>(&g.ctl->k2); k3 = ldwf<P>(&g.ctl->k3); k4 = ldwf<P>(&g.ctl->k4); k5 = ldwf<P>(&g.ctl->k5);
         }
     }
-    if constexpr (EPI == EPI_ESTEP) { k1 = g.ctl->k1; k2 = g.ctl->k2; k3 = g.ctl->k3; }
+    if constexpr (EPI == EPI_ESTEP) { k1 = ldwf<P>(&g.ctl->k1); k2 = ldwf<P>(&g.ctl->k2); k3 = ldwf<P>(&g.ctl->k3); }
     const int m0 = mt_first * 16;
     f32x4 acc[TNW];
 #pragma unroll
@@ -1109,7 +1120,7 @@ __device__ __forceinline__ void loc_body(const LocArgs& a, int h, int w, int b) 
     __shared__ float sc[W][W2 + 2];
     const int tid = threadIdx.x;
     const int* tp = a.ctl ? &a.ctl->tA : a.t_arr + b;      // select the ADDRESS, then one unconditional load
-    const int t = *tp;
+    const int t = ldw<P>(tp);
     const int col0 = h * HD, ntok = a.T + 1, f0 = (w - 1) * W;
 
     // ---- every global load of the block is issued up front, unconditionally (clamped indices, selects afterwards)

@@ -344,8 +344,8 @@ def test_xcd_pinned_lane_equals_fenced_submission(monkeypatch):
     """DSG_PIN=1 (opt-in): the batch-1 step as XCD-pinned dispatches -- no acquire / release between the packets of the loop,
     loop-written data read past the L1 -- gives the fenced submission's sample bit for bit (a stale read would not), over two
     consecutive windows; the path is reported as such."""
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
     from diffusestylegesture_amd.model import DSGDenoiser
-    from diffusestylegesture_amd.synth import synth_state_dict, synth_window_inputs
     cfg = C.ZEGGS
     shape = (1, cfg.njoints, 1, cfg.n_poses)
     d = create_gaussian_diffusion()
@@ -362,3 +362,27 @@ def test_xcd_pinned_lane_equals_fenced_submission(monkeypatch):
         got = d.manual_seed(11, w).p_sample_loop(m, shape, clip_denoised=False, model_kwargs=y, skip_timesteps=700)
         assert m.last_sample_path() == "aql-pinned"
         assert np.array_equal(np.asarray(got), np.asarray(want))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [1, 3])
+def test_fence_free_loop_equals_fenced_loop(monkeypatch, batch):
+    """Default submission: loop-written buffers in uncached memory, AQL packets without acquire / release (dsg_hip.cpp uc_mode).
+    Same kernels, same arithmetic as DSG_UC=0 (cached buffers, agent-scope fences): the samples must be bit-identical -- a
+    stale line in any cache would show."""
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    from diffusestylegesture_amd.model import DSGDenoiser
+    cfg = C.ZEGGS
+    shape = (batch, cfg.njoints, 1, cfg.n_poses)
+    d = create_gaussian_diffusion()
+    ms = {}
+    for uc in ("0", "1"):
+        monkeypatch.setenv("DSG_UC", uc)
+        ms[uc] = DSGDenoiser(cfg, precision="bf16", max_batch=batch)
+        ms[uc].load_state_dict(synth_state_dict(cfg, 1))
+    for w in range(2):
+        y = {"y": synth_window_inputs(cfg, batch, window=w, seed_pose_scale=0.2)}
+        outs = {uc: np.asarray(d.manual_seed(21, w).p_sample_loop(ms[uc], shape, clip_denoised=False, model_kwargs=y, skip_timesteps=600))
+                for uc in ("0", "1")}
+        assert ms["1"].last_sample_path() == "aql" and ms["0"].last_sample_path() == "aql"
+        assert np.array_equal(outs["0"], outs["1"])

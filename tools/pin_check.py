@@ -1,5 +1,5 @@
-"""XCD-pinned lanes on the GPU: bit-identity with the fenced submission and time per step.
-   python tools/pin_check.py [--lanes 1,8,16] [--skip 0] [--windows 2]
+"""XCD-pinned lanes (or any other submission variant selected by --env) on the GPU: bit-identity with the fenced submission and
+time per step.   python tools/pin_check.py [--lanes 1,8,16] [--skip 0] [--windows 2] [--env DSG_PIN=1]
 Every lane's sample must equal the sample of the same (seed, stream) through DSG_PIN=0 exactly -- a stale read through a cache
 the missing fences no longer invalidate shows up as a difference."""
 import argparse
@@ -16,8 +16,10 @@ from diffusestylegesture_amd.model import DSGDenoiser                # noqa: E40
 from diffusestylegesture_amd.synth import synth_state_dict, synth_window_inputs      # noqa: E402
 
 
-def model(cfg, pin):
-    os.environ["DSG_PIN"] = str(pin)
+def model(cfg, env):
+    for kv in env.split(","):
+        k, v = kv.split("=")
+        os.environ[k] = v
     m = DSGDenoiser(cfg, precision="bf16", max_batch=1)
     m.load_state_dict(synth_state_dict(cfg, 1))
     return m
@@ -29,17 +31,19 @@ def main():
     p.add_argument("--skip", type=int, default=0)
     p.add_argument("--windows", type=int, default=2)
     p.add_argument("--config", default="zeggs")
+    p.add_argument("--base-env", default="DSG_PIN=0,DSG_UC=0", help="environment of the reference handle (NAME=VALUE,...)")
+    p.add_argument("--env", default="DSG_PIN=1", help="environment of the handle under test")
     a = p.parse_args()
     cfg = C.CONFIGS[a.config]
     shape = (1, cfg.njoints, 1, cfg.n_poses)
     d = create_gaussian_diffusion()
     nmax = max(int(x) for x in a.lanes.split(","))
     ys = [[{"y": synth_window_inputs(cfg, 1, window=w, clip0=i, seed_pose_scale=0.2)} for i in range(nmax)] for w in range(a.windows)]
-    m0 = model(cfg, 0)
+    m0 = model(cfg, a.base_env)
     want = [[d.manual_seed(100 + i, i).p_sample_loop(m0, shape, clip_denoised=False, model_kwargs=ys[w][i], skip_timesteps=a.skip)
              for i in range(nmax)] for w in range(a.windows)]
     print("fenced: path", m0.last_sample_path(), "%.2f us/step" % d.last_step_time_us(), flush=True)
-    m = model(cfg, 1)
+    m = model(cfg, a.env)
     lanes = [m] + [m.clone() for _ in range(nmax - 1)]
     bad = 0
     for n in (int(x) for x in a.lanes.split(",")):
