@@ -309,6 +309,7 @@ def main():
                        "frames_emitted_per_clip": emitted, "denoise_steps_per_window": n_denoise, "parallelism": f"clips x{world}"},
             "value_emitted_frames": round(n_clips * emitted / dt, 2),
             "sample_path": diffusion.last_sample_path(),
+            "fence_free_packets": bool(model.last_sample_fence_free()),
             "us_per_denoise_step": round(us, 2),
             "roofline": roof,
         }

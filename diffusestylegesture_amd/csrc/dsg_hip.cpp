@@ -152,6 +152,7 @@ struct dsg_handle {
                                          // step SLOWER than the pose-space loop (117.3 vs 115.0 us, profiles/r02_h_*) -- the first and last
                                          // kernel of the step get 2.7 us shorter, but the noise embedding beside the step costs more
     bool emode = false;                  // the current dsg_sample runs the embedded-space loop
+    bool last_nofence = false;           // ... and whether its packets went without fences
     int last_path = -1;                  // submission path of the last dsg_sample: 0 HIP launches, 1 AQL packets, 2 hipGraph replay
     bool dbg_warned = false;
     // state / activations
@@ -1647,7 +1648,7 @@ static int sample_prepare(dsg_handle* h, const dsg_sample_args* a, int B, void* 
     job.spg = h->cfg.steps_per_graph == 0 ? -1 : h->cfg.steps_per_graph;
     if (job.dumping || ext) job.spg = -1;            // rare paths run eagerly (ext pointer / dump points are per call)
     h->aql_timing = false;
-    h->last_path = 0;
+    h->last_path = 0; h->last_nofence = false;
     job.aql = false;
     job.pin = false;
     {
@@ -1682,7 +1683,7 @@ static int sample_prepare(dsg_handle* h, const dsg_sample_args* a, int B, void* 
             h->aql.recording = false;
             // fence-free packets (see uc_mode; 2: uncached buffers behind the usual fences); the overlapped-launch experiment
             // synchronises through cached counters and keeps the fences
-            h->aql.nofence = h->uc_mode == 1 && !h->overlap;
+            h->aql.nofence = h->uc_mode == 1 && !h->overlap && !h->emode;
         }
         if (!planned) {
             if (!h->aql_warned) { fprintf(stderr, "libdsg_hip: AQL path unavailable (%s); using HIP launches\n", h->aql.err.c_str()); h->aql_warned = true; }
@@ -1860,6 +1861,7 @@ static int run_pinned(dsg_handle** hs, int n, std::vector<SampleJob>& jobs, bool
     for (int i = 0; i < n; ++i) {
         jobs[i].done = jobs[i].n_run;
         hs[i]->last_path = use_aql ? 3 : 4;
+        hs[i]->last_nofence = use_aql && getenv("DSG_PIN_FENCED") == nullptr;
 #ifndef DSG_EMU
         if (use_aql) { hs[i]->aql_timing = true; hs[i]->aql_ms = hs[8 * (i / 8)]->aql.last_ms; }
 #endif
@@ -1882,7 +1884,7 @@ extern "C" int dsg_sample(dsg_handle* h, const dsg_sample_args* a, float* out, i
         if (!dsg_aql::run(h->aql, job[0].n_run, 60.0 + 0.01 * job[0].n_run)) return fail(DSG_E_RUNTIME, "AQL run: " + h->aql.err);
         job[0].done = job[0].n_run;
         h->aql_timing = true; h->aql_ms = h->aql.last_ms;
-        h->last_path = 1;
+        h->last_path = 1; h->last_nofence = h->aql.nofence;
     }
 #endif
     CHK(sample_run_hip(h, a, job[0]));
@@ -1938,7 +1940,7 @@ extern "C" int dsg_sample_multi(dsg_handle** hs, int n, const dsg_sample_args* a
         if (!dsg_aql::run_multi(ctxs.data(), steps.data(), n, tmax, err)) return fail(DSG_E_RUNTIME, "AQL run: " + err);
         for (int i = 0; i < n; ++i) {
             jobs[i].done = jobs[i].n_run;
-            hs[i]->aql_timing = true; hs[i]->aql_ms = hs[i]->aql.last_ms; hs[i]->last_path = 1;
+            hs[i]->aql_timing = true; hs[i]->aql_ms = hs[i]->aql.last_ms; hs[i]->last_path = 1; hs[i]->last_nofence = hs[i]->aql.nofence;
         }
     }
 #endif
@@ -1982,6 +1984,14 @@ extern "C" int dsg_last_sample_path(dsg_handle* h, int* path) {
     if (!h || !path) return fail(DSG_E_INVALID, "null argument");
     if (!h->timing_valid) return fail(DSG_E_STATE, "no dsg_sample has run");
     *path = h->last_path;
+    return 0;
+}
+
+// 1 when the packets of the last dsg_sample's loop carried no acquire / release fences (AQL paths only)
+extern "C" int dsg_last_sample_fence_free(dsg_handle* h, int* fence_free) {
+    if (!h || !fence_free) return fail(DSG_E_INVALID, "null argument");
+    if (!h->timing_valid) return fail(DSG_E_STATE, "no dsg_sample has run");
+    *fence_free = h->last_nofence ? 1 : 0;
     return 0;
 }
 

@@ -54,6 +54,7 @@ SYMBOLS = {
     "dsg_sync": (_I, [_P]),
     "dsg_last_sample_ms": (_I, [_P, C.POINTER(C.c_float), C.POINTER(_I)]),
     "dsg_last_sample_path": (_I, [_P, C.POINTER(_I)]),
+    "dsg_last_sample_fence_free": (_I, [_P, C.POINTER(_I)]),
     "dsg_noise": (_I, [_P, _I, _I, _I, C.c_uint64, C.c_uint64, C.c_uint32, _P]),
     "dsg_pose2bvh": (_I, [_P, _I, _I, _P, _P, _I, C.c_char_p]),
     "dsg_pose2bvh_channels": (_I, [_P, _I, _I, _P, _P, _I, _P, _P]),
@@ -87,7 +88,7 @@ class DSGLibrary:
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(self.cdll, name)          # AttributeError if the library does not export it
             fn.restype, fn.argtypes = res, args
-        if self.cdll.dsg_version() < 200:
+        if self.cdll.dsg_version() < 201:
             raise DSGError("libdsg_hip.so is older than this package")
 
     def check(self, rc: int):

@@ -181,6 +181,13 @@ class DSGDenoiser:
         self.lib.check(self.lib.cdll.dsg_last_sample_path(self.handle, C.byref(p)))
         return {0: "hip", 1: "aql", 2: "graph", 3: "aql-pinned", 4: "hip-pinned"}[p.value]
 
+    def last_sample_fence_free(self) -> bool:
+        """True when the AQL packets of the last sampling call's loop carried no acquire / release fences (loop-written buffers
+        in uncached memory: the default for max_batch <= 16; DSG_UC=0 turns it off)."""
+        p = C.c_int()
+        self.lib.check(self.lib.cdll.dsg_last_sample_fence_free(self.handle, C.byref(p)))
+        return bool(p.value)
+
     def last_sample_ms(self):
         ms, n = C.c_float(), C.c_int()
         self.lib.check(self.lib.cdll.dsg_last_sample_ms(self.handle, C.byref(ms), C.byref(n)))

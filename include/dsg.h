@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define DSG_VERSION 200
+#define DSG_VERSION 201
 
 enum {
     DSG_OK = 0,
@@ -167,6 +167,9 @@ int dsg_last_sample_ms(dsg_handle* h, float* ms, int* n_steps);
  * 3 = AQL packets of XCD-pinned lanes (batch 1, bf16: up to 8 handles per dispatch, lane l on XCD l, no fences between the
  * packets of the loop), 4 = the pinned kernels through HIP launches (DSG_PIN=2; tests) */
 int dsg_last_sample_path(dsg_handle* h, int* path);
+/* 1 when the AQL packets of that loop carried no acquire / release fences: the buffers the loop writes live in uncached device
+ * memory (default for handles of max_batch <= 16; DSG_UC=0 selects cached buffers + agent-scope fences), or path 3 */
+int dsg_last_sample_fence_free(dsg_handle* h, int* fence_free);
 /* the framework's noise stream as a tensor: out [B, J, 1, T] (device) = draw `draw` of (seed, stream_id), i.e. exactly the
  * noise the fused sampler uses for that draw index (x_T is draw_base, step i is draw_base + 1 + i).  Stands in for
  * th.randn / th.randn_like of gaussian_diffusion.py:704, :542 in the generic loop. */

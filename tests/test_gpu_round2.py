@@ -385,4 +385,5 @@ def test_fence_free_loop_equals_fenced_loop(monkeypatch, batch):
         outs = {uc: np.asarray(d.manual_seed(21, w).p_sample_loop(ms[uc], shape, clip_denoised=False, model_kwargs=y, skip_timesteps=600))
                 for uc in ("0", "1")}
         assert ms["1"].last_sample_path() == "aql" and ms["0"].last_sample_path() == "aql"
+        assert ms["1"].last_sample_fence_free() and not ms["0"].last_sample_fence_free()
         assert np.array_equal(outs["0"], outs["1"])
