@@ -1071,8 +1071,10 @@ static int launch_attn_mid(dsg_handle* h, const AttnMidArgs& a) {
 static bool use_latency_mode(const dsg_handle* h, int B) {
     if (h->latency_mode >= 0) return h->latency_mode != 0;
     if (h->D > 384) return false;   // k_mid pulls all of W_o (2 D^2 bytes) through every CU: at D = 512 the un-fused set wins (TWH: 219 vs 238 us)
-    return B <= 2;          // redundant recompute pays only while every launch is a latency chain (tools/b_sweep.sh: batch 3+ is
-                            // as fast or faster with the un-fused set: 182 vs 187 us at batch 3, 195 vs 197 at batch 4)
+    // redundant recompute pays only while every launch is a latency chain (tools/b_sweep.sh: batch 3+ is as fast or faster with
+    // the un-fused set: 182 vs 187 us at batch 3, 195 vs 197 at batch 4); several lanes share the CUs, so there the redundancy
+    // costs from batch 2 (4 lanes x 2: 3507 frames/s un-fused + k_attn_op against 3303 fused, profiles/r02_u_kernel_sets.log)
+    return h->lanes_now > 1 ? B <= 1 : B <= 2;
 }
 
 static StepTables step_tables(const dsg_handle* h) {
@@ -1136,7 +1138,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
     // batched kernel set: attention fused with out_proj + LayerNorm1 (k_attn_op) where an instantiation exists
     // (bf16 only: in fp32 W_o is 16 k-blocks x DT tiles per wave and does not fit the register file next to the attention)
     const bool attn_op = sizeof(typename P::elem) == 2 && !lat && !fuse_attn && h->attn_op != 0 && h->H == 4 && ((D == 256 && h->Tp == 96) || (D == 128 && h->Tp == 32)) &&
-                         (h->attn_op > 0 || M >= 256);
+                         (h->attn_op > 0 || M >= (h->lanes_now > 1 ? 170 : 256));
     // (attention -> k_mid) as an overlapped pair: k_mid's packet carries no barrier bit, it requests W_o / W_1 / operands
     // while the attention kernel still runs and synchronises with it in-kernel (DepWait).  Correct (bit-identical, tested)
     // but measured SLOWER on MI355X: 158 vs 144 us/step -- the agent-scope (L2-bypassing) stores / loads of the handed-off
