@@ -16,11 +16,14 @@ from diffusestylegesture_amd.model import DSGDenoiser                # noqa: E40
 from diffusestylegesture_amd.synth import synth_state_dict, synth_window_inputs      # noqa: E402
 
 
+BATCH = 1
+
+
 def model(cfg, env):
     for kv in env.split(","):
         k, v = kv.split("=")
         os.environ[k] = v
-    m = DSGDenoiser(cfg, precision="bf16", max_batch=1)
+    m = DSGDenoiser(cfg, precision="bf16", max_batch=BATCH)
     m.load_state_dict(synth_state_dict(cfg, 1))
     return m
 
@@ -33,20 +36,30 @@ def main():
     p.add_argument("--config", default="zeggs")
     p.add_argument("--base-env", default="DSG_PIN=0,DSG_UC=0", help="environment of the reference handle (NAME=VALUE,...)")
     p.add_argument("--env", default="DSG_PIN=1", help="environment of the handle under test")
+    p.add_argument("--batch", type=int, default=1, help="clips per lane")
     a = p.parse_args()
+    global BATCH
+    BATCH = a.batch
     cfg = C.CONFIGS[a.config]
-    shape = (1, cfg.njoints, 1, cfg.n_poses)
+    shape = (a.batch, cfg.njoints, 1, cfg.n_poses)
     d = create_gaussian_diffusion()
     nmax = max(int(x) for x in a.lanes.split(","))
-    ys = [[{"y": synth_window_inputs(cfg, 1, window=w, clip0=i, seed_pose_scale=0.2)} for i in range(nmax)] for w in range(a.windows)]
+    ys = [[{"y": synth_window_inputs(cfg, a.batch, window=w, clip0=i * a.batch, seed_pose_scale=0.2)} for i in range(nmax)] for w in range(a.windows)]
     m0 = model(cfg, a.base_env)
     want = [[d.manual_seed(100 + i, i).p_sample_loop(m0, shape, clip_denoised=False, model_kwargs=ys[w][i], skip_timesteps=a.skip)
              for i in range(nmax)] for w in range(a.windows)]
     print("fenced: path", m0.last_sample_path(), "%.2f us/step" % d.last_step_time_us(), flush=True)
+    lanes0 = [m0] + [m0.clone() for _ in range(nmax - 1)]
     m = model(cfg, a.env)
     lanes = [m] + [m.clone() for _ in range(nmax - 1)]
     bad = 0
     for n in (int(x) for x in a.lanes.split(",")):
+        if n > 1 and a.batch > 1:       # lanes pick their kernel set by lane count and batch: the reference runs the same arrangement
+            for w in range(a.windows):
+                ref = d.manual_seed(0, 0).p_sample_loop_multi(lanes0[:n], shape, ys[w][:n], seeds=[100 + i for i in range(n)],
+                                                              stream_ids=list(range(n)), skip_timesteps=a.skip)
+                for i in range(n):
+                    want[w][i] = np.asarray(ref[i]).copy()
         for rep in range(2):
             for w in range(a.windows):
                 t0 = time.perf_counter()
