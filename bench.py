@@ -52,6 +52,10 @@ def parse(argv=None):
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-postprocess", action="store_true")
     p.add_argument("--cpu-baseline-steps", type=int, default=1000)
+    p.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for a single rank")
+    p.add_argument("--config3", default="auto", choices=["auto", "on", "off"],
+                   help="second timed pass at config[3]'s per-GPU share (16 clips: 4 lanes x batch 4) reported as `config3` "
+                        "(auto: whenever --gpus > 1 runs the default 1-clip-per-GPU workload)")
     a = p.parse_args(argv)
     if a.batch and not a.clips_per_gpu:
         a.clips_per_gpu, a.mode = a.batch, "lockstep"
@@ -147,7 +151,7 @@ def cpu_baseline(n_steps, one_core_steps=None):
         dt = time.perf_counter() - t0
     ms_step = 1000.0 * dt / n_steps
     fps = lambda ms: round(320.0 / (4000 * ms / 1000.0), 3)
-    out = {"value": fps(ms_step), "unit": "frames/s", "cores": int(cores), "kind": "port",
+    out = {"value": fps(ms_step), "unit": "frames/s", "cores": int(cores), "kind": "port, 1 window x 4",
            "ms_per_denoise_step": round(ms_step, 3), "host": host_cpu(),
            "sample": f"{n_steps} DDPM steps of one 88-frame ZEGGS window (batch 1, fp32 numpy oracle, {cores} BLAS threads); "
                      f"a 320-frame clip is 4 such windows of 1000 steps"}
@@ -169,7 +173,7 @@ def main():
     if not emu:
         torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or a.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo" if emu else "nccl")          # "nccl" = RCCL on ROCm
@@ -234,6 +238,39 @@ def main():
             if not emu:
                 torch.cuda.synchronize()
 
+    def config3_pass():
+        """BASELINE config[3]'s per-GPU share -- 16 clips as 4 lanes x batch 4 -- timed like the main region (barrier + synchronize on
+        both sides, max over ranks), so that the multi-GPU runs the driver launches (1 clip per GPU by default, to agree with the
+        1-GPU bench line) ALSO carry the 16-clips-per-GPU number: N GPUs x 16 clips, 128 at N = 8."""
+        NL3, B3 = 4, 4
+        m3 = DSGDenoiser(cfg, precision=a.precision, max_batch=B3, device=local, library=library)
+        m3.load_state_dict(synth_state_dict(cfg, 20240))
+        lanes3 = [m3] + [m3.clone() for _ in range(NL3 - 1)]
+        feats3 = [[to_dev(synth_window_inputs(cfg, B3, window=w, clip0=rank * 16 + ln * B3)["audio"]) for w in range(n_windows)]
+                  for ln in range(NL3)]
+        if emu:
+            feats3 = [[f.numpy() for f in fl] for fl in feats3]
+        run3 = lambda i: generate_clips_streams(lanes3, diffusion, feats3, style, seed=777 + i, smoothing=True, skip_timesteps=skip,
+                                                stream_ids=[rank * NL3 + ln for ln in range(NL3)])
+        run3(0)
+        sync()
+        t3 = time.perf_counter()
+        p3 = run3(1)
+        if dist is not None:
+            from diffusestylegesture_amd.parallel import gather_poses
+            gather_poses(p3, world * 16, dist, dst=0, device=None if emu else f"cuda:{local}")
+        sync()
+        dt3 = time.perf_counter() - t3
+        if dist is not None:
+            tt3 = torch.tensor([dt3], dtype=torch.float64, device="cpu" if emu else f"cuda:{local}")
+            dist.all_reduce(tt3, op=dist.ReduceOp.MAX)
+            dt3 = float(tt3.item())
+        us3 = max(1000.0 * ln.last_sample_ms()[0] / max(ln.last_sample_ms()[1], 1) for ln in lanes3)
+        return {"workload": f"{world} GPU(s) x 16 clips (4 lanes x batch 4), {frames_per_clip}-frame ZEGGS clips, DDPM {a.precision}",
+                "clips": world * 16, "value": round(world * 16 * frames_per_clip / dt3, 2), "unit": "frames/s", "passes": 1,
+                "ms_per_pass": round(1000.0 * dt3, 3), "us_per_denoise_step_16_clips": round(us3, 2),
+                "kernel_set": lanes3[0].last_kernel_set(), "sample_path": lanes3[0].last_sample_path()}
+
     for i in range(a.warmup):
         one_pass(i)
     sync()
@@ -256,6 +293,8 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if emu else f"cuda:{local}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    want_c3 = a.config3 == "on" or (a.config3 == "auto" and a.gpus > 1 and NC == 1)
+    c3 = config3_pass() if (want_c3 and cfg.variant == 3 and a.sampler == "ddpm") else None
     if rank == 0:
         n_clips = world * NC * a.steps
         value = n_clips * frames_per_clip / dt
@@ -309,6 +348,8 @@ def main():
                        "frames_emitted_per_clip": emitted, "denoise_steps_per_window": n_denoise, "parallelism": f"clips x{world}"},
             "value_emitted_frames": round(n_clips * emitted / dt, 2),
             "sample_path": diffusion.last_sample_path(),
+            "kernel_set": model.last_kernel_set(),
+            "collective_backend": (None if dist is None else ("gloo" if emu else "nccl")),
             "fence_free_packets": bool(model.last_sample_fence_free()),
             "us_per_denoise_step": round(us, 2),
             "roofline": roof,
@@ -329,6 +370,8 @@ def main():
             out["postprocess_ms_per_clip"] = round(1000.0 * post / g.shape[0], 3)
             out["postprocess_ms_per_pass"] = round(1000.0 * post, 3)
             out["value_end_to_end"] = round(n_clips * frames_per_clip / (dt + post * a.steps), 2)
+        if c3 is not None:
+            out["config3"] = c3
         if world == 1 and not a.no_cpu_baseline and a.config == "zeggs" and a.sampler == "ddpm" and not emu:
             out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_steps)
         print(json.dumps(out), flush=True)

@@ -55,6 +55,8 @@ def pose_to_channels(poses, length, smoothing=False, *, mean=None, std=None, lib
     """(offsets [75, 3], motion [3 * length, 228] in file order) -- the numbers of the file without the text."""
     lib = library or L.default_library()
     a, dt = _arr(poses)
+    if a.ndim != 2 or a.shape[0] != length:      # the C++ side reads `length` rows: never let it run past the buffer
+        raise ValueError(f"poses {a.shape} vs length {length}")
     m, s, mp, sp = _ms(mean, std)
     off = np.zeros((NJOINTS, 3), np.float64)
     mot = np.zeros((3 * int(length), N_CHANNELS), np.float64)

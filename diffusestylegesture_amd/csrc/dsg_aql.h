@@ -34,7 +34,7 @@
 namespace dsg_aql {
 
 struct Kernel { uint64_t object = 0; uint32_t kernarg_size = 0, group = 0, priv = 0; };
-struct Launch { Kernel k; unsigned gx, gy, gz, bx, by, bz; size_t ka_off; bool overlap; };
+struct Launch { Kernel k; unsigned gx, gy, gz, bx, by, bz; size_t ka_off; };
 
 struct Ctx {
     bool tried = false, ready = false, recording = false;
@@ -49,10 +49,9 @@ struct Ctx {
     std::vector<char> ka_host;
     std::vector<Launch> plan;
     double last_ms = 0.0;
-    int acquire_scope = HSA_FENCE_SCOPE_AGENT;      // DSG_AQL_ACQUIRE=0 -> NONE (experiment)
-    int overlap_acquire_scope = HSA_FENCE_SCOPE_AGENT;      // acquire scope of the packets WITHOUT barrier bit (DSG_OVL_ACQUIRE=0 -> NONE)
     bool nofence = false;   // no acquire / release between the packets of the loop: everything the loop writes is coherent without
-                            // cache maintenance (uncached buffers, dsg_hip.cpp uc_mode; or XCD-pinned lanes, dsg_kernels.h)
+                            // cache maintenance (uncached buffers, dsg_hip.cpp uc_mode)
+    char bdf[32] = {0};     // PCI address of the agent the queue lives on (== the HIP device's: checked in init)
 };
 
 inline bool hsa_ok(Ctx& c, hsa_status_t s, const char* what) {
@@ -78,8 +77,9 @@ inline bool init(Ctx& c, int hip_device, const void* addr_in_library) {
     AgentPick pick;
     DSG_AQL_CK(c, hsa_iterate_agents(agent_cb, &pick));
     if (pick.gpus.empty()) { c.err = "no HSA GPU agent"; return false; }
-    c.gpu = pick.gpus[0];
-    if (pick.gpus.size() > 1) {
+    {   // The HSA agent must be the HIP device this handle was created on (one rank per GPU: torch.cuda.set_device(LOCAL_RANK) ->
+        // dsg_config.device): matched by PCI domain:bus:device.function, ALSO when only one agent is visible -- a queue on the
+        // wrong GPU would run the packets against memory of another device.
         char bus[64] = {0};
         unsigned dom = 0, b = 0, d = 0, f = 0;
         if (hipDeviceGetPCIBusId(bus, sizeof bus, hip_device) != hipSuccess || sscanf(bus, "%x:%x:%x.%x", &dom, &b, &d, &f) != 4) {
@@ -92,7 +92,14 @@ inline bool init(Ctx& c, int hip_device, const void* addr_in_library) {
             hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &domain);
             if (bdf == ((b << 8) | (d << 3) | f) && domain == dom) { c.gpu = a; found = true; break; }
         }
-        if (!found) { c.err = "no HSA agent matches the HIP device's PCI id"; return false; }
+        if (!found) { c.err = std::string("no HSA agent matches the HIP device's PCI id ") + bus; return false; }
+        snprintf(c.bdf, sizeof c.bdf, "%04x:%02x:%02x.%x", dom, b, d, f);
+        static bool said[64] = {false};      // once per device and process (= once per rank)
+        if (getenv("LOCAL_RANK") && !said[hip_device & 63]) {
+            said[hip_device & 63] = true;
+            fprintf(stderr, "libdsg_hip: rank-local HIP device %d <-> HSA agent %s: AQL queue created there (%zu GPU agent(s) visible)\n",
+                    hip_device, c.bdf, pick.gpus.size());
+        }
     }
     Dl_info info;
     if (!dladdr(addr_in_library, &info) || !info.dli_fname) { c.err = "dladdr failed"; return false; }
@@ -145,9 +152,7 @@ inline bool lookup(Ctx& c, const void* host_fn, hipStream_t stream, Kernel& out)
 // one launch of the step: explicit argument struct + the hidden arguments of code object v5 behind it
 // (llvm AMDGPUUsage "Code Object V5 Kernel Argument": block counts u32 x3 at +0, group sizes u16 x3 at +12, remainders
 // u16 x3 at +18, global offsets u64 x3 at +40, grid dims u16 at +64)
-// overlap: the packet carries no barrier bit -- the kernel starts while its predecessor runs and synchronises with it
-// in-kernel (dsg_kernels.h: DepWait); everything after it is barrier'ed again, so at most two kernels are in flight
-inline bool record(Ctx& c, const void* host_fn, hipStream_t stream, dim3 grid, dim3 block, const void* args, size_t size, bool overlap = false) {
+inline bool record(Ctx& c, const void* host_fn, hipStream_t stream, dim3 grid, dim3 block, const void* args, size_t size) {
     Kernel k;
     if (!lookup(c, host_fn, stream, k)) return false;
     const size_t hidden = (size + 7) & ~(size_t)7;
@@ -162,7 +167,7 @@ inline bool record(Ctx& c, const void* host_fn, hipStream_t stream, dim3 grid, d
     std::memcpy(p + hidden + 12, gs, sizeof gs);
     const uint16_t dims = 3;
     std::memcpy(p + hidden + 64, &dims, 2);
-    c.plan.push_back(Launch{k, grid.x, grid.y, grid.z, block.x, block.y, block.z, off, overlap});
+    c.plan.push_back(Launch{k, grid.x, grid.y, grid.z, block.x, block.y, block.z, off});
     return true;
 }
 
@@ -205,8 +210,8 @@ inline void submit_step(Ctx& c, bool first_step, bool last_step) {
         // bit orders the packets
         const int mid_scope = c.nofence ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT;
         const int rel = last ? HSA_FENCE_SCOPE_SYSTEM : mid_scope;
-        const int acq = first_step && i == 0 ? HSA_FENCE_SCOPE_SYSTEM : (c.nofence ? HSA_FENCE_SCOPE_NONE : (l.overlap ? c.overlap_acquire_scope : c.acquire_scope));
-        const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | ((l.overlap ? 0 : 1) << HSA_PACKET_HEADER_BARRIER) |
+        const int acq = first_step && i == 0 ? HSA_FENCE_SCOPE_SYSTEM : mid_scope;
+        const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
                                            (acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
                                            (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
         __atomic_store_n((uint16_t*)p, header, __ATOMIC_RELEASE);

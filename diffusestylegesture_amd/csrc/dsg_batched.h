@@ -1,5 +1,5 @@
-// dsg_batched.h -- throughput GEMMs for the batched step (M = tokens x batch >= 512 rows): 64-row x 64/128-column output
-// blocks per workgroup instead of dsg_kernels.h's one 16 x 16 tile per wave.
+// dsg_batched.h -- block GEMMs for the batched step (kernel set DSG_KSET_BLOCK): 32-row x 64-column output blocks per
+// workgroup instead of dsg_kernels.h's one 16 x 16 tile per wave.
 //
 // Why: the latency GEMM (gemm_body) re-fetches a weight tile for every 16-row tile and recomputes the LayerNorm-on-read of
 // its rows once per 64 output columns.  At batch 1 (6 row tiles) that redundancy is free; at batch 16 (89 row tiles) it is
@@ -286,140 +286,6 @@ __global__ __launch_bounds__(256) void k_gemm_blk_k(const GemmArgs g) {
 #pragma unroll
     for (int w2 = 1; w2 < 4; ++w2) sum += *(const f32x4*)&red[w2][rt * CT + t][lane][0];
     gemm_epilogue_tile<P, EPI>(g, mt, (nt0 + t) * 16, lr, lg, ks, true, sum, ops, 0.f, 0.f, 0.f, 0.f, 0.f);
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// k_gemm_tp: BM x 128 blocks (BM = 128, or 64 when the LDS block would not fit), the textbook throughput shape: the A rows are
-// staged in LDS once (LayerNorm-on-read or copy), the 4 waves form a 2 x 2 grid of (BM/2) x 64 sub-blocks, per k-block a wave
-// reads BM/32 A fragments from LDS and 4 weight fragments from global memory for (BM/32) x 4 MFMAs (16 accumulators).
-// EXPERIMENT, off by default (DSG_GEMM_TP=1): on MI355X it is SLOWER than the 32-row blocks above at every batch size tried,
-// including 5696 rows (batch 64: QKV 31.8 vs 23.9 us, linear1 25.5 vs 23.0, pose head 70.7 vs 55.2 us per launch).  These
-// GEMMs have K = 256: eight k-blocks.  There is no long K loop to pipeline behind, so a workgroup's life is a chain of
-// memory round trips of 1.5-2 us each (LayerNorm row loads, weight fragments one k-block ahead, per-tile epilogue operands)
-// with 128 MFMAs per wave in between, and with 1-2 resident workgroups per CU nothing covers them.  The small shapes finish
-// in one round trip per workgroup and let 3-4 workgroups per CU overlap.  What would be needed (all loads of a block in ONE
-// batch: 128 rows x 1 KB + 32 weight fragments + column operands, ~260 VGPRs) no longer fits the register file.
-// ---------------------------------------------------------------------------------------------------------
-template <class P, int PRO, int EPI, int DMAX, int BM>
-__global__ __launch_bounds__(256) void k_gemm_tp(const GemmArgs g) {
-    typedef typename P::elem elem;
-    constexpr int ES = (int)sizeof(elem), WR = BM / 32, CT = 4;      // row tiles / column tiles per wave
-    static_assert(EPI != EPI_PARTIAL, "split-K partials come from k_gemm_blk_k");
-    static_assert(BM == 64 || BM == 128, "block rows");
-    __shared__ __attribute__((aligned(16))) char lds_a[BM * (DMAX * ES + 16)];
-    preload_kernargs(g);
-    const int NGT = (g.NT + 7) / 8;                  // 128-column groups (the last one may be partial)
-    const int ng = xcd_ngroup<P>(), mb = blockIdx.y;
-    const int MB = (g.MT * 16 + BM - 1) / BM;
-    if constexpr (EPI == EPI_OUT) {
-        if (mb >= MB) {      // extra grid row: step bookkeeping (see gemm_body)
-            if (g.ctl && blockIdx.x == 0 && threadIdx.x == 0 && g.out_mode != OUT_FORWARD) step_advance_A(g.ctl, g.st, g.n_tab);
-            return;
-        }
-    }
-    if (ng >= NGT || mb >= MB) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = mb * BM;
-    const int nt0 = ng * 8 + wc * 4;                 // first 16-column tile of this wave
-    const int KBtot = g.KBtot, kb_last = KBtot - 1, nt_last = g.NT - 1;
-    const f32x4* wbase = (const f32x4*)g.Wp + lane;
-    // Q / K columns use the swapped product (4 consecutive features per lane), V the direct one; a wave's 64 columns never
-    // straddle the boundary (H * hd is a multiple of 64)
-    const bool swapped = !(EPI == EPI_QKV && (nt0 * 16) >= 2 * (g.H * g.hd));
-    f32x4 bcur[CT], bnxt[CT];
-    auto load_b = [&](f32x4 (&dst)[CT], int kb) {
-        const int kc = min(kb, kb_last);
-#pragma unroll
-        for (int t = 0; t < CT; ++t) dst[t] = wbase[((size_t)min(nt0 + t, nt_last) * KBtot + kc) * 64];
-    };
-    load_b(bcur, 0);
-    int step = 0;
-    float k1 = 0.f, k2 = 0.f, k3 = 0.f, k4 = 0.f, k5 = 0.f;
-    if constexpr (EPI == EPI_OUT) {
-        if (g.out_mode != OUT_FORWARD) {
-            step = ldw<P>(&g.ctl->stepB);
-            k1 = ldwf<P>(&g.ctl->k1); k2 = ldwf<P>(&g.ctl->k2); k3 = ldwf<P>(&g.ctl->k3); k4 = ldwf<P>(&g.ctl->k4); k5 = ldwf<P>(&g.ctl->k5);
-        }
-    }
-    // ---- stage the BM A rows in LDS
-    const int K = KBtot * P::KB;
-    const int pitch = K * ES + 16;
-    if constexpr (PRO == PRO_LN) {
-        const bool wrx = g.Xn != nullptr && ng == 0;
-        const int nch = g.D >> 6;
-#pragma unroll 1
-        for (int r0 = 0; r0 < BM; r0 += 32) {
-            if constexpr (DMAX <= 256) {
-                if (nch == 4) ln_rows_blk<P, 4, 2>(g, m0 + r0, tid, lds_a + r0 * pitch, pitch, wrx);
-                else if (nch == 2) ln_rows_blk<P, 2, 2>(g, m0 + r0, tid, lds_a + r0 * pitch, pitch, wrx);
-                else if (nch == 3) ln_rows_blk<P, 3, 2>(g, m0 + r0, tid, lds_a + r0 * pitch, pitch, wrx);
-                else ln_rows_blk<P, 1, 2>(g, m0 + r0, tid, lds_a + r0 * pitch, pitch, wrx);
-            } else {
-                if (nch == 8) ln_rows_blk<P, 8, 2>(g, m0 + r0, tid, lds_a + r0 * pitch, pitch, wrx);
-                else if (nch == 6) ln_rows_blk<P, 6, 2>(g, m0 + r0, tid, lds_a + r0 * pitch, pitch, wrx);
-                else if (nch == 5) ln_rows_blk<P, 5, 2>(g, m0 + r0, tid, lds_a + r0 * pitch, pitch, wrx);
-                else ln_rows_blk<P, 7, 2>(g, m0 + r0, tid, lds_a + r0 * pitch, pitch, wrx);
-            }
-        }
-    } else {
-        const int cpr = K * ES / 16;                       // 16-byte chunks per row
-        const int total = BM * cpr;
-        for (int e0 = 0; e0 < total; e0 += 256 * 4) {
-            f32x4 tmp[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = min(e0 + u * 256 + tid, total - 1);
-                const char* src;
-                if (g.a_frag) src = (const char*)g.A + ((size_t)(m0 >> 4) * KBtot * 64 + e) * 16;
-                else { const int r = e / cpr, cc = e - r * cpr; src = (const char*)g.A + ((size_t)(m0 + r) * g.lda) * ES + cc * 16; }
-                tmp[u] = *(const f32x4*)src;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + u * 256 + tid;
-                if (e < total) {
-                    int r, boff;
-                    if (g.a_frag) { const int ln = e & 63, kb = (e >> 6) % KBtot, rt = (e >> 6) / KBtot; r = rt * 16 + (ln & 15); boff = (kb * P::KB + P::E * (ln >> 4)) * ES; }
-                    else { r = e / cpr; boff = (e - r * cpr) * 16; }
-                    *(f32x4*)(lds_a + r * pitch + boff) = tmp[u];
-                }
-            }
-        }
-    }
-    DSG_LDS_BARRIER();
-    // ---- main loop
-    f32x4 acc[WR][CT];
-#pragma unroll
-    for (int rt = 0; rt < WR; ++rt)
-#pragma unroll
-        for (int t = 0; t < CT; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const char* arow = lds_a + (wr * (BM / 2) + lr) * pitch + P::E * lg * ES;
-    for (int kb = 0; kb < KBtot; ++kb) {
-        load_b(bnxt, kb + 1);                              // next k-block's weight fragments under this block's MFMAs
-        f32x4 a[WR];
-#pragma unroll
-        for (int rt = 0; rt < WR; ++rt) a[rt] = *(const f32x4*)(arow + rt * 16 * pitch + kb * P::KB * ES);
-#pragma unroll
-        for (int rt = 0; rt < WR; ++rt)
-#pragma unroll
-            for (int t = 0; t < CT; ++t) acc[rt][t] = swapped ? P::mma(bcur[t], a[rt], acc[rt][t]) : P::mma(a[rt], bcur[t], acc[rt][t]);
-#pragma unroll
-        for (int t = 0; t < CT; ++t) bcur[t] = bnxt[t];
-    }
-    // ---- epilogue, tile by tile (throughput regime: other workgroups of the CU cover the operand latency)
-#pragma unroll
-    for (int rt = 0; rt < WR; ++rt) {
-        const int mt = m0 + wr * (BM / 2) + rt * 16;
-        if (mt >= g.MT * 16) continue;                      // wave-uniform
-#pragma unroll
-        for (int t = 0; t < CT; ++t) {
-            if (nt0 + t > nt_last) continue;                // wave-uniform: partial last column group
-            TileOps o;
-            gemm_prefetch_tile<P, EPI>(g, mt, (nt0 + t) * 16, lr, lg, step, o);
-            gemm_epilogue_tile<P, EPI>(g, mt, (nt0 + t) * 16, lr, lg, 0, swapped, acc[rt][t], o, k1, k2, k3, k4, k5);
-        }
-    }
 }
 
 }  // namespace dsg

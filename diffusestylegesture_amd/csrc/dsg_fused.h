@@ -1,14 +1,12 @@
 // dsg_fused.h -- latency-mode kernels: the same arithmetic as dsg_kernels.h, regrouped so that one denoising step is
-// 2 + 4*L dispatches (k_inloc, L x {QKV GEMM, k_attn, k_mid, linear2 GEMM}, pose head) instead of 3 + 5*L; with the opt-in
-// k_qkv_attn / k_attn_mid 2 + 3*L.  At batch 1 every launch is a latency chain (kernel boundary + dependent loads +
+// 2 + 4*L dispatches (k_inloc, L x {QKV GEMM, k_attn, k_mid, linear2 GEMM}, pose head) instead of 3 + 5*L; with
+// k_attn_mid (batch 1) 2 + 3*L.  At batch 1 every launch is a latency chain (kernel boundary + dependent loads +
 // load -> MFMA -> store), so the lever is the NUMBER of dependent launches, not FLOPs: the fused kernels recompute
 // small things redundantly (K/V of a head per query tile, out_proj + LayerNorm per hidden slice, the pose embedding
 // of the previous window's frames) to avoid an all-to-all hand-off.
 //
 //   k_inloc     = k_in + k_loc      pose-embedding GEMM for {previous, own} window x one local head (K split over
 //                                   the 4 waves, reduced in LDS) -> rotary -> local attention -> token -> rotary
-//   k_qkv_attn  = [LayerNorm2-on-read] + in_proj for ONE self-attention head (K, V of all tokens; Q of one 16-query
-//                 tile) + softmax(QK^T/sqrt(hd))V, all staged in LDS; grid = batch x heads x query tiles
 //   k_mid       = out_proj + residual + LayerNorm1 (rows owned whole by the workgroup) + linear1 slice + GELU
 //   (linear2 + residual and the pose head + sampler update stay k_gemm<RESID> / k_gemm<OUT> of dsg_kernels.h)
 // Reference arithmetic: main/model/mdm.py:196-233 and torch's TransformerEncoderLayer (post-norm) -- see dsg_kernels.h.
@@ -37,7 +35,7 @@ __device__ __forceinline__ void inloc_body(const InLocArgs& g) {
     preload_kernargs(g);
     const LocArgs& a = g.loc;
     if (blockIdx.z == gridDim.z - 1) {      // an EXTRA grid slice: its first workgroup does the step bookkeeping (see StepCtl), off the critical path
-        if (g.ctl_upd && vbx<P>() == 0 && blockIdx.y == 0 && threadIdx.x == 0) step_advance_B<P>(g.ctl_upd, g.st, g.n_tab);
+        if (g.ctl_upd && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) step_advance_B<P>(g.ctl_upd, g.st, g.n_tab);
         return;
     }
     constexpr int W2 = 2 * W, half = HD / 2, NP1 = W2 * half, NPI = (NP1 + 255) / 256;
@@ -46,7 +44,7 @@ __device__ __forceinline__ void inloc_body(const InLocArgs& g) {
     __shared__ __attribute__((aligned(16))) float red[4][2][NL][64][4];      // per-wave partial accumulators
     __shared__ float rot[W2][HD + 1];
     __shared__ float sc[W][W2 + 2];
-    const int h = vbx<P>(), w = blockIdx.y, b = blockIdx.z;            // grid (local heads, windows, batch [+1 bookkeeping])
+    const int h = (int)blockIdx.x, w = blockIdx.y, b = blockIdx.z;            // grid (local heads, windows, batch [+1 bookkeeping])
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
     const int col0 = h * HD, ntok = a.T + 1, f0 = (w - 1) * W;
     const int* tp = a.ctl ? &a.ctl->tA : a.t_arr + b;      // select the ADDRESS, then one unconditional load
@@ -169,210 +167,6 @@ template <class P, int HD, int W>
 __global__ __launch_bounds__(256) void k_inloc(const InLocArgs g) { inloc_body<P, HD, W>(g); }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_qkv_attn
-// ---------------------------------------------------------------------------------------------------------
-struct QkvAttnArgs {
-    const void* Xa;         // layer 0: encoder input rows, P::elem [rows][D] (no LayerNorm)
-    const float* X;         // layer > 0: pre-LayerNorm rows fp32 [rows][D]
-    const float* ln_g; const float* ln_b;
-    float* Xn;              // layer > 0: LayerNorm output rows (fp32), written by the head-0 workgroups
-    const void* Wp;         // packed in_proj weight [3D/16][KD][64][16 B]
-    const float* bias;      // [3D]
-    void* out;              // [rows][D] P::elem attention output (heads concatenated)
-    int B, H, ntok;
-};
-
-template <class P, int HD, int NKT, int DD>
-__global__ __launch_bounds__(256) void k_qkv_attn(const QkvAttnArgs g) {
-    typedef typename P::elem elem;
-    constexpr int ES = (int)sizeof(elem);
-    constexpr int Tp = NKT * 16;
-    constexpr int KD = DD / P::KB;                   // k-blocks of the projection
-    constexpr int KH = HD / P::KB;                   // k-blocks of QK^T
-    constexpr int NTH = HD / 16;                     // 16-col tiles per head (2 or 4)
-    constexpr int MSPLIT = 4 / NTH;                  // waves sharing one n-tile split the row tiles
-    static_assert(NTH == 2 || NTH == 4, "head dim 32 or 64");
-    constexpr int XP = DD * ES + 16, KP = HD * ES + 16, VP = Tp * ES + 16;
-    __shared__ __attribute__((aligned(16))) char lds[Tp * XP + Tp * KP + HD * VP + 16 * KP];
-    char* const xs = lds;
-    char* const kk = xs + Tp * XP;
-    char* const vt = kk + Tp * KP;
-    char* const qq = vt + HD * VP;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
-    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;          // grid (query tiles, heads, batch)
-    const size_t row0 = (size_t)b * g.ntok;
-
-    // ---- (1) this wave's weight fragments: n-tile (wave % NTH) of Q, K and V of head h -- issued first
-    const int wnt = wave % NTH, wms = wave / NTH;
-    const f32x4* wbase = (const f32x4*)g.Wp + lane;
-    f32x4 wf[3][KD];
-#pragma unroll
-    for (int mat = 0; mat < 3; ++mat) {
-        const int nt = (mat * DD + h * HD) / 16 + wnt;
-#pragma unroll
-        for (int kb = 0; kb < KD; ++kb) wf[mat][kb] = wbase[((size_t)nt * KD + kb) * 64];
-    }
-    const f32x4 bq = *(const f32x4*)(g.bias + 0 * DD + h * HD + wnt * 16 + 4 * lg);
-    const f32x4 bk = *(const f32x4*)(g.bias + 1 * DD + h * HD + wnt * 16 + 4 * lg);
-    const float bv = g.bias[2 * DD + h * HD + wnt * 16 + lr];
-
-    // ---- (2) token rows of this batch element -> LDS (LayerNorm-on-read for layers > 0)
-    if (g.X) {
-        constexpr int NCH = DD / 64;                 // float4 chunks per thread per row
-        const int row = tid >> 4, c = tid & 15;
-        f32x4 v[NKT][NCH];
-#pragma unroll
-        for (int p = 0; p < NKT; ++p)
-#pragma unroll
-            for (int i = 0; i < NCH; ++i)
-                v[p][i] = *(const f32x4*)(g.X + (row0 + p * 16 + row) * DD + c * 4 + 64 * i);
-        f32x4 gg[NCH], bb[NCH];
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            gg[i] = *(const f32x4*)(g.ln_g + c * 4 + 64 * i);
-            bb[i] = *(const f32x4*)(g.ln_b + c * 4 + 64 * i);
-        }
-#pragma unroll
-        for (int p = 0; p < NKT; ++p) {
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < NCH; ++i) s += (v[p][i][0] + v[p][i][1]) + (v[p][i][2] + v[p][i][3]);
-            s = row16_sum(s);
-            const float mean = s / (float)DD;
-            float q = 0.f;
-#pragma unroll
-            for (int i = 0; i < NCH; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { const float d = v[p][i][e] - mean; q += d * d; }
-            q = row16_sum(q);
-            const float rstd = 1.0f / sqrtf(q / (float)DD + 1e-5f);
-            const int srow = p * 16 + row;
-            const bool wr = g.Xn && h == 0 && p == qt && srow < g.ntok;
-#pragma unroll
-            for (int i = 0; i < NCH; ++i) {
-                const int col = c * 4 + 64 * i;
-                f32x4 y;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = (v[p][i][e] - mean) * rstd * gg[i][e] + bb[i][e];
-                P::store4((elem*)(xs + srow * XP) + col, y);
-                if (wr) *(f32x4*)(g.Xn + (row0 + srow) * DD + col) = y;
-            }
-        }
-    } else {
-        constexpr int CPR = DD * ES / 16;            // 16-byte chunks per row
-        constexpr int NCP = Tp * CPR / 256;
-        static_assert((Tp * CPR) % 256 == 0, "copy tiling");
-        f32x4 v[NCP];
-#pragma unroll
-        for (int i = 0; i < NCP; ++i) {
-            const int e = tid + 256 * i, r = e / CPR, cc = e % CPR;
-            v[i] = *(const f32x4*)((const char*)g.Xa + ((row0 + r) * DD) * ES + cc * 16);
-        }
-#pragma unroll
-        for (int i = 0; i < NCP; ++i) {
-            const int e = tid + 256 * i, r = e / CPR, cc = e % CPR;
-            *(f32x4*)(xs + r * XP + cc * 16) = v[i];
-        }
-    }
-    DSG_LDS_BARRIER();
-
-    // ---- (3) K_h, V_h for every token and Q_h for this query tile (results stay in LDS)
-    for (int mt = wms; mt < NKT; mt += MSPLIT) {
-        f32x4 af[KD];
-#pragma unroll
-        for (int kb = 0; kb < KD; ++kb) af[kb] = *(const f32x4*)(xs + (mt * 16 + lr) * XP + (kb * P::KB + P::E * lg) * ES);
-        f32x4 ck = (f32x4){0.f, 0.f, 0.f, 0.f}, cv = ck;
-#pragma unroll
-        for (int kb = 0; kb < KD; ++kb) {
-            ck = P::mma(wf[1][kb], af[kb], ck);      // D[dim 4lg+r][token lr]
-            cv = P::mma(af[kb], wf[2][kb], cv);      // D[token 4lg+r][dim lr]
-        }
-        P::store4((elem*)(kk + (mt * 16 + lr) * KP) + wnt * 16 + 4 * lg, ck + bk);
-        f32x4 vv;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) vv[e] = cv[e] + bv;
-        P::store4((elem*)(vt + (wnt * 16 + lr) * VP) + mt * 16 + 4 * lg, vv);
-        if (mt == qt) {
-            f32x4 cq = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kb = 0; kb < KD; ++kb) cq = P::mma(wf[0][kb], af[kb], cq);
-            P::store4((elem*)(qq + lr * KP) + wnt * 16 + 4 * lg, cq + bq);
-        }
-    }
-    DSG_LDS_BARRIER();
-
-    // ---- (4) attention for the 16 queries of this tile; every wave forms the scores, wave w owns output dims
-    f32x4 qf[KH];
-#pragma unroll
-    for (int kb = 0; kb < KH; ++kb) qf[kb] = *(const f32x4*)(qq + lr * KP + (kb * P::KB + P::E * lg) * ES);
-    f32x4 s[NKT];
-#pragma unroll
-    for (int nt = 0; nt < NKT; ++nt) {
-        s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kb = 0; kb < KH; ++kb) {
-            const f32x4 kf = *(const f32x4*)(kk + (nt * 16 + lr) * KP + (kb * P::KB + P::E * lg) * ES);
-            s[nt] = P::mma(kf, qf[kb], s[nt]);       // D[key 4lg+r][query lr]
-        }
-    }
-    const float scale = 1.0f / sqrtf((float)HD);
-    float mx = -DSG_FLT_MAX;
-#pragma unroll
-    for (int nt = 0; nt < NKT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int key = nt * 16 + 4 * lg + r;
-            const float v = key < g.ntok ? s[nt][r] * scale : -DSG_FLT_MAX;
-            s[nt][r] = v;
-            mx = fmaxf(mx, v);
-        }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float sum = 0.f;
-#pragma unroll
-    for (int nt = 0; nt < NKT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int key = nt * 16 + 4 * lg + r;
-            const float p = key < g.ntok ? P::exp_sm(s[nt][r] - mx) : 0.f;
-            s[nt][r] = p;
-            sum += p;
-        }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
-    const float inv = 1.0f / sum;
-    if (wave < NTH) {
-        const int dt = wave;
-        f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const char* vrow = vt + (dt * 16 + lr) * VP;
-        if constexpr (P::E == 4) {
-#pragma unroll
-            for (int nt = 0; nt < NKT; ++nt) o = P::mma(*(const f32x4*)(vrow + (nt * 16 + 4 * lg) * ES), s[nt], o);
-        } else {
-            static_assert(P::E == 4 || (NKT % 2) == 0, "bf16 pairs key tiles");
-#pragma unroll
-            for (int kb = 0; kb < NKT / 2; ++kb) {
-                const f32x2 v0 = *(const f32x2*)(vrow + ((2 * kb) * 16 + 4 * lg) * ES);
-                const f32x2 v1 = *(const f32x2*)(vrow + ((2 * kb + 1) * 16 + 4 * lg) * ES);
-                typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
-                u16x8 pp;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { pp[e] = f2bf(s[2 * kb][e]); pp[4 + e] = f2bf(s[2 * kb + 1][e]); }
-                o = P::mma((f32x4){v0[0], v0[1], v1[0], v1[1]}, __builtin_bit_cast(f32x4, pp), o);
-            }
-        }
-        const int q = qt * 16 + lr;
-        if (q < g.ntok) {
-            f32x4 y;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = o[e] * inv;
-            P::store4((elem*)g.out + qk_off<P>((int)(row0 + q), h * HD + dt * 16 + 4 * lg, DD / P::KB), y);     // fragment-major rows
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // k_mid: pre1 = R + attn.Wo^T + bo ; x1 = LayerNorm1(pre1) ; hidden[:, slice] = gelu(x1.W1[slice]^T + b1)
 // ---------------------------------------------------------------------------------------------------------
 struct MidArgs {
@@ -384,7 +178,6 @@ struct MidArgs {
     float* X1;              // LayerNorm1 output rows (fp32), written by hidden-slice 0
     void* hidden;           // [rows][ff] P::elem
     int M, MT, ff;
-    DepWait dep;            // overlapped launch: wait for the attention workgroups before reading A (dep.ctr null: don't)
 };
 
 // Shared tail of k_mid / k_attn_mid: acc = out_proj result tiles of this wave (D[n = 4*lg + r][row = lr]); adds bias +
@@ -465,10 +258,9 @@ __device__ __forceinline__ void mid_tail(const MidArgs& g, f32x4 (&acc)[DT], con
     }
 }
 
-// OVL: overlapped launch (DSG_OVERLAP=1): everything that does not come from the attention kernel is requested before
-// waiting for it.  Otherwise activation and weight fragments are requested k-block by k-block, PD ahead of the MFMA that
-// consumes them, so the first MFMA starts after ~25 loads instead of ~57 (measured: 10.7 k vs 12.3 k cycles per kernel).
-template <class P, int DT, bool OVL = false>      // DT = D / 64 : 16-col tiles of the out_proj output per wave
+// Activation and weight fragments are requested k-block by k-block, PD ahead of the MFMA that consumes them, so the first
+// MFMA starts after ~25 loads instead of ~57 (measured: 10.7 k vs 12.3 k cycles per kernel).
+template <class P, int DT>      // DT = D / 64 : 16-col tiles of the out_proj output per wave
 __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
     typedef typename P::elem elem;
     constexpr int ES = (int)sizeof(elem);
@@ -512,11 +304,9 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
     f32x4 pbo[DT], pr[DT], pg[DT], pbt[DT], pb1;
     f32x4 w1f[KD <= CH ? KD : 1];
     const int n1t = ng * 4 + wave;                   // this wave's 16-col tile of the hidden layer
-    constexpr bool ALLW = OVL && KD <= CH;           // all of W_o resident in registers before the wait
-    constexpr int NPRE = ALLW ? KD : PD;
 #pragma unroll
-    for (int kb = 0; kb < NPRE; ++kb) {
-        if constexpr (!OVL) af[kb] = *(const f32x4*)(arow + (size_t)kb * 64 * P::E);
+    for (int kb = 0; kb < PD; ++kb) {
+        af[kb] = *(const f32x4*)(arow + (size_t)kb * 64 * P::E);
 #pragma unroll
         for (int t = 0; t < DT; ++t) bf[kb][t] = wo[((size_t)(wave * DT + t) * KD + kb) * 64];
     }
@@ -532,29 +322,17 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
         }
         pb1 = *(const f32x4*)(g.b1 + n1t * 16 + 4 * lg);
     };
-    if constexpr (OVL) {
-        if constexpr (ALLW) load_operands();
-        DSG_LOADS_ISSUED();
-        dep_wait(g.dep);                              // the attention rows are read with agent-scope loads from here on
-#pragma unroll
-        for (int kb = 0; kb < PD; ++kb) af[kb] = load16_agent(arow + (size_t)kb * 64 * P::E);
-    }
     f32x4 acc[DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < KD; ++kb) {
         if (kb + PD < KD) {
-            if constexpr (OVL) af[kb + PD] = load16_agent(arow + (size_t)(kb + PD) * 64 * P::E);
-            else af[kb + PD] = *(const f32x4*)(arow + (size_t)(kb + PD) * 64 * P::E);
-            if constexpr (!ALLW) {
+            af[kb + PD] = *(const f32x4*)(arow + (size_t)(kb + PD) * 64 * P::E);
 #pragma unroll
-                for (int t = 0; t < DT; ++t) bf[kb + PD][t] = wo[((size_t)(wave * DT + t) * KD + kb + PD) * 64];
-            }
+            for (int t = 0; t < DT; ++t) bf[kb + PD][t] = wo[((size_t)(wave * DT + t) * KD + kb + PD) * 64];
         }
-        if constexpr (!ALLW) {
-            if (kb + PD == KD) load_operands();       // all fragments requested: now the operands of the later phases
-        }
+        if (kb + PD == KD) load_operands();           // all fragments requested: now the operands of the later phases
         DSG_LOADS_ISSUED();
         if (kb == 0) DSG_STAMP(0, 1);
 #pragma unroll
@@ -784,46 +562,6 @@ template <class P, int DT, int NKT>
 __global__ __launch_bounds__(256) void k_attn_mid(const AttnMidArgs ga) { attn_mid_body<P, DT, NKT>(ga); }
 
 // ---------------------------------------------------------------------------------------------------------
-// XCD-pinned lanes (dsg_kernels.h): the batch-1 step kernels for up to 8 lanes per dispatch.  a[lane] holds what the
-// lane's own launch would have received as kernel arguments.
-// ---------------------------------------------------------------------------------------------------------
-// the lanes' arguments travel in the kernel-argument segment itself (scalar loads, like any kernel's arguments)
-template <class T> struct PinTab { T a[8]; int nl; int pad; unsigned* err; };
-__device__ __forceinline__ void pin_check_xcd(unsigned* err) {
-#ifndef DSG_EMU
-    // HW_REG_XCC_ID (id 20), bits 3:0
-    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
-    if (threadIdx.x == 0 && (xcc & 7u) != (blockIdx.x & 7u) && err)
-        __hip_atomic_store(err, 0x80000000u | (blockIdx.z << 24) | (blockIdx.y << 16) | (blockIdx.x << 4) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-    (void)err;
-#endif
-}
-// (the LayerNorm GEMMs in their 3-waves-per-SIMD form, ln_rows LEAN: a lane has 32 CUs for its 72-108 workgroups)
-template <int PRO, int EPI, int WN, int WK, int TNW>
-__global__ __launch_bounds__(256, PRO == PRO_LN ? 3 : 1) void k_gemm_x(const PinTab<GemmArgs> t) {
-    const int lane = blockIdx.x & 7;
-    if (lane >= t.nl) return;
-    gemm_body<PBF16X, PRO, EPI, WN, WK, TNW, PRO == PRO_LN>(t.a[lane]);
-    pin_drain<PBF16X>();
-}
-template <int HD, int W>
-__global__ __launch_bounds__(256) void k_inloc_x(const PinTab<InLocArgs> t) {
-    const int lane = blockIdx.x & 7;
-    if (lane >= t.nl) return;
-    pin_check_xcd(t.err);
-    inloc_body<PBF16X, HD, W>(t.a[lane]);
-    pin_drain<PBF16X>();
-}
-template <int DT, int NKT>
-__global__ __launch_bounds__(256, 2) void k_attn_mid_x(const PinTab<AttnMidArgs> t) {
-    const int lane = blockIdx.x & 7;
-    if (lane >= t.nl) return;
-    attn_mid_body<PBF16X, DT, NKT>(t.a[lane]);
-    pin_drain<PBF16X>();
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // k_attn_op (batched step): self-attention of one (batch element, 16-query tile) for all 4 heads (wave = head), then
 // out_proj + bias + residual + LayerNorm1 on the 16 full rows -- k_attn_mid without the linear1 slice, so nothing is
 // recomputed per hidden slice and it scales with the batch (grid = query tiles x batch).  One dispatch and one round trip
@@ -1009,131 +747,6 @@ __global__ __launch_bounds__(256) void k_attn_op(const AttnOpArgs g) {
             *(f32x4*)(g.X1 + m * D + n) = y;
             P::store4((elem*)g.X1a + qk_off<P>((int)m, n, D / P::KB), y);
         }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Embedded-space state (batch <= 2 sampling loop).  The denoiser only ever sees x_t through the pose embedding
-// E(x_t) = Wfold . x_t (Wfold = input_process2[:, D:2D] . poseEmbedding, [D x J]), and the sampler update is linear in
-// (x0, x_t, z):  x_{t-1} = a x0 + b x_t + c z  (DDPM: posterior mean + sigma z, gaussian_diffusion.py:264-267, :557; DDIM:
-// :773-791 rearranged).  So the loop carries E(x_t) [T x D] instead of x_t [T x J]:
-//     E(x_{t-1}) = a (W_io . h + b_io) + b E(x_t) + c E(z),      W_io = Wfold . W_out [D x D],  b_io = Wfold . b_out
-// which takes both J-wide GEMMs off the critical path of a step: the pose embedding (K = J = 1141) disappears from the first
-// kernel of the step (k_loc_e = the local-attention kernel reading E(x_t) directly) and the pose head shrinks from N = J to
-// N = D (EPI_ESTEP).  E(z) = Wfold . z needs a K = J GEMM on fresh noise every step, but depends on nothing: k_enoise runs
-// beside the step's first kernel (AQL packet without the barrier bit) on CUs that kernel leaves idle.  The last step of DDPM /
-// DDIM has a = 1, b = c = 0, i.e. x_0 = W_out . h + b_out: one ordinary pose-head launch after the loop produces the sample.
-// Rounding: identical operands to the reference order except that x_t is never rounded to the GEMM type (its embedding is
-// carried in fp32) and W_io is rounded once -- fp32 mode agrees with the pose-space loop to ~1e-6, bf16 mode stays within the
-// stated 3e-2 (the parity tests run it against the same goldens).  Not used with dump_steps, replayed noise, const_noise,
-// clip_denoised (non-linear in x0) or guidance: those take the pose-space loop.
-// STATUS: opt-in (DSG_ECARRY=1).  Measured on MI355X (profiles/r02_f_*, r02_h_*): the step's first + last kernel get 2.7 us
-// shorter (111.5 vs 114.2 us/step with the noise embedding left out), but E(z) costs 4-5 us per step however it is scheduled --
-// as a packet without barrier bit behind the step's first kernel or behind the layer-0 attention kernel, with 6 or 18 K
-// splits, 256- or 1024-thread workgroups, with or without an acquire fence: 115.9-118.7 us/step against 113.1-115.7 for the
-// pose-space loop on the same boxes.  The command processor handles the extra packet and its fences in line with the chain.
-// ---------------------------------------------------------------------------------------------------------
-struct LocEArgs {
-    LocArgs loc;            // partial = E(x_t) rows, KS = 1
-    StepCtl* ctl_upd;       // first kernel of a step: an extra grid slice advances the B side of the step control
-    StepTables st; int n_tab;
-};
-template <class P, int HD, int W>
-__global__ __launch_bounds__(256) void k_loc_e(const LocEArgs g) {
-    preload_kernargs(g);
-    if (blockIdx.z == gridDim.z - 1) {
-        if (g.ctl_upd && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) step_advance_B(g.ctl_upd, g.st, g.n_tab);
-        return;
-    }
-    loc_body<P, HD, W>(g.loc, blockIdx.x, blockIdx.y, blockIdx.z);
-}
-
-// E(z) partial sums: workgroup (ks, mt) = 16 frames x one K range of the noise; all D output columns.  The noise of the range
-// is generated ONCE (Philox, the draw the pose-space epilogue would use for this step), staged in LDS in the GEMM element
-// type, and multiplied with the Wfold fragments, which were requested before the first Philox round.
-struct ENoiseArgs {
-    const void* Wp;         // packed Wfold [D/16][KBtot][64][16 B]
-    int KBtot, kb_per_split, KS;
-    float* ez;              // [KS][ez_rows][D]
-    int ez_rows;
-    const StepCtl* ctl;     // step index = ctl->stepA (stable for the whole step)
-    const unsigned* dyn;    // {seed lo, seed hi, stream lo, stream hi, draw index of step 0}
-    int B, T, J, Jq, D;
-};
-// Many small workgroups: the Philox rounds are the long part (one quad = ~350 instructions) and the kernel has to be over
-// before the kernel it runs beside is, so K is split 18 ways -- at the ZEGGS sizes 2 k-blocks = one quad per lane -- and the
-// 18 partial sums are added by the consumer's operand prefetch.  (6 splits with 3 quads per lane, or 1024-thread workgroups,
-// ran 5-6 us and showed up in the step time: profiles/r02_f_ecarry_ab.log.)
-template <class P, int DT>      // DT = D / 64: 16-column tiles per wave
-__global__ __launch_bounds__(256) void k_enoise(const ENoiseArgs g) {
-    typedef typename P::elem elem;
-    constexpr int ES = (int)sizeof(elem), KMAX = 8;           // k-blocks per split the LDS tile is sized for
-    __shared__ __attribute__((aligned(16))) char za[16 * (KMAX * P::KB * ES + 16)];
-    preload_kernargs(g);
-    const int ks = blockIdx.x, mt = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
-    const int kb_lo = min(ks * g.kb_per_split, g.KBtot), nkb = min(g.kb_per_split, g.KBtot - kb_lo);
-    const int kb_last = g.KBtot - 1;
-    const f32x4* wbase = (const f32x4*)g.Wp + lane;
-    // ---- Wfold fragments of this wave's column tiles: in flight during the Philox rounds
-    constexpr int CHK = DT >= 6 ? 2 : 4;                      // k-blocks per pass (register budget: CHK * DT fragments)
-    f32x4 bf[CHK][DT];
-    auto load_b = [&](int c0) {
-#pragma unroll
-        for (int c = 0; c < CHK; ++c) {
-            const int kb = min(kb_lo + c0 + c, kb_last);
-#pragma unroll
-            for (int t = 0; t < DT; ++t) bf[c][t] = wbase[((size_t)(wave * DT + t) * g.KBtot + kb) * 64];
-        }
-    };
-    load_b(0);
-    // (agent-scope load: this kernel's packet may carry no acquire fence, and the word was rewritten by the previous step)
-    const int step = __hip_atomic_load(&g.ctl->stepA, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const NoiseKey nk = {g.dyn[0], g.dyn[1], g.dyn[2], g.dyn[3]};
-    const unsigned draw = g.dyn[4] + (unsigned)step;
-    // ---- noise of 16 frames x this K range -> LDS
-    const int pitch = KMAX * P::KB * ES + 16;
-    const int qpr = nkb * P::KB / 4;                          // quads per row
-    for (int e = tid; e < 16 * qpr; e += 256) {
-        const int r = e / qpr, qi = e - r * qpr;
-        const int m = mt * 16 + r, j0 = kb_lo * P::KB + 4 * qi;
-        f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (m < g.B * g.T && j0 < g.J) {
-            z = philox_normal4((unsigned)(((size_t)m * g.Jq + j0) >> 2), draw, nk);      // m = b * T + f
-#pragma unroll
-            for (int q = 0; q < 4; ++q) if (j0 + q >= g.J) z[q] = 0.f;
-        }
-        P::store4((elem*)(za + r * pitch) + 4 * qi, z);
-    }
-    DSG_LDS_BARRIER();
-    f32x4 acc[DT];
-#pragma unroll
-    for (int t = 0; t < DT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int c0 = 0; c0 < nkb; c0 += CHK) {
-#pragma unroll
-        for (int c = 0; c < CHK; ++c) {
-            const bool live = c0 + c < nkb;
-            f32x4 a = *(const f32x4*)(za + lr * pitch + (min(c0 + c, max(nkb - 1, 0)) * P::KB + P::E * lg) * ES);
-            a = live ? a : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int t = 0; t < DT; ++t) acc[t] = P::mma(bf[c][t], a, acc[t]);      // D[col 4lg+r][row lr]
-        }
-        if (c0 + CHK < nkb) load_b(c0 + CHK);
-    }
-    const int m = mt * 16 + lr;
-    if (m < g.B * g.T) {       // (a split past the end of K writes zeros: the consumer sums all KS slices)
-#pragma unroll
-        for (int t = 0; t < DT; ++t)
-            *(f32x4*)(g.ez + ((size_t)ks * g.ez_rows + m) * g.D + (wave * DT + t) * 16 + 4 * lg) = acc[t];
-    }
-}
-
-// once per window: E(x_T) = sum of the split-K partials of the pose-embedding GEMM
-__global__ void k_sum_partials(float* out, const float* partial, int KS, size_t stride, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float v = 0.f;
-        for (int s2 = 0; s2 < KS; ++s2) v += partial[(size_t)s2 * stride + i];
-        out[i] = v;
     }
 }
 

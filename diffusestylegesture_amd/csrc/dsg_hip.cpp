@@ -111,15 +111,6 @@ struct SharedWeights {
     ~SharedWeights() { for (void* p : allocs) (void)hipFree(p); }
 };
 
-// one launch of a lane's step, recorded for the pinned submission: the pinned twin of the kernel + the lane's arguments
-struct PinLaunch {
-    const void* fnx;        // pinned kernel (host pointer)
-    void (*launch)(hipStream_t, dim3, dim3, const void* tab);
-    dim3 grid, block;       // the lane's own grid
-    size_t tab_size, nl_off, err_off;      // layout of the pinned kernel's argument struct (PinTab<Args>)
-    std::vector<char> args;
-};
-
 struct dsg_handle {
     dsg_config cfg;
     int prec = 0, es = 4, kbk = 16;      // element size / k-block of the precision policy
@@ -145,39 +136,23 @@ struct dsg_handle {
     unsigned char* mask = nullptr; int mb = 1; int nomask = 0;
     // classifier-free guidance (dsg_set_window_cond_cfg): cfgB user batch elements + their unconditional twins = condB rows
     int cfgB = 0; float* cfg_scale = nullptr;
-    // embedded-space state (dsg_fused.h): E(x_t), E(z) partial sums, W_io = Wfold . W_out, b_io = Wfold . b_out
-    float *epose = nullptr, *ez = nullptr, *b_io = nullptr; void* W_io = nullptr;
-    int ez_ks = 0, ez_rows = 0;
-    int ecarry = 0;                      // DSG_ECARRY=1: embedded-space state in the latency kernel set.  OFF by default: measured 2 us per
-                                         // step SLOWER than the pose-space loop (117.3 vs 115.0 us, profiles/r02_h_*) -- the first and last
-                                         // kernel of the step get 2.7 us shorter, but the noise embedding beside the step costs more
-    bool emode = false;                  // the current dsg_sample runs the embedded-space loop
-    bool last_nofence = false;           // ... and whether its packets went without fences
     int last_path = -1;                  // submission path of the last dsg_sample: 0 HIP launches, 1 AQL packets, 2 hipGraph replay
-    bool dbg_warned = false;
+    bool last_nofence = false;           // ... and whether its packets went without fences
+    int kset_req = DSG_KSET_AUTO;        // dsg_set_kernel_set: the kernel set every step of this handle runs (AUTO: by batch, select_kernels)
+    int last_kset = -1;                  // ... and the one the last dsg_forward / dsg_sample ran
     // state / activations
     float *xs32 = nullptr, *partial = nullptr, *X0 = nullptr, *pre1 = nullptr, *pre2 = nullptr, *Xn = nullptr,
           *X1 = nullptr, *fwd_out = nullptr, *io_tmp = nullptr, *io_tmp2 = nullptr, *ext_noise = nullptr;
     size_t ext_noise_cap = 0;
     void *xsA = nullptr, *X0a = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *attn = nullptr, *hidden = nullptr;
     void* X1a = nullptr;                 // LayerNorm1 rows in the GEMM type, fragment-major (k_attn_op -> linear1)
-    int attn_op = -1;                    // DSG_ATTN_OP: -1 auto (batched kernel set, shapes with an instantiation), 0 never
     int* ctr = nullptr;                  // scratch counter for diagnostics
     StepCtl* ctl = nullptr;              // device-resident step control (dsg_kernels.h: StepCtl)
     int* t_arr = nullptr; unsigned* dyn = nullptr;
-    int latency_mode = -1;               // -1 auto (fused kernels when the batch is small), 0 never, 1 always
+    int latency_mode = -1;               // dsg_config.latency_mode: -1 auto, 0 never the LATENCY set, 1 always
 #ifndef DSG_EMU
     dsg_aql::Ctx aql;                    // hand-written AQL submission of the step loop (dsg_aql.h)
 #endif
-    // XCD-pinned lanes (dsg_kernels.h): the batch-1 step of up to 8 handles in shared dispatches, lane l on XCD l, no fences
-    // between the packets of the loop.  DSG_PIN: 0 (default) never, 1 when the AQL path is available, 2 also through HIP launches
-    // (no fence to save there -- for the emulator tests).  OFF by default -- measured on MI355X (profiles/r02_n_pinned_lanes.log):
-    // bit-identical to the fenced submission, but a lane then has ONE XCD's 32 CUs for kernels shaped for 256: 203 us/step for
-    // one lane against 115 fenced (the same kernels behind agent fences: 217, so the fences themselves are 0.5 us per packet);
-    // 8 lanes 243 us/step = 2.9 k frames/s, the same as 4 fenced lanes x 2 clips; 16 lanes (two packet chains) 2.0 k.  And once
-    // a grid exceeds what an XCD can hold, the dispatcher no longer deals workgroup i to XCD i % 8 (seen: the last workgroups of
-    // a 1024-workgroup k_inloc_x) -- the in-kernel placement check then sends the call to the fenced path.
-    int pin_mode = 0;
     // Fence-free step loop (DSG_UC, default 1): every buffer the loop WRITES (state, activations, step control) lives in
     // uncached device memory (MTYPE UC: neither the CUs' L1 nor the XCDs' L2 hold its lines, so a kernel on any XCD reads what
     // the previous kernel wrote without cache maintenance), the step control is read with vector loads (never through the
@@ -186,42 +161,24 @@ struct dsg_handle {
     // (profiles/r02_q_*): the fences are worth ~6 us per batch-1 step, the uncached buffers cost ~3 (117 us with uncached buffers
     // behind the usual fences, DSG_UC=2): 111.0 vs 114.2 us/step, bit-identical samples; 16 clips in 4 lanes: 5628 vs 5120 frames/s.
     // DSG_UC=0: cached buffers, agent-scope fences.  HIP launches / hipGraph keep the runtime's own fences either way.
+    // The first fence-free run of a process checks the premise on the device it runs on (uc_selfcheck) and falls back to fenced
+    // packets with a warning if a hand-off through uncached memory is ever seen stale.
     int uc_mode = 1;
     bool alloc_uc = false;               // dalloc target: a loop-written buffer
-    bool pin_rec = false, pin_unsupported = false;   // run_step is being recorded into pin_plan
-    std::vector<PinLaunch> pin_plan;
     int aql_mode = 1;                    // DSG_AQL: 1 (default) = AQL packets for the eager step loop, 0 = HIP launches
-    bool overlap = false;                // DSG_OVERLAP=1: (attention -> k_mid) as an overlapped, barrier-less pair (measured slower)
-    bool overlap_next = false;           // the next step_launch is such a consumer
-    unsigned* dep_ctr = nullptr;         // producer counters of the overlapped pairs (dsg_kernels.h: DepWait)
     bool aql_warned = false;
     bool aql_timing = false;             // the last dsg_sample was timed by the host clock around the AQL run
     double aql_ms = 0.0;
-    int gemm_blk = -1;                   // DSG_GEMM_BLK: -1 by size (block GEMMs of dsg_batched.h), 0 never, 1 always
-    int lanes_now = 1;                   // lanes advanced together by the current dsg_sample_multi call (1: dsg_sample)
-    int gemm_tp_mask = 1 | 4 | 16;       // DSG_GEMM_TP_MASK: which GEMMs take k_gemm_tp (bits as DSG_GEMM_BLK_MASK)
-    int gemm_tp = 0;                     // DSG_GEMM_TP=1: k_gemm_tp (BM x 128 blocks) for the GEMMs of DSG_GEMM_TP_MASK (experiment: slower)
-    int gemm_blk_tnw = 0;                // DSG_GEMM_BLK_TNW: column tiles per wave in k_gemm_blk (default 1)
-    int kin_ks = 0;                      // DSG_KIN_KS: workgroup split-K of the pose embedding on the block path (default 2)
-    int gemm_blk_rt = 0;                 // DSG_GEMM_BLK_RT: 16-row tiles per workgroup in k_gemm_blk: 2 (default) or 4
-    int gemm_blk_mask = 1 | 4 | 8 | 32;      // DSG_GEMM_BLK_MASK: which GEMMs of the batched step use the block kernels: 1 QKV, 2 out_proj,
-                                         // 4 linear1, 8 linear2, 16 pose head, 32 pose embedding.  Measured per GEMM in the real
-                                         // batch-16 step (profiles/r02_c_blk_sweep.log): QKV -13 us, linear1 -7, embedding -9.5 per
-                                         // step; out_proj +4 and the pose head +3.5 (few, long workgroups) stay on the 16 x 16 kernels
-    int gemm_lean = -1;                  // DSG_GEMM_LEAN: -1 by batch size, 0 never, 1 always (LayerNorm GEMMs compiled for 4 waves per SIMD)
-    int gemm_tm = 0;                     // DSG_GEMM_TM: row tiles per workgroup in the GEMMs (0 = by batch size)
-    int gemm_tnw = 0;                    // DSG_GEMM_TNW: 16-col tiles per wave in the batched GEMMs (0 = by batch size)
-    int dbg_skip = 0;                    // DSG_DEBUG_SKIP bit mask: timing experiments only (results become garbage)
-    bool fuse_attn = false;
     bool fuse_attn_mid = true;           // k_attn_mid (attention inside the out_proj/LN/linear1 kernel) at batch 1; DSG_FUSE_ATTN_MID=0 to A/B
     int* st_tmodel = nullptr; float* st_c[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int st_cap = 0, n_run = 1;
-    bool st_valid = false, st_emode = false; int st_mode = -1, st_skip = -1; float st_eta = 0.f;      // what the device tables hold
+    bool st_valid = false; int st_mode = -1, st_skip = -1; float st_eta = 0.f;      // what the device tables hold
     Sched sched;
-    // graphs: key = (B, out_mode, ext_noise?, const_noise) -> exec
-    // n_run is part of the key: the captured kernels carry the step-table length as an argument (n_tab)
-    struct GKey { int B, mode, mb, cn, n_run, flags; bool operator<(const GKey& o) const {
-        return std::tie(B, mode, mb, cn, n_run, flags) < std::tie(o.B, o.mode, o.mb, o.cn, o.n_run, o.flags); } };
+    // graphs: key = (B, out_mode, mask batch, const_noise, steps, flags, kernel set) -> exec
+    // n_run is part of the key: the captured kernels carry the step-table length as an argument (n_tab); so is the kernel set
+    // (a graph captured under one set must never be replayed for a call that asked for another)
+    struct GKey { int B, mode, mb, cn, n_run, flags, kset; bool operator<(const GKey& o) const {
+        return std::tie(B, mode, mb, cn, n_run, flags, kset) < std::tie(o.B, o.mode, o.mb, o.cn, o.n_run, o.flags, o.kset); } };
     struct GVal { hipGraphExec_t exec; hipGraph_t graph; int steps; };
     std::map<GKey, GVal> graphs;
     float last_ms = -1.f; int last_steps = 0; bool timing_valid = false;
@@ -352,26 +309,16 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     if (h->n_te > c->pe_max_len) { delete h; return fail(DSG_E_INVALID, "train_steps > pe_max_len"); }
     h->layers.resize(h->L);
     h->latency_mode = c->latency_mode == 1 ? 0 : (c->latency_mode == 2 ? 1 : -1);
-    if (const char* e = getenv("DSG_LATENCY_MODE")) h->latency_mode = atoi(e);
-    if (const char* e = getenv("DSG_DEBUG_SKIP")) h->dbg_skip = atoi(e);
-    if (const char* e = getenv("DSG_GEMM_TNW")) h->gemm_tnw = atoi(e);
-    if (const char* e = getenv("DSG_GEMM_TM")) h->gemm_tm = atoi(e);
-    if (const char* e = getenv("DSG_GEMM_LEAN")) h->gemm_lean = atoi(e);
-    if (const char* e = getenv("DSG_ECARRY")) h->ecarry = atoi(e);
-    if (const char* e = getenv("DSG_ATTN_OP")) h->attn_op = atoi(e);
-    if (const char* e = getenv("DSG_GEMM_BLK")) h->gemm_blk = atoi(e);
-    if (const char* e = getenv("DSG_GEMM_TP")) h->gemm_tp = atoi(e);
-    if (const char* e = getenv("DSG_GEMM_TP_MASK")) h->gemm_tp_mask = atoi(e);
-    if (const char* e = getenv("DSG_GEMM_BLK_TNW")) h->gemm_blk_tnw = atoi(e);
-    if (const char* e = getenv("DSG_GEMM_BLK_RT")) h->gemm_blk_rt = atoi(e);
-    if (const char* e = getenv("DSG_KIN_KS")) h->kin_ks = atoi(e);
-    if (const char* e = getenv("DSG_PIN")) h->pin_mode = atoi(e);
+    // Environment switches of the release library (everything else is an API / config field):
+    //   DSG_KSET  kernel set for every handle (1 latency, 2 tile, 3 block, 4 stream; overrides dsg_set_kernel_set)   [A/B runs]
+    //   DSG_UC    0: cached loop buffers + fenced packets, 1: uncached + fence-free, 2: uncached + fenced
+    //   DSG_AQL   0: HIP launches instead of hand-written AQL packets
+    //   DSG_FUSE_ATTN_MID  0: k_attn + k_mid instead of k_attn_mid at batch 1 (bit-identical; A/B)
+    if (const char* e = getenv("DSG_KSET")) h->kset_req = atoi(e);
     // large batches re-read their activations from the L2 often enough that the uncached buffers cost what the fences save
     // (64 clips in 4 lanes x 16: 9667 vs 9680 frames/s): cached + fenced from batch 32
     if (c->max_batch > 16) h->uc_mode = 0;
     if (const char* e = getenv("DSG_UC")) h->uc_mode = atoi(e);
-    if (const char* e = getenv("DSG_GEMM_BLK_MASK")) h->gemm_blk_mask = atoi(e);
-    if (const char* e = getenv("DSG_OVERLAP")) h->overlap = atoi(e) != 0;
     if (const char* e = getenv("DSG_AQL")) h->aql_mode = atoi(e);
     else {
         // under a profiler the HSA queues are intercepted and rewritten (rocprofv3 crashed on hand-written packets), so
@@ -381,14 +328,8 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
             if (val && (strstr(val, "rocprof") || strstr(v, "ROCPROF"))) h->aql_mode = 0;
         }
     }
-    if (const char* e = getenv("DSG_FUSE_ATTN")) h->fuse_attn = atoi(e) != 0;
     if (const char* e = getenv("DSG_FUSE_ATTN_MID")) h->fuse_attn_mid = atoi(e) != 0;
-    // experiment switches that knowingly break the results are never silent
-    if (h->dbg_skip || getenv("DSG_AQL_ACQUIRE")) {
-        static bool warned = false;
-        if (!warned) fprintf(stderr, "libdsg_hip: WARNING: DSG_DEBUG_SKIP / DSG_AQL_ACQUIRE are timing experiments -- results are not valid samples\n");
-        warned = true;
-    }
+    *out = h;
     *out = h;
 
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -419,10 +360,6 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     CHK(dalloc_bytes(h, &h->k, qkv_elems * h->es));
     CHK(dalloc_bytes(h, &h->vt, qkv_elems * h->es));
     CHK(dalloc(h, &h->ctl, 1));
-    CHK(dalloc(h, &h->dep_ctr, 64));
-    h->ez_ks = DSG_EZ_MAXKS; h->ez_rows = (int)Min_pad;
-    CHK(dalloc(h, &h->epose, Min_pad * D));
-    CHK(dalloc(h, &h->ez, (size_t)h->ez_ks * Min_pad * D));
     h->alloc_uc = false;                 // ---- inputs / outputs / conditioning: constant while the loop runs
     CHK(dalloc(h, &h->fwd_out, (size_t)B * h->J * h->T));
     CHK(dalloc(h, &h->io_tmp, (size_t)B * h->J * h->T));
@@ -477,7 +414,8 @@ extern "C" int dsg_clone(dsg_handle* src, int max_batch, dsg_handle** out) {
     h->raw = src->raw;
     h->Wp_in = src->Wp_in; h->Wp_out = src->Wp_out; h->b_out = src->b_out; h->layers = src->layers;
     h->TE = src->TE; h->TE2 = src->TE2; h->rcos = src->rcos; h->rsin = src->rsin; h->cbase = src->cbase;
-    h->zero_bias = src->zero_bias; h->W_io = src->W_io; h->b_io = src->b_io;
+    h->zero_bias = src->zero_bias;
+    h->kset_req = src->kset_req;
     h->finalized = true;
     *out = h;
     return 0;
@@ -596,14 +534,6 @@ static int finalize_weights(dsg_handle* h) {
     CHK(launch_mm(h, h->cbase, D, R("input_process.poseEmbedding.bias"), 0, 1, W2 + D, W2ld, 1,
                   R("input_process2.bias"), nullptr, 0, 1, 1, D, D, 0));
     CHK(pack(h, &h->Wp_in, Wfold, J, D, J, D, h->Jp));
-    {   // embedded-space state: W_io[d][k] = sum_j Wfold[d][j] W_out[j][k],  b_io[d] = sum_j Wfold[d][j] b_out[j]
-        float* Wio = nullptr;
-        CHK(dalloc(h, &Wio, (size_t)D * D));
-        CHK(launch_mm(h, Wio, D, Wfold, J, 1, R("output_process.poseFinal.weight"), 1, D, nullptr, nullptr, 0, 1, D, D, J, 0));
-        CHK(pack(h, &h->W_io, Wio, D, D, D, D, D));
-        CHK(dalloc(h, &h->b_io, (size_t)D));
-        CHK(launch_mm(h, h->b_io, D, R("output_process.poseFinal.bias"), 0, 1, Wfold, J, 1, nullptr, nullptr, 0, 1, 1, D, J, 0));
-    }
     CHK(dalloc(h, &h->zero_bias, (size_t)std::max(D, h->Jp)));
     for (int i = 0; i < L; ++i) {
         const std::string p = "seqTransEncoder.layers." + std::to_string(i) + ".";
@@ -796,151 +726,145 @@ extern "C" int dsg_set_window_cond_cfg(dsg_handle* h, const float* style, const 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// one denoising step = 3 + 5*L dispatches (un-fused set) or 2 + 4*L (latency set, batch <= 2)
+// Kernel sets.  ONE function decides which kernels a step of B batch rows runs (select_kernels); nothing else in this file
+// looks at sizes.  A set is a property of the handle (dsg_set_kernel_set) or, with DSG_KSET_AUTO, a function of the batch
+// alone -- never of how many lanes happen to run together -- so the same (handle, batch, seed) gives the same bits whether
+// it is sampled by dsg_sample or as one lane of dsg_sample_multi.  What the sets are and the measurements behind the
+// automatic rule (MI355X, ZEGGS dims, bf16; profiles/r02_u_kernel_sets.log, r02_i_lanes.log, r02_c_blk_sweep.log):
+//
+//   set      kernels of one step                                                  dispatches   wins at
+//   LATENCY  k_inloc, L x {QKV 16x16, k_attn_mid | k_attn + k_mid, linear2}, head   2 + 3L      one lane, batch <= 2: 106.7 us vs
+//                                                                                               122.0 (no k_attn_mid) / 125.5 (TILE)
+//   TILE     k_in, k_loc, L x {QKV, k_attn_op | k_attn + out_proj, linear1,          3 + 4L      batch 3 .. 11 (182 vs 187 us at 3,
+//            linear2} on 16 x 16 tiles (LayerNorm GEMMs "lean" from 512 rows), head              195 vs 197 at 4, 227 vs 235 at 8)
+//   BLOCK    the same with 32-row block GEMMs for QKV / linear1 / linear2 / embedding 3 + 4L      >= 1000 rows in one lane (254 vs 293
+//            (dsg_batched.h); out_proj and the pose head stay on 16 x 16 tiles                    us at 16); from 300 rows per lane when
+//                                                                                               several lanes share the CUs (4 x 4:
+//                                                                                               4691 vs 4400 frames/s, 4 x 16: 8243 vs 6447)
+//   With several lanes sharing the GPU the redundant recompute of LATENCY costs from batch 2 (4 x 2: 3507 frames/s TILE vs
+//   3303 LATENCY): dsg_recommend_kernel_set(B, lanes) encodes the multi-lane column; the caller applies it to its lanes.
+//   k_attn_op (attention + out_proj + LayerNorm1 in one kernel) replaces k_attn + out_proj in TILE / BLOCK wherever an
+//   instantiation exists (bf16, 4 heads, ZEGGS / tiny dims): 1 x 16: 292 -> 254 us, 4 x 4: 4640 -> 5074 frames/s.  Within a set
+//   nothing depends on the batch but the grid (and the register budget of the LayerNorm GEMMs from 512 rows, same arithmetic):
+//   a row's result is bit-identical whatever the batch it rides in.
+// ---------------------------------------------------------------------------------------------------------
+struct KernelSel {
+    int set = DSG_KSET_TILE;
+    bool lat = false;           // LATENCY: fused first kernel (k_inloc) and k_mid / k_attn_mid
+    bool attn_in_mid = false;   // ... with the attention inside k_mid (batch 1)
+    bool blk = false;           // BLOCK: 32-row block GEMMs
+    bool attn_op = false;       // k_attn_op instead of k_attn + out_proj
+};
+static bool have_attn_mid(const dsg_handle* h, int B) {
+    return B == 1 && h->H == 4 && ((h->D == 256 && h->Tp == 96) || (h->D == 128 && h->Tp == 32));
+}
+static bool have_attn_op(const dsg_handle* h) {
+    // bf16 only: in fp32 W_o is 16 k-blocks x DT tiles per wave and does not fit the register file next to the attention
+    return h->prec == DSG_PREC_BF16 && h->H == 4 && ((h->D == 256 && h->Tp == 96) || (h->D == 128 && h->Tp == 32));
+}
+static bool latency_set_ok(const dsg_handle* h) {
+    // k_mid pulls all of W_o (2 D^2 bytes) through every CU: at D = 512 the un-fused sets win (TWH: 219 vs 238 us)
+    const int dt = h->D / 64;
+    return h->D <= 384 && (dt == 1 || dt == 2 || dt == 4 || dt == 6);
+}
+static int auto_kernel_set(const dsg_handle* h, int B, int lanes) {
+    const int rows = B * h->ntok;
+    if (lanes <= 1) {
+        if (B <= 2 && latency_set_ok(h)) return DSG_KSET_LATENCY;
+        return rows >= 1000 ? DSG_KSET_BLOCK : DSG_KSET_TILE;
+    }
+    if (B <= 1 && latency_set_ok(h)) return DSG_KSET_LATENCY;
+    return rows >= 300 ? DSG_KSET_BLOCK : DSG_KSET_TILE;
+}
+static int select_kernels(const dsg_handle* h, int B, KernelSel& k) {
+    int set = h->kset_req;
+    if (set == DSG_KSET_AUTO) {
+        set = auto_kernel_set(h, B, 1);
+        if (h->latency_mode == 0 && set == DSG_KSET_LATENCY) set = DSG_KSET_TILE;
+        if (h->latency_mode == 1) set = DSG_KSET_LATENCY;
+    }
+    if (set == DSG_KSET_LATENCY && h->D > 512) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set LATENCY: latent_dim > 512");
+    if (set < DSG_KSET_LATENCY || set > DSG_KSET_BLOCK) return fail(DSG_E_INVALID, "unknown kernel set");
+    k = KernelSel();
+    k.set = set;
+    k.lat = set == DSG_KSET_LATENCY;
+    k.attn_in_mid = k.lat && h->fuse_attn_mid && have_attn_mid(h, B);
+    k.blk = set == DSG_KSET_BLOCK;
+    k.attn_op = !k.lat && have_attn_op(h);
+    return 0;
+}
+
+extern "C" int dsg_set_kernel_set(dsg_handle* h, int set) {
+    if (!h) return fail(DSG_E_INVALID, "null handle");
+    if (set < DSG_KSET_AUTO || set > DSG_KSET_BLOCK) return fail(DSG_E_INVALID, "dsg_set_kernel_set: unknown kernel set");
+    if (set == DSG_KSET_LATENCY && h->D > 512) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set LATENCY: latent_dim > 512");
+    if (getenv("DSG_KSET")) return 0;          // an A/B run pinned the set for the whole process
+    h->kset_req = set;
+    return 0;
+}
+extern "C" int dsg_recommend_kernel_set(dsg_handle* h, int B, int lanes, int* set) {
+    if (!h || !set || B <= 0 || lanes <= 0) return fail(DSG_E_INVALID, "dsg_recommend_kernel_set: bad argument");
+    *set = auto_kernel_set(h, B, lanes);
+    return 0;
+}
+extern "C" int dsg_last_kernel_set(dsg_handle* h, int* set) {
+    if (!h || !set) return fail(DSG_E_INVALID, "null argument");
+    if (h->last_kset < 0) return fail(DSG_E_STATE, "no step has run");
+    *set = h->last_kset;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// one denoising step = 3 + 4*L dispatches (TILE / BLOCK with k_attn_op; 3 + 5*L without) or 2 + 3*L (LATENCY, batch 1)
 // ---------------------------------------------------------------------------------------------------------
 struct StepCtx {
     int B;                  // batch rows the kernels run on (with guidance: conditional elements + their twins)
     int out_mode; bool use_ctr; const float* ext_noise; int const_noise;
     int clip_x0 = 0;        // clip_denoised=True
-    bool emode = false;     // embedded-space state (dsg_fused.h): k_loc_e + k_enoise ... EPI_ESTEP instead of k_inloc ... EPI_OUT
-    bool only_head = false; // just the pose head on the final-layer rows already in place (the sample after an embedded-space loop)
+    KernelSel ks;           // what select_kernels chose for this call
 };
 
-// kernel -> its XCD-pinned twin (dsg_fused.h): only the batch-1 bf16 kernel set has one
-template <auto K> struct PinOf { static constexpr bool have = false; };
-#define DSG_PIN_PAIR(K, KX, ARGS)                                                                                       \
-    template <> struct PinOf<&K> {                                                                                      \
-        static constexpr bool have = true;                                                                              \
-        typedef PinTab<ARGS> Tab;                                                                                       \
-        static const void* fnx() { return (const void*)&KX; }                                                           \
-        static void launch(hipStream_t st, dim3 grid, dim3 block, const void* tab) {                                    \
-            hipLaunchKernelGGL((KX), grid, block, 0, st, *(const Tab*)tab);                                             \
-        }                                                                                                               \
-    }
-#define DSG_COMMA ,
-DSG_PIN_PAIR(k_gemm<PBF16 DSG_COMMA PRO_DIRECT DSG_COMMA EPI_QKV DSG_COMMA 4 DSG_COMMA 1 DSG_COMMA 1 DSG_COMMA 1>, k_gemm_x<PRO_DIRECT DSG_COMMA EPI_QKV DSG_COMMA 4 DSG_COMMA 1 DSG_COMMA 1>, GemmArgs);
-DSG_PIN_PAIR(k_gemm<PBF16 DSG_COMMA PRO_LN DSG_COMMA EPI_QKV DSG_COMMA 4 DSG_COMMA 1 DSG_COMMA 1 DSG_COMMA 1>, k_gemm_x<PRO_LN DSG_COMMA EPI_QKV DSG_COMMA 4 DSG_COMMA 1 DSG_COMMA 1>, GemmArgs);
-DSG_PIN_PAIR(k_gemm<PBF16 DSG_COMMA PRO_DIRECT DSG_COMMA EPI_RESID DSG_COMMA 1 DSG_COMMA 4 DSG_COMMA 1 DSG_COMMA 1>, k_gemm_x<PRO_DIRECT DSG_COMMA EPI_RESID DSG_COMMA 1 DSG_COMMA 4 DSG_COMMA 1>, GemmArgs);
-DSG_PIN_PAIR(k_gemm<PBF16 DSG_COMMA PRO_LN DSG_COMMA EPI_OUT DSG_COMMA 4 DSG_COMMA 1 DSG_COMMA 1 DSG_COMMA 1>, k_gemm_x<PRO_LN DSG_COMMA EPI_OUT DSG_COMMA 4 DSG_COMMA 1 DSG_COMMA 1>, GemmArgs);
-DSG_PIN_PAIR(k_inloc<PBF16 DSG_COMMA 32 DSG_COMMA 11>, k_inloc_x<32 DSG_COMMA 11>, InLocArgs);
-DSG_PIN_PAIR(k_inloc<PBF16 DSG_COMMA 16 DSG_COMMA 11>, k_inloc_x<16 DSG_COMMA 11>, InLocArgs);
-DSG_PIN_PAIR(k_attn_mid<PBF16 DSG_COMMA 4 DSG_COMMA 6>, k_attn_mid_x<4 DSG_COMMA 6>, AttnMidArgs);
-DSG_PIN_PAIR(k_attn_mid<PBF16 DSG_COMMA 2 DSG_COMMA 2>, k_attn_mid_x<2 DSG_COMMA 2>, AttnMidArgs);
-#undef DSG_COMMA
-
 // Every kernel of the denoising step goes through here: a HIP launch on the handle's stream, or -- while dsg_sample is
-// recording the step for the AQL path -- an entry of the packet plan (dsg_aql.h), or an entry of the pinned plan.
+// recording the step for the AQL path -- an entry of the packet plan (dsg_aql.h).
 template <auto K, class A>
 static int step_launch(dsg_handle* h, dim3 grid, dim3 block, const A& args) {
-    if (h->pin_rec) {
-        h->overlap_next = false;
-        if constexpr (PinOf<K>::have) {
-            PinLaunch l;
-            typedef typename PinOf<K>::Tab Tab;
-            static_assert(sizeof(Tab) <= 4096 && sizeof(((Tab*)nullptr)->a[0]) == sizeof(A), "pinned argument table");
-            l.fnx = PinOf<K>::fnx(); l.launch = &PinOf<K>::launch; l.grid = grid; l.block = block;
-            l.tab_size = sizeof(Tab); l.nl_off = offsetof(Tab, nl); l.err_off = offsetof(Tab, err);
-            l.args.assign((const char*)&args, (const char*)&args + sizeof(A));
-            h->pin_plan.push_back(std::move(l));
-        } else {
-            h->pin_unsupported = true;
-        }
-        return 0;
-    }
 #ifndef DSG_EMU
-    const bool overlap = h->overlap_next;
-    h->overlap_next = false;
     if (h->aql.recording) {
-        if (!dsg_aql::record(h->aql, (const void*)K, h->stream, grid, block, &args, sizeof(A), overlap))
+        if (!dsg_aql::record(h->aql, (const void*)K, h->stream, grid, block, &args, sizeof(A)))
             return fail(DSG_E_RUNTIME, "AQL plan: " + h->aql.err);
         return 0;
     }
-#else
-    h->overlap_next = false;
 #endif
     hipLaunchKernelGGL(K, grid, block, 0, h->stream, args);
     HIPCHK(hipGetLastError());
     return 0;
 }
 
-template <class P, int PRO, int EPI, int WN, int WK, int TNW, int TM = 1>
+template <class P, int PRO, int EPI, int WN, int WK>
 static int launch_gemm(dsg_handle* h, GemmArgs g) {
     if (g.KS == 1) g.kb_per_split = g.KBtot;
-    const int NG = g.NT / (WN * TNW);
-    if (NG * WN * TNW != g.NT) return fail(DSG_E_INVALID, "gemm: NT not divisible by the workgroup tile");
+    const int NG = g.NT / WN;
+    if (NG * WN != g.NT) return fail(DSG_E_INVALID, "gemm: NT not divisible by the workgroup tile");
     if (WK > 1 && (g.KS != 1 || g.KBtot % WK)) return fail(DSG_E_INVALID, "gemm: k-blocks not divisible by the wave split");
     if (g.KS < 1 || g.kb_per_split * g.KS < g.KBtot) return fail(DSG_E_INVALID, "gemm: split-K does not cover K");
     // EPI_PARTIAL / EPI_OUT carry one extra grid row whose first workgroup does the step bookkeeping
-    const int extra = (EPI == EPI_PARTIAL || EPI == EPI_OUT || EPI == EPI_ESTEP) ? 1 : 0;
+    const int extra = (EPI == EPI_PARTIAL || EPI == EPI_OUT) ? 1 : 0;
     g.inv_ntok = fastdiv_inv(g.ntok); g.inv_hd = fastdiv_inv(g.hd);
-    return step_launch<&k_gemm<P, PRO, EPI, WN, WK, TNW, TM>>(h, dim3(xcd_grid_x(NG), cdiv(g.MT, TM) + extra, g.KS), dim3(256), g);
+    return step_launch<&k_gemm<P, PRO, EPI, WN, WK, 1>>(h, dim3(xcd_grid_x(NG), g.MT + extra, g.KS), dim3(256), g);
 }
-
-// Workgroup width of the GEMMs: 4 waves x TNW 16-col tiles.  A wider workgroup normalises its 16 rows once for more
-// columns (the LayerNorm-on-read prologue is otherwise recomputed by every n-group) and there are fewer workgroups,
-// but each one pulls TNW times more weight bytes through ONE CU's load path.  Measured on MI355X (tools/b_sweep.sh,
-// tools/b16_sweep.sh, ZEGGS bf16): TNW 2 is within noise of TNW 1 at every batch size and TNW 4 is 40 % slower at
-// batch 16 (554 vs 398 us/step), so the narrow shape stays the default; DSG_GEMM_TNW overrides it for experiments.
-static int pick_tnw(const dsg_handle* h, int NT) {
-    int t = h->gemm_tnw > 0 ? h->gemm_tnw : 1;
-    while (t > 1 && NT % (4 * t)) t >>= 1;
-    return t > 2 ? 2 : t;
-}
-// Row tiles per workgroup (TM = 4, gemm_body_mt): measured slower than one tile per workgroup at every batch size (see the
-// comment there), so it is an experiment switch only (DSG_GEMM_TM=4; covered by the emulator parity tests).
-static int pick_tm(const dsg_handle* h, int M) {
-    (void)M;
-    return h->gemm_tm >= 4 ? 4 : 1;
-}
-// Batched path: 64-row block GEMMs (dsg_batched.h).  From 512 rows up (batch 6 at ZEGGS dims) unless DSG_GEMM_BLK overrides.
-static bool use_blk(const dsg_handle* h, int M, int which) {
-    // One lane: from ~1000 rows (batch 12 at ZEGGS dims) -- at 712 rows (batch 8) the 16 x 16 tile kernels still win (227 vs
-    // 235 us/step): a single chain is latency-bound and prefers many short workgroups.  Several lanes at once are
-    // throughput-bound (their kernels share the CUs), and the blocks' smaller footprint wins from ~300 rows per lane
-    // (4 lanes x batch 4: 4691 vs 4400 frames/s, x batch 8: 6835 vs 5722, x batch 16: 8243 vs 6447; profiles/r02_i_*)
-    if (!(h->gemm_blk_mask & which)) return false;
-    if (h->gemm_blk >= 0) return h->gemm_blk != 0;
-    return M >= (h->lanes_now > 1 ? 300 : 1000);
-}
-template <class P, int PRO, int EPI, int DMAX>
-static int launch_blk_d(dsg_handle* h, const GemmArgs& g, int tnw, int rt) {
-    const int extra = EPI == EPI_OUT ? 1 : 0;
-    const dim3 grid(xcd_grid_x(g.NT / (4 * tnw)), cdiv(g.MT, rt) + extra, 1);
-    if (rt == 2) {
-        if (tnw == 2) return step_launch<&k_gemm_blk<P, PRO, EPI, DMAX, 2, 2>>(h, grid, dim3(256), g);
-        return step_launch<&k_gemm_blk<P, PRO, EPI, DMAX, 1, 2>>(h, grid, dim3(256), g);
-    }
-    if (tnw == 2) return step_launch<&k_gemm_blk<P, PRO, EPI, DMAX, 2, 4>>(h, grid, dim3(256), g);
-    return step_launch<&k_gemm_blk<P, PRO, EPI, DMAX, 1, 4>>(h, grid, dim3(256), g);
-}
-// large batches: BM x 128 blocks (k_gemm_tp)
-// OFF unless DSG_GEMM_TP=1: measured SLOWER than the 32-row blocks at every size tried (batch 64: QKV 31.8 vs 23.9 us, linear1
-// 25.5 vs 23.0, pose head 70.7 vs 55.2; profiles/r02_k_b64_kernel_stats_tp.csv) -- see the note at k_gemm_tp
-static bool use_tp(const dsg_handle* h, int M) { (void)M; return h->gemm_tp > 0; }
-template <class P, int PRO, int EPI>
-static int launch_tp(dsg_handle* h, GemmArgs g) {
-    g.KS = 1; g.kb_per_split = g.KBtot;
-    g.inv_ntok = fastdiv_inv(g.ntok); g.inv_hd = fastdiv_inv(g.hd);
-    const int K = g.KBtot * P::KB;
-    constexpr int BM = sizeof(typename P::elem) == 2 ? 128 : 64;        // fp32 rows are twice as wide in LDS
-    const int extra = EPI == EPI_OUT ? 1 : 0;
-    const dim3 grid(xcd_grid_x(cdiv(g.NT, 8)), cdiv(g.MT * 16, BM) + extra, 1);
-    if (K <= 256) return step_launch<&k_gemm_tp<P, PRO, EPI, 256, BM>>(h, grid, dim3(256), g);
-    if (K > 512) return fail(DSG_E_NOT_IMPLEMENTED, "k_gemm_tp: K > 512");
-    return step_launch<&k_gemm_tp<P, PRO, EPI, 512, BM>>(h, grid, dim3(256), g);
-}
+// 32-row x 64-column blocks, K = D whole (dsg_batched.h).  Measured per GEMM in the real batch-16 step
+// (profiles/r02_c_blk_sweep.log): QKV -13 us, linear1 -7, embedding -9.5 per step; out_proj +4 and the pose head +3.5 (few,
+// long workgroups) stay on the 16 x 16 kernels.  Wider / taller blocks (128-column waves, 64 rows) lose (335 -> 380 / 364 us).
 template <class P, int PRO, int EPI>
 static int launch_blk(dsg_handle* h, GemmArgs g) {
     g.KS = 1; g.kb_per_split = g.KBtot;
     g.inv_ntok = fastdiv_inv(g.ntok); g.inv_hd = fastdiv_inv(g.hd);
     const int K = g.KBtot * P::KB;
-    int tnw = h->gemm_blk_tnw > 0 ? h->gemm_blk_tnw : 1;
-    if (g.NT % (4 * tnw)) tnw = 1;
     if (g.NT % 4) return fail(DSG_E_INVALID, "gemm: NT not divisible by the workgroup tile");
-    const int rt = h->gemm_blk_rt == 4 ? 4 : 2;
-    if (K <= 256) return launch_blk_d<P, PRO, EPI, 256>(h, g, tnw, rt);
+    const dim3 grid(xcd_grid_x(g.NT / 4), cdiv(g.MT, 2) + (EPI == EPI_OUT ? 1 : 0), 1);
+    if (K <= 256) return step_launch<&k_gemm_blk<P, PRO, EPI, 256, 1, 2>>(h, grid, dim3(256), g);
     if (K > 512) return fail(DSG_E_NOT_IMPLEMENTED, "k_gemm_blk: K > 512");
-    return launch_blk_d<P, PRO, EPI, 512>(h, g, tnw, rt);
+    return step_launch<&k_gemm_blk<P, PRO, EPI, 512, 1, 2>>(h, grid, dim3(256), g);
 }
 template <class P, int EPI>
 static int launch_blk_k(dsg_handle* h, GemmArgs g) {
@@ -955,37 +879,30 @@ static int launch_blk_k(dsg_handle* h, GemmArgs g) {
     return step_launch<&k_gemm_blk_k<P, EPI, 4>>(h, grid, dim3(256), g);
 }
 
+// a K = D GEMM of the un-fused sets: block kernel (BLOCK, the GEMMs it wins), else 16 x 16 tiles -- LayerNorm GEMMs from 512
+// rows in the 3-waves-per-SIMD form (k_gemm_lean; tools/b16_lean.sh: batch 8: 250 vs 267 us/step, batch 16: 360 vs 378)
 template <class P, int PRO, int EPI>
-static int launch_gemm_w(dsg_handle* h, const GemmArgs& g) {
+static int launch_gemm_w(dsg_handle* h, const GemmArgs& g, const KernelSel& ks) {
+    constexpr bool blk_wins = EPI == EPI_QKV || EPI == EPI_GELU;
     if constexpr (EPI != EPI_PARTIAL) {
-        constexpr int which = EPI == EPI_QKV ? 1 : (EPI == EPI_RESID ? 2 : (EPI == EPI_GELU ? 4 : 16));
-        if (use_tp(h, g.M) && g.KBtot * P::KB <= 512 && g.NT % 4 == 0 && (h->gemm_tp_mask & which)) return launch_tp<P, PRO, EPI>(h, g);
-        if (use_blk(h, g.M, which) && g.KBtot * P::KB <= 512) return launch_blk<P, PRO, EPI>(h, g);
+        if (ks.blk && blk_wins && g.KBtot * P::KB <= 512) return launch_blk<P, PRO, EPI>(h, g);
     }
-    const int tnw = pick_tnw(h, g.NT);
-    // the multi-tile shape holds the whole K range in one chunk of 8 k-blocks and stages TM x 16 LayerNorm rows in LDS
-    const bool mt_ok = g.KBtot <= 8 && g.KS == 1 && (PRO != PRO_LN || g.D <= (sizeof(typename P::elem) == 2 ? 512 : 256));
-    if constexpr (PRO == PRO_LN) {      // batched path: the high-occupancy variant (DSG_GEMM_LEAN=0/1 overrides the batch rule)
-        // measured (tools/b16_lean.sh, ZEGGS bf16, un-fused set): batch 8: 250 vs 267 us/step, batch 16: 360 vs 378; neutral at 3-4
-        const bool lean = h->gemm_lean >= 0 ? h->gemm_lean != 0 : g.M >= 512;
-        if (lean && tnw == 1 && pick_tm(h, g.M) == 1) {
+    if constexpr (PRO == PRO_LN) {
+        if (g.M >= 512) {
             GemmArgs gl = g;
             gl.KS = 1; gl.kb_per_split = gl.KBtot;
             gl.inv_ntok = fastdiv_inv(gl.ntok); gl.inv_hd = fastdiv_inv(gl.hd);
-            const int extra = EPI == EPI_OUT ? 1 : 0;
             if (gl.NT % 4) return fail(DSG_E_INVALID, "gemm: NT not divisible by the workgroup tile");
-            return step_launch<&k_gemm_lean<P, EPI>>(h, dim3(xcd_grid_x(gl.NT / 4), gl.MT + extra, 1), dim3(256), gl);
+            return step_launch<&k_gemm_lean<P, EPI>>(h, dim3(xcd_grid_x(gl.NT / 4), gl.MT + (EPI == EPI_OUT ? 1 : 0), 1), dim3(256), gl);
         }
     }
-    if (pick_tm(h, g.M) == 4 && mt_ok)
-        return tnw == 2 ? launch_gemm<P, PRO, EPI, 4, 1, 2, 4>(h, g) : launch_gemm<P, PRO, EPI, 4, 1, 1, 4>(h, g);
-    return tnw == 2 ? launch_gemm<P, PRO, EPI, 4, 1, 2, 1>(h, g) : launch_gemm<P, PRO, EPI, 4, 1, 1, 1>(h, g);
+    return launch_gemm<P, PRO, EPI, 4, 1>(h, g);
 }
 // linear2: K = ff split over the 4 waves of the workgroup
 template <class P>
-static int launch_gemm_k4(dsg_handle* h, const GemmArgs& g) {
-    if (use_blk(h, g.M, 8)) return launch_blk_k<P, EPI_RESID>(h, g);
-    return launch_gemm<P, PRO_DIRECT, EPI_RESID, 1, 4, 1, 1>(h, g);
+static int launch_gemm_k4(dsg_handle* h, const GemmArgs& g, const KernelSel& ks) {
+    if (ks.blk) return launch_blk_k<P, EPI_RESID>(h, g);
+    return launch_gemm<P, PRO_DIRECT, EPI_RESID, 1, 4>(h, g);
 }
 
 template <class P, int HD, int NKT>
@@ -1020,36 +937,15 @@ static int launch_attn(dsg_handle* h, const AttnArgs& a) {
                                                     std::to_string(h->hdl) + ", " + std::to_string(h->W) + ")");     \
     } while (0)
 
-template <class P, int HD, int NKT, int DD>
-static int launch_qkv_attn_t(dsg_handle* h, const QkvAttnArgs& a) {
-    const int nqt = cdiv(a.ntok, 16);
-    return step_launch<&k_qkv_attn<P, HD, NKT, DD>>(h, dim3(nqt, a.H, a.B), dim3(256), a);
-}
-// fused LayerNorm + in_proj + attention exists for the shapes whose token block fits in LDS
-static bool have_qkv_attn(const dsg_handle* h) {
-    return (h->hd == 64 && h->Tp == 96 && h->D == 256) || (h->hd == 32 && h->Tp == 32 && (h->D == 128 || h->D == 64));
-}
-template <class P>
-static int launch_qkv_attn(dsg_handle* h, const QkvAttnArgs& a) {
-    if (h->hd == 64 && h->Tp == 96 && h->D == 256) return launch_qkv_attn_t<P, 64, 6, 256>(h, a);
-    if (h->hd == 32 && h->Tp == 32 && h->D == 128) return launch_qkv_attn_t<P, 32, 2, 128>(h, a);
-    if (h->hd == 32 && h->Tp == 32 && h->D == 64) return launch_qkv_attn_t<P, 32, 2, 64>(h, a);
-    return fail(DSG_E_NOT_IMPLEMENTED, "no fused qkv+attention instantiation");
-}
-template <class P, int DT>
-static int launch_mid_t(dsg_handle* h, const MidArgs& a) {
-    const dim3 grid(xcd_grid_x(a.ff / 64), a.MT);
-    if (a.dep.ctr) return step_launch<&k_mid<P, DT, true>>(h, grid, dim3(256), a);       // overlapped launch (DSG_OVERLAP=1)
-    return step_launch<&k_mid<P, DT, false>>(h, grid, dim3(256), a);
-}
 template <class P>
 static int launch_mid(dsg_handle* h, const MidArgs& a) {
+    const dim3 grid(xcd_grid_x(a.ff / 64), a.MT);
     switch (h->D / 64) {
-        case 1: return launch_mid_t<P, 1>(h, a);
-        case 2: return launch_mid_t<P, 2>(h, a);
-        case 4: return launch_mid_t<P, 4>(h, a);
-        case 6: return launch_mid_t<P, 6>(h, a);
-        case 8: return launch_mid_t<P, 8>(h, a);
+        case 1: return step_launch<&k_mid<P, 1>>(h, grid, dim3(256), a);
+        case 2: return step_launch<&k_mid<P, 2>>(h, grid, dim3(256), a);
+        case 4: return step_launch<&k_mid<P, 4>>(h, grid, dim3(256), a);
+        case 6: return step_launch<&k_mid<P, 6>>(h, grid, dim3(256), a);
+        case 8: return step_launch<&k_mid<P, 8>>(h, grid, dim3(256), a);
         default: return fail(DSG_E_NOT_IMPLEMENTED, "k_mid: latent_dim / 64 must be 1, 2, 4, 6 or 8");
     }
 }
@@ -1058,23 +954,12 @@ static int launch_mid(dsg_handle* h, const MidArgs& a) {
 // K / V^T fragment loads queue on ONE CU's load path (38 loads in ~6100 cycles) instead of running on 24 otherwise idle
 // CUs, which costs what the saved launch gains.  With the AQL submission the balance tips (136.0 vs 140.8 us/step,
 // measured twice on the same box), so it is on by default; DSG_FUSE_ATTN_MID=0 selects the separate kernels.
-static bool have_attn_mid(const dsg_handle* h, int B) {
-    return B == 1 && h->H == 4 && ((h->D == 256 && h->Tp == 96) || (h->D == 128 && h->Tp == 32));
-}
 template <class P>
 static int launch_attn_mid(dsg_handle* h, const AttnMidArgs& a) {
     const dim3 grid(xcd_grid_x(a.mid.ff / 64), a.mid.MT);
     if (h->D == 256 && h->Tp == 96) return step_launch<&k_attn_mid<P, 4, 6>>(h, grid, dim3(256), a);
     if (h->D == 128 && h->Tp == 32) return step_launch<&k_attn_mid<P, 2, 2>>(h, grid, dim3(256), a);
     return fail(DSG_E_NOT_IMPLEMENTED, "no fused attention+mid instantiation");
-}
-static bool use_latency_mode(const dsg_handle* h, int B) {
-    if (h->latency_mode >= 0) return h->latency_mode != 0;
-    if (h->D > 384) return false;   // k_mid pulls all of W_o (2 D^2 bytes) through every CU: at D = 512 the un-fused set wins (TWH: 219 vs 238 us)
-    // redundant recompute pays only while every launch is a latency chain (tools/b_sweep.sh: batch 3+ is as fast or faster with
-    // the un-fused set: 182 vs 187 us at batch 3, 195 vs 197 at batch 4); several lanes share the CUs, so there the redundancy
-    // costs from batch 2 (4 lanes x 2: 3507 frames/s un-fused + k_attn_op against 3303 fused, profiles/r02_u_kernel_sets.log)
-    return h->lanes_now > 1 ? B <= 1 : B <= 2;
 }
 
 static StepTables step_tables(const dsg_handle* h) {
@@ -1089,31 +974,23 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
     const int Min = B * T, M = B * ntok;
     const int MTin = cdiv(Min, 16), MT = cdiv(M, 16);
     const int KB = P::KB;
+    const KernelSel& ks = c.ks;
     GemmArgs z;
     memset(&z, 0, sizeof(z));
     z.KS = 1; z.kb_per_split = 0; z.B = B; z.ntok = ntok; z.Tp = h->Tp; z.H = h->H; z.hd = h->hd; z.T = T; z.J = h->J; z.Jp = h->Jp;
     z.Jq = h->Jq; z.D = D;
 
-    const bool lat = use_latency_mode(h, B);
     LocArgs la;
     memset(&la, 0, sizeof(la));
     // split-K of the pose-embedding GEMM across workgroups: one split per 256 pose features for the 16 x 16 tile kernel; the
     // block kernel splits K over its 4 waves already, so 2 workgroup splits keep a wave's share at <= 8 k-blocks (one batch of
-    // loads) without fragmenting the work 5 ways (DSG_KIN_KS overrides)
-    const int ks_in = use_blk(h, Min, 32) ? std::min(h->KSin, h->kin_ks > 0 ? h->kin_ks : 2) : h->KSin;
+    // loads) without fragmenting the work 5 ways
+    const int ks_in = ks.blk ? std::min(h->KSin, 2) : h->KSin;
     la.partial = h->partial; la.KS = ks_in; la.Min_pad = MTin * 16; la.Cf = h->Cf; la.TE2 = h->TE2; la.TE = h->TE;
     la.emb1 = h->emb1; la.ctl = c.use_ctr ? h->ctl : nullptr; la.t_arr = h->t_arr;
     la.rcos = h->rcos; la.rsin = h->rsin; la.mask = h->mask; la.mb = h->mb; la.inv_mask_div = fastdiv_inv((int)((long long)B * h->Hl / h->mb)); la.B = B; la.T = T; la.D = D; la.Hl = h->Hl;
     la.hd = h->hdl; la.W = h->W; la.X0 = h->X0; la.X0a = h->X0a; la.nomask = h->nomask;
-    // drop-one timing experiments: 1 in/loc, 2 QKV, 4 attention, 8 mid, 16 linear2, 32 head
-    const int skip = c.only_head ? (1 | 2 | 4 | 8 | 16) : h->dbg_skip;
-    if (skip & 1) {
-    } else if (c.emode) {      // embedded-space state: local attention straight from E(x_t); E(z) beside it
-        LocEArgs a;
-        a.loc = la; a.loc.partial = h->epose; a.loc.KS = 1; a.loc.Min_pad = 0;
-        a.ctl_upd = h->ctl; a.st = step_tables(h); a.n_tab = h->n_run;
-        DSG_LOC_DISPATCH(k_loc_e, a, dim3(h->Hl, T / h->W, B + 1));
-    } else if (lat) {          // pose embedding + local attention in one launch
+    if (ks.lat) {              // pose embedding + local attention in one launch
         InLocArgs a;
         a.xs = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; a.Jp = h->Jp; a.Wp = h->Wp_in; a.KBtot = h->Jp / KB;
         a.loc = la; a.ctl_upd = c.use_ctr ? h->ctl : nullptr; a.st = step_tables(h); a.n_tab = h->n_run;
@@ -1126,82 +1003,48 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
             g.A = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; g.lda = h->Jp;
             g.out = h->partial; g.ldo = D;
             g.ctl = c.use_ctr ? h->ctl : nullptr; g.st = step_tables(h); g.n_tab = h->n_run;
-            if (use_blk(h, g.M, 32)) CHK((launch_blk_k<P, EPI_PARTIAL>(h, g)));
-            else CHK((launch_gemm<P, PRO_DIRECT, EPI_PARTIAL, 4, 1, 1>(h, g)));
+            if (ks.blk) CHK((launch_blk_k<P, EPI_PARTIAL>(h, g)));
+            else CHK((launch_gemm<P, PRO_DIRECT, EPI_PARTIAL, 4, 1>(h, g)));
         }
         DSG_LOC_DISPATCH(k_loc, la, dim3(h->Hl, T / h->W, B));
     }
-    // k_qkv_attn is correct but, measured on MI355X (profiles/r01_c_*), its 192 KB per workgroup and 6x redundant K/V
-    // GEMM make it slower (15 us) than LN+QKV followed by k_attn (6.2 + 4.6 us): opt-in only (DSG_FUSE_ATTN=1)
-    const bool fuse_attn = lat && have_qkv_attn(h) && h->fuse_attn;
-    const bool attn_in_mid = lat && !fuse_attn && h->fuse_attn_mid && have_attn_mid(h, B);
-    // batched kernel set: attention fused with out_proj + LayerNorm1 (k_attn_op) where an instantiation exists
-    // (bf16 only: in fp32 W_o is 16 k-blocks x DT tiles per wave and does not fit the register file next to the attention)
-    const bool attn_op = sizeof(typename P::elem) == 2 && !lat && !fuse_attn && h->attn_op != 0 && h->H == 4 && ((D == 256 && h->Tp == 96) || (D == 128 && h->Tp == 32)) &&
-                         (h->attn_op > 0 || M >= (h->lanes_now > 1 ? 170 : 256));
-    // (attention -> k_mid) as an overlapped pair: k_mid's packet carries no barrier bit, it requests W_o / W_1 / operands
-    // while the attention kernel still runs and synchronises with it in-kernel (DepWait).  Correct (bit-identical, tested)
-    // but measured SLOWER on MI355X: 158 vs 144 us/step -- the agent-scope (L2-bypassing) stores / loads of the handed-off
-    // rows and the counter round trip cost more than the command processor's barrier + fence (1.5 us) they replace; with
-    // __threadfence() instead it was 190 us (each fence writes back and invalidates the XCD's L2).  Opt-in (DSG_OVERLAP=1),
-    // sampling loop and latency kernel set only
-    const bool overlap_mid = lat && !fuse_attn && !attn_in_mid && c.use_ctr && h->overlap && !(skip & (4 | 8));
     for (int l = 0; l < h->L; ++l) {
-        const Layer& ly = h->layers[(skip & 64) ? 0 : l];      // 64: every layer reads layer 0's weights (L2 residency experiment)
-        if (fuse_attn) {   // [LayerNorm2] + in_proj + attention per (batch, head, query tile)
-            if (!(skip & 2)) {
-                QkvAttnArgs a;
-                memset(&a, 0, sizeof(a));
-                if (l == 0) a.Xa = h->X0a;
-                else { a.X = h->pre2; a.ln_g = h->layers[l - 1].g2; a.ln_b = h->layers[l - 1].be2; a.Xn = h->Xn; }
-                a.Wp = ly.Wqkv; a.bias = ly.bqkv; a.out = h->attn; a.B = B; a.H = h->H; a.ntok = ntok;
-                CHK(launch_qkv_attn<P>(h, a));
-            }
-        } else {
-            if (!(skip & 2)) {   // QKV projection (LayerNorm2 of the previous layer applied on read)
-                GemmArgs g = z;
-                g.M = M; g.MT = MT; g.NT = 3 * D / 16; g.KBtot = D / KB; g.Wp = ly.Wqkv; g.bias = ly.bqkv;
-                g.q = h->q; g.k = h->k; g.vt = h->vt;
-                if (l == 0) {
-                    g.A = h->X0a; g.lda = D;
-                    CHK((launch_gemm_w<P, PRO_DIRECT, EPI_QKV>(h, g)));
-                } else {
-                    g.X = h->pre2; g.ln_g = h->layers[l - 1].g2; g.ln_b = h->layers[l - 1].be2; g.Xn = h->Xn;
-                    CHK((launch_gemm_w<P, PRO_LN, EPI_QKV>(h, g)));
-                }
-            }
-            if (!(skip & 4) && !attn_in_mid && !attn_op) {   // attention
-                AttnArgs a;
-                memset(&a, 0, sizeof(a));
-                if (overlap_mid) a.done_ctr = h->dep_ctr + 0;
-                a.q = h->q; a.k = h->k; a.vt = h->vt; a.out = h->attn; a.B = B; a.H = h->H; a.ntok = ntok; a.Tp = h->Tp;
-                a.D = D;
-                CHK(launch_attn<P>(h, a));
+        const Layer& ly = h->layers[l];
+        {   // QKV projection (LayerNorm2 of the previous layer applied on read)
+            GemmArgs g = z;
+            g.M = M; g.MT = MT; g.NT = 3 * D / 16; g.KBtot = D / KB; g.Wp = ly.Wqkv; g.bias = ly.bqkv;
+            g.q = h->q; g.k = h->k; g.vt = h->vt;
+            if (l == 0) {
+                g.A = h->X0a; g.lda = D;
+                CHK((launch_gemm_w<P, PRO_DIRECT, EPI_QKV>(h, g, ks)));
+            } else {
+                g.X = h->pre2; g.ln_g = h->layers[l - 1].g2; g.ln_b = h->layers[l - 1].be2; g.Xn = h->Xn;
+                CHK((launch_gemm_w<P, PRO_LN, EPI_QKV>(h, g, ks)));
             }
         }
-        if (skip & 8) {
-        } else if (lat) {      // [attention +] out_proj + residual + LayerNorm1 + linear1 slice + GELU
+        if (!ks.attn_in_mid && !ks.attn_op) {   // attention
+            AttnArgs a;
+            memset(&a, 0, sizeof(a));
+            a.q = h->q; a.k = h->k; a.vt = h->vt; a.out = h->attn; a.B = B; a.H = h->H; a.ntok = ntok; a.Tp = h->Tp;
+            a.D = D;
+            CHK(launch_attn<P>(h, a));
+        }
+        if (ks.lat) {      // [attention +] out_proj + residual + LayerNorm1 + linear1 slice + GELU
             MidArgs a;
             memset(&a, 0, sizeof(a));
-            if (overlap_mid) {      // launched without a barrier: W_o / operands stream in while the attention kernel runs
-                a.dep.ctr = h->dep_ctr + 0; a.dep.epoch = &h->ctl->stepB; a.dep.per_step = h->L; a.dep.seq = l + 1;
-                a.dep.n_prod = (unsigned)(cdiv(ntok, 16) * h->H * B);
-                a.dep.err = h->dep_ctr + 63;
-                h->overlap_next = true;
-            }
             a.A = h->attn; a.R = l == 0 ? h->X0 : h->Xn; a.Wo = ly.Wo; a.bo = ly.bo; a.ln_g = ly.g1; a.ln_b = ly.be1;
             a.W1 = ly.W1; a.b1 = ly.b1; a.X1 = h->X1; a.hidden = h->hidden; a.M = M; a.MT = MT; a.ff = h->ff;
-            if (attn_in_mid) {
+            if (ks.attn_in_mid) {
                 AttnMidArgs am;
                 am.mid = a; am.q = h->q; am.k = h->k; am.vt = h->vt; am.ntok = ntok; am.Tp = h->Tp;
                 CHK(launch_attn_mid<P>(h, am));
             } else {
                 CHK(launch_mid<P>(h, a));
             }
-        } else if (attn_op) {
+        } else if (ks.attn_op) {
             // attention + out_proj + residual + LayerNorm1 in one kernel per (query tile, batch element); linear1 reads the
             // normalised rows in the GEMM type
-            if (!(skip & 4)) {
+            {
                 AttnOpArgs a;
                 a.q = h->q; a.k = h->k; a.vt = h->vt; a.R = l == 0 ? h->X0 : h->Xn; a.Wo = ly.Wo; a.bo = ly.bo; a.ln_g = ly.g1; a.ln_b = ly.be1;
                 a.X1 = h->X1; a.X1a = h->X1a; a.B = B; a.ntok = ntok; a.Tp = h->Tp;
@@ -1215,55 +1058,30 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                 GemmArgs g = z;
                 g.M = M; g.MT = MT; g.NT = h->ff / 16; g.KBtot = D / KB; g.Wp = ly.W1; g.bias = ly.b1;
                 g.A = h->X1a; g.lda = D; g.a_frag = 1; g.out = h->hidden; g.ldo = h->ff; g.out_frag = 1;
-                CHK((launch_gemm_w<P, PRO_DIRECT, EPI_GELU>(h, g)));
+                CHK((launch_gemm_w<P, PRO_DIRECT, EPI_GELU>(h, g, ks)));
             }
         } else {
             {   // out_proj + residual -> pre1
                 GemmArgs g = z;
                 g.M = M; g.MT = MT; g.NT = D / 16; g.KBtot = D / KB; g.Wp = ly.Wo; g.bias = ly.bo;
                 g.A = h->attn; g.lda = D; g.a_frag = 1; g.out = h->pre1; g.ldo = D; g.R = l == 0 ? h->X0 : h->Xn;
-                CHK((launch_gemm_w<P, PRO_DIRECT, EPI_RESID>(h, g)));
+                CHK((launch_gemm_w<P, PRO_DIRECT, EPI_RESID>(h, g, ks)));
             }
             {   // LayerNorm1-on-read + linear1 + GELU -> hidden ; X1 = LN1(pre1)
                 GemmArgs g = z;
                 g.M = M; g.MT = MT; g.NT = h->ff / 16; g.KBtot = D / KB; g.Wp = ly.W1; g.bias = ly.b1;
                 g.X = h->pre1; g.ln_g = ly.g1; g.ln_b = ly.be1; g.Xn = h->X1; g.out = h->hidden; g.ldo = h->ff; g.out_frag = 1;
-                CHK((launch_gemm_w<P, PRO_LN, EPI_GELU>(h, g)));
+                CHK((launch_gemm_w<P, PRO_LN, EPI_GELU>(h, g, ks)));
             }
         }
-        if (c.emode && l == 0 && !c.only_head && h->ecarry != 2) {       // (DSG_ECARRY=2: timing experiment without the noise embedding)
-            // E(z) of this step (k_enoise): depends on nothing of the step and is needed only by its last kernel, so its AQL
-            // packet carries no barrier bit and sits behind the longest kernel of the step -- it runs on the CUs the layer-0
-            // attention / mid kernel leaves idle and is done before that kernel is (placed behind the step's FIRST kernel it
-            // delayed the QKV projection: 117.0 vs 116.2 us/step, profiles/r02_d_*)
-            ENoiseArgs e;
-            e.Wp = h->Wp_in; e.KBtot = h->Jp / KB; e.KS = h->ez_ks; e.kb_per_split = cdiv(e.KBtot, e.KS);
-            e.ez = h->ez; e.ez_rows = h->ez_rows; e.ctl = h->ctl; e.dyn = h->dyn; e.B = B; e.T = T; e.J = h->J; e.Jq = h->Jq; e.D = D;
-            h->overlap_next = true;
-            const dim3 eg(e.KS, MTin, 1);
-            switch (D / 64) {
-                case 1: CHK((step_launch<&k_enoise<P, 1>>(h, eg, dim3(256), e))); break;
-                case 2: CHK((step_launch<&k_enoise<P, 2>>(h, eg, dim3(256), e))); break;
-                case 4: CHK((step_launch<&k_enoise<P, 4>>(h, eg, dim3(256), e))); break;
-                case 6: CHK((step_launch<&k_enoise<P, 6>>(h, eg, dim3(256), e))); break;
-                default: return fail(DSG_E_NOT_IMPLEMENTED, "embedded-space state: latent_dim / 64 must be 1, 2, 4 or 6");
-            }
-        }
-        if (!(skip & 16)) {   // linear2 + residual -> pre2   (K = ff split over the 4 waves of the workgroup)
+        {   // linear2 + residual -> pre2   (K = ff split over the 4 waves of the workgroup)
             GemmArgs g = z;
             g.M = M; g.MT = MT; g.NT = D / 16; g.KBtot = h->ff / KB; g.Wp = ly.W2; g.bias = ly.b2;
             g.A = h->hidden; g.lda = h->ff; g.a_frag = 1; g.out = h->pre2; g.ldo = D; g.R = h->X1;
-            CHK(launch_gemm_k4<P>(h, g));
+            CHK(launch_gemm_k4<P>(h, g, ks));
         }
     }
-    if (!(skip & 32) && c.emode) {   // final LayerNorm-on-read + W_io + sampler update in embedded space
-        GemmArgs g = z;
-        g.M = M; g.MT = MT; g.NT = D / 16; g.KBtot = D / KB; g.Wp = h->W_io; g.bias = h->b_io;
-        g.X = h->pre2; g.ln_g = h->layers[h->L - 1].g2; g.ln_b = h->layers[h->L - 1].be2; g.Xn = nullptr;
-        g.ctl = h->ctl; g.st = step_tables(h); g.n_tab = h->n_run;
-        g.epose = h->epose; g.ez = h->ez; g.ez_ks = h->ez_ks; g.ez_rows = h->ez_rows;
-        CHK((launch_gemm<P, PRO_LN, EPI_ESTEP, 4, 1, 1>(h, g)));
-    } else if (!(skip & 32)) {   // final LayerNorm-on-read + pose head + sampler update
+    {   // final LayerNorm-on-read + pose head + sampler update
         GemmArgs g = z;
         g.M = M; g.MT = MT; g.NT = h->Jp / 16; g.KBtot = D / KB; g.Wp = h->Wp_out; g.bias = h->b_out;
         g.X = h->pre2; g.ln_g = h->layers[h->L - 1].g2; g.ln_b = h->layers[h->L - 1].be2; g.Xn = nullptr;
@@ -1277,15 +1095,16 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
             if (g.NT % 4) return fail(DSG_E_INVALID, "gemm: NT not divisible by the workgroup tile");
             CHK((step_launch<&k_gemm_cfg<P>>(h, dim3(xcd_grid_x(g.NT / 4), g.MT + 1, 1), dim3(256), g)));
         } else {
-            CHK((launch_gemm_w<P, PRO_LN, EPI_OUT>(h, g)));
+            CHK((launch_gemm_w<P, PRO_LN, EPI_OUT>(h, g, ks)));
         }
     }
+    h->last_kset = ks.set;
     return 0;
 }
 // ---- diagnostics: time a chain of ONE phase kernel (graph replay) to separate launch floor, kernel body and
 //      weight coldness.  which: 0 null, 1 out_proj GEMM of layer 0 (same weights every launch), 2 out_proj cycling
 //      over the layers, 3 LN+linear1+GELU cycling, 4 linear2 cycling, 5 k_attn, 6 k_loc, 7 k_in, 8 pose head (forward),
-//      9 LN+QKV cycling, 10 k_mid cycling, 11 k_qkv_attn cycling, 12 k_inloc
+//      9 LN+QKV cycling, 10 k_mid cycling, 12 k_inloc
 template <class P>
 static int debug_launch(dsg_handle* h, int which, int i, int B) {
     const int D = h->D, T = h->T, ntok = h->ntok, M = B * ntok, MT = cdiv(M, 16), Min = B * T, MTin = cdiv(Min, 16);
@@ -1309,15 +1128,15 @@ static int debug_launch(dsg_handle* h, int which, int i, int B) {
         case 1: case 2: {
             GemmArgs g = z; g.M = M; g.MT = MT; g.NT = D / 16; g.KBtot = D / KB; g.Wp = ly.Wo; g.bias = ly.bo;
             g.A = h->attn; g.lda = D; g.a_frag = 1; g.out = (i & 1) ? h->pre1 : h->pre2; g.ldo = D; g.R = h->X0;
-            return launch_gemm<P, PRO_DIRECT, EPI_RESID, 4, 1, 1>(h, g); }
+            return launch_gemm<P, PRO_DIRECT, EPI_RESID, 4, 1>(h, g); }
         case 3: {
             GemmArgs g = z; g.M = M; g.MT = MT; g.NT = h->ff / 16; g.KBtot = D / KB; g.Wp = ly.W1; g.bias = ly.b1;
             g.X = h->pre1; g.ln_g = ly.g1; g.ln_b = ly.be1; g.Xn = h->X1; g.out = h->hidden; g.ldo = h->ff; g.out_frag = 1;
-            return launch_gemm<P, PRO_LN, EPI_GELU, 4, 1, 1>(h, g); }
+            return launch_gemm<P, PRO_LN, EPI_GELU, 4, 1>(h, g); }
         case 4: {
             GemmArgs g = z; g.M = M; g.MT = MT; g.NT = D / 16; g.KBtot = h->ff / KB; g.Wp = ly.W2; g.bias = ly.b2;
             g.A = h->hidden; g.lda = h->ff; g.a_frag = 1; g.out = h->pre2; g.ldo = D; g.R = h->X1;
-            return launch_gemm<P, PRO_DIRECT, EPI_RESID, 1, 4, 1>(h, g); }
+            return launch_gemm<P, PRO_DIRECT, EPI_RESID, 1, 4>(h, g); }
         case 5: {
             AttnArgs a; memset(&a, 0, sizeof(a)); a.q = h->q; a.k = h->k; a.vt = h->vt; a.out = h->attn; a.B = B; a.H = h->H; a.ntok = ntok;
             a.Tp = h->Tp; a.D = D; return launch_attn<P>(h, a); }
@@ -1325,25 +1144,20 @@ static int debug_launch(dsg_handle* h, int which, int i, int B) {
         case 7: {
             GemmArgs g = z; g.M = Min; g.MT = MTin; g.NT = D / 16; g.KBtot = h->Jp / KB; g.KS = h->KSin; g.Wp = h->Wp_in;
             g.kb_per_split = cdiv(g.KBtot, g.KS); g.A = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; g.lda = h->Jp;
-            g.out = h->partial; g.ldo = D; return launch_gemm<P, PRO_DIRECT, EPI_PARTIAL, 4, 1, 1>(h, g); }
+            g.out = h->partial; g.ldo = D; return launch_gemm<P, PRO_DIRECT, EPI_PARTIAL, 4, 1>(h, g); }
         case 8: {
             GemmArgs g = z; g.M = M; g.MT = MT; g.NT = h->Jp / 16; g.KBtot = D / KB; g.Wp = h->Wp_out; g.bias = h->b_out;
             g.X = h->pre2; g.ln_g = ly.g2; g.ln_b = ly.be2; g.out_mode = OUT_FORWARD; g.xs32 = h->xs32; g.fwd_out = h->fwd_out;
             g.ctl = nullptr; g.st = step_tables(h); g.n_tab = 1; g.dyn = h->dyn;
-            return launch_gemm<P, PRO_LN, EPI_OUT, 4, 1, 1>(h, g); }
+            return launch_gemm<P, PRO_LN, EPI_OUT, 4, 1>(h, g); }
         case 9: {
             GemmArgs g = z; g.M = M; g.MT = MT; g.NT = 3 * D / 16; g.KBtot = D / KB; g.Wp = ly.Wqkv; g.bias = ly.bqkv;
             g.q = h->q; g.k = h->k; g.vt = h->vt; g.X = h->pre2; g.ln_g = ly.g2; g.ln_b = ly.be2; g.Xn = h->Xn;
-            return launch_gemm<P, PRO_LN, EPI_QKV, 4, 1, 1>(h, g); }
+            return launch_gemm<P, PRO_LN, EPI_QKV, 4, 1>(h, g); }
         case 10: {
             MidArgs a; memset(&a, 0, sizeof(a)); a.A = h->attn; a.R = h->Xn; a.Wo = ly.Wo; a.bo = ly.bo; a.ln_g = ly.g1; a.ln_b = ly.be1;
             a.W1 = ly.W1; a.b1 = ly.b1; a.X1 = h->X1; a.hidden = h->hidden; a.M = M; a.MT = MT; a.ff = h->ff;
             return launch_mid<P>(h, a); }
-        case 11: {
-            if (!have_qkv_attn(h)) return fail(DSG_E_NOT_IMPLEMENTED, "no fused attention for these dims");
-            QkvAttnArgs a; memset(&a, 0, sizeof(a));
-            a.X = h->pre2; a.ln_g = ly.g2; a.ln_b = ly.be2; a.Xn = h->Xn; a.Wp = ly.Wqkv; a.bias = ly.bqkv; a.out = h->attn;
-            a.B = B; a.H = h->H; a.ntok = ntok; return launch_qkv_attn<P>(h, a); }
         case 12: {
             InLocArgs a; a.xs = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; a.Jp = h->Jp; a.Wp = h->Wp_in;
             a.KBtot = h->Jp / KB; a.loc = la; a.ctl_upd = nullptr; a.st = step_tables(h); a.n_tab = 1;
@@ -1503,6 +1317,7 @@ extern "C" int dsg_forward(dsg_handle* h, const float* x, const int64_t* t, floa
     NoiseKey nk = {0, 0, 0, 0};
     CHK(launch_x_in(h, xd, nullptr, 0, 0.f, 0.f, 0, nk, 0, B));
     StepCtx c; c.B = rows; c.out_mode = OUT_FORWARD; c.use_ctr = false; c.ext_noise = nullptr; c.const_noise = 0;
+    CHK(select_kernels(h, rows, c.ks));
     CHK(run_step_p(h, c));
     CHK(from_dev(h, out, h->fwd_out, n));
     CHK(order_before(h, stream));
@@ -1510,13 +1325,13 @@ extern "C" int dsg_forward(dsg_handle* h, const float* x, const int64_t* t, floa
 }
 
 // per-step coefficient tables in execution order (gaussian_diffusion.py:1617 `.float()` of the float64 tables)
-static int build_step_tables(dsg_handle* h, int mode, int skip, float eta, bool emode, int* n_run_out) {
+static int build_step_tables(dsg_handle* h, int mode, int skip, float eta, int* n_run_out) {
     const Sched& s = h->sched;
     if (s.n == 0) return fail(DSG_E_STATE, "dsg_sample before dsg_set_schedule");
     if (skip < 0 || skip >= s.n) return fail(DSG_E_INVALID, "skip_timesteps out of range");
     const int n_run = s.n - skip;
     // every window of a clip asks for the same tables: they stay on the device until schedule / mode / skip / eta change
-    if (h->st_valid && h->st_mode == mode && h->st_skip == skip && h->st_eta == eta && h->st_emode == emode) {
+    if (h->st_valid && h->st_mode == mode && h->st_skip == skip && h->st_eta == eta) {
         *n_run_out = n_run; h->n_run = n_run;
         return 0;
     }
@@ -1541,57 +1356,84 @@ static int build_step_tables(dsg_handle* h, int mode, int skip, float eta, bool 
             c[4][i] = nz * sigma;
         }
     }
-    if (emode) {      // x_{t-1} = a x0 + b x_t + c z, the three coefficients of the embedded-space update (EPI_ESTEP)
-        if (mode == DSG_MODE_DDIM) {
-            // x0 sqrt(abar_prev) + dir (sqrt_recip x_t - x0) / sqrt_recipm1 + nz sigma z   (gaussian_diffusion.py:773-791)
-            for (int i = 0; i < n_run; ++i) {
-                const float k1 = c[0][i], k2 = c[1][i], k3 = c[2][i], k4 = c[3][i], k5 = c[4][i];
-                c[0][i] = k3 - k4 / k2; c[1][i] = k4 * k1 / k2; c[2][i] = k5; c[3][i] = 0.f; c[4][i] = 0.f;
-            }
-        }
-    }
     HIPCHK(hipMemcpyAsync(h->st_tmodel, tm.data(), n_run * sizeof(int), hipMemcpyHostToDevice, h->stream));
     for (int k = 0; k < 5; ++k)
         HIPCHK(hipMemcpyAsync(h->st_c[k], c[k].data(), n_run * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     *n_run_out = n_run;
     h->n_run = n_run;
-    h->st_valid = true; h->st_mode = mode; h->st_skip = skip; h->st_eta = eta; h->st_emode = emode;
+    h->st_valid = true; h->st_mode = mode; h->st_skip = skip; h->st_eta = eta;
     return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// dsg_sample = prepare (x_T, step tables, control block, [AQL packet plan]) -> step loop -> finish (x_0 out, error word).
-// dsg_sample_multi runs the step loops of several handles ("lanes": one clip each, own HSA queue, shared weights)
-// concurrently from one host thread.
+// dsg_sample = prepare (x_T, step tables, control block, [AQL packet plan]) -> step loop -> finish (x_0 out).
+// dsg_sample_multi runs the step loops of several handles ("lanes": own HSA queue each, shared weights) concurrently from one
+// host thread.
 // ---------------------------------------------------------------------------------------------------------
 struct SampleJob {
     StepCtx c;
     int n_run = 0, B = 0, done = 0;
-    bool dumping = false, aql = false, pin = false;
+    bool dumping = false, aql = false;
     int spg = -1;
 };
 
-static bool g_pin_broken = false;      // the XCD placement check failed once in this process: pinned lanes stay off
+#ifndef DSG_EMU
+// One-time check of the premise of the fence-free loop on the device it is about to run on (advisor, round 2): a hand-off
+// through uncached memory between two dependent AQL packets WITHOUT acquire / release must never be stale, whichever XCDs
+// the writer and the reader run on.  64 x {k_uc_probe_w, k_uc_probe_r} on the handle's own queue, the same protocol as the
+// step loop (device-resident iteration word, read with vector loads, advanced by an extra workgroup of the other kernel).
+// A mismatch (another ASIC / ROCm version mapping hipDeviceMallocUncached differently) turns fence-free submission off for
+// the process, with a warning; dsg_last_sample_fence_free then reports 0.
+static int g_uc_checked[64] = {0};      // per device: 0 not yet, 1 ok, 2 broken
+static bool uc_selfcheck(dsg_handle* h) {
+    const int dev = h->cfg.device & 63;
+    if (g_uc_checked[dev]) return g_uc_checked[dev] == 1;
+    const int n_wg = 256, iters = 64;
+    unsigned* buf = nullptr;
+    if (hipExtMallocWithFlags((void**)&buf, (size_t)(n_wg * 256 + 64) * sizeof(unsigned), hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        g_uc_checked[dev] = 2;
+        return false;
+    }
+    bool ok = hipMemset(buf, 0, (size_t)(n_wg * 256 + 64) * sizeof(unsigned)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    UcProbeArgs a;
+    a.buf = buf; a.ctl = (int*)(buf + n_wg * 256); a.err = buf + n_wg * 256 + 16; a.n_wg = n_wg;
+    if (ok) {
+        dsg_aql::begin(h->aql);
+        ok = dsg_aql::record(h->aql, (const void*)&k_uc_probe_w, h->stream, dim3(n_wg + 1), dim3(256), &a, sizeof a) &&
+             dsg_aql::record(h->aql, (const void*)&k_uc_probe_r, h->stream, dim3(n_wg + 1), dim3(256), &a, sizeof a);
+        ok = dsg_aql::finish(h->aql) && ok;
+        h->aql.nofence = true;
+        ok = ok && dsg_aql::run(h->aql, iters, 10.0);
+        h->aql.nofence = false;
+    }
+    unsigned res[2] = {1u, 0u};
+    if (ok) ok = hipMemcpy(res, a.err, sizeof res, hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(buf);
+    const bool good = ok && res[0] == 0u && res[1] == (unsigned)iters;      // no stale word seen, and the reader really ran `iters` times
+    if (!good)
+        fprintf(stderr, "libdsg_hip: WARNING: uncached-memory hand-off check failed on device %d (stale words: %u, iterations seen: %u of %d); "
+                        "the step loop keeps its acquire / release fences\n", h->cfg.device, res[0], res[1], iters);
+    g_uc_checked[dev] = good ? 1 : 2;
+    return good;
+}
+#endif
 
-static int sample_prepare(dsg_handle* h, const dsg_sample_args* a, int B, void* stream, SampleJob& job, bool want_pin = false) {
+static int sample_prepare(dsg_handle* h, const dsg_sample_args* a, int B, void* stream, SampleJob& job) {
     if (!h || !a) return fail(DSG_E_INVALID, "dsg_sample: null argument");
     if (!h->finalized || !h->cond_set) return fail(DSG_E_STATE, "dsg_sample before finalize / set_window_cond");
     int rows = 0;
     CHK(rows_for(h, B, &rows));
     if (a->mode != DSG_MODE_DDPM && a->mode != DSG_MODE_DDIM) return fail(DSG_E_INVALID, "mode");
-    if (a->mode == DSG_MODE_DDIM && (a->n_dump > 0 || a->const_noise))
-        return fail(DSG_E_NOT_IMPLEMENTED, "ddim_sample_loop: dump_steps / const_noise (gaussian_diffusion.py:913-916)");
+    // (dump points are allowed with DDIM: ddim_sample_loop_progressive is built on them; the Python ddim_sample_loop itself
+    // refuses dump_steps like the reference, gaussian_diffusion.py:913-916)
+    if (a->mode == DSG_MODE_DDIM && a->const_noise)
+        return fail(DSG_E_NOT_IMPLEMENTED, "ddim_sample_loop: const_noise (gaussian_diffusion.py:915-916)");
     HIPCHK(hipSetDevice(h->cfg.device));
     CHK(order_after(h, stream));
-    // embedded-space state (dsg_fused.h): whenever the update is linear in (x0, x_t, z) and nobody needs x_t itself
-    const bool dumping_ = a->n_dump > 0 && a->dump_steps && a->dump_out;
-    const int kb_in = h->Jp / h->kbk;
-    h->emode = h->ecarry > 0 && use_latency_mode(h, rows) && !dumping_ && !a->step_noise && !a->const_noise && !a->clip_denoised &&
-               h->cfgB == 0 && h->D <= 384 && (h->D / 64 == 1 || h->D / 64 == 2 || h->D / 64 == 4 || h->D / 64 == 6) &&
-               cdiv(kb_in, h->ez_ks) <= 8 && !(h->dbg_skip & 1);
     int n_run = 0;
-    CHK(build_step_tables(h, a->mode, a->skip_timesteps, a->eta, h->emode, &n_run));
+    CHK(build_step_tables(h, a->mode, a->skip_timesteps, a->eta, &n_run));
     const size_t n = (size_t)B * h->J * h->T;
     NoiseKey nk;
     nk.k0 = (unsigned)(a->seed & 0xffffffffu); nk.k1 = (unsigned)(a->seed >> 32);
@@ -1616,23 +1458,7 @@ static int sample_prepare(dsg_handle* h, const dsg_sample_args* a, int B, void* 
             ext = h->ext_noise;
         }
     }
-    if (h->emode) {      // E(x_T) = Wfold . x_T: the pose-embedding GEMM once per window, its split-K partials summed
-        GemmArgs g;
-        memset(&g, 0, sizeof(g));
-        const int Min = rows * h->T, MTin = cdiv(Min, 16);
-        g.B = rows; g.ntok = h->ntok; g.Tp = h->Tp; g.H = h->H; g.hd = h->hd; g.T = h->T; g.J = h->J; g.Jp = h->Jp; g.Jq = h->Jq; g.D = h->D;
-        g.M = Min; g.MT = MTin; g.NT = h->D / 16; g.KBtot = kb_in; g.KS = h->KSin; g.Wp = h->Wp_in;
-        g.kb_per_split = cdiv(g.KBtot, g.KS);
-        g.A = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; g.lda = h->Jp;
-        g.out = h->partial; g.ldo = h->D;
-        if (h->prec == DSG_PREC_BF16) CHK((launch_gemm<PBF16, PRO_DIRECT, EPI_PARTIAL, 4, 1, 1>(h, g)));
-        else CHK((launch_gemm<PF32, PRO_DIRECT, EPI_PARTIAL, 4, 1, 1>(h, g)));
-        const size_t ne = (size_t)Min * h->D;
-        hipLaunchKernelGGL(k_sum_partials, dim3((int)std::min<size_t>((ne + 255) / 256, 1024)), dim3(256), 0, h->stream, h->epose, h->partial,
-                           h->KSin, (size_t)MTin * 16 * h->D, ne);
-        HIPCHK(hipGetLastError());
-    }
-    hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(64), 0, h->stream, h->ctl, h->st_tmodel, h->dep_ctr, 64);
+    hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(64), 0, h->stream, h->ctl, h->st_tmodel);
     HIPCHK(hipGetLastError());
     {
         const unsigned dyn[5] = {nk.k0, nk.k1, nk.s0, nk.s1, a->draw_base + 1u};
@@ -1641,7 +1467,8 @@ static int sample_prepare(dsg_handle* h, const dsg_sample_args* a, int B, void* 
     }
     StepCtx& c = job.c;
     c.B = rows; c.out_mode = a->mode == DSG_MODE_DDPM ? OUT_DDPM : OUT_DDIM; c.use_ctr = true; c.ext_noise = ext;
-    c.const_noise = a->const_noise; c.clip_x0 = a->clip_denoised ? 1 : 0; c.emode = h->emode;
+    c.const_noise = a->const_noise; c.clip_x0 = a->clip_denoised ? 1 : 0;
+    CHK(select_kernels(h, rows, c.ks));
     job.n_run = n_run; job.B = B; job.done = 0;
     job.dumping = a->n_dump > 0 && a->dump_steps && a->dump_out;
     // steps_per_graph: 0 = default = no hipGraph.  Measured on MI355X / ROCm 7.2: hipGraph replay of the step is slower than
@@ -1652,40 +1479,21 @@ static int sample_prepare(dsg_handle* h, const dsg_sample_args* a, int B, void* 
     h->aql_timing = false;
     h->last_path = 0; h->last_nofence = false;
     job.aql = false;
-    job.pin = false;
-    {
-        // XCD-pinned lanes: record the step as (pinned kernel, this lane's arguments); the caller merges the lanes' plans
-        bool pin_ok = want_pin && !g_pin_broken && h->pin_mode != 0 && h->prec == DSG_PREC_BF16 && rows == 1 && !job.dumping &&
-                      !(job.spg > 0 && n_run >= job.spg) && n_run > 0 && !h->emode && !h->overlap && h->dbg_skip == 0;
-#ifndef DSG_EMU
-        if (pin_ok && h->pin_mode == 1) pin_ok = h->aql_mode == 1 && dsg_aql::init(h->aql, h->cfg.device, (const void*)&dsg_version);
-#else
-        if (pin_ok && h->pin_mode == 1) pin_ok = false;
-#endif
-        if (pin_ok) {
-            h->pin_plan.clear(); h->pin_unsupported = false; h->pin_rec = true;
-            const int rc = run_step_p(h, c);
-            h->pin_rec = false;
-            job.pin = rc == 0 && !h->pin_unsupported && !h->pin_plan.empty();
-        }
-    }
 #ifndef DSG_EMU
     // The step loop as hand-written AQL packets (dsg_aql.h): one recording pass of run_step (no launch), argument
     // blocks to device memory, then n_run x the same packets on the handle's own HSA queue.  Any failure before the
     // first packet falls back to the HIP launches; a failure after submission is an error.
     const bool graph_wanted = job.spg > 0 && n_run >= job.spg;
-    if (!job.pin && h->aql_mode == 1 && !job.dumping && !graph_wanted && n_run > 0) {
+    if (h->aql_mode == 1 && !job.dumping && !graph_wanted && n_run > 0) {
         bool planned = dsg_aql::init(h->aql, h->cfg.device, (const void*)&dsg_version);
-        if (const char* e = getenv("DSG_AQL_ACQUIRE")) h->aql.acquire_scope = atoi(e) ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE;
-        if (const char* e = getenv("DSG_OVL_ACQUIRE")) h->aql.overlap_acquire_scope = atoi(e) ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE;
+        bool nofence = false;
+        if (planned && h->uc_mode == 1) nofence = uc_selfcheck(h);
         if (planned) {
             dsg_aql::begin(h->aql);
             const int rc = run_step_p(h, c);
             planned = dsg_aql::finish(h->aql) && rc == 0;
             h->aql.recording = false;
-            // fence-free packets (see uc_mode; 2: uncached buffers behind the usual fences); the overlapped-launch experiment
-            // synchronises through cached counters and keeps the fences
-            h->aql.nofence = h->uc_mode == 1 && !h->overlap && !h->emode;
+            h->aql.nofence = nofence;            // fence-free packets (see uc_mode; 2: uncached buffers behind the usual fences)
         }
         if (!planned) {
             if (!h->aql_warned) { fprintf(stderr, "libdsg_hip: AQL path unavailable (%s); using HIP launches\n", h->aql.err.c_str()); h->aql_warned = true; }
@@ -1705,10 +1513,11 @@ static int sample_run_hip(dsg_handle* h, const dsg_sample_args* a, SampleJob& jo
     const int n_run = job.n_run, B = job.B, spg = job.spg;
     const StepCtx& c = job.c;
     const size_t n = (size_t)B * h->J * h->T;
-    if (spg > 0 && n_run >= spg) {
+    if (spg > 0 && n_run >= spg && job.done == 0) {
         // everything that varies between calls (step index, coefficients, noise key, conditioning) lives in device
-        // memory, so one captured graph per (batch, sampler, mask batch, const_noise, steps, flags) serves every window and clip
-        dsg_handle::GKey key = {c.B, c.out_mode, h->mb, c.const_noise, n_run, (c.clip_x0 ? 1 : 0) | (h->cfgB ? 2 : 0) | (h->nomask ? 4 : 0)};
+        // memory, so one captured graph per (batch, sampler, mask batch, const_noise, steps, flags, kernel set) serves every window and clip
+        dsg_handle::GKey key = {c.B, c.out_mode, h->mb, c.const_noise, n_run, (c.clip_x0 ? 1 : 0) | (h->cfgB ? 2 : 0) | (h->nomask ? 4 : 0) | (c.ks.attn_in_mid ? 8 : 0),
+                                c.ks.set};
         auto it = h->graphs.find(key);
         bool ok = true;
         if (it == h->graphs.end()) {
@@ -1731,6 +1540,7 @@ static int sample_run_hip(dsg_handle* h, const dsg_sample_args* a, SampleJob& jo
         if (ok) {
             while (n_run - job.done >= spg) { HIPCHK(hipGraphLaunch(it->second.exec, h->stream)); job.done += spg; }
             h->last_path = 2;
+            h->last_kset = c.ks.set;
         }
     }
     int di = 0;
@@ -1750,153 +1560,36 @@ static int sample_run_hip(dsg_handle* h, const dsg_sample_args* a, SampleJob& jo
 
 static int sample_finish(dsg_handle* h, float* out, void* stream, SampleJob& job) {
     const size_t n = (size_t)job.B * h->J * h->T;
-    if (job.c.emode) {
-        // the last step of DDPM / DDIM is x_0 = x0-prediction (posterior_mean_coef1[0] = 1, coef2[0] = 0, no noise at t = 0;
-        // DDIM: abar_prev = 1): one pose-head launch on the last step's final-layer rows gives the sample in the caller's layout
-        StepCtx f = job.c;
-        f.emode = false; f.out_mode = OUT_FORWARD; f.use_ctr = false; f.only_head = true;
-        CHK(run_step_p(h, f));
-    }
     HIPCHK(hipEventRecord(h->ev_t1, h->stream));
     h->last_steps = job.n_run; h->timing_valid = true;
-    if (!job.c.emode) CHK(launch_x_out(h, h->fwd_out, job.B));
+    h->last_kset = job.c.ks.set;
+    CHK(launch_x_out(h, h->fwd_out, job.B));
     CHK(from_dev(h, out, h->fwd_out, n));
-    if (h->overlap) {       // overlapped (barrier-less) launches: a consumer that gave up waiting raised the error word
-        unsigned err = 0;
-        HIPCHK(hipMemcpyAsync(&err, h->dep_ctr + 63, sizeof err, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        if (err) return fail(DSG_E_RUNTIME, "dsg_sample: an overlapped consumer kernel timed out waiting for its producer (DSG_OVERLAP); the sample is invalid");
-    }
     CHK(order_before(h, stream));
-    return 0;
-}
-
-// The step loop of n prepared batch-1 lanes as XCD-pinned dispatches: groups of 8 lanes, one packet chain (one HSA queue)
-// per group, led by the group's first handle.  retry = true: the placement check failed -- nothing of the result may be used,
-// the caller prepares again and runs the fenced path.
-static int run_pinned(dsg_handle** hs, int n, std::vector<SampleJob>& jobs, bool& retry) {
-    retry = false;
-    const size_t L = hs[0]->pin_plan.size();
-    for (int i = 0; i < n; ++i) {
-        const auto& pl = hs[i]->pin_plan;
-        if (pl.size() != L || jobs[i].n_run != jobs[0].n_run) return fail(DSG_E_STATE, "pinned lanes: the lanes' steps differ");
-        for (size_t k = 0; k < L; ++k)
-            if (pl[k].fnx != hs[0]->pin_plan[k].fnx || pl[k].args.size() != hs[0]->pin_plan[k].args.size() || pl[k].grid.x != hs[0]->pin_plan[k].grid.x ||
-                pl[k].grid.y != hs[0]->pin_plan[k].grid.y || pl[k].grid.z != hs[0]->pin_plan[k].grid.z)
-                return fail(DSG_E_STATE, "pinned lanes: the lanes' steps differ");
-    }
-    const int n_run = jobs[0].n_run, G = cdiv(n, 8);
-    bool use_aql = false;
-#ifndef DSG_EMU
-    use_aql = true;
-    for (int g = 0; g < G; ++g) use_aql = use_aql && hs[8 * g]->aql_mode == 1 && dsg_aql::init(hs[8 * g]->aql, hs[8 * g]->cfg.device, (const void*)&dsg_version);
-#endif
-    // argument structs of the pinned kernels, per group: the lanes' own arguments side by side + lane count + error word
-    std::vector<std::vector<std::vector<char>>> tabs(G, std::vector<std::vector<char>>(L));
-    for (int g = 0; g < G; ++g) {
-        dsg_handle* ld = hs[8 * g];
-        const int nl = std::min(8, n - 8 * g);
-        unsigned* errw = ld->dep_ctr + 62;
-        for (size_t k = 0; k < L; ++k) {
-            const PinLaunch& pl = ld->pin_plan[k];
-            std::vector<char>& t = tabs[g][k];
-            t.assign(pl.tab_size, 0);
-            for (int l = 0; l < nl; ++l) {
-                const auto& a = hs[8 * g + l]->pin_plan[k].args;
-                std::memcpy(t.data() + (size_t)l * a.size(), a.data(), a.size());
-            }
-            std::memcpy(t.data() + pl.nl_off, &nl, sizeof nl);
-            std::memcpy(t.data() + pl.err_off, &errw, sizeof errw);
-        }
-#ifndef DSG_EMU
-        if (use_aql) {
-            dsg_aql::Ctx& c = ld->aql;
-            dsg_aql::begin(c);
-            bool ok = true;
-            for (size_t k = 0; k < L && ok; ++k) {
-                const PinLaunch& pl = ld->pin_plan[k];
-                ok = dsg_aql::record(c, pl.fnx, ld->stream, dim3(pl.grid.x * 8, pl.grid.y, pl.grid.z), pl.block, tabs[g][k].data(), tabs[g][k].size());
-            }
-            ok = dsg_aql::finish(c) && ok;
-            c.recording = false;
-            c.nofence = getenv("DSG_PIN_FENCED") == nullptr;      // (DSG_PIN_FENCED: the pinned kernels behind agent-scope fences, to price the fences alone)
-            if (!ok) return fail(DSG_E_RUNTIME, "pinned lanes: AQL plan: " + c.err);
-        }
-#endif
-    }
-#ifndef DSG_EMU
-    if (use_aql) {
-        std::vector<dsg_aql::Ctx*> ctxs(G);
-        std::vector<int> steps(G, n_run);
-        for (int g = 0; g < G; ++g) ctxs[g] = &hs[8 * g]->aql;
-        std::string err;
-        const bool ok = dsg_aql::run_multi(ctxs.data(), steps.data(), G, 60.0 + 0.01 * n_run * G, err);
-        for (int g = 0; g < G; ++g) ctxs[g]->nofence = false;
-        if (!ok) return fail(DSG_E_RUNTIME, "AQL run (pinned lanes): " + err);
-    }
-#endif
-    if (!use_aql) {
-        for (int sidx = 0; sidx < n_run; ++sidx)
-            for (int g = 0; g < G; ++g) {
-                dsg_handle* ld = hs[8 * g];
-                for (size_t k = 0; k < L; ++k) {
-                    const PinLaunch& pl = ld->pin_plan[k];
-                    pl.launch(ld->stream, dim3(pl.grid.x * 8, pl.grid.y, pl.grid.z), pl.block, tabs[g][k].data());
-                    HIPCHK(hipGetLastError());
-                }
-            }
-        for (int g = 0; g < G; ++g) HIPCHK(hipStreamSynchronize(hs[8 * g]->stream));
-    }
-    for (int g = 0; g < G; ++g) {
-        dsg_handle* ld = hs[8 * g];
-        unsigned err = 0;
-        HIPCHK(hipMemcpyAsync(&err, ld->dep_ctr + 62, sizeof err, hipMemcpyDeviceToHost, ld->stream));
-        HIPCHK(hipStreamSynchronize(ld->stream));
-        if (err && !getenv("DSG_PIN_NOCHECK")) {      // (DSG_PIN_NOCHECK: placement experiments)
-            fprintf(stderr, "libdsg_hip: XCD placement check failed (workgroup (%u, %u, %u) on XCC %u); pinned lanes disabled, using the fenced submission\n",
-                    (err >> 4) & 0xfffu, (err >> 16) & 0xffu, (err >> 24) & 0x7fu, err & 0xfu);
-            g_pin_broken = true;
-            retry = true;
-            return 0;
-        }
-    }
-    for (int i = 0; i < n; ++i) {
-        jobs[i].done = jobs[i].n_run;
-        hs[i]->last_path = use_aql ? 3 : 4;
-        hs[i]->last_nofence = use_aql && getenv("DSG_PIN_FENCED") == nullptr;
-#ifndef DSG_EMU
-        if (use_aql) { hs[i]->aql_timing = true; hs[i]->aql_ms = hs[8 * (i / 8)]->aql.last_ms; }
-#endif
-    }
     return 0;
 }
 
 extern "C" int dsg_sample(dsg_handle* h, const dsg_sample_args* a, float* out, int B, void* stream) {
     if (!h || !a || !out) return fail(DSG_E_INVALID, "dsg_sample: null argument");
-    std::vector<SampleJob> job(1);
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        CHK(sample_prepare(h, a, B, stream, job[0], attempt == 0));
-        if (!job[0].pin) break;
-        bool retry = false;
-        CHK(run_pinned(&h, 1, job, retry));
-        if (!retry) break;
-    }
+    SampleJob job;
+    CHK(sample_prepare(h, a, B, stream, job));
 #ifndef DSG_EMU
-    if (job[0].aql) {
-        if (!dsg_aql::run(h->aql, job[0].n_run, 60.0 + 0.01 * job[0].n_run)) return fail(DSG_E_RUNTIME, "AQL run: " + h->aql.err);
-        job[0].done = job[0].n_run;
+    if (job.aql) {
+        if (!dsg_aql::run(h->aql, job.n_run, 60.0 + 0.01 * job.n_run)) return fail(DSG_E_RUNTIME, "AQL run: " + h->aql.err);
+        job.done = job.n_run;
         h->aql_timing = true; h->aql_ms = h->aql.last_ms;
         h->last_path = 1; h->last_nofence = h->aql.nofence;
     }
 #endif
-    CHK(sample_run_hip(h, a, job[0]));
-    return sample_finish(h, out, stream, job[0]);
+    CHK(sample_run_hip(h, a, job));
+    return sample_finish(h, out, stream, job);
 }
 
 // n lanes (handles of ONE device, normally a handle and its clones), one independent sampling call each, advanced
-// concurrently.  Batch-1 bf16 lanes run XCD-pinned (run_pinned: 8 lanes per packet chain, up to 64 lanes); otherwise, with
-// the AQL submission, every lane has its own HSA queue and the host thread deals the steps round-robin (the queues' dependent
-// packet chains overlap on the GPU); with HIP launches the lanes' streams are fed step by step.
+// concurrently.  With the AQL submission every lane has its own HSA queue and the host thread deals the steps round-robin (the
+// queues' dependent packet chains overlap on the GPU); with HIP launches the lanes' streams are fed step by step.  Every lane
+// runs the kernel set ITS handle selects (dsg_set_kernel_set / the batch): the call changes nothing about the arithmetic, so
+// lane i's sample is bit-identical to dsg_sample(lanes[i], &args[i], ...) on its own.
 extern "C" int dsg_sample_multi(dsg_handle** hs, int n, const dsg_sample_args* args, float** outs, int B, void* stream) {
     if (!hs || !args || !outs || n <= 0) return fail(DSG_E_INVALID, "dsg_sample_multi: bad argument");
     for (int i = 0; i < n; ++i) {
@@ -1904,36 +1597,13 @@ extern "C" int dsg_sample_multi(dsg_handle** hs, int n, const dsg_sample_args* a
         for (int j = 0; j < i; ++j) if (hs[j] == hs[i]) return fail(DSG_E_INVALID, "dsg_sample_multi: a handle appears twice");
         if (hs[i]->cfg.device != hs[0]->cfg.device) return fail(DSG_E_INVALID, "dsg_sample_multi: lanes must live on one device");
     }
-    if (n > 64) return fail(DSG_E_INVALID, "dsg_sample_multi: at most 64 lanes");
+    if (n > 16) return fail(DSG_E_INVALID, "dsg_sample_multi: at most 16 lanes (4 overlap on the hardware; put further clips into the lanes' batches)");
     std::vector<SampleJob> jobs(n);
-    struct LaneScope {      // the kernel-shape rules see how many lanes run together, for the duration of this call
-        dsg_handle** hs; int n;
-        LaneScope(dsg_handle** h, int k) : hs(h), n(k) { for (int i = 0; i < n; ++i) hs[i]->lanes_now = n; }
-        ~LaneScope() { for (int i = 0; i < n; ++i) hs[i]->lanes_now = 1; }
-    } scope(hs, n);
+    for (int i = 0; i < n; ++i) CHK(sample_prepare(hs[i], &args[i], B, stream, jobs[i]));
     bool all_aql = true;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        for (int i = 0; i < n; ++i) CHK(sample_prepare(hs[i], &args[i], B, stream, jobs[i], attempt == 0));
-        bool all_pin = true;
-        for (int i = 0; i < n; ++i) all_pin = all_pin && jobs[i].pin && jobs[i].n_run == jobs[0].n_run;
-        if (!all_pin) {
-            bool any_pin = false;
-            for (int i = 0; i < n; ++i) any_pin = any_pin || jobs[i].pin;
-            if (any_pin) {      // mixed lanes: everybody takes the fenced path
-                for (int i = 0; i < n; ++i) CHK(sample_prepare(hs[i], &args[i], B, stream, jobs[i], false));
-            }
-            break;
-        }
-        bool retry = false;
-        CHK(run_pinned(hs, n, jobs, retry));
-        if (!retry) break;
-    }
-    bool pinned_done = true;
-    for (int i = 0; i < n; ++i) pinned_done = pinned_done && jobs[i].pin && jobs[i].done == jobs[i].n_run;
-    if (!pinned_done && n > 16) return fail(DSG_E_INVALID, "dsg_sample_multi: more than 16 lanes need the pinned submission (batch 1, bf16, AQL path)");
     for (int i = 0; i < n; ++i) all_aql = all_aql && jobs[i].aql;
 #ifndef DSG_EMU
-    if (!pinned_done && all_aql) {
+    if (all_aql) {
         std::vector<dsg_aql::Ctx*> ctxs(n);
         std::vector<int> steps(n);
         double tmax = 60.0;
@@ -1946,7 +1616,7 @@ extern "C" int dsg_sample_multi(dsg_handle** hs, int n, const dsg_sample_args* a
         }
     }
 #endif
-    if (!pinned_done && !all_aql) {
+    if (!all_aql) {
         // HIP launches: an AQL plan that was recorded for some lanes is simply not used; step s of every lane, then s + 1
         bool plain = true;
         for (int i = 0; i < n; ++i) plain = plain && !jobs[i].dumping && !(jobs[i].spg > 0 && jobs[i].n_run >= jobs[i].spg);
@@ -2010,12 +1680,13 @@ extern "C" int dsg_noise(float* out, int B, int J, int T, uint64_t seed, uint64_
     float* dst = out;
     if (!dev) HIPCHK(hipMalloc((void**)&dst, bytes));
     hipLaunchKernelGGL(k_noise, dim3((int)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, dst, B, J, Jq, T, nk, draw);
-    HIPCHK(hipGetLastError());
-    if (!dev) {
-        HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-        HIPCHK(hipMemcpy(out, dst, bytes, hipMemcpyDeviceToHost));
-        HIPCHK(hipFree(dst));
+    hipError_t e = hipGetLastError();
+    if (!dev) {          // host output: the temporary is released on every path
+        if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+        if (e == hipSuccess) e = hipMemcpy(out, dst, bytes, hipMemcpyDeviceToHost);
+        (void)hipFree(dst);
     }
+    if (e != hipSuccess) return fail(DSG_E_RUNTIME, std::string("dsg_noise: ") + hipGetErrorString(e));
     return 0;
 }
 

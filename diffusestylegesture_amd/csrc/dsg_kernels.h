@@ -36,7 +36,6 @@ typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short bf16_t;
 
 #define DSG_FLT_MAX 3.402823466e+38f
-#define DSG_EZ_MAXKS 18         // K splits of the noise embedding (k_enoise), summed on read by the EPI_ESTEP epilogue
 
 // ---------------------------------------------------------------------------------------------------------
 // precision policies
@@ -67,7 +66,6 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 struct PF32 {                       // fp32 storage, v_mfma_f32_16x16x4_f32
     typedef float elem;
-    static constexpr bool PIN = false;
     static constexpr int E = 4;     // elements per 16-byte fragment
     static constexpr int KB = 16;   // k-values per k-block (4 lane groups x E)
     static __device__ __forceinline__ elem cvt(float f) { return f; }
@@ -81,16 +79,9 @@ struct PF32 {                       // fp32 storage, v_mfma_f32_16x16x4_f32
         return c;
     }
     static __device__ __forceinline__ void store4(elem* p, f32x4 v) { *(f32x4*)p = v; }
-    static __device__ __forceinline__ void store4_agent(elem* p, f32x4 v) {     // agent-scope (write-through) store, 2 x 8 bytes
-        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-        const u64x2 b = __builtin_bit_cast(u64x2, v);
-        __hip_atomic_store((unsigned long long*)p, b[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store((unsigned long long*)p + 1, b[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
 };
 struct PBF16 {                      // bf16 storage, v_mfma_f32_16x16x32_bf16, fp32 accumulate
     typedef bf16_t elem;
-    static constexpr bool PIN = false;
     static constexpr int E = 8;
     static constexpr int KB = 32;
     static __device__ __forceinline__ elem cvt(float f) { return f2bf(f); }
@@ -104,44 +95,13 @@ struct PBF16 {                      // bf16 storage, v_mfma_f32_16x16x32_bf16, f
         typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
         *(bf16x4v*)p = __builtin_convertvector(v, bf16x4v);
     }
-    static __device__ __forceinline__ void store4_agent(elem* p, f32x4 v) {     // same values, agent-scope (write-through) store
-        typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
-        __hip_atomic_store((unsigned long long*)p, __builtin_bit_cast(unsigned long long, __builtin_convertvector(v, bf16x4v)),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
 };
 
-// ---------------------------------------------------------------------------------------------------------
-// XCD-pinned lanes (dsg_hip.cpp: "pinned lanes"): up to 8 independent batch-1 sampling calls ("lanes") share every dispatch
-// of the step, lane = blockIdx.x & 7.  Workgroups are dealt round-robin to the 8 XCDs in linear launch order and the
-// x extent of these grids is a multiple of 8, so lane l runs on XCD l and NOTHING a lane reads during the loop was written
-// on another XCD: its activations are handed from kernel to kernel through that XCD's L2, the dispatch packets carry no
-// acquire / release fence (no L2 write-back / invalidate per kernel boundary), and a dependent load is an L2 hit instead of
-// a round trip through memory.  What the missing acquire no longer does is invalidate the CUs' vector L1 and scalar caches,
-// so every load of data that CHANGES during the loop (activations, state, step control) bypasses them (sc1: served by the
-// L2); weights, tables and conditioning are constant during the loop and stay plain loads.  The placement is an observed
-// property, not a promise, so one kernel per step compares HW_REG_XCC_ID with its lane and raises an error word that makes
-// the host fall back to the fenced submission.
-// The kernels are the SAME bodies, instantiated for a policy with PIN = true.
-// ---------------------------------------------------------------------------------------------------------
-struct PBF16X : PBF16 { static constexpr bool PIN = true; };
-constexpr int DSG_PIN_SH = 3;                       // 8 lanes per dispatch
-template <class P> __device__ __forceinline__ int vbx() {      // blockIdx.x of the lane's own grid
-    if constexpr (P::PIN) return (int)(blockIdx.x >> DSG_PIN_SH); else return (int)blockIdx.x;
-}
-// 16 bytes at base + off of data another kernel of the loop wrote (off < 4 GB)
-template <class P> __device__ __forceinline__ f32x4 lda16(const void* base, size_t off) {
-#ifndef DSG_EMU
-    if constexpr (P::PIN) {
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xffffffff, 0x00020000);
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(unsigned)off, 0, 16);      // aux 16 = sc1
-        return __builtin_bit_cast(f32x4, v);
-    }
-#endif
-    return *(const f32x4*)((const char*)base + off);
-}
-template <class P> __device__ __forceinline__ int ldw(const int* p) {      // one word of the step control: never through the scalar cache
+// Loads of data another kernel of the step loop wrote.  The loop-written buffers live in uncached device memory (dsg_hip.cpp:
+// uc_mode), so a plain load is coherent; the step control is a few words that must never come through the scalar cache
+// (nothing invalidates it between the fence-free packets): agent-scope atomic loads are vector loads.
+template <class P> __device__ __forceinline__ f32x4 lda16(const void* base, size_t off) { return *(const f32x4*)((const char*)base + off); }
+template <class P> __device__ __forceinline__ int ldw(const int* p) {
 #ifndef DSG_EMU
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
@@ -149,10 +109,6 @@ template <class P> __device__ __forceinline__ int ldw(const int* p) {      // on
 #endif
 }
 template <class P> __device__ __forceinline__ float ldwf(const float* p) { return __builtin_bit_cast(float, ldw<P>((const int*)p)); }
-// end of a pinned kernel: this wave's stores have reached the L2 before the wave retires (the packet releases nothing)
-template <class P> __device__ __forceinline__ void pin_drain() {
-    if constexpr (P::PIN) __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0)
-}
 
 // Q, K and V^T of the self-attention live in HBM in MFMA-FRAGMENT order, so that every fragment a wave loads is one
 // contiguous 1 KB block (8 cache lines) instead of 16 rows x 64 B (16 half-used lines): the attention kernels' load
@@ -305,63 +261,15 @@ __device__ __forceinline__ void step_advance_A(StepCtl* c, const StepTables& st,
     c->stepA = s;
     c->tA = st.tmodel[s < n ? s : n - 1];
 }
-__global__ void k_ctl_init(StepCtl* c, const int* tmodel, unsigned* dep_ctr, int n_ctr) {
+__global__ void k_ctl_init(StepCtl* c, const int* tmodel) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { c->stepA = 0; c->tA = tmodel[0]; c->stepB = -1; c->k1 = c->k2 = c->k3 = c->k4 = c->k5 = 0.f; }
-    if (blockIdx.x == 0 && (int)threadIdx.x < n_ctr) dep_ctr[threadIdx.x] = 0u;
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// In-kernel producer -> consumer hand-off (used with the AQL submission path, dsg_aql.h): the consumer's packet carries
-// NO barrier bit, so the command processor starts it while the producer is still running; the consumer first requests
-// everything that does not depend on the producer (its weights -- the load phase that bounds k_mid), then waits here
-// until every producer workgroup has released its stores.  Counters only ever count up inside one dsg_sample call
-// (zeroed by k_ctl_init): target = (step index * launches per step + launch number in the step) * producer workgroups.
-// Run back to back (HIP launches) the wait is satisfied on the first poll.  Polling is bounded: a missing producer does
-// not hang the GPU -- the consumer gives up, raises DepWait::err, and dsg_sample fails with DSG_E_RUNTIME.
-// ---------------------------------------------------------------------------------------------------------
-struct DepWait {
-    const unsigned* ctr;       // null: no waiting (forward pass / batched path)
-    const int* epoch;          // device word holding the current step index (StepCtl::stepB)
-    int per_step, seq;         // launches of the producer per step, 1-based number of this one
-    unsigned n_prod;           // workgroups per producer launch
-    unsigned* err;             // device error word: set to 1 when the bounded poll gives up (dsg_sample turns it into DSG_E_RUNTIME)
-};
-// The handed-off data itself bypasses the non-coherent cache levels instead of being fenced: the producer writes it
-// with agent-scope (sc1, write-through) stores and the consumer reads it with agent-scope loads, so no cache-wide
-// write-back / invalidate is needed -- an in-kernel __threadfence() per wave made the step 48 us SLOWER (it writes back
-// and invalidates the XCD's whole L2, weights included).
-__device__ __forceinline__ void store8_agent(void* p, unsigned long long v) {
-    __hip_atomic_store((unsigned long long*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ f32x4 load16_agent(const void* p) {
-    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-    u64x2 v;
-    v[0] = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    v[1] = __hip_atomic_load((const unsigned long long*)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return __builtin_bit_cast(f32x4, v);
-}
-// producer side: this wave's agent-scope stores have been acknowledged (vmcnt(0)) before the count goes up
-__device__ __forceinline__ void dep_signal(unsigned* ctr, bool one_lane) {
-    __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0) expcnt(7) lgkmcnt(15)
-    if (one_lane) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// consumer side: called by the whole workgroup; returns when the producer's data may be read (with load16_agent)
-__device__ __forceinline__ void dep_wait(const DepWait& d) {
-    if (d.ctr == nullptr) return;
-    if (threadIdx.x == 0) {
-        const unsigned target = (unsigned)(*d.epoch * d.per_step + d.seq) * d.n_prod;
-        int spins = 0;
-        while (__hip_atomic_load(d.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(1);
-        if (spins >= (1 << 22) && d.err) __hip_atomic_store(d.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the producer never arrived
-    }
-    __builtin_amdgcn_s_barrier();
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // GEMM  (skinny-M, weight-stationary-per-XCD):  Out[m][n] = sum_k Act[m][k] * W[n][k]  (+ epilogue)
 // ---------------------------------------------------------------------------------------------------------
 enum { PRO_DIRECT = 0, PRO_LN = 1 };
-enum { EPI_PARTIAL = 0, EPI_QKV = 1, EPI_RESID = 2, EPI_GELU = 3, EPI_OUT = 4, EPI_ESTEP = 5 };
+enum { EPI_PARTIAL = 0, EPI_QKV = 1, EPI_RESID = 2, EPI_GELU = 3, EPI_OUT = 4 };
 enum { OUT_FORWARD = 0, OUT_DDPM = 1, OUT_DDIM = 2 };
 
 struct GemmArgs {
@@ -414,13 +322,6 @@ struct GemmArgs {
     int cfgB, cfg_off;
     const float* cfg_scale; // [cfgB]
     int clip_x0;            // EPI_OUT: clamp x0 to [-1, 1] (clip_denoised=True, gaussian_diffusion.py:377-379)
-    // EPI_ESTEP: the sampler update carried in EMBEDDED space (dsg_fused.h: "embedded-space state").  epose [B*T][D] fp32 holds
-    // E(x_t) = Wfold . x_t; this GEMM multiplies the final LayerNorm rows with W_io = Wfold . W_out, so acc + bias = E(x0), and
-    // the update E(x_{t-1}) = k1 E(x0) + k2 E(x_t) + k3 E(z) is written back in place.  ez: ez_ks partial sums of E(z)
-    // ([ez_ks][ez_rows][D], k_enoise) added on read.
-    float* epose;
-    const float* ez;
-    int ez_ks, ez_rows;
 };
 
 // Workgroup -> n-group with the n-group pinned to an XCD (workgroups are dealt round-robin to the 8 XCDs in linear
@@ -428,7 +329,7 @@ struct GemmArgs {
 // the same XCD's L2 and stays resident there across the 1000 steps.  Row tile / k-split come from blockIdx.y / .z --
 // the hardware hands them over for free, whereas decomposing a flat id costs integer divisions (~40 instructions
 // each, and at one wave per SIMD every instruction is ~2 ns of critical path).
-template <class P> __device__ __forceinline__ int xcd_ngroup() { const int x = vbx<P>(); return (x & 7) + 8 * (x >> 3); }
+template <class P> __device__ __forceinline__ int xcd_ngroup() { const int x = (int)blockIdx.x; return (x & 7) + 8 * (x >> 3); }
 __host__ __device__ inline int xcd_grid_x(int NG) { return 8 * ((NG + 7) / 8); }
 
 // x / d for 0 <= x, x * d < 2^32, as one v_mul_hi_u32: inv = ceil(2^32 / d) (host: fastdiv_inv; d == 1 -> inv 0)
@@ -529,21 +430,6 @@ __device__ __forceinline__ void gemm_prefetch_tile(const GemmArgs& g, int m0, in
         } else if constexpr (EPI == EPI_QKV) {
             o.pb = *(const f32x4*)(g.bias + n0 + 4 * lg);      // both forms loaded unconditionally (no branchy loads)
             o.pbs = g.bias[n0 + lr];
-        } else if constexpr (EPI == EPI_ESTEP) {
-            const int m = m0 + lr, n = n0 + 4 * lg;
-            const int b = fdiv(m, g.inv_ntok), sx = m - b * g.ntok;
-            o.ovalid = m < g.M && sx > 0;
-            o.pb = *(const f32x4*)(g.bias + n);
-            const int bc = b < g.B ? b : g.B - 1, fc = sx > 0 ? sx - 1 : 0;      // clamped row: unconditional loads
-            const size_t row = (size_t)bc * g.T + fc;
-            o.pr = *(const f32x4*)(g.epose + row * g.D + n);
-#pragma unroll
-            for (int s2 = 0; s2 < DSG_EZ_MAXKS; ++s2) {      // branch-free: clamped slice, weighted out
-                const float wgt = s2 < g.ez_ks ? 1.f : 0.f;
-                const f32x4 zz = *(const f32x4*)(g.ez + ((size_t)min(s2, g.ez_ks - 1) * g.ez_rows + row) * g.D + n);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o.pz[e] += wgt * zz[e];
-            }
         } else if constexpr (EPI == EPI_OUT) {
             const int m = m0 + lr, j0 = n0 + 4 * lg;
             const int b = fdiv(m, g.inv_ntok), sx = m - b * g.ntok;
@@ -620,16 +506,6 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmArgs& g, int m0, in
                     }
                 }
             }
-        } else if constexpr (EPI == EPI_ESTEP) {
-            const int m = m0 + lr, n = n0 + 4 * lg;
-            const int b = fdiv(m, g.inv_ntok), sx = m - b * g.ntok;
-            if (o.ovalid) {
-                const f32x4 e0 = acc + o.pb;
-                f32x4 en;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) en[e] = (k1 * e0[e] + k2 * o.pr[e]) + k3 * o.pz[e];
-                *(f32x4*)(g.epose + ((size_t)b * g.T + (sx - 1)) * g.D + n) = en;
-            }
         } else if constexpr (EPI == EPI_OUT) {
             const int m = m0 + lr, j0 = n0 + 4 * lg;
             const int b = fdiv(m, g.inv_ntok), sx = m - b * g.ntok;
@@ -699,13 +575,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
     const int NG = g.NT / (WN * TNW);
     const int ng = xcd_ngroup<P>(), ks = blockIdx.z;
     const int mt_first = blockIdx.y;
-    if constexpr (EPI == EPI_PARTIAL || EPI == EPI_OUT || EPI == EPI_ESTEP) {
+    if constexpr (EPI == EPI_PARTIAL || EPI == EPI_OUT) {
         // step bookkeeping runs in ONE EXTRA workgroup (first block of an extra grid row), concurrently with the real
         // work and off every critical path; see StepCtl for why this is race free
         if (mt_first >= g.MT) {
-            if (g.ctl && vbx<P>() == 0 && ks == 0 && threadIdx.x == 0) {
+            if (g.ctl && blockIdx.x == 0 && ks == 0 && threadIdx.x == 0) {
                 if constexpr (EPI == EPI_PARTIAL) step_advance_B<P>(g.ctl, g.st, g.n_tab);
-                else if (EPI == EPI_ESTEP || g.out_mode != OUT_FORWARD) step_advance_A<P>(g.ctl, g.st, g.n_tab);
+                else if (g.out_mode != OUT_FORWARD) step_advance_A<P>(g.ctl, g.st, g.n_tab);
             }
             return;
         }
@@ -753,7 +629,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
             k1 = ldwf<P>(&g.ctl->k1); k2 = ldwf<P>(&g.ctl->k2); k3 = ldwf<P>(&g.ctl->k3); k4 = ldwf<P>(&g.ctl->k4); k5 = ldwf<P>(&g.ctl->k5);
         }
     }
-    if constexpr (EPI == EPI_ESTEP) { k1 = ldwf<P>(&g.ctl->k1); k2 = ldwf<P>(&g.ctl->k2); k3 = ldwf<P>(&g.ctl->k3); }
     const int m0 = mt_first * 16;
     f32x4 acc[TNW];
 #pragma unroll
@@ -872,151 +747,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
     DSG_STAMP(1 + EPI, 5);
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Multi-tile shape of the same GEMM (experiment, DSG_GEMM_TM=4): TM row tiles per workgroup, EVERYTHING of all tiles
-// requested up front (one memory round trip per workgroup), the weight fragments loaded once and reused for TM x 16 rows,
-// all TM x TNW MFMA chains interleaved.  Correct (emulator + GPU parity) but measured SLOWER than one tile per workgroup
-// at every batch size on MI355X (tools/b16_sweep.sh: batch 16: 513 vs 380 us/step; a first version that looped over the
-// tiles serially: 537): at M = 1424 rows the 4x fewer, 4x longer workgroups quantise badly over 256 CUs (368 workgroups
-// = 2 rounds of 4 units against 5.6 rounds of 1 unit) and the LayerNorm recomputed per n-group dominates either way.
-// Constraints: 4 waves side by side (no split-K), the whole K range in one chunk of 8 k-blocks, LayerNorm rows up to
-// 512 (bf16) / 256 (fp32) wide.
-// ---------------------------------------------------------------------------------------------------------
-template <class P, int PRO, int EPI, int TNW, int TM>
-__device__ __forceinline__ void gemm_body_mt(const GemmArgs& g) {
-    typedef typename P::elem elem;
-    constexpr int ES = (int)sizeof(elem), WN = 4, CH = 8;
-    constexpr int DMAX = ES == 2 ? 512 : 256;
-    __shared__ __attribute__((aligned(16))) char lds_a[PRO == PRO_LN ? TM * 16 * (DMAX * ES + 16) : 16];
-    preload_kernargs(g);
-    const int NG = g.NT / (WN * TNW);
-    const int ng = xcd_ngroup<P>();
-    const int mt_first = blockIdx.y * TM;
-    if constexpr (EPI == EPI_PARTIAL || EPI == EPI_OUT) {
-        if (mt_first >= g.MT) {      // extra grid row: step bookkeeping (see gemm_body)
-            if (g.ctl && blockIdx.x == 0 && threadIdx.x == 0) {
-                if constexpr (EPI == EPI_PARTIAL) step_advance_B(g.ctl, g.st, g.n_tab);
-                else if (g.out_mode != OUT_FORWARD) step_advance_A(g.ctl, g.st, g.n_tab);
-            }
-            return;
-        }
-    }
-    if (ng >= NG || mt_first >= g.MT) return;
-    const int tid = threadIdx.x, lane = tid & 63, wn = wave_id();
-    const int lr = lane & 15, lg = lane >> 4;
-    const int nt0 = (ng * WN + wn) * TNW;
-    const int kb_last = g.KBtot - 1;
-    const f32x4* wbase = (const f32x4*)g.Wp + lane;
-    bool swapped[TNW];
-#pragma unroll
-    for (int t = 0; t < TNW; ++t) swapped[t] = !(EPI == EPI_QKV && ((nt0 + t) * 16) >= 2 * (g.H * g.hd));
-    f32x4 bf[CH][TNW];
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-#pragma unroll
-        for (int t = 0; t < TNW; ++t) bf[c][t] = wbase[((size_t)(nt0 + t) * g.KBtot + min(c, kb_last)) * 64];
-    int step = 0;
-    float k1 = 0.f, k2 = 0.f, k3 = 0.f, k4 = 0.f, k5 = 0.f;
-    if constexpr (EPI == EPI_OUT) {
-        if (g.out_mode != OUT_FORWARD) {
-            step = ldw<P>(&g.ctl->stepB);
-            k1 = ldwf<P>(&g.ctl->k1); k2 = ldwf<P>(&g.ctl->k2); k3 = ldwf<P>(&g.ctl->k3); k4 = ldwf<P>(&g.ctl->k4); k5 = ldwf<P>(&g.ctl->k5);
-        }
-    }
-    int m0s[TM];
-    bool live[TM];
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi) { live[mi] = mt_first + mi < g.MT; m0s[mi] = min(mt_first + mi, g.MT - 1) * 16; }   // clamped loads, predicated stores
-    TileOps ops[TM][TNW];
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-        for (int t = 0; t < TNW; ++t) gemm_prefetch_tile<P, EPI>(g, m0s[mi], (nt0 + t) * 16, lr, lg, step, ops[mi][t]);
-
-    // ---- A side: LayerNorm of TM x 16 rows into LDS (loads of all tiles first), or the activation fragments themselves
-    f32x4 af[PRO == PRO_DIRECT ? TM : 1][CH];
-    int pitch = 0;
-    if constexpr (PRO == PRO_LN) {
-        const int D = g.D, nch = D >> 6;
-        pitch = DSG_LDS_ROW_BYTES(D, ES);
-        const int row = tid >> 4, c = tid & 15;
-        f32x4 v[TM][8], gg[8], bb[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int col = c * 4 + 64 * (i < nch ? i : 0);
-            gg[i] = *(const f32x4*)(g.ln_g + col);
-            bb[i] = *(const f32x4*)(g.ln_b + col);
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi) v[mi][i] = *(const f32x4*)(g.X + (size_t)(m0s[mi] + row) * D + col);
-        }
-        DSG_LOADS_ISSUED();
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) s += (i < nch ? 1.f : 0.f) * ((v[mi][i][0] + v[mi][i][1]) + (v[mi][i][2] + v[mi][i][3]));
-            s = row16_sum(s);
-            const float mean = s / (float)D;
-            float q = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { const float d = v[mi][i][e] - mean; q += (i < nch ? 1.f : 0.f) * d * d; }
-            q = row16_sum(q);
-            const float rstd = 1.0f / sqrtf(q / (float)D + 1e-5f);
-            const bool wr = (g.Xn != nullptr) && ng == 0 && live[mi] && (m0s[mi] + row) < g.M;
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (i < nch) {
-                    f32x4 y;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) y[e] = (v[mi][i][e] - mean) * rstd * gg[i][e] + bb[i][e];
-                    P::store4((elem*)(lds_a + (mi * 16 + row) * pitch) + c * 4 + 64 * i, y);
-                    if (wr) *(f32x4*)(g.Xn + (size_t)(m0s[mi] + row) * D + c * 4 + 64 * i) = y;
-                }
-        }
-        DSG_LDS_BARRIER();
-    } else {
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
-            const elem* arow = (const elem*)g.A + (size_t)(m0s[mi] + lr) * g.lda + P::E * lg;
-#pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                const int kb = min(c, kb_last);
-                const elem* ap = g.a_frag ? (const elem*)g.A + ((size_t)((m0s[mi] >> 4) * g.KBtot + kb) * 64 + lane) * P::E : arow + (size_t)kb * P::KB;
-                af[mi][c] = *(const f32x4*)ap;
-            }
-        }
-        DSG_LOADS_ISSUED();
-    }
-    f32x4 acc[TM][TNW];
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-        for (int t = 0; t < TNW; ++t) acc[mi][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-        const bool on = c < g.KBtot;                 // wave-uniform; k-blocks past the end contribute zeros
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
-            f32x4 a;
-            if constexpr (PRO == PRO_DIRECT) a = af[mi][c];
-            else a = *(const f32x4*)(lds_a + (mi * 16 + lr) * pitch + (min(c, kb_last) * P::KB + P::E * lg) * ES);
-            a = on ? a : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int t = 0; t < TNW; ++t)
-                acc[mi][t] = swapped[t] ? P::mma(bf[c][t], a, acc[mi][t]) : P::mma(a, bf[c][t], acc[mi][t]);
-        }
-    }
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi)
-        if (live[mi]) {
-#pragma unroll
-            for (int t = 0; t < TNW; ++t)
-                gemm_epilogue_tile<P, EPI>(g, m0s[mi], (nt0 + t) * 16, lr, lg, 0, swapped[t], acc[mi][t], ops[mi][t], k1, k2, k3, k4, k5);
-        }
-}
-
 // batched LayerNorm-GEMM: compiled for 3 waves per SIMD (<= 168 VGPRs; at 128 it spills to scratch; requesting the weights
 // only after the LayerNorm fits 5 waves per SIMD but measured slower: 370 vs 360 us/step at batch 16), see ln_rows LEAN
 template <class P, int EPI>
@@ -1026,11 +756,8 @@ __global__ __launch_bounds__(256, 3) void k_gemm_lean(const GemmArgs g) { gemm_b
 template <class P>
 __global__ __launch_bounds__(256) void k_gemm_cfg(const GemmArgs g) { gemm_body<P, PRO_LN, EPI_OUT, 4, 1, 1, false, true>(g); }
 
-template <class P, int PRO, int EPI, int WN, int WK, int TNW, int TM = 1>
-__global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
-    if constexpr (TM == 1) gemm_body<P, PRO, EPI, WN, WK, TNW>(g);
-    else { static_assert(WN == 4 && WK == 1, "multi-tile shape: 4 waves side by side"); gemm_body_mt<P, PRO, EPI, TNW, TM>(g); }
-}
+template <class P, int PRO, int EPI, int WN, int WK, int TNW>
+__global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) { gemm_body<P, PRO, EPI, WN, WK, TNW>(g); }
 // ---------------------------------------------------------------------------------------------------------
 // k_loc: per (batch, window, local head).  h = sum_s partial_s + Cframe + TE2[t]; rotary(pos = frame);
 //        causal local attention over {previous window, own window} with q = k = v; prepend token; rotary(pos+1)
@@ -1200,7 +927,6 @@ struct AttnArgs {
     const void* q; const void* k; const void* vt;   // [B][H][Tp][hd], [B][H][Tp][hd], [B][H][hd][Tp]
     void* out;                                       // [M_pad][D] P::elem
     int B, H, ntok, Tp, D;
-    unsigned* done_ctr;                              // producer counter for the overlapped consumer (k_mid), or null
 };
 
 template <class P, int HD, int NKT>
@@ -1311,11 +1037,9 @@ __global__ __launch_bounds__(64) void k_attn(const AttnArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = o[e] * inv;
             elem* dst = (elem*)a.out + qk_off<P>(b * a.ntok + q, h * HD + dt * 16 + 4 * lg, a.D / P::KB);      // fragment-major rows (the next GEMM's A operand)
-            if (a.done_ctr) P::store4_agent(dst, y);       // read by an overlapped consumer on other XCDs: write through
-            else P::store4(dst, y);
+            P::store4(dst, y);
         }
     }
-    if (a.done_ctr) dep_signal(a.done_ctr, lane == 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1386,6 +1110,26 @@ __global__ void k_x_out(const float* xs32, float* out, int B, int J, int Jp, int
         const int j = (int)(bj % J), b = (int)(bj / J);
         out[i] = xs32[((size_t)b * T + f) * Jp + j];
     }
+}
+// Self-check of the fence-free hand-off (dsg_hip.cpp: uc_selfcheck): `buf` is uncached device memory; the two kernels run as
+// dependent AQL packets WITHOUT acquire / release, 64 times over.  Writer workgroup b fills chunk b with a pattern of the
+// iteration; reader workgroup b verifies chunk b + 1 -- written on another XCD -- and counts stale words.  The iteration
+// words follow the StepCtl protocol (no kernel reads what it writes; an extra workgroup advances the other kernel's word).
+struct UcProbeArgs { unsigned* buf; int* ctl; unsigned* err; int n_wg; };
+__device__ __forceinline__ unsigned uc_probe_pattern(unsigned i, unsigned it) { return (i * 2654435761u) ^ (it * 0x9E3779B9u) ^ 0x5bd1e995u; }
+__global__ __launch_bounds__(256) void k_uc_probe_w(const UcProbeArgs a) {
+    const int it = ldw<PF32>(&a.ctl[0]);
+    const int b = blockIdx.x;
+    if (b == a.n_wg) { if (threadIdx.x == 0) a.ctl[1] = it; return; }
+    const unsigned i = (unsigned)b * 256u + threadIdx.x;
+    a.buf[i] = uc_probe_pattern(i, (unsigned)it);
+}
+__global__ __launch_bounds__(256) void k_uc_probe_r(const UcProbeArgs a) {
+    const int it = ldw<PF32>(&a.ctl[1]);
+    const int b = blockIdx.x;
+    if (b == a.n_wg) { if (threadIdx.x == 0) { a.ctl[0] = it + 1; a.err[1] = (unsigned)(it + 1); } return; }
+    const unsigned i = (unsigned)((b + 1) % a.n_wg) * 256u + threadIdx.x;
+    if (a.buf[i] != uc_probe_pattern(i, (unsigned)it)) __hip_atomic_fetch_add(&a.err[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __global__ void k_ctr_set(int* ctr, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) *ctr = v; }
 __global__ void k_ctr_inc(int* ctr) { if (threadIdx.x == 0 && blockIdx.x == 0) *ctr += 1; }

@@ -122,13 +122,17 @@ class DSGDiffusion:
             raise NotImplementedError("denoised_fn / cond_fn / randomize_class / cond_fn_with_grad are not supported")
 
     @staticmethod
-    def _library_model(model):
+    def _library_model(model, batch=None):
         """(denoiser, guided) when the whole step loop can run inside the library: a DSGDenoiser, or the classifier-free
-        guidance wrapper around one with room for the unconditional twins."""
+        guidance wrapper around one WITH ROOM for the unconditional twins (max_batch >= 2 * batch).  A wrapper around a
+        smaller denoiser is not a library model: the generic loop takes it (two library calls per step, the same Philox
+        stream), as it did before guidance was fused."""
         from .model import ClassifierFreeSampleModel, DSGDenoiser
         if isinstance(model, DSGDenoiser):
             return model, False
         if isinstance(model, ClassifierFreeSampleModel) and isinstance(model.model, DSGDenoiser):
+            if batch is not None and model.model.max_batch < 2 * int(batch):
+                return None, False
             return model.model, True
         return None, False
 
@@ -195,12 +199,44 @@ class DSGDiffusion:
                       randomize_class=False, cond_fn_with_grad=False, dump_steps=None, const_noise=False,
                       *, step_noise=None, seed=None, draw_base=None):
         self._check_unsupported(denoised_fn, cond_fn, randomize_class, cond_fn_with_grad)
-        inner, guided = self._library_model(model)
+        inner, guided = self._library_model(model, shape[0])
         if inner is not None:
             return self._fused(L.MODE_DDPM, inner, guided, shape, noise, model_kwargs, skip_timesteps, init_image,
                                dump_steps, const_noise, 0.0, step_noise, seed, draw_base, clip_denoised)
         return self._generic_loop(False, model, shape, noise, model_kwargs, skip_timesteps, init_image, dump_steps,
                                   const_noise, 0.0, device, clip_denoised)
+
+    def _progressive(self, ddim, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device, skip_timesteps,
+                     init_image, randomize_class, cond_fn_with_grad, const_noise, eta):
+        """Generator form of the loops: one {"sample": x_{t-1}} per denoising step, in loop order.  The steps run inside the
+        library in ONE call (every step's sample is dumped: the eager HIP-launch path), then are handed out one by one -- the
+        reference computes them lazily, which only matters to a caller that abandons the generator early."""
+        self._check_unsupported(denoised_fn, cond_fn, randomize_class, cond_fn_with_grad)
+        inner, guided = self._library_model(model, shape[0])
+        n_run = self.num_timesteps - skip_timesteps
+        if inner is not None:
+            outs = self._fused(L.MODE_DDIM if ddim else L.MODE_DDPM, inner, guided, shape, noise, model_kwargs, skip_timesteps,
+                               init_image, list(range(n_run)), const_noise, eta, None, None, None, clip_denoised)
+        else:
+            outs = self._generic_loop(ddim, model, shape, noise, model_kwargs, skip_timesteps, init_image, list(range(n_run)),
+                                      const_noise, eta, device, clip_denoised)
+        for o in outs:
+            yield {"sample": o}
+
+    def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                                  model_kwargs=None, device=None, progress=False, skip_timesteps=0, init_image=None,
+                                  randomize_class=False, cond_fn_with_grad=False, const_noise=False):
+        """`GaussianDiffusion.p_sample_loop_progressive` (gaussian_diffusion.py:673-740): yields a dict per step; key "sample"
+        (the reference's "pred_xstart" is not produced: no caller on the path reads it)."""
+        return self._progressive(False, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device, skip_timesteps,
+                                 init_image, randomize_class, cond_fn_with_grad, const_noise, 0.0)
+
+    def ddim_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                                     model_kwargs=None, device=None, progress=False, eta=0.0, skip_timesteps=0, init_image=None,
+                                     randomize_class=False, cond_fn_with_grad=False):
+        """`GaussianDiffusion.ddim_sample_loop_progressive` (gaussian_diffusion.py:938-1003)."""
+        return self._progressive(True, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device, skip_timesteps,
+                                 init_image, randomize_class, cond_fn_with_grad, False, eta)
 
     def p_sample_loop_multi(self, models, shape, model_kwargs_list, *, seeds=None, stream_ids=None, clip_denoised=False,
                             skip_timesteps=0, init_images=None, noises=None, ddim=False, eta=0.0):
@@ -208,7 +244,9 @@ class DSGDiffusion:
         `clone()`s: one copy of the weights), one independent sampling problem each, advanced concurrently inside the
         library (dsg_sample_multi: every lane owns an HSA queue; "one clip per stream").  Lane i draws from the Philox stream
         (seeds[i], stream_ids[i]) at this object's current draw counter, which advances once for all lanes -- so lane i
-        reproduces `manual_seed(seeds[i], stream_ids[i])` + the same sequence of single-lane calls bit for bit."""
+        reproduces `manual_seed(seeds[i], stream_ids[i])` + the same sequence of single-lane calls ON THE SAME LANE bit for
+        bit: every lane runs the kernel set of its own handle (`DSGDenoiser.set_kernel_set`), the call itself changes nothing
+        about the arithmetic."""
         models = list(models)
         n = len(models)
         if n == 0 or len(model_kwargs_list) != n:
@@ -219,7 +257,7 @@ class DSGDiffusion:
         args = (L.dsg_sample_args * n)()
         outs, keeps, use_torch = [], [], False
         for i, m in enumerate(models):
-            inner, guided = self._library_model(m)
+            inner, guided = self._library_model(m, shape[0])
             if inner is None:
                 raise TypeError("p_sample_loop_multi drives library denoisers (DSGDenoiser lanes)")
             a, keep, _, ut = self._prepare(L.MODE_DDIM if ddim else L.MODE_DDPM, inner, guided, shape,
@@ -251,7 +289,7 @@ class DSGDiffusion:
         if const_noise:
             raise NotImplementedError()
         self._check_unsupported(denoised_fn, cond_fn, randomize_class, cond_fn_with_grad)
-        inner, guided = self._library_model(model)
+        inner, guided = self._library_model(model, shape[0])
         if inner is not None:
             return self._fused(L.MODE_DDIM, inner, guided, shape, noise, model_kwargs, skip_timesteps, init_image, None,
                                False, eta, step_noise, seed, draw_base, clip_denoised)

@@ -16,6 +16,8 @@ DEFAULT_LIB = os.path.join(_HERE, "csrc", "libdsg_hip.so")
 E_INVALID, E_RUNTIME, E_UNEXPECTED_KEY, E_MISSING_KEY, E_NOT_IMPLEMENTED, E_STATE = -1, -2, -3, -4, -5, -6
 PREC_FP32, PREC_BF16 = 0, 1
 MODE_DDPM, MODE_DDIM = 0, 1
+KERNEL_SETS = {"auto": 0, "latency": 1, "tile": 2, "block": 3}          # DSG_KSET_* of include/dsg.h
+KERNEL_SET_NAMES = {v: k for k, v in KERNEL_SETS.items()}
 
 
 class dsg_config(C.Structure):
@@ -51,6 +53,9 @@ SYMBOLS = {
     "dsg_forward": (_I, [_P, _P, _P, _P, _I, _P]),
     "dsg_sample": (_I, [_P, C.POINTER(dsg_sample_args), _P, _I, _P]),
     "dsg_sample_multi": (_I, [C.POINTER(_P), _I, C.POINTER(dsg_sample_args), C.POINTER(_P), _I, _P]),
+    "dsg_set_kernel_set": (_I, [_P, _I]),
+    "dsg_recommend_kernel_set": (_I, [_P, _I, _I, C.POINTER(_I)]),
+    "dsg_last_kernel_set": (_I, [_P, C.POINTER(_I)]),
     "dsg_sync": (_I, [_P]),
     "dsg_last_sample_ms": (_I, [_P, C.POINTER(C.c_float), C.POINTER(_I)]),
     "dsg_last_sample_path": (_I, [_P, C.POINTER(_I)]),
@@ -88,7 +93,7 @@ class DSGLibrary:
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(self.cdll, name)          # AttributeError if the library does not export it
             fn.restype, fn.argtypes = res, args
-        if self.cdll.dsg_version() < 201:
+        if self.cdll.dsg_version() < 300:
             raise DSGError("libdsg_hip.so is older than this package")
 
     def check(self, rc: int):

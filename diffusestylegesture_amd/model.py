@@ -174,12 +174,31 @@ class DSGDenoiser:
         self.lib.check(self.lib.cdll.dsg_sync(self.handle))
 
     def last_sample_path(self) -> str:
-        """How the step loop of the last sampling call was submitted: "hip" launches, hand-written "aql" packets, "graph"
-        replays, "aql-pinned" (XCD-pinned lanes: shared dispatches without fences) or "hip-pinned" (the pinned kernels through
-        HIP launches: DSG_PIN=2, tests)."""
+        """How the step loop of the last sampling call was submitted: "hip" launches, hand-written "aql" packets or "graph"
+        replays."""
         p = C.c_int()
         self.lib.check(self.lib.cdll.dsg_last_sample_path(self.handle, C.byref(p)))
-        return {0: "hip", 1: "aql", 2: "graph", 3: "aql-pinned", 4: "hip-pinned"}[p.value]
+        return {0: "hip", 1: "aql", 2: "graph"}[p.value]
+
+    # ---- kernel sets (include/dsg.h DSG_KSET_*) -------------------------------------------------------------------
+    def set_kernel_set(self, name: str):
+        """Which hand-written kernels a denoising step of this lane is made of: "auto" (by batch), "latency", "tile", "block".
+        Sticky; `clone()`s made afterwards inherit it.  Sets differ in the last bits (bf16): a lane reproduces another run bit
+        for bit only under the same set."""
+        self.lib.check(self.lib.cdll.dsg_set_kernel_set(self.handle, L.KERNEL_SETS[name]))
+        return self
+
+    def recommend_kernel_set(self, batch: int, lanes: int = 1) -> str:
+        """The set measured fastest for `lanes` lanes of `batch` clips advanced together (dsg_recommend_kernel_set)."""
+        p = C.c_int()
+        self.lib.check(self.lib.cdll.dsg_recommend_kernel_set(self.handle, int(batch), int(lanes), C.byref(p)))
+        return L.KERNEL_SET_NAMES[p.value]
+
+    def last_kernel_set(self) -> str:
+        """The set the last forward / sampling call of this lane ran."""
+        p = C.c_int()
+        self.lib.check(self.lib.cdll.dsg_last_kernel_set(self.handle, C.byref(p)))
+        return L.KERNEL_SET_NAMES[p.value]
 
     def last_sample_fence_free(self) -> bool:
         """True when the AQL packets of the last sampling call's loop carried no acquire / release fences (loop-written buffers

@@ -109,13 +109,15 @@ def generate_clip(model, diffusion, feats, style, seed=123456, smoothing=True, s
 
 
 def generate_clips_streams(lanes, diffusion, feats_per_lane, styles, seed=123456, smoothing=True, skip_timesteps=0,
-                           stream_ids=None, ddim=False, eta=0.0):
+                           stream_ids=None, ddim=False, eta=0.0, kernel_set="recommended"):
     """Several clips of one GPU advanced concurrently on sampling LANES ("one clip per stream", BASELINE config[3]): `lanes`
     are N DSGDenoiser lanes over one copy of the weights (`model.clone()`); lane i samples the B clips of
     feats_per_lane[i] (K per-window features [B, T, A_src]; B = 1: one clip per lane) on its own HSA queue and the library
     interleaves the lanes' step loops (DSGDiffusion.p_sample_loop_multi).  Same window loop / stitching as `generate_clip`;
-    lane i uses the Philox stream (seed, stream_ids[i]) and is bit-identical to `generate_clip(..., stream_id=stream_ids[i])`
-    run alone.  The command processor serves one queue per compute pipe: up to 4 lanes overlap, more than 4 share pipes and
+    lane i uses the Philox stream (seed, stream_ids[i]) and is bit-identical to `generate_clip(lanes[i], ..., stream_id=
+    stream_ids[i])` run alone on the same lane.  `kernel_set`: "recommended" applies the set measured fastest for this many
+    lanes x this batch to every lane (sticky: `DSGDenoiser.set_kernel_set`), None leaves the lanes as they are, a name forces
+    that set.  The command processor serves one queue per compute pipe: up to 4 lanes overlap, more than 4 share pipes and
     block each other (measured: 4 lanes 2.7x one lane, 8 lanes slower than one) -- put the remaining clips into the lanes'
     batches.  Returns [N * B, K*stride - n_seed, J], lane-major."""
     n = len(lanes)
@@ -127,6 +129,10 @@ def generate_clips_streams(lanes, diffusion, feats_per_lane, styles, seed=123456
     use_torch = L.is_torch(feats_per_lane[0][0])
     B = int(feats_per_lane[0][0].shape[0])
     stream_ids = list(range(n)) if stream_ids is None else list(stream_ids)
+    if kernel_set is not None:
+        ks = lanes[0].recommend_kernel_set(B, n) if kernel_set == "recommended" else kernel_set
+        for ln in lanes:
+            ln.set_kernel_set(ks)
     diffusion.manual_seed(seed, 0)
     shape = (B, J, 1, T)
     dev = feats_per_lane[0][0].device if use_torch else None

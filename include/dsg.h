@@ -22,7 +22,7 @@
  *        GaussianDiffusion.p_sample_loop / ddim_sample_loop          main/diffusion/gaussian_diffusion.py:608-671, :889-936
  *   dsg_set_window_cond_cfg
  *        ClassifierFreeSampleModel.forward (y['scale'], y['uncond'])   main/model/cfg_sampler.py:8-31
- *   dsg_clone / dsg_sample_multi
+ *   dsg_clone / dsg_sample_multi / dsg_set_kernel_set / dsg_recommend_kernel_set / dsg_last_kernel_set
  *        (no reference counterpart: the reference samples one clip at a time, sample.py:418 batch_size = 1; these run
  *         several clips of one GPU concurrently over one copy of the weights -- BASELINE config[3] "one clip per stream")
  *   dsg_noise
@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define DSG_VERSION 201
+#define DSG_VERSION 300
 
 enum {
     DSG_OK = 0,
@@ -61,6 +61,15 @@ enum {
 };
 
 enum { DSG_PREC_FP32 = 0, DSG_PREC_BF16 = 1 };
+/* kernel sets (dsg_set_kernel_set): which hand-written kernels one denoising step is made of.  Same arithmetic, different
+ * grouping / tiling, i.e. last-bit differences between sets in bf16 -- which is why the set is an explicit, sticky property of
+ * a handle and never depends on how a call is issued. */
+enum {
+    DSG_KSET_AUTO = 0,      /* by batch: LATENCY for batch <= 2, TILE below 1000 token rows, BLOCK from there */
+    DSG_KSET_LATENCY = 1,   /* fused redundant-compute kernels, 2 + 3L dispatches: one clip in flight */
+    DSG_KSET_TILE = 2,      /* one 16 x 16 MFMA tile per wave: small batches */
+    DSG_KSET_BLOCK = 3      /* 32-row block GEMMs + fused attention/out_proj/LayerNorm: large batches, several lanes */
+};
 enum { DSG_MODE_DDPM = 0, DSG_MODE_DDIM = 1 };
 
 typedef struct dsg_config {
@@ -83,7 +92,7 @@ typedef struct dsg_config {
     int32_t precision;      /* DSG_PREC_* */
     int32_t device;         /* HIP device ordinal */
     int32_t steps_per_graph;/* > 0: denoising steps captured per hipGraph replay; 0 = default (eager: measured faster), -1 = eager */
-    int32_t latency_mode;   /* 0 = auto (fused redundant-compute kernels when batch <= 4), 1 = never, 2 = always */
+    int32_t latency_mode;   /* DSG_KSET_AUTO only: 0 = by batch, 1 = never the LATENCY set, 2 = always */
     int32_t reserved[4];
 } dsg_config;
 
@@ -154,21 +163,27 @@ typedef struct dsg_sample_args {
  * returns when the steps have run; with HIP launches (DSG_AQL=0, or under a profiler) it only enqueues and is asynchronous
  * w.r.t. the host when `out` is device memory. */
 int dsg_sample(dsg_handle* h, const dsg_sample_args* args, float* out, int B, void* stream);
-/* n lanes (a handle and its dsg_clone()s: one device, shared weights), one independent sampling call each, run
+/* n lanes (a handle and its dsg_clone()s: one device, shared weights; n <= 16), one independent sampling call each, run
  * concurrently from this one host thread -- "one clip per stream": every lane owns an HSA queue, the dependent packet chains
- * of the lanes overlap on the GPU.  args[n], outs[n]; every lane samples a batch of B.  Results are bit-identical to n
- * separate dsg_sample calls. */
+ * of the lanes overlap on the GPU.  args[n], outs[n]; every lane samples a batch of B.  Every lane runs the kernel set of ITS
+ * handle, so lane i's result is bit-identical to dsg_sample(lanes[i], &args[i], outs[i], B, stream) issued on its own. */
 int dsg_sample_multi(dsg_handle** lanes, int n, const dsg_sample_args* args, float** outs, int B, void* stream);
+/* Kernel set of a handle (DSG_KSET_*; sticky; clones inherit the source's at dsg_clone).  dsg_recommend_kernel_set: the set
+ * measured fastest for `lanes` lanes of batch B advanced together (lanes = 1: what DSG_KSET_AUTO picks) -- several lanes share
+ * the CUs and prefer the throughput-shaped sets earlier; the caller applies it to each lane.  dsg_last_kernel_set: the set the
+ * last dsg_forward / dsg_sample of the handle ran. */
+int dsg_set_kernel_set(dsg_handle* h, int set);
+int dsg_recommend_kernel_set(dsg_handle* h, int B, int lanes, int* set);
+int dsg_last_kernel_set(dsg_handle* h, int* set);
 int dsg_sync(dsg_handle* h);
 /* time of the step loop of the last dsg_sample (HIP events on the handle's stream; AQL path: first doorbell to the completion
  * signal of the last packet), and its step count */
 int dsg_last_sample_ms(dsg_handle* h, float* ms, int* n_steps);
-/* how the step loop of the last dsg_sample was submitted: 0 = HIP launches, 1 = hand-written AQL packets, 2 = hipGraph replay,
- * 3 = AQL packets of XCD-pinned lanes (batch 1, bf16: up to 8 handles per dispatch, lane l on XCD l, no fences between the
- * packets of the loop), 4 = the pinned kernels through HIP launches (DSG_PIN=2; tests) */
+/* how the step loop of the last dsg_sample was submitted: 0 = HIP launches, 1 = hand-written AQL packets, 2 = hipGraph replay */
 int dsg_last_sample_path(dsg_handle* h, int* path);
 /* 1 when the AQL packets of that loop carried no acquire / release fences: the buffers the loop writes live in uncached device
- * memory (default for handles of max_batch <= 16; DSG_UC=0 selects cached buffers + agent-scope fences), or path 3 */
+ * memory (default for handles of max_batch <= 16; DSG_UC=0 selects cached buffers + agent-scope fences) and the one-time
+ * hand-off self-check of the device passed */
 int dsg_last_sample_fence_free(dsg_handle* h, int* fence_free);
 /* the framework's noise stream as a tensor: out [B, J, 1, T] (device) = draw `draw` of (seed, stream_id), i.e. exactly the
  * noise the fused sampler uses for that draw index (x_T is draw_base, step i is draw_base + 1 + i).  Stands in for

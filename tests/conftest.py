@@ -16,6 +16,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _blas_threads():
+    """The numpy oracle multiplies small matrices (89 x 256 x 1024 at most): on a 256-thread host the default BLAS pool is ~20x
+    SLOWER than 8 threads (bench.py's cpu_baseline sweep finds the same), which turned the oracle-backed GPU tests into a
+    17-minute run.  Every test runs under an 8-thread limit."""
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:
+        yield
+        return
+    with threadpool_limits(limits=8):
+        yield
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

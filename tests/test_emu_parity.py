@@ -136,31 +136,67 @@ def test_classifier_free_guidance_wrapper(tiny):
         w(x, ts, y)
 
 
-@pytest.mark.parametrize("tnw,tm,lean", [("2", "1", "0"), ("1", "4", "0"), ("2", "4", "0"), ("1", "1", "1")])
-def test_batched_gemm_workgroup_shapes(tiny, emu_lib, golden_dir, tnw, tm, lean, monkeypatch):
-    """The batched path runs 4 row tiles per workgroup (weight fragments reused; selected by batch size on the GPU, forced
-    here) and can widen a workgroup to 2 column tiles per wave: same results as the batch-1 shape for every GEMM
-    epilogue, at the tiny dims (ragged last row tile) and at the ZEGGS dims."""
-    monkeypatch.setenv("DSG_GEMM_TNW", tnw)
-    monkeypatch.setenv("DSG_GEMM_TM", tm)
-    monkeypatch.setenv("DSG_GEMM_LEAN", lean)          # "1": the high-occupancy LayerNorm GEMM the batched path uses from batch 6 up
+@pytest.mark.parametrize("kset", ["tile", "block"])
+def test_kernel_sets_tiny(tiny, emu_lib, golden_dir, kset):
+    """Explicit kernel sets (dsg_set_kernel_set) at the tiny dims against the same goldens as the latency kernels, incl. the
+    ragged last row tile (bf16: with k_attn_op); at batch 8 and batch 23 (529 rows: the 3-waves-per-SIMD LayerNorm GEMMs from
+    512 rows) against the oracle; the set that ran is reported (dsg_last_kernel_set) and sticky."""
+    from oracle.mdm import MDMOracle
     gt, _, y, x = tiny
+    sd = synth_state_dict(C.TINY, int(gt["wseed"]))
     for prec in ("fp32", "bf16"):
-        m = DSGDenoiser(C.TINY, precision=prec, max_batch=2, library=emu_lib, latency_mode="off")
-        m.load_state_dict(synth_state_dict(C.TINY, int(gt["wseed"])))
+        m = DSGDenoiser(C.TINY, precision=prec, max_batch=2, library=emu_lib).set_kernel_set(kset)
+        m.load_state_dict(sd)
         assert rel_l2(m(x, np.array([998, 17]), dict(y, mask_local=gt["mask2"])), gt["fwd_mask2"]) < TOL[prec]
+        assert m.last_kernel_set() == kset
     d = create_gaussian_diffusion(library=emu_lib)
     s = d.manual_seed(77, 3).p_sample_loop(m, (2, C.TINY.njoints, 1, C.TINY.n_poses), clip_denoised=False,
                                            model_kwargs={"y": y}, skip_timesteps=990)
-    assert rel_l2(s, gt["ddpm_skip990"]) < TOL["bf16"]
-    if lean == "1":
+    assert rel_l2(s, gt["ddpm_skip990"]) < TOL["bf16"] and m.last_kernel_set() == kset
+    ref = MDMOracle(sd, C.TINY)
+    for B, precs in ((8, ("bf16",)), (23, ("fp32", "bf16"))):
+        yb = synth_window_inputs(C.TINY, B, window=1, seed_pose_scale=0.3)
+        xb = np.random.RandomState(B).randn(B, C.TINY.njoints, 1, C.TINY.n_poses).astype(np.float32)
+        ts = np.arange(B) * 40 + 3
+        want = ref(xb, list(ts), yb)
+        for prec in precs:
+            mb = DSGDenoiser(C.TINY, precision=prec, max_batch=B, library=emu_lib).set_kernel_set(kset)
+            mb.load_state_dict(sd)
+            assert rel_l2(mb(xb, ts, yb), want) < TOL[prec], (B, prec)
+    if kset == "tile":
         g2 = _g(golden_dir, "g2_forward_zeggs.npz")
         cfg = C.ZEGGS
-        mz = DSGDenoiser(cfg, precision="fp32", max_batch=2, library=emu_lib, latency_mode="off")
+        mz = DSGDenoiser(cfg, precision="fp32", max_batch=2, library=emu_lib).set_kernel_set("tile")
         mz.load_state_dict(synth_state_dict(cfg, int(g2["wseed"])))
         yz = synth_window_inputs(cfg, 2, window=1, seed_pose_scale=0.5)
         xz = np.random.RandomState(4244).randn(2, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
         assert rel_l2(mz(xz, np.array([999, 3]), yz), g2["b2_t999_3_out"]) < TOL["fp32"]
+
+
+def test_kernel_set_is_a_property_of_the_lane_not_of_the_call(tiny, emu_lib):
+    """Round-2 advisor finding: the same (handle, batch, seed) must give the same bits whether it is sampled alone or as one
+    lane of dsg_sample_multi, also at batch >= 2 per lane -- the kernel set is chosen per handle (explicitly, or by batch),
+    never by the number of lanes in the call.  `recommend_kernel_set` is what differs with the lane count."""
+    gt, _, _, _ = tiny
+    cfg = C.TINY
+    m = DSGDenoiser(cfg, precision="bf16", max_batch=2, library=emu_lib)
+    m.load_state_dict(synth_state_dict(cfg, int(gt["wseed"])))
+    assert m.recommend_kernel_set(1, 1) == "latency" and m.recommend_kernel_set(2, 1) == "latency"
+    assert m.recommend_kernel_set(1, 4) == "latency" and m.recommend_kernel_set(2, 4) == "tile"
+    assert m.recommend_kernel_set(14, 4) == "block" and m.recommend_kernel_set(14, 1) == "tile" and m.recommend_kernel_set(44, 1) == "block"
+    shape = (2, cfg.njoints, 1, cfg.n_poses)
+    d = create_gaussian_diffusion(library=emu_lib)
+    ys = [{"y": synth_window_inputs(cfg, 2, window=w, clip0=2 * w, seed_pose_scale=0.2)} for w in range(2)]
+    for kset in ("auto", "tile", "block"):
+        lanes = [m.set_kernel_set(kset), m.clone()]
+        multi = d.manual_seed(9, 0).p_sample_loop_multi(lanes, shape, ys, seeds=[9, 9], stream_ids=[0, 1], skip_timesteps=994)
+        want_set = "latency" if kset == "auto" else kset
+        assert all(ln.last_kernel_set() == want_set for ln in lanes)
+        for i in range(2):
+            alone = d.manual_seed(9, i).p_sample_loop(lanes[i], shape, clip_denoised=False, model_kwargs=ys[i], skip_timesteps=994)
+            assert np.array_equal(multi[i], alone), (kset, i)
+    with pytest.raises(ValueError):
+        emu_lib.check(emu_lib.cdll.dsg_set_kernel_set(m.handle, 9))
 
 
 def test_error_behaviour(tiny, emu_lib):

@@ -62,10 +62,12 @@ def test_guidance_fused_forward_and_chain(emu_lib, golden_dir, prec):
     r = sampler.ddim_sample_loop(OracleDiffusion(timestep_respacing="ddim50"), sampler.CFGModel(ref), shape,
                                  sampler.philox_noise_fn(shape, 22, 1), {"y": dict(y, scale=scale)}, skip_timesteps=44, eta=0.5)
     assert rel_l2(s, r) < 3 * TOL[prec]
-    # guidance needs room for the twins
+    # the fused loop needs room for the twins; a wrapper around a smaller denoiser is handed to the generic loop (two library
+    # calls per step, the same Philox stream -- executed on the GPU by test_gpu_round3.py), it does not raise
     small = _model(cfg, prec, emu_lib, max_batch=2, wseed=int(gt["wseed"]))
-    with pytest.raises(ValueError, match="max_batch"):
-        d.p_sample_loop(ClassifierFreeSampleModel(small), shape, clip_denoised=False, model_kwargs={"y": dict(y, scale=scale)}, skip_timesteps=998)
+    assert d._library_model(ClassifierFreeSampleModel(small), 2) == (None, False)
+    assert d._library_model(ClassifierFreeSampleModel(small), 1) == (small, True)
+    assert d._library_model(small, 2) == (small, False)
 
 
 def test_guidance_dsgplus_variants(emu_lib):
@@ -162,21 +164,11 @@ def test_attention3_beat_twh_tree(emu_lib, golden_dir, cfgname):
         assert rel_l2(m(x, np.array([ts] * B), y, uncond_info=True), g[cfgname + "_uncond"]) < TOL[prec]
 
 
-@pytest.mark.parametrize("tnw", ["1", "2", "tp"])
-def test_block_gemms_of_the_batched_path(emu_lib, golden_dir, monkeypatch, tnw):
-    """dsg_batched.h (64-row block GEMMs, used from 512 rows up) forced on at the small test dims (DSG_GEMM_BLK=1, un-fused
-    kernel set): forward with masks / uncond, DDPM + DDIM chains, guidance, the DSG+ / DSG++ models, and ZEGGS dims at batch 2
-    -- against the same reference goldens as the latency kernels"""
-    zeggs_too = tnw == "2"
-    if tnw == "tp":                                          # k_gemm_tp: the BM x 128 blocks (experiment, off by default)
-        monkeypatch.setenv("DSG_GEMM_TP", "1")
-        monkeypatch.setenv("DSG_GEMM_TP_MASK", "127")
-        tnw = "2"
-    monkeypatch.setenv("DSG_ATTN_OP", "1")                   # attention + out_proj + LayerNorm1 fused (k_attn_op), as from 256 rows up
-    monkeypatch.setenv("DSG_GEMM_BLK", "1")
-    monkeypatch.setenv("DSG_GEMM_BLK_MASK", "127")          # every GEMM of the step, not only the ones the default mask selects
-    monkeypatch.setenv("DSG_GEMM_BLK_RT", "4" if tnw == "2" else "2")
-    monkeypatch.setenv("DSG_GEMM_BLK_TNW", tnw)
+def test_block_gemms_of_the_batched_path(emu_lib, golden_dir):
+    """Kernel set "block" (dsg_batched.h: 32-row block GEMMs for QKV / linear1 / linear2 / embedding, used from 1000 rows up)
+    forced at the small test dims: forward with masks / uncond, DDPM + DDIM chains, guidance, the DSG+ / DSG++ models, and ZEGGS
+    dims at batch 2 -- against the same reference goldens as the latency kernels"""
+    zeggs_too = True
     gt = _g(golden_dir, "gt_tiny_zeggs.npz")
     cfg = C.TINY
     y = synth_window_inputs(cfg, 2, window=2, seed_pose_scale=0.3)
@@ -184,7 +176,7 @@ def test_block_gemms_of_the_batched_path(emu_lib, golden_dir, monkeypatch, tnw):
     ts = np.array([998, 17])
     shape = (2, cfg.njoints, 1, cfg.n_poses)
     for prec in ("fp32", "bf16"):
-        m = _model(cfg, prec, emu_lib, max_batch=4, wseed=int(gt["wseed"]), latency_mode="off")
+        m = _model(cfg, prec, emu_lib, max_batch=4, wseed=int(gt["wseed"])).set_kernel_set("block")
         assert rel_l2(m(x, ts, y), gt["fwd_allones"]) < TOL[prec]
         assert rel_l2(m(x, ts, dict(y, mask_local=gt["mask2"])), gt["fwd_mask2"]) < TOL[prec]
         assert rel_l2(m(x, ts, y, uncond_info=True), gt["fwd_uncond"]) < TOL[prec]
@@ -201,69 +193,13 @@ def test_block_gemms_of_the_batched_path(emu_lib, golden_dir, monkeypatch, tnw):
     for cfg, gold in ((C.TINY4, g5["tiny4_out"]), (C.TINY5, g10["tiny5_out"])):
         yy = synth_window_inputs(cfg, 2, window=3, seed_pose_scale=0.1)
         xx = np.random.RandomState(33).randn(2, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
-        m = _model(cfg, "fp32", emu_lib, wseed=int(g5["wseed"]), latency_mode="off")
+        m = _model(cfg, "fp32", emu_lib, wseed=int(g5["wseed"])).set_kernel_set("block")
         assert rel_l2(m(xx, np.array([500, 500]), yy), gold) < TOL["fp32"]
     if zeggs_too:
         g2 = _g(golden_dir, "g2_forward_zeggs.npz")
         cfg = C.ZEGGS
-        for prec in ("bf16",):           # (fp32 at these dims: test_emu_parity.py::test_batched_gemm_workgroup_shapes)
-            mz = _model(cfg, prec, emu_lib, wseed=int(g2["wseed"]), latency_mode="off")
+        for prec in ("bf16",):           # (fp32 at these dims: test_emu_parity.py::test_kernel_sets_tiny)
+            mz = _model(cfg, prec, emu_lib, wseed=int(g2["wseed"])).set_kernel_set("block")
             yz = synth_window_inputs(cfg, 2, window=1, seed_pose_scale=0.5)
             xz = np.random.RandomState(4244).randn(2, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
             assert rel_l2(mz(xz, np.array([999, 3]), yz), g2["b2_t999_3_out"]) < TOL[prec]
-
-
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
-def test_embedded_space_state_option(emu_lib, golden_dir, monkeypatch, prec):
-    """DSG_ECARRY=1 (opt-in, measured slower on the hardware): the loop carries E(x_t) = Wfold . x_t instead of x_t, the noise
-    enters through its embedding, the pose head runs once after the loop -- same goldens, DDPM and DDIM, start from an image"""
-    monkeypatch.setenv("DSG_ECARRY", "1")
-    gt = _g(golden_dir, "gt_tiny_zeggs.npz")
-    cfg = C.TINY
-    m = _model(cfg, prec, emu_lib, wseed=int(gt["wseed"]))
-    y = synth_window_inputs(cfg, 2, window=2, seed_pose_scale=0.3)
-    shape = (2, cfg.njoints, 1, cfg.n_poses)
-    d, d50 = create_gaussian_diffusion(library=emu_lib), create_gaussian_diffusion("ddim50", library=emu_lib)
-    tol = 3 * TOL[prec]
-    assert rel_l2(d.manual_seed(77, 3).p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=990), gt["ddpm_skip990"]) < tol
-    init = np.random.RandomState(5).randn(*shape).astype(np.float32)
-    assert rel_l2(d.manual_seed(77, 4).p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=992, init_image=init),
-                  gt["ddpm_init_skip992"]) < tol
-    assert rel_l2(d50.manual_seed(77, 9).ddim_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, eta=1.0, skip_timesteps=40),
-                  gt["ddim50_eta1_skip40"]) < tol
-    assert rel_l2(d.manual_seed(77, 10).p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=960)[0],
-                  d.manual_seed(77, 10).p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=960)[0]) == 0.0
-
-
-def test_xcd_pinned_lanes(emu_lib, monkeypatch):
-    """XCD-pinned lanes (dsg_kernels.h): batch-1 bf16 lanes share every dispatch of the step, lane = blockIdx.x & 7, arguments
-    from a per-lane table.  Same arithmetic as a lane's own launches: bit-identical samples, for 1, 3 and 10 lanes (two packet
-    chains), with DDPM and DDIM, and the single-call path (dsg_sample) takes it too.  (The emulator has no caches: what the
-    missing fences would break is covered by the GPU twin of this test.)"""
-    cfg = C.TINY
-    shape = (1, cfg.njoints, 1, cfg.n_poses)
-    monkeypatch.setenv("DSG_PIN", "0")
-    m0 = _model(cfg, "bf16", emu_lib, max_batch=1)
-    d = create_gaussian_diffusion(library=emu_lib)
-    ys = [{"y": synth_window_inputs(cfg, 1, window=w % 4, clip0=w, seed_pose_scale=0.2)} for w in range(10)]
-    want = [d.manual_seed(5 + i, i).p_sample_loop(m0, shape, clip_denoised=False, model_kwargs=ys[i], skip_timesteps=994) for i in range(10)]
-    assert m0.last_sample_path() == "hip"
-    monkeypatch.setenv("DSG_PIN", "2")
-    m = _model(cfg, "bf16", emu_lib, max_batch=1)
-    lanes = [m] + [m.clone() for _ in range(9)]
-    for n in (1, 3, 10):
-        got = d.manual_seed(0, 0).p_sample_loop_multi(lanes[:n], shape, ys[:n], seeds=[5 + i for i in range(n)], stream_ids=list(range(n)), skip_timesteps=994)
-        assert all(l.last_sample_path() == "hip-pinned" for l in lanes[:n])
-        for i in range(n):
-            assert np.array_equal(got[i], want[i]), (n, i)
-    one = d.manual_seed(7, 2).p_sample_loop(m, shape, clip_denoised=False, model_kwargs=ys[2], skip_timesteps=994)
-    assert m.last_sample_path() == "hip-pinned" and np.array_equal(one, want[2])
-    dd = create_gaussian_diffusion(library=emu_lib, timestep_respacing="ddim5")
-    w2 = dd.manual_seed(3, 1).ddim_sample_loop(m0, shape, clip_denoised=False, model_kwargs=ys[1])
-    g2 = dd.manual_seed(3, 1).ddim_sample_loop(m, shape, clip_denoised=False, model_kwargs=ys[1])
-    assert m.last_sample_path() == "hip-pinned" and np.array_equal(g2, w2)
-    # fp32 handles and batches > 1 keep their own launches
-    mf = _model(cfg, "fp32", emu_lib, max_batch=2)
-    d.manual_seed(1, 0).p_sample_loop(mf, (2,) + shape[1:], clip_denoised=False,
-                                      model_kwargs={"y": synth_window_inputs(cfg, 2, window=0)}, skip_timesteps=997)
-    assert mf.last_sample_path() == "hip"

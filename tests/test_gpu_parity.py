@@ -3,7 +3,8 @@
   (b) the CPU oracle on the same seeded inputs, and
   (c) size-independent properties at full ZEGGS / batch-16 sizes (determinism, graph == eager, batch consistency).
 Tolerances (rel-L2 on normalised poses): fp32 kernels 2e-5 per forward / 1e-4 after a 1000-step chain;
-bf16 kernels (bf16 MFMA operands, fp32 accumulate / state / LayerNorm / softmax) 3e-2."""
+bf16 kernels (bf16 MFMA operands, fp32 accumulate / state / LayerNorm / softmax) 1.2e-2 per forward, 2e-2 per chain
+(at most twice what was measured on MI355X, so that a 2x regression of any kernel fails)."""
 import os
 
 import numpy as np
@@ -15,8 +16,8 @@ from tests.util import rel_l2
 
 pytestmark = pytest.mark.gpu
 
-TOL_FWD = {"fp32": 2e-5, "bf16": 3e-2}
-TOL_CHAIN = {"fp32": 1e-4, "bf16": 3e-2}
+TOL_FWD = {"fp32": 2e-5, "bf16": 1.2e-2}     # bf16: <= 2x the 4.5e-3 .. 6.7e-3 measured on MI355X
+TOL_CHAIN = {"fp32": 1e-4, "bf16": 2e-2}     # bf16: <= 2x the 9.3e-3 measured after 1000 steps
 
 
 def _g(golden_dir, name):
@@ -220,10 +221,8 @@ def test_aql_step_loop_is_bit_identical_to_hip_launches(gpu, prec, monkeypatch):
     from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
     cfg = C.ZEGGS
     outs = {}
-    for mode in ("1", "0", "overlap"):
-        monkeypatch.setenv("DSG_AQL", "1" if mode == "overlap" else mode)
-        monkeypatch.setenv("DSG_OVERLAP", "1" if mode == "overlap" else "0")     # barrier-less (attention -> k_mid) pair ...
-        monkeypatch.setenv("DSG_FUSE_ATTN_MID", "0" if mode == "overlap" else "1")   # ... which needs the separate kernels
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DSG_AQL", mode)
         m = _model(cfg, prec, max_batch=1)
         d = create_gaussian_diffusion()
         res = []
@@ -236,8 +235,8 @@ def test_aql_step_loop_is_bit_identical_to_hip_launches(gpu, prec, monkeypatch):
                                                                        model_kwargs={"y": y})).copy())
         assert m.last_sample_path() == ("hip" if mode == "0" else "aql"), "the comparison is void if the requested path did not run"
         outs[mode] = res
-    for a, b, c in zip(outs["1"], outs["0"], outs["overlap"]):
-        assert np.isfinite(a).all() and np.array_equal(a, b) and np.array_equal(a, c)
+    for a, b in zip(outs["1"], outs["0"]):
+        assert np.isfinite(a).all() and np.array_equal(a, b)
 
 
 def test_graph_equals_eager_and_deterministic(gpu):
@@ -295,9 +294,8 @@ def test_throughput_kernel_set_vs_reference(gpu, golden_dir, prec):
 
 def test_batch16_consistency(gpu, monkeypatch):
     """B = 16 identical clips with shared noise: all 16 results are bit-identical (rows are independent), and they agree
-    with the B = 1 run (a different kernel set: latency mode) to rounding-order level.  From 512 rows up the batched path
-    uses the 32-row block GEMMs (dsg_batched.h) and k_attn_op; forced on at batch 1 they must reproduce the batch-16 rows
-    bit for bit."""
+    with the B = 1 run (a different kernel set: latency) to rounding-order level.  From 1000 rows up `auto` is the "block" set
+    (32-row block GEMMs of dsg_batched.h + k_attn_op); selected at batch 1 it must reproduce the batch-16 rows bit for bit."""
     from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
     from oracle import philox
     cfg = C.ZEGGS
@@ -315,13 +313,13 @@ def test_batch16_consistency(gpu, monkeypatch):
     for b in range(1, B):
         assert np.array_equal(sB[b], sB[0]), f"batch element {b} differs"
     assert rel_l2(sB[0], s1[0]) < 1e-2
-    for blk, exact in (("1", True), ("0", False)):
-        monkeypatch.setenv("DSG_GEMM_BLK", blk)
-        monkeypatch.setenv("DSG_ATTN_OP", blk)           # batch 16 also fuses attention + out_proj + LayerNorm1 (k_attn_op)
-        m1 = _model(cfg, "bf16", max_batch=1, latency_mode="off")
+    assert m.last_kernel_set() == "block"
+    for kset, exact in (("block", True), ("tile", False)):
+        m1 = _model(cfg, "bf16", max_batch=1).set_kernel_set(kset)
         d.manual_seed(3, 0)
         s1_off = d.p_sample_loop(m1, (1, cfg.njoints, 1, cfg.n_poses), noise=x1, clip_denoised=False,
                                  model_kwargs={"y": y1}, skip_timesteps=960, const_noise=True)
+        assert m1.last_kernel_set() == kset
         if exact:
             assert np.array_equal(sB[0], s1_off[0]), "same kernel set must be bit-identical across batch sizes"
         else:

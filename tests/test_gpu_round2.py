@@ -13,8 +13,8 @@ from tests.util import rel_l2
 
 pytestmark = pytest.mark.gpu
 
-TOL_FWD = {"fp32": 2e-5, "bf16": 3e-2}
-TOL_CHAIN = {"fp32": 1e-4, "bf16": 3e-2}
+TOL_FWD = {"fp32": 2e-5, "bf16": 1.2e-2}     # bf16: <= 2x the 4.5e-3 .. 6.7e-3 measured on MI355X
+TOL_CHAIN = {"fp32": 1e-4, "bf16": 2e-2}     # bf16: <= 2x the 9.3e-3 measured after 1000 steps
 
 
 def _g(golden_dir, name):
@@ -42,8 +42,8 @@ def _model(cfg, prec, max_batch=1, wseed=20240, spg=0, latency_mode="auto"):
 # pose2bvh driven with the same Philox noise (G12 poses, G13 .bvh channels).
 #   stated tolerance, fp32 kernels: rel-L2 <= 1e-5 on de-normalised poses; BVH rotations max <= 2e-3 deg, root position <= 1e-3 cm
 #       (measured on MI355X: 2.0e-7; 1.1e-4 deg; 2.7e-5 cm)
-#   stated tolerance, bf16 kernels: rel-L2 <= 3e-2 on NORMALISED poses (the per-window bound; windows are chained);
-#       BVH rotation channels max <= 3 deg, median <= 0.1 deg; root position <= 1 cm
+#   stated tolerance, bf16 kernels: rel-L2 <= 2e-2 on NORMALISED poses (the per-window bound; windows are chained);
+#       BVH rotation channels max <= 1.5 deg, median <= 0.03 deg; root position <= 0.7 cm   (~2x the measured values)
 #       (measured: 9.3e-3; max 0.72 / p99 0.26 / median 0.011 deg; 0.32 cm)
 # (the measured values are printed by the test and recorded in DESIGN.md s2 / profiles/)
 # ---------------------------------------------------------------------------------------------------------------------
@@ -80,7 +80,7 @@ def test_full_clip_1000_steps_bvh_parity(gpu, golden_dir, tmp_path, prec):
     if prec == "fp32":
         assert e_den < 1e-5 and drot.max() < 2e-3 and dpos.max() < 1e-3, stats
     else:
-        assert e_norm < 3e-2 and drot.max() < 3.0 and np.median(drot) < 0.1 and dpos.max() < 1.0, stats
+        assert e_norm < 2e-2 and drot.max() < 1.5 and np.median(drot) < 0.03 and dpos.max() < 0.7, stats
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
@@ -161,7 +161,9 @@ def test_dsgplus_callers_vs_reference_inference(gpu, golden_dir, name, cfg):
         seq = generate_clip_dsgplus(m, d, [w[None] for w in wins], [1.0, 0.0], seed0, real_n, seed=int(g["noise_seed"]),
                                     skip_timesteps=int(g["skip_timesteps"]), seed_last=seed0 if cfg.variant == 5 else None)[0]
         out = np.multiply(seq, std) + mean
-        assert rel_l2(out, g[name]) < (2e-5 if prec == "fp32" else 3e-2), (name, prec, rel_l2(out, g[name]))
+        e = rel_l2(out, g[name])
+        print(f"G11 {name} {prec}: {e:.3e}")
+        assert e < (2e-5 if prec == "fp32" else 1.2e-2), (name, prec, e)
 
 
 def test_attention3_beat_dims_vs_reference(gpu, golden_dir):
@@ -337,32 +339,6 @@ def test_command_lines_end_to_end(gpu, tmp_path):
             argv += ["--seed_last_npy", str(tmp_path / "seed.npy")]
         res = np.load(sample_plus.main(argv))
         assert res.shape == (200, c.njoints // 3) and np.isfinite(res).all()
-
-
-@pytest.mark.gpu
-def test_xcd_pinned_lane_equals_fenced_submission(monkeypatch):
-    """DSG_PIN=1 (opt-in): the batch-1 step as XCD-pinned dispatches -- no acquire / release between the packets of the loop,
-    loop-written data read past the L1 -- gives the fenced submission's sample bit for bit (a stale read would not), over two
-    consecutive windows; the path is reported as such."""
-    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
-    from diffusestylegesture_amd.model import DSGDenoiser
-    cfg = C.ZEGGS
-    shape = (1, cfg.njoints, 1, cfg.n_poses)
-    d = create_gaussian_diffusion()
-    monkeypatch.setenv("DSG_PIN", "0")
-    m0 = DSGDenoiser(cfg, precision="bf16", max_batch=1)
-    m0.load_state_dict(synth_state_dict(cfg, 1))
-    monkeypatch.setenv("DSG_PIN", "1")
-    m = DSGDenoiser(cfg, precision="bf16", max_batch=1)
-    m.load_state_dict(synth_state_dict(cfg, 1))
-    for w in range(2):
-        y = {"y": synth_window_inputs(cfg, 1, window=w, seed_pose_scale=0.2)}
-        want = d.manual_seed(11, w).p_sample_loop(m0, shape, clip_denoised=False, model_kwargs=y, skip_timesteps=700)
-        assert m0.last_sample_path() == "aql"
-        got = d.manual_seed(11, w).p_sample_loop(m, shape, clip_denoised=False, model_kwargs=y, skip_timesteps=700)
-        # (the in-kernel placement check may route a call to the fenced path on a busy GPU: still the same sample)
-        assert m.last_sample_path() in ("aql-pinned", "aql")
-        assert np.array_equal(np.asarray(got), np.asarray(want))
 
 
 @pytest.mark.gpu

@@ -1,0 +1,225 @@
+"""MI355X parity tests (-m gpu), round 3: BASELINE config[3]'s real per-GPU arrangement (4 sampling lanes x batch 4) against
+the oracle row by row, with the kernel set that ran asserted; the fence-free loop soaked in that arrangement over the full
+4 windows x 1000 steps; a 1000-step chain at config[4]'s dims (TWH, latent 512); kernel sets as explicit, sticky properties
+of a lane; the guidance wrapper's fall-back to the generic loop; one real RCCL rank through bench.py.
+Tolerances (rel-L2 on normalised poses): fp32 kernels 2e-5 per forward / 1e-4 per chain; bf16 kernels 1.2e-2 per forward,
+2e-2 per chain (<= 2x the values measured on MI355X: 4.5e-3 .. 6.7e-3 per forward, 9.3e-3 after 1000 steps)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from diffusestylegesture_amd import config as C
+from diffusestylegesture_amd.synth import synth_state_dict, synth_window_inputs
+from tests.conftest import ROOT
+from tests.util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL_CHAIN = {"fp32": 1e-4, "bf16": 2e-2}
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from diffusestylegesture_amd import lib as L
+    return L.default_library()
+
+
+def _model(cfg, prec, max_batch=1, wseed=20240):
+    from diffusestylegesture_amd.model import DSGDenoiser
+    m = DSGDenoiser(cfg, precision=prec, max_batch=max_batch, device=0)
+    m.load_state_dict(synth_state_dict(cfg, wseed))
+    return m
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# config[3]: "128 ZEGGS clips sharded one-clip-per-stream" = 16 clips per GPU = 4 lanes (own HSA queue each) x batch 4,
+# the arrangement bench.py --clips-per-gpu 16 runs.  Every clip has its own conditioning and its own Philox rows; the
+# oracle samples a clip on its own (rows and lanes are independent), through the same window loop / stitching.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_config3_arrangement_4_lanes_x_batch_4_vs_oracle(gpu, prec):
+    import torch
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    from diffusestylegesture_amd.sample import generate_clips_streams
+    from oracle import philox, sampler
+    from oracle.mdm import MDMOracle
+    from oracle.schedule import OracleDiffusion
+    cfg, NL, B, K, n_run = C.ZEGGS, 4, 4, 2, 60
+    skip = 1000 - n_run
+    m = _model(cfg, prec, max_batch=B)
+    lanes = [m] + [m.clone() for _ in range(NL - 1)]
+    d = create_gaussian_diffusion()
+    feats_np = [[synth_window_inputs(cfg, B, window=w, clip0=ln * B)["audio"] for w in range(K)] for ln in range(NL)]
+    feats = [[torch.from_numpy(f).cuda() for f in fl] for fl in feats_np]
+    style = [0, 0, 1, 0, 0, 0]
+    sids = [7 + ln for ln in range(NL)]
+    got = generate_clips_streams(lanes, d, feats, style, seed=4242, skip_timesteps=skip, stream_ids=sids)
+    assert got.shape == (NL * B, K * cfg.stride - cfg.n_seed, cfg.njoints) and np.isfinite(got).all()
+    # the arrangement that ships: AQL packets on 4 queues, fence-free, the kernel set recommended for 4 lanes x 356 rows
+    assert m.recommend_kernel_set(B, NL) == "block"
+    assert all(ln.last_kernel_set() == "block" and ln.last_sample_path() == "aql" and ln.last_sample_fence_free() for ln in lanes)
+    ref, od = MDMOracle(synth_state_dict(cfg, 20240), cfg), OracleDiffusion()
+    shape = (B, cfg.njoints, 1, cfg.n_poses)
+    worst = 0.0
+    for ln, b in ((0, 0), (0, 3), (1, 1), (2, 2), (3, 0), (3, 3)):
+        def sample_window(c, y, ln=ln, b=b):
+            nf = lambda k: philox.normal_bj1t(shape, 4242, c * (1 + n_run) + k, sids[ln])[b:b + 1]
+            return sampler.p_sample_loop(od, ref, (1,) + shape[1:], nf, {"y": y}, skip_timesteps=skip)
+        want = sampler.zeggs_clip(sample_window, cfg, [f[b:b + 1] for f in feats_np[ln]], style)
+        e = rel_l2(got[ln * B + b], want)
+        worst = max(worst, e)
+        assert e < TOL_CHAIN[prec], (ln, b, e)
+    print(f"config[3] arrangement {prec}: worst rel-L2 of 6 clips vs oracle = {worst:.3e}")
+    assert not np.array_equal(got[0], got[1]) and not np.array_equal(got[0], got[B])
+    # and a lane reproduces itself bit for bit when sampled alone (same handle = same kernel set)
+    from diffusestylegesture_amd.sample import generate_clip
+    alone = generate_clip(lanes[2], d, feats[2], style, seed=4242, skip_timesteps=skip, stream_id=sids[2])
+    assert lanes[2].last_kernel_set() == "block" and np.array_equal(alone, got[2 * B:3 * B])
+
+
+def test_config3_fence_free_soak_full_clip(gpu, monkeypatch):
+    """The fence-free loop (uncached loop buffers, AQL packets without acquire / release) in the arrangement that ships -- 4 lanes x
+    batch 4 -- over the WHOLE config workload, 4 windows x 1000 steps = 560 000 fence-free packets on 4 queues at once: bit-identical
+    to cached buffers + agent-scope fences (DSG_UC=0).  One stale line anywhere in 4000 steps would show."""
+    import torch
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    from diffusestylegesture_amd.model import DSGDenoiser
+    from diffusestylegesture_amd.sample import generate_clips_streams
+    cfg, NL, B, K = C.ZEGGS, 4, 4, 4
+    feats = [[torch.from_numpy(synth_window_inputs(cfg, B, window=w, clip0=ln * B)["audio"]).cuda() for w in range(K)] for ln in range(NL)]
+    outs = {}
+    for uc in ("1", "0"):
+        monkeypatch.setenv("DSG_UC", uc)
+        m = DSGDenoiser(cfg, precision="bf16", max_batch=B)
+        m.load_state_dict(synth_state_dict(cfg, 20240))
+        lanes = [m] + [m.clone() for _ in range(NL - 1)]
+        d = create_gaussian_diffusion()
+        outs[uc] = generate_clips_streams(lanes, d, feats, [1, 0, 0, 0, 0, 0], seed=99, skip_timesteps=0, stream_ids=[0, 1, 2, 3])
+        assert all(ln.last_sample_path() == "aql" and ln.last_kernel_set() == "block" for ln in lanes)
+        assert all(ln.last_sample_fence_free() == (uc == "1") for ln in lanes)
+    assert outs["1"].shape == (16, 312, cfg.njoints) and np.isfinite(outs["1"]).all()
+    assert np.array_equal(outs["0"], outs["1"])
+
+
+def test_twh_1000_step_chain_bf16_vs_oracle(gpu):
+    """config[4] dims (TWH: latent 512, K = 2232 pose features, 151 tokens; the TILE kernel set): one whole window, 1000 DDPM
+    steps in bf16 against the fp32 oracle -- the drift number config[4] (16 windows x 1000 steps) rests on.  ~40 s of CPU."""
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    from oracle import sampler
+    from oracle.mdm import MDMOracle
+    from oracle.schedule import OracleDiffusion
+    cfg = C.TWH
+    sd = synth_state_dict(cfg, 20240)
+    shape = (1, cfg.njoints, 1, cfg.n_poses)
+    y = synth_window_inputs(cfg, 1, window=1, seed_pose_scale=0.1)
+    r = sampler.p_sample_loop(OracleDiffusion(), MDMOracle(sd, cfg), shape, sampler.philox_noise_fn(shape, 21, 3), {"y": y})
+    errs = {}
+    for prec in ("bf16", "fp32"):
+        m = _model(cfg, prec)
+        s = create_gaussian_diffusion().manual_seed(21, 3).p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y})
+        assert m.last_kernel_set() == "tile" and m.last_sample_path() == "aql"
+        errs[prec] = rel_l2(s, r)
+    print(f"TWH 1000-step chain vs oracle: bf16 {errs['bf16']:.3e}, fp32 {errs['fp32']:.3e}")
+    assert errs["fp32"] < TOL_CHAIN["fp32"] and errs["bf16"] < TOL_CHAIN["bf16"], errs
+
+
+def test_kernel_sets_are_sticky_lane_properties(gpu):
+    """dsg_set_kernel_set / dsg_last_kernel_set on the hardware: every set against the oracle at ZEGGS dims (batch 3, 40 steps),
+    clones inherit the source's set, AUTO follows the batch, and a lane of batch 2 gives the same bits alone and inside
+    dsg_sample_multi (round-2 advisor finding: the choice used to depend on the number of lanes in the call)."""
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    from oracle import philox, sampler
+    from oracle.mdm import MDMOracle
+    from oracle.schedule import OracleDiffusion
+    cfg, B = C.ZEGGS, 3
+    shape = (B, cfg.njoints, 1, cfg.n_poses)
+    y = synth_window_inputs(cfg, B, window=2, clip0=5, seed_pose_scale=0.2)
+    ref, od = MDMOracle(synth_state_dict(cfg, 20240), cfg), OracleDiffusion()
+    y1 = {k: (v[1:2] if k != "mask_local" else v) for k, v in y.items()}
+    want = sampler.p_sample_loop(od, ref, (1,) + shape[1:], lambda k: philox.normal_bj1t(shape, 8, k, 2)[1:2], {"y": y1}, skip_timesteps=960)
+    m = _model(cfg, "bf16", max_batch=B)
+    d = create_gaussian_diffusion()
+    res = {}
+    for kset in ("auto", "latency", "tile", "block"):
+        m.set_kernel_set(kset)
+        res[kset] = np.asarray(d.manual_seed(8, 2).p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=960)).copy()
+        assert m.last_kernel_set() == ("tile" if kset == "auto" else kset)
+        assert rel_l2(res[kset][1], want[0]) < TOL_CHAIN["bf16"], kset
+    assert np.array_equal(res["auto"], res["tile"]) and not np.array_equal(res["tile"], res["block"])
+    c = m.clone()
+    assert c.recommend_kernel_set(2, 4) == "tile" and c.recommend_kernel_set(2, 1) == "latency"
+    shape2 = (2,) + shape[1:]
+    ys = [{"y": synth_window_inputs(cfg, 2, window=w, clip0=2 * w, seed_pose_scale=0.2)} for w in range(2)]
+    for kset in ("latency", "tile"):
+        lanes = [m.set_kernel_set(kset), c.set_kernel_set(kset)]
+        multi = d.manual_seed(9, 0).p_sample_loop_multi(lanes, shape2, ys, seeds=[9, 9], stream_ids=[0, 1], skip_timesteps=950)
+        for i in range(2):
+            alone = d.manual_seed(9, i).p_sample_loop(lanes[i], shape2, clip_denoised=False, model_kwargs=ys[i], skip_timesteps=950)
+            assert lanes[i].last_kernel_set() == kset and np.array_equal(np.asarray(multi[i]), np.asarray(alone)), (kset, i)
+
+
+def test_guidance_wrapper_without_room_for_twins_uses_generic_loop(gpu):
+    """Round-2 advisor finding: ClassifierFreeSampleModel around a denoiser of max_batch < 2B must still sample (generic loop: two
+    library calls per step, the same Philox stream), not raise -- and agree with the fused 2B-row loop."""
+    import torch
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    from diffusestylegesture_amd.model import ClassifierFreeSampleModel
+    cfg = C.ZEGGS
+    shape = (1, cfg.njoints, 1, cfg.n_poses)
+    y = synth_window_inputs(cfg, 1, window=1, seed_pose_scale=0.3)
+    yt = {k: torch.from_numpy(v).cuda() for k, v in y.items()}
+    yt["scale"] = torch.tensor([2.5], device="cuda")
+    d = create_gaussian_diffusion()
+    small, big = _model(cfg, "fp32", max_batch=1), _model(cfg, "fp32", max_batch=2)
+    a = d.manual_seed(3, 9).p_sample_loop(ClassifierFreeSampleModel(small), shape, clip_denoised=False, model_kwargs={"y": yt}, skip_timesteps=990)
+    b = d.manual_seed(3, 9).p_sample_loop(ClassifierFreeSampleModel(big), shape, clip_denoised=False, model_kwargs={"y": yt}, skip_timesteps=990)
+    assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-4
+
+
+def test_progressive_generators_match_dump_steps(gpu):
+    """p_sample_loop_progressive / ddim_sample_loop_progressive (gaussian_diffusion.py:673-740, :938-1003) as generators of
+    {"sample": x_{t-1}} per step: the same intermediate samples as dump_steps, the last one equal to the plain loop's result."""
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    cfg = C.ZEGGS
+    shape = (1, cfg.njoints, 1, cfg.n_poses)
+    y = synth_window_inputs(cfg, 1, window=0, seed_pose_scale=0.2)
+    m = _model(cfg, "fp32")
+    d = create_gaussian_diffusion()
+    full = np.asarray(d.manual_seed(4, 1).p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=990))
+    steps = [np.asarray(o["sample"]) for o in d.manual_seed(4, 1).p_sample_loop_progressive(m, shape, clip_denoised=False, model_kwargs={"y": y},
+                                                                                              skip_timesteps=990)]
+    assert len(steps) == 10 and np.array_equal(steps[-1], full)
+    dumped = d.manual_seed(4, 1).p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=990, dump_steps=[0, 4, 9])
+    assert all(np.array_equal(np.asarray(dumped[i]), steps[s]) for i, s in enumerate((0, 4, 9)))
+    d5 = create_gaussian_diffusion("ddim5")
+    full5 = np.asarray(d5.manual_seed(4, 2).ddim_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, eta=0.3))
+    steps5 = [np.asarray(o["sample"]) for o in d5.manual_seed(4, 2).ddim_sample_loop_progressive(m, shape, clip_denoised=False,
+                                                                                                 model_kwargs={"y": y}, eta=0.3)]
+    assert len(steps5) == 5 and rel_l2(steps5[-1], full5) < 1e-6
+
+
+def test_bench_one_real_rccl_rank(gpu):
+    """bench.py under torch.distributed.run with ONE rank and backend "nccl": real init_process_group, real dist.gather /
+    all_reduce (RCCL), the per-rank AQL queue created after set_device(LOCAL_RANK) on the agent whose PCI address matches the
+    HIP device (printed once per rank) -- what every rank of the 8-GPU run does, on the one GPU a lease has.  The rate must
+    agree with the un-launched run."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    args = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-postprocess"]
+    plain = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args, capture_output=True, text=True, timeout=600, env=env)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    ranked = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                             "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist"] + args,
+                            capture_output=True, text=True, timeout=600, env=env)
+    assert ranked.returncode == 0, ranked.stderr[-2000:]
+    a = json.loads([ln for ln in plain.stdout.splitlines() if ln.startswith("{")][-1])
+    b = json.loads([ln for ln in ranked.stdout.splitlines() if ln.startswith("{")][-1])
+    assert b["n_gpus"] == 1 and b["sample_path"] == "aql" and b["fence_free_packets"] and b["collective_backend"] == "nccl"
+    assert "HSA agent" in ranked.stderr and "rank-local HIP device 0" in ranked.stderr
+    print(f"bench: plain {a['value']:.1f} frames/s, one RCCL rank {b['value']:.1f} frames/s")
+    assert abs(b["value"] / a["value"] - 1.0) < 0.05
