@@ -4,29 +4,29 @@ HIPCC ?= /opt/rocm/bin/hipcc
 HOSTCXX ?= /opt/rocm/lib/llvm/bin/clang++
 CSRC := diffusestylegesture_amd/csrc
 # one tag for the library and the bare code object: dsg_aql.h refuses a dsg_kernels.hsaco built from other sources
-TAG := $(shell cat $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h $(CSRC)/dsg_batched.h $(CSRC)/dsg_aql.h include/dsg.h | cksum | cut -d' ' -f1)
+TAG := $(shell cat $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h $(CSRC)/dsg_batched.h $(CSRC)/dsg_stream.h $(CSRC)/dsg_aql.h include/dsg.h | cksum | cut -d' ' -f1)
 LIB := $(CSRC)/libdsg_hip.so
 EMU := tests/emu/_build/libdsg_emu.so
 
 all: $(LIB) $(CSRC)/dsg_kernels.hsaco
 
 # dsg_bvh.cpp is plain host C++ (the BVH post-processing behind the same C ABI), compiled along
-$(LIB): $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h $(CSRC)/dsg_batched.h $(CSRC)/dsg_aql.h include/dsg.h $(CSRC)/dsg_bvh.cpp
+$(LIB): $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h $(CSRC)/dsg_batched.h $(CSRC)/dsg_stream.h $(CSRC)/dsg_aql.h include/dsg.h $(CSRC)/dsg_bvh.cpp
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed -DDSG_BUILD_TAG=$(TAG)u $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_bvh.cpp -L/opt/rocm/lib -lhsa-runtime64 -lpthread -o $@
 
 # the device side of the same translation unit as a bare code object: loaded through the HSA loader by the AQL
 # submission path (dsg_aql.h), which needs kernel descriptors the HIP runtime does not hand out
-$(CSRC)/dsg_kernels.hsaco: $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h $(CSRC)/dsg_batched.h $(CSRC)/dsg_aql.h include/dsg.h
+$(CSRC)/dsg_kernels.hsaco: $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h $(CSRC)/dsg_batched.h $(CSRC)/dsg_stream.h $(CSRC)/dsg_aql.h include/dsg.h
 	$(HIPCC) --offload-arch=gfx950 --cuda-device-only --no-gpu-bundle-output -O3 -std=c++17 -Wno-pass-failed -DDSG_BUILD_TAG=$(TAG)u \
 	    -Rpass-analysis=kernel-resource-usage $(CSRC)/dsg_hip.cpp -o $@ 2> $(CSRC)/dsg_kernels.resources.txt || (cat $(CSRC)/dsg_kernels.resources.txt >&2; exit 1)
 
 # diagnostics build: the same sources with cycle stamps at the phase boundaries of the step kernels (tools/stamps.py)
 stamps: $(CSRC)/libdsg_hip_stamps.so
-$(CSRC)/libdsg_hip_stamps.so: $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h $(CSRC)/dsg_batched.h include/dsg.h $(CSRC)/dsg_bvh.cpp
+$(CSRC)/libdsg_hip_stamps.so: $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h $(CSRC)/dsg_batched.h $(CSRC)/dsg_stream.h include/dsg.h $(CSRC)/dsg_bvh.cpp
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed -DDSG_STAMPS=1 $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_bvh.cpp -L/opt/rocm/lib -lhsa-runtime64 -lpthread -o $@
 
 emu: $(EMU)
-$(EMU): $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h $(CSRC)/dsg_batched.h include/dsg.h tests/emu/shim/hip/hip_runtime.h tests/emu/emu_rt.cpp $(CSRC)/dsg_bvh.cpp
+$(EMU): $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h $(CSRC)/dsg_batched.h $(CSRC)/dsg_stream.h include/dsg.h tests/emu/shim/hip/hip_runtime.h tests/emu/emu_rt.cpp $(CSRC)/dsg_bvh.cpp
 	mkdir -p tests/emu/_build
 	$(HOSTCXX) -O2 -g -std=c++17 -fPIC -shared -pthread -Itests/emu/shim -DDSG_EMU=1 \
 	    $(CSRC)/dsg_hip.cpp tests/emu/emu_rt.cpp $(CSRC)/dsg_bvh.cpp -o $@

@@ -3,6 +3,7 @@
 // See dsg_kernels.h for the kernels and the reference file:line each one replaces.
 #include "dsg_fused.h"
 #include "dsg_batched.h"
+#include "dsg_stream.h"
 #include "../../include/dsg.h"
 #include "dsg_aql.h"
 
@@ -741,6 +742,9 @@ extern "C" int dsg_set_window_cond_cfg(dsg_handle* h, const float* style, const 
 //            (dsg_batched.h); out_proj and the pose head stay on 16 x 16 tiles                    us at 16); from 300 rows per lane when
 //                                                                                               several lanes share the CUs (4 x 4:
 //                                                                                               4691 vs 4400 frames/s, 4 x 16: 8243 vs 6447)
+//   STREAM   BLOCK with linear1 / linear2 as weight-stationary persistent GEMMs (dsg_stream.h:   3 + 4L      >= 2800 rows per lane (batch 32: 369 ->
+//            W panel in registers, activations global -> LDS, 32x32x16 MFMA)                    357 us, batch 64: 611 -> 544; 4 x 16: 510 -> 500);
+//                                                                                               slower below (batch 16: 234 -> 243 us)
 //   With several lanes sharing the GPU the redundant recompute of LATENCY costs from batch 2 (4 x 2: 3507 frames/s TILE vs
 //   3303 LATENCY): dsg_recommend_kernel_set(B, lanes) encodes the multi-lane column; the caller applies it to its lanes.
 //   k_attn_op (attention + out_proj + LayerNorm1 in one kernel) replaces k_attn + out_proj in TILE / BLOCK wherever an
@@ -754,6 +758,7 @@ struct KernelSel {
     bool attn_in_mid = false;   // ... with the attention inside k_mid (batch 1)
     bool blk = false;           // BLOCK: 32-row block GEMMs
     bool attn_op = false;       // k_attn_op instead of k_attn + out_proj
+    bool stream = false;        // STREAM: BLOCK with the weight-stationary persistent FFN GEMMs of dsg_stream.h (linear1, linear2)
 };
 static bool have_attn_mid(const dsg_handle* h, int B) {
     return B == 1 && h->H == 4 && ((h->D == 256 && h->Tp == 96) || (h->D == 128 && h->Tp == 32));
@@ -767,8 +772,14 @@ static bool latency_set_ok(const dsg_handle* h) {
     const int dt = h->D / 64;
     return h->D <= 384 && (dt == 1 || dt == 2 || dt == 4 || dt == 6);
 }
+static bool stream_set_ok(const dsg_handle* h) {
+    // k_ws keeps 64 columns x K = D of W per wave in registers (D = 128 / 256), k_ws2 a quarter of K = ff (ff = 128 / 1024);
+    // linear1 reads the fragment-major LayerNorm1 rows k_attn_op writes
+    return have_attn_op(h) && (h->D == 256 || h->D == 128) && (h->ff == 1024 || h->ff == 128) && h->Jp % 128 == 0;
+}
 static int auto_kernel_set(const dsg_handle* h, int B, int lanes) {
     const int rows = B * h->ntok;
+    if (rows >= 2800 && stream_set_ok(h)) return DSG_KSET_STREAM;
     if (lanes <= 1) {
         if (B <= 2 && latency_set_ok(h)) return DSG_KSET_LATENCY;
         return rows >= 1000 ? DSG_KSET_BLOCK : DSG_KSET_TILE;
@@ -784,20 +795,23 @@ static int select_kernels(const dsg_handle* h, int B, KernelSel& k) {
         if (h->latency_mode == 1) set = DSG_KSET_LATENCY;
     }
     if (set == DSG_KSET_LATENCY && h->D > 512) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set LATENCY: latent_dim > 512");
-    if (set < DSG_KSET_LATENCY || set > DSG_KSET_BLOCK) return fail(DSG_E_INVALID, "unknown kernel set");
+    if (set == DSG_KSET_STREAM && !stream_set_ok(h)) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set STREAM: bf16, latent_dim 128 / 256, 4 heads, ff 128 / 1024 only");
+    if (set < DSG_KSET_LATENCY || set > DSG_KSET_STREAM) return fail(DSG_E_INVALID, "unknown kernel set");
     k = KernelSel();
     k.set = set;
     k.lat = set == DSG_KSET_LATENCY;
     k.attn_in_mid = k.lat && h->fuse_attn_mid && have_attn_mid(h, B);
-    k.blk = set == DSG_KSET_BLOCK;
+    k.stream = set == DSG_KSET_STREAM;
+    k.blk = set == DSG_KSET_BLOCK || k.stream;      // (STREAM: QKV, pose embedding and pose head as in BLOCK)
     k.attn_op = !k.lat && have_attn_op(h);
     return 0;
 }
 
 extern "C" int dsg_set_kernel_set(dsg_handle* h, int set) {
     if (!h) return fail(DSG_E_INVALID, "null handle");
-    if (set < DSG_KSET_AUTO || set > DSG_KSET_BLOCK) return fail(DSG_E_INVALID, "dsg_set_kernel_set: unknown kernel set");
+    if (set < DSG_KSET_AUTO || set > DSG_KSET_STREAM) return fail(DSG_E_INVALID, "dsg_set_kernel_set: unknown kernel set");
     if (set == DSG_KSET_LATENCY && h->D > 512) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set LATENCY: latent_dim > 512");
+    if (set == DSG_KSET_STREAM && !stream_set_ok(h)) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set STREAM: bf16, latent_dim 128 / 256, 4 heads, ff 128 / 1024 only");
     if (getenv("DSG_KSET")) return 0;          // an A/B run pinned the set for the whole process
     h->kset_req = set;
     return 0;
@@ -879,11 +893,46 @@ static int launch_blk_k(dsg_handle* h, GemmArgs g) {
     return step_launch<&k_gemm_blk_k<P, EPI, 4>>(h, grid, dim3(256), g);
 }
 
+// STREAM (dsg_stream.h): persistent grid = 128-column panels x row-block groups.  Groups: enough workgroups for `occ` per CU,
+// never more than there are row blocks, a multiple of 8 (one group per XCD slot)
+static int ws_groups(int n_panels, int n_blocks, int occ) {
+    int G = (256 * occ / n_panels) & ~7;
+    G = std::max(G, 8);
+    return std::min(G, rup(n_blocks, 8));
+}
+static int launch_ws(dsg_handle* h, GemmArgs g) {
+    g.KS = 1; g.kb_per_split = g.KBtot;
+    g.inv_ntok = fastdiv_inv(g.ntok); g.inv_hd = fastdiv_inv(g.hd);
+    if (g.NT % 8) return fail(DSG_E_INVALID, "k_ws: N must be a multiple of 128");
+    const int P = g.NT / 8, MB = cdiv(g.M, 64);
+    g.ws_G = ws_groups(P, MB, 2);
+    const dim3 grid(ws_grid_x(P, g.ws_G));
+    const int K = g.KBtot * 32;
+    if (K == 256) return step_launch<&k_ws<16>>(h, grid, dim3(256), g);
+    if (K == 128) return step_launch<&k_ws<8>>(h, grid, dim3(256), g);
+    return fail(DSG_E_NOT_IMPLEMENTED, "k_ws: K must be 128 or 256");
+}
+static int launch_ws2(dsg_handle* h, GemmArgs g) {
+    g.KS = 1; g.kb_per_split = g.KBtot;
+    g.inv_ntok = fastdiv_inv(g.ntok); g.inv_hd = fastdiv_inv(g.hd);
+    if (g.NT % 4) return fail(DSG_E_INVALID, "k_ws2: N must be a multiple of 64");
+    const int P = g.NT / 4, MB = cdiv(g.M, 32);
+    g.ws_G = ws_groups(P, MB, 1);
+    const dim3 grid(ws_grid_x(P, g.ws_G));
+    const int K = g.KBtot * 32;
+    if (K == 1024) return step_launch<&k_ws2<16>>(h, grid, dim3(256), g);
+    if (K == 128) return step_launch<&k_ws2<2>>(h, grid, dim3(256), g);
+    return fail(DSG_E_NOT_IMPLEMENTED, "k_ws2: K must be 128 or 1024");
+}
+
 // a K = D GEMM of the un-fused sets: block kernel (BLOCK, the GEMMs it wins), else 16 x 16 tiles -- LayerNorm GEMMs from 512
 // rows in the 3-waves-per-SIMD form (k_gemm_lean; tools/b16_lean.sh: batch 8: 250 vs 267 us/step, batch 16: 360 vs 378)
 template <class P, int PRO, int EPI>
 static int launch_gemm_w(dsg_handle* h, const GemmArgs& g, const KernelSel& ks) {
     constexpr bool blk_wins = EPI == EPI_QKV || EPI == EPI_GELU;
+    if constexpr (sizeof(typename P::elem) == 2 && PRO == PRO_DIRECT && EPI == EPI_GELU) {
+        if (ks.stream && g.a_frag) return launch_ws(h, g);      // STREAM: linear1 on the fragment-major LayerNorm1 rows of k_attn_op
+    }
     if constexpr (EPI != EPI_PARTIAL) {
         if (ks.blk && blk_wins && g.KBtot * P::KB <= 512) return launch_blk<P, PRO, EPI>(h, g);
     }
@@ -901,6 +950,9 @@ static int launch_gemm_w(dsg_handle* h, const GemmArgs& g, const KernelSel& ks) 
 // linear2: K = ff split over the 4 waves of the workgroup
 template <class P>
 static int launch_gemm_k4(dsg_handle* h, const GemmArgs& g, const KernelSel& ks) {
+    if constexpr (sizeof(typename P::elem) == 2) {
+        if (ks.stream && g.a_frag) return launch_ws2(h, g);
+    }
     if (ks.blk) return launch_blk_k<P, EPI_RESID>(h, g);
     return launch_gemm<P, PRO_DIRECT, EPI_RESID, 1, 4>(h, g);
 }

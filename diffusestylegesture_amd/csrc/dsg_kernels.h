@@ -313,6 +313,7 @@ struct GemmArgs {
     const float* ext_noise; // optional [n_steps][B][J][T] replayed noise, else null
     int B;
     int const_noise;
+    int ws_G;               // dsg_stream.h: row-block groups of the persistent grid (multiple of 8)
     int a_frag;             // PRO_DIRECT: A is stored fragment-major ([row tile][k-block][64 lanes][16 B], qk_off) -- hidden, attention rows
     int out_frag;           // EPI_GELU: the output goes out fragment-major (it is the next GEMM's A operand)
     // EPI_OUT, classifier-free guidance (main/model/cfg_sampler.py:8-31): the batch holds cfgB conditional elements followed

@@ -1,0 +1,250 @@
+// dsg_stream.h -- kernel set DSG_KSET_STREAM: weight-stationary, persistent FFN GEMMs for large batches (bf16).
+//
+// Why (round-2 profile of the BLOCK set, profiles/r02_j_b64_kernel_stats.csv): at 5696 rows linear1 took 12.8-22.9 us and linear2
+// 16.4 us while moving ~180 MB through the CUs' load paths -- 32 x 64 output blocks re-read an activation block 16 times and a
+// weight slice 178 times (16 FLOP per byte pulled into a CU), and every fragment went through VGPRs.  Here:
+//   * WEIGHTS ARE STATIONARY IN REGISTERS.  A workgroup owns one 128-column panel of W for its whole life; each of its 4 waves
+//     (2 x 2 over a 64-row x 128-column block) keeps its 64 columns x K = 256 slice as v_mfma_f32_32x32x16_bf16 operand fragments
+//     (128 VGPRs), loaded ONCE, and walks the row blocks  mb = group, group + G, ...  (persistent: grid = panels x groups ~ 2
+//     workgroups per CU).  Per 64 x 128 block a CU pulls 32 KB of activations for 4.2 MFLOP: 128 FLOP per byte.
+//   * ACTIVATIONS GO GLOBAL -> LDS DIRECTLY (global_load_lds_dwordx4, no VGPR staging), the whole block in one batch of 8
+//     instructions per wave, DOUBLE BUFFERED: the next block's loads are issued before the current block's MFMA loop.  The A
+//     operand is stored fragment-major by its producer (k_attn_op / the GELU epilogue), so a block is one contiguous span and the
+//     LDS image is conflict-free for ds_read_b128 as it lies.
+//   * 32 x 32 x 16 MFMA: half the LDS operand bytes per FLOP of the 16 x 16 x 32 form (one 1 KB A fragment feeds two MFMAs of
+//     32 K FLOP each), 4 waves x 1 KB per 64 cycles = 64 B/clk of the CU's 256 B/clk LDS read rate.
+//   * linear2 (K = ff = 1024, k_ws2): the 4 waves split K; each keeps W[64 columns x its 256-wide K quarter] in registers, the 32-row
+//     block of `hidden` (64 KB, fragment-major, contiguous) is double buffered in LDS, the four partial 32 x 64 blocks are reduced
+//     through the retired buffer in a fixed order.
+// Epilogues are the ones of dsg_kernels.h (gemm_prefetch_tile / gemm_epilogue_tile), called per accumulator quad with the
+// (token, feature) the 32 x 32 C layout gives the lane -- same arithmetic per element; the set differs from the others only in the
+// order of the k sums.
+// Measured on MI355X (profiles/r03_c_*_kernel_stats.csv, r03_d_*, r03_e_*; per launch, HIP-launch path under rocprofv3):
+//     rows (clips)      linear1  blk -> k_ws      linear2  blk_k -> k_ws2      step (AQL), BLOCK -> STREAM
+//     5696 (1 x 64)         12.8 -> 10.1 us            16.3 -> 10.5 us            611 -> 544 us   (+12 % clips/s)
+//     2848 (1 x 32)                                                                369 -> 357 us
+//     4 x 1424 (4 x 16)                                                            510 -> 500 us
+//     1424 (1 x 16)           5.5 -> 5.95 us            6.95 -> 5.9 us            234 -> 243 us   (slower: see below)
+// i.e. it pays from ~2800 rows per lane; select_kernels() picks it there.  Below that a workgroup gets ONE block, so the register-
+// resident panel is loaded for nothing and the persistent loop has nothing to overlap; and with the fence-free loop (uncached
+// activation buffers, max_batch <= 16) the 128 KB-LDS linear2 kernel, faster on its own, makes the chain slower.
+// The same design with LayerNorm-on-read (QKV of layers > 0, pose head; 64 fp32 rows staged through registers, one workgroup per
+// CU) was built and measured SLOWER than the block kernels at every size (QKV 28.0 vs 23.0 us at 5696 rows, 17.4 vs 8.4 at 1424;
+// head 53.4 vs 52.3 / 18.5 vs 17.0) -- the synchronous fp32 staging serialises load, LayerNorm and MFMA phases -- and removed again;
+// those GEMMs stay on dsg_batched.h.
+// Reference arithmetic being replaced: linear1 / linear2 of torch's TransformerEncoderLayer (main/model/mdm.py:79-86) at M = 89 B.
+#pragma once
+#include "dsg_batched.h"
+
+namespace dsg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// 16 bytes per lane, global -> LDS without a VGPR round trip: LDS address = lds_base (wave-uniform) + lane * 16
+__device__ __forceinline__ void glds16(const void* gsrc_lane, void* lds_base_uniform, int lane) {
+#ifndef DSG_EMU
+    (void)lane;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                     (__attribute__((address_space(3))) void*)lds_base_uniform, 16, 0, 0);
+#else
+    *(f32x4*)((char*)lds_base_uniform + lane * 16) = *(const f32x4*)gsrc_lane;
+#endif
+}
+// D[i][j] += sum_k A[i][k] B[k][j], 32 x 32 x 16: lane l gives row / column (l & 31) and the 8 k-values of group (l >> 5) of
+// either operand (same k map on both sides, so the hardware's k order is irrelevant); D: column j = l & 31,
+// row i = (r & 3) + 8 (r >> 2) + 4 (l >> 5) for register r.
+__device__ __forceinline__ f32x16 mma32(f32x4 a, f32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// wave-level wait for this wave's outstanding global -> LDS loads (they count as vector memory operations)
+__device__ __forceinline__ void glds_wait() { __builtin_amdgcn_s_waitcnt(0x0F70); }       // vmcnt(0) expcnt(7) lgkmcnt(15)
+
+// workgroup id -> (panel, group): the panels of one group share blockIdx.x & 7, i.e. (as workgroups are dealt) one XCD -- the
+// activation block they all read is fetched into ONE L2 (cached mode); groups are spread over the XCDs
+struct WsId { int panel, grp; bool work; };
+__device__ __forceinline__ WsId ws_id(int n_panels, int G) {
+    const int x = (int)blockIdx.x, t = x >> 3;
+    WsId w;
+    w.panel = t % n_panels;
+    w.grp = (x & 7) + 8 * (t / n_panels);
+    w.work = t < n_panels * (G >> 3);
+    return w;
+}
+__host__ __device__ inline int ws_grid_x(int n_panels, int G) { return 8 * n_panels * (G >> 3); }
+
+// ---------------------------------------------------------------------------------------------------------
+// k_ws: linear1 (K = D <= 256, bias + GELU), 64 x 128 blocks, W panel stationary in registers.   KD16 = K / 16
+// ---------------------------------------------------------------------------------------------------------
+template <int KD16>
+__global__ __launch_bounds__(256, 2) void k_ws(const GemmArgs g) {
+    typedef PBF16 P;
+    constexpr int EPI = EPI_GELU;
+    constexpr int K = 16 * KD16, KB = K / 32, BM = 64;
+    constexpr int ABYTES = BM * K * 2;
+    static_assert(KD16 % 4 == 0 && KD16 <= 16, "K = 64, 128, 192 or 256");
+    __shared__ __attribute__((aligned(16))) char lds[2 * ABYTES];
+    preload_kernargs(g);
+    const int n_panels = g.NT >> 3, G = g.ws_G;
+    const WsId id = ws_id(n_panels, G);
+    const int MB = (g.M + BM - 1) / BM;
+    if (!id.work || id.grp >= MB) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    // ---- this wave's 64 columns x K of W: 2 column tiles of 32, KD16 fragments each, resident for the life of the workgroup
+    const f32x4* wbase = (const f32x4*)g.Wp;
+    f32x4 wf[2][KD16];
+    int nb[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        nb[ct] = id.panel * 128 + wn * 64 + ct * 32;
+        const int nt = (nb[ct] >> 4) + (l31 >> 4);
+#pragma unroll
+        for (int s = 0; s < KD16; ++s)
+            wf[ct][s] = wbase[((size_t)nt * KB + (s >> 1)) * 64 + (2 * (s & 1) + lhi) * 16 + (lane & 15)];
+    }
+    // activation block mb -> LDS buffer (fragment-major operand: one contiguous 4 KB-tiles x KB span)
+    auto issue_a = [&](int mb, int buf) {
+        const char* src = (const char*)g.A + (size_t)mb * (BM * K * 2);
+        char* dst = lds + buf * ABYTES;
+#pragma unroll
+        for (int c = 0; c < (BM * K * 2) / 4096; ++c) {
+            const int chunk = c * 4 + wave;                        // 1 KB per wave instruction
+            glds16(src + chunk * 1024 + lane * 16, dst + chunk * 1024, lane);
+        }
+    };
+    int cur = 0;
+    issue_a(id.grp, 0);
+#pragma unroll 1
+    for (int mb = id.grp; mb < MB; mb += G) {
+        const int m0 = mb * BM;
+        glds_wait();
+        DSG_LDS_BARRIER();             // the block has landed for every wave; every wave is done with the other buffer
+        if (mb + G < MB) issue_a(mb + G, cur ^ 1);
+        f32x16 acc[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+        const char* abase = lds + cur * ABYTES + ((size_t)((2 * wm + (l31 >> 4)) * KB) * 64 + lhi * 16 + (lane & 15)) * 16;
+#pragma unroll
+        for (int s = 0; s < KD16; ++s) {
+            const f32x4 a = *(const f32x4*)(abase + ((s >> 1) * 64 + 2 * (s & 1) * 16) * 16);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) acc[ct] = mma32(wf[ct][s], a, acc[ct]);      // D[feature][token]: 4 consecutive features per lane
+        }
+        // ---- epilogue: per column tile, the 4 accumulator quads of the lane
+        const int mw = m0 + 32 * wm;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            TileOps ops[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gemm_prefetch_tile<P, EPI>(g, mw, nb[ct] + 8 * q + 4 * lhi, l31, 0, 0, ops[q]);      // token mw + l31, 4 features
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = {acc[ct][4 * q], acc[ct][4 * q + 1], acc[ct][4 * q + 2], acc[ct][4 * q + 3]};
+                gemm_epilogue_tile<P, EPI>(g, mw, nb[ct] + 8 * q + 4 * lhi, l31, 0, 0, true, v, ops[q], 0.f, 0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        cur ^= 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_ws2: linear2 (K = ff), 32 x 64 blocks, the 4 waves split K, W slice stationary in registers.   KW16 = K / 64
+// ---------------------------------------------------------------------------------------------------------
+template <int KW16>
+__global__ __launch_bounds__(256, 1) void k_ws2(const GemmArgs g) {
+    typedef PBF16 P;
+    constexpr int K = 64 * KW16, KB = K / 32, BM = 32;
+    constexpr int ABYTES = BM * K * 2;
+    constexpr int REDBYTES = 4 * 2 * 16 * 64 * 4;                 // 4 waves x 2 column tiles x 16 registers x 64 lanes, fp32
+    constexpr bool RED_IN_A = ABYTES >= REDBYTES;                  // the partial sums go through the retired activation buffer
+    __shared__ __attribute__((aligned(16))) char lds[2 * ABYTES + (RED_IN_A ? 0 : REDBYTES)];
+    preload_kernargs(g);
+    const int n_panels = g.NT >> 2, G = g.ws_G;
+    const WsId id = ws_id(n_panels, G);
+    const int MB = (g.M + BM - 1) / BM;
+    if (!id.work || id.grp >= MB) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const f32x4* wbase = (const f32x4*)g.Wp;
+    // ---- W[64 columns x this wave's K quarter]: KW16 fragments per 32-column tile
+    f32x4 wf[2][KW16];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int nt = id.panel * 4 + ct * 2 + (l31 >> 4);
+#pragma unroll
+        for (int s = 0; s < KW16; ++s) {
+            const int ks = wave * KW16 + s;                        // k16 step of the whole K range
+            wf[ct][s] = wbase[((size_t)nt * KB + (ks >> 1)) * 64 + (2 * (ks & 1) + lhi) * 16 + (lane & 15)];
+        }
+    }
+    // ---- the 2 output quads this wave finishes: column tile wave >> 1, registers 8 (wave & 1) .. + 7
+    const int ct_f = wave >> 1, q0 = 2 * (wave & 1);
+    f32x4 pbias[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) pbias[j] = *(const f32x4*)(g.bias + id.panel * 64 + ct_f * 32 + 8 * (q0 + j) + 4 * lhi);
+    auto issue_a = [&](int mb, int buf) {
+        const char* src = (const char*)g.A + (size_t)mb * ABYTES;      // fragment-major: 2 row tiles x KB k-blocks, contiguous
+        char* dst = lds + buf * ABYTES;
+#pragma unroll
+        for (int c = 0; c < (ABYTES + 4095) / 4096; ++c) {
+            const int chunk = c * 4 + wave;
+            if (chunk * 1024 < ABYTES) glds16(src + chunk * 1024 + lane * 16, dst + chunk * 1024, lane);
+        }
+    };
+    int cur = 0;
+    issue_a(id.grp, 0);
+#pragma unroll 1
+    for (int mb = id.grp; mb < MB; mb += G) {
+        const int m0 = mb * BM;
+        glds_wait();
+        DSG_LDS_BARRIER();
+        if (mb + G < MB) issue_a(mb + G, cur ^ 1);
+        // residual rows of this wave's quads: in flight during the MFMA loop
+        f32x4 pres[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            pres[j] = lda16<P>(g.R, ((size_t)(m0 + l31) * g.ldo + id.panel * 64 + ct_f * 32 + 8 * (q0 + j) + 4 * lhi) * sizeof(float));
+        f32x16 acc[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+        const char* abase = lds + cur * ABYTES + ((size_t)((l31 >> 4) * KB) * 64 + lhi * 16 + (lane & 15)) * 16;
+#pragma unroll
+        for (int s = 0; s < KW16; ++s) {
+            const int ks = wave * KW16 + s;
+            const f32x4 a = *(const f32x4*)(abase + ((ks >> 1) * 64 + 2 * (ks & 1) * 16) * 16);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) acc[ct] = mma32(wf[ct][s], a, acc[ct]);      // D[feature][token]
+        }
+        // ---- reduce the 4 K quarters in a fixed order through LDS
+        float* red = (float*)(RED_IN_A ? lds + cur * ABYTES : lds + 2 * ABYTES);
+        if constexpr (RED_IN_A) DSG_LDS_BARRIER();                 // every wave is done reading the activation block
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((wave * 2 + ct) * 16 + r) * 64 + lane] = acc[ct][r];
+        DSG_LDS_BARRIER();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * (q0 + j) + e;
+                float sum = red[((0 * 2 + ct_f) * 16 + r) * 64 + lane];
+#pragma unroll
+                for (int w2 = 1; w2 < 4; ++w2) sum += red[((w2 * 2 + ct_f) * 16 + r) * 64 + lane];
+                v[e] = sum;
+            }
+            const int m = m0 + l31, n = id.panel * 64 + ct_f * 32 + 8 * (q0 + j) + 4 * lhi;
+            if (m < g.M) *(f32x4*)((float*)g.out + (size_t)m * g.ldo + n) = v + pbias[j] + pres[j];
+        }
+        if constexpr (!RED_IN_A) DSG_LDS_BARRIER();                // the separate partial-sum area is rewritten by the next block
+        cur ^= 1;
+    }
+}
+
+}  // namespace dsg

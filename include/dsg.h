@@ -68,7 +68,9 @@ enum {
     DSG_KSET_AUTO = 0,      /* by batch: LATENCY for batch <= 2, TILE below 1000 token rows, BLOCK from there */
     DSG_KSET_LATENCY = 1,   /* fused redundant-compute kernels, 2 + 3L dispatches: one clip in flight */
     DSG_KSET_TILE = 2,      /* one 16 x 16 MFMA tile per wave: small batches */
-    DSG_KSET_BLOCK = 3      /* 32-row block GEMMs + fused attention/out_proj/LayerNorm: large batches, several lanes */
+    DSG_KSET_BLOCK = 3,     /* 32-row block GEMMs + fused attention/out_proj/LayerNorm: large batches, several lanes */
+    DSG_KSET_STREAM = 4     /* weight-stationary persistent GEMMs (32x32x16 MFMA, global->LDS staging, 64-row blocks): bf16,
+                               latent_dim 128 / 256, 4 heads -- the ZEGGS model; DSG_E_NOT_IMPLEMENTED elsewhere */
 };
 enum { DSG_MODE_DDPM = 0, DSG_MODE_DDIM = 1 };
 

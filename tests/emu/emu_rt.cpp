@@ -115,6 +115,30 @@ f32x4_t mfma_16x16x32_bf16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
     }
     return d;
 }
+// v_mfma_f32_32x32x16_bf16: lane l holds row / column (l & 31) and the 8 k-values of group (l >> 5) of A / B;
+// D: column j = l & 31, row i = (r & 3) + 8 (r >> 2) + 4 (l >> 5) for register r (cdna_hip_programming.md s3)
+f32x16_t mfma_32x32x16_bf16(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+    Worker* w = tw; Fiber& f = w->fibers[w->cur]; Wave& wv = w->waves[f.wave];
+    const int p = wave_parity(wv);
+    typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+    const u16x8 au = __builtin_bit_cast(u16x8, a), bu = __builtin_bit_cast(u16x8, b);
+    for (int e = 0; e < 8; ++e) { wv.a16[p][f.lane][e] = au[e]; wv.b16[p][f.lane][e] = bu[e]; }
+    wave_sync(wv);
+    const int j = f.lane & 31, hi = f.lane >> 5;
+    f32x16_t d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int g = 0; g < 2; ++g)
+            for (int e = 0; e < 8; ++e) {
+                const float x = __builtin_bit_cast(float, (unsigned)wv.a16[p][i + 32 * g][e] << 16);
+                const float y = __builtin_bit_cast(float, (unsigned)wv.b16[p][j + 32 * g][e] << 16);
+                acc += x * y;
+            }
+        d[r] = acc;
+    }
+    return d;
+}
 f32x4_t mfma_16x16x4_f32(float a, float b, f32x4_t c) {
     Worker* w = tw; Fiber& f = w->fibers[w->cur]; Wave& wv = w->waves[f.wave];
     const int p = wave_parity(wv);

@@ -35,6 +35,8 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 f32x4_t mfma_16x16x32_bf16(bf16x8_t a, bf16x8_t b, f32x4_t c);
 f32x4_t mfma_16x16x4_f32(float a, float b, f32x4_t c);
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+f32x16_t mfma_32x32x16_bf16(bf16x8_t a, bf16x8_t b, f32x16_t c);
 bool is_device(const void* p);
 void* dmalloc(size_t n);
 void dfree(void* p);
@@ -77,6 +79,7 @@ static inline float __shfl_xor(float v, int m) {
 static inline int __shfl_xor(int v, int m) { return (int)emu::shfl_xor_u32((unsigned)v, m); }
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu::mfma_16x16x32_bf16(a, b, c)
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu::mfma_16x16x4_f32(a, b, c)
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu::mfma_32x32x16_bf16(a, b, c)
 
 static inline void sincospif(float x, float* s, float* c) {
     const double a = 3.14159265358979323846 * (double)x;

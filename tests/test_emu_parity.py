@@ -136,15 +136,19 @@ def test_classifier_free_guidance_wrapper(tiny):
         w(x, ts, y)
 
 
-@pytest.mark.parametrize("kset", ["tile", "block"])
+@pytest.mark.parametrize("kset", ["tile", "block", "stream"])
 def test_kernel_sets_tiny(tiny, emu_lib, golden_dir, kset):
     """Explicit kernel sets (dsg_set_kernel_set) at the tiny dims against the same goldens as the latency kernels, incl. the
-    ragged last row tile (bf16: with k_attn_op); at batch 8 and batch 23 (529 rows: the 3-waves-per-SIMD LayerNorm GEMMs from
+    ragged last row tile (bf16: with k_attn_op; "stream": the weight-stationary FFN GEMMs of dsg_stream.h); at batch 8 and batch 23 (529 rows: the 3-waves-per-SIMD LayerNorm GEMMs from
     512 rows) against the oracle; the set that ran is reported (dsg_last_kernel_set) and sticky."""
     from oracle.mdm import MDMOracle
     gt, _, y, x = tiny
     sd = synth_state_dict(C.TINY, int(gt["wseed"]))
-    for prec in ("fp32", "bf16"):
+    all_precs = ("bf16",) if kset == "stream" else ("fp32", "bf16")       # "stream" (dsg_stream.h) is a bf16 set
+    if kset == "stream":
+        with pytest.raises(NotImplementedError):
+            DSGDenoiser(C.TINY, precision="fp32", max_batch=2, library=emu_lib).set_kernel_set("stream")
+    for prec in all_precs:
         m = DSGDenoiser(C.TINY, precision=prec, max_batch=2, library=emu_lib).set_kernel_set(kset)
         m.load_state_dict(sd)
         assert rel_l2(m(x, np.array([998, 17]), dict(y, mask_local=gt["mask2"])), gt["fwd_mask2"]) < TOL[prec]
@@ -159,7 +163,7 @@ def test_kernel_sets_tiny(tiny, emu_lib, golden_dir, kset):
         xb = np.random.RandomState(B).randn(B, C.TINY.njoints, 1, C.TINY.n_poses).astype(np.float32)
         ts = np.arange(B) * 40 + 3
         want = ref(xb, list(ts), yb)
-        for prec in precs:
+        for prec in (p for p in precs if p in all_precs):
             mb = DSGDenoiser(C.TINY, precision=prec, max_batch=B, library=emu_lib).set_kernel_set(kset)
             mb.load_state_dict(sd)
             assert rel_l2(mb(xb, ts, yb), want) < TOL[prec], (B, prec)
@@ -184,6 +188,7 @@ def test_kernel_set_is_a_property_of_the_lane_not_of_the_call(tiny, emu_lib):
     assert m.recommend_kernel_set(1, 1) == "latency" and m.recommend_kernel_set(2, 1) == "latency"
     assert m.recommend_kernel_set(1, 4) == "latency" and m.recommend_kernel_set(2, 4) == "tile"
     assert m.recommend_kernel_set(14, 4) == "block" and m.recommend_kernel_set(14, 1) == "tile" and m.recommend_kernel_set(44, 1) == "block"
+    assert m.recommend_kernel_set(130, 1) == "stream" and m.recommend_kernel_set(130, 4) == "stream"      # from 2800 token rows per lane
     shape = (2, cfg.njoints, 1, cfg.n_poses)
     d = create_gaussian_diffusion(library=emu_lib)
     ys = [{"y": synth_window_inputs(cfg, 2, window=w, clip0=2 * w, seed_pose_scale=0.2)} for w in range(2)]

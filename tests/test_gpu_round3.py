@@ -164,6 +164,48 @@ def test_kernel_sets_are_sticky_lane_properties(gpu):
             assert lanes[i].last_kernel_set() == kset and np.array_equal(np.asarray(multi[i]), np.asarray(alone)), (kset, i)
 
 
+@pytest.mark.parametrize("B", [3, 16])
+def test_stream_kernel_set_vs_oracle(gpu, B):
+    """Kernel set "stream" (dsg_stream.h: weight-stationary persistent GEMMs, 32x32x16 MFMA, global->LDS staging, 64-row blocks) at
+    ZEGGS dims: a forward with ragged last blocks (267 / 1424 rows) and a 40-step DDPM chain with distinct rows against the oracle,
+    row by row; DDIM on top at batch 16 (config[2]'s shape)."""
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    from oracle import philox, sampler
+    from oracle.mdm import MDMOracle
+    from oracle.schedule import OracleDiffusion
+    cfg = C.ZEGGS
+    shape = (B, cfg.njoints, 1, cfg.n_poses)
+    y = synth_window_inputs(cfg, B, window=2, clip0=11, seed_pose_scale=0.2)
+    ref = MDMOracle(synth_state_dict(cfg, 20240), cfg)
+    m = _model(cfg, "bf16", max_batch=B).set_kernel_set("stream")
+    x = np.random.RandomState(B).randn(*shape).astype(np.float32)
+    ts = (np.arange(B) * 61 + 5) % 1000
+    out = np.asarray(m(x, ts, y))
+    assert m.last_kernel_set() == "stream"
+    rows = [0, B - 1] if B > 3 else [0, 1, 2]
+    for b in rows:
+        yb = {k: (v[b:b + 1] if k != "mask_local" else v) for k, v in y.items()}
+        e = rel_l2(out[b], ref(x[b:b + 1], [int(ts[b])], yb)[0])
+        assert e < 1.2e-2, (b, e)
+    d = create_gaussian_diffusion()
+    s = np.asarray(d.manual_seed(5, 3).p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=960))
+    assert m.last_kernel_set() == "stream" and m.last_sample_path() == "aql" and np.isfinite(s).all()
+    od = OracleDiffusion()
+    for b in rows[:2]:
+        yb = {k: (v[b:b + 1] if k != "mask_local" else v) for k, v in y.items()}
+        r = sampler.p_sample_loop(od, ref, (1,) + shape[1:], lambda k, b=b: philox.normal_bj1t(shape, 5, k, 3)[b:b + 1], {"y": yb}, skip_timesteps=960)
+        e = rel_l2(s[b], r[0])
+        print(f"stream set, batch {B}, row {b}: 40-step chain rel-L2 {e:.3e}")
+        assert e < TOL_CHAIN["bf16"], (b, e)
+    if B == 16:
+        d50 = create_gaussian_diffusion("ddim50")
+        s50 = np.asarray(d50.manual_seed(6, 1).ddim_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=0, eta=0.0))
+        yb = {k: (v[7:8] if k != "mask_local" else v) for k, v in y.items()}
+        r = sampler.ddim_sample_loop(OracleDiffusion(timestep_respacing="ddim50"), ref, (1,) + shape[1:],
+                                     lambda k: philox.normal_bj1t(shape, 6, k, 1)[7:8], {"y": yb}, eta=0.0)
+        assert rel_l2(s50[7], r[0]) < TOL_CHAIN["bf16"]
+
+
 def test_guidance_wrapper_without_room_for_twins_uses_generic_loop(gpu):
     """Round-2 advisor finding: ClassifierFreeSampleModel around a denoiser of max_batch < 2B must still sample (generic loop: two
     library calls per step, the same Philox stream), not raise -- and agree with the fused 2B-row loop."""
