@@ -20,10 +20,14 @@ $(CSRC)/dsg_kernels.hsaco: $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg
 	$(HIPCC) --offload-arch=gfx950 --cuda-device-only --no-gpu-bundle-output -O3 -std=c++17 -Wno-pass-failed -DDSG_BUILD_TAG=$(TAG)u \
 	    -Rpass-analysis=kernel-resource-usage $(CSRC)/dsg_hip.cpp -o $@ 2> $(CSRC)/dsg_kernels.resources.txt || (cat $(CSRC)/dsg_kernels.resources.txt >&2; exit 1)
 
-# diagnostics build: the same sources with cycle stamps at the phase boundaries of the step kernels (tools/stamps.py)
-stamps: $(CSRC)/libdsg_hip_stamps.so
-$(CSRC)/libdsg_hip_stamps.so: $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h $(CSRC)/dsg_batched.h $(CSRC)/dsg_stream.h include/dsg.h $(CSRC)/dsg_bvh.cpp
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed -DDSG_STAMPS=1 $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_bvh.cpp -L/opt/rocm/lib -lhsa-runtime64 -lpthread -o $@
+# timeline build: the same sources with first-wave-start / last-wave-end stamps in every step kernel (dsg_kernels.h: TlScope), as a
+# library + its OWN code object with the same tag, so that tools/aql_timeline.py traces the fence-free AQL path itself
+STAMPS_SRC := $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h $(CSRC)/dsg_batched.h $(CSRC)/dsg_stream.h $(CSRC)/dsg_aql.h include/dsg.h
+stamps: $(CSRC)/libdsg_hip_stamps.so $(CSRC)/dsg_kernels_stamps.hsaco
+$(CSRC)/libdsg_hip_stamps.so: $(STAMPS_SRC) $(CSRC)/dsg_bvh.cpp
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed -DDSG_STAMPS=1 -DDSG_BUILD_TAG=$(TAG)u $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_bvh.cpp -L/opt/rocm/lib -lhsa-runtime64 -lpthread -o $@
+$(CSRC)/dsg_kernels_stamps.hsaco: $(STAMPS_SRC)
+	$(HIPCC) --offload-arch=gfx950 --cuda-device-only --no-gpu-bundle-output -O3 -std=c++17 -Wno-pass-failed -DDSG_STAMPS=1 -DDSG_BUILD_TAG=$(TAG)u $(CSRC)/dsg_hip.cpp -o $@
 
 emu: $(EMU)
 $(EMU): $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h $(CSRC)/dsg_batched.h $(CSRC)/dsg_stream.h include/dsg.h tests/emu/shim/hip/hip_runtime.h tests/emu/emu_rt.cpp $(CSRC)/dsg_bvh.cpp

@@ -34,7 +34,31 @@
 namespace dsg_aql {
 
 struct Kernel { uint64_t object = 0; uint32_t kernarg_size = 0, group = 0, priv = 0; };
-struct Launch { Kernel k; unsigned gx, gy, gz, bx, by, bz; size_t ka_off; };
+struct Launch { Kernel k; unsigned gx, gy, gz, bx, by, bz; size_t ka_off, hidden_off; std::string name; };
+
+// Per-packet timeline of the step loop AS IT IS TIMED (diagnostics: dsg_debug_trace_arm / tools/aql_timeline.py).  rocprofv3
+// cannot see hand-written packets, so the profile of this path comes from the path itself, in one of two ways:
+//   product library: the queue is put in profiling mode and every packet of the traced steps carries its own completion signal;
+//       hsa_amd_profiling_get_dispatch_time returns the command processor's start / end timestamps of each dispatch.  Costs
+//       ~0.8 us per traced packet (the traced steps run ~20 % slower), and "start" is when the packet is taken up, not when its
+//       first wave runs: busy includes the dispatch overhead, the gaps read 0.
+//   timeline build (-DDSG_STAMPS, `make stamps`): every WAVE of a traced kernel stores the 100 MHz steady counter at its start and
+//       its end into its own entry of a ring (dsg_kernels.h: TlScope); slot index and ring pointer travel in reserved dwords of
+//       the packet's implicit-argument block -- the traced steps get their own copies of the argument blocks with the slots filled
+//       in, every other packet carries slot -1.  first-wave start = min, last-wave end = max over the entries of a slot.
+//       (A first version with one atomic min / max per wave on a shared slot made the traced steps 2.6x slower: ~12 ns per
+//       contended atomic x 400-1200 waves per kernel.)
+// The un-traced steps of the same run keep the plain packets.
+struct Trace {
+    bool armed = false;
+    int first = 0, n = 0;                    // traced steps [first, first + n)
+    std::vector<hsa_signal_t> sig;           // n x packets-per-step (product library)
+    char* ka_trace = nullptr; size_t ka_trace_cap = 0;      // timeline build: n copies of the argument blocks with slot indices
+    char* ring = nullptr; size_t ring_cap = 0;              // ... and the per-wave stamp ring
+    std::vector<double> us;                  // result: [n][packets][2] = start, end in us relative to the first traced start
+    std::vector<std::string> names;          // kernel of each packet of a step
+    double traced_span_us = 0.0;             // first traced start -> last traced end
+};
 
 struct Ctx {
     bool tried = false, ready = false, recording = false;
@@ -52,6 +76,7 @@ struct Ctx {
     bool nofence = false;   // no acquire / release between the packets of the loop: everything the loop writes is coherent without
                             // cache maintenance (uncached buffers, dsg_hip.cpp uc_mode)
     char bdf[32] = {0};     // PCI address of the agent the queue lives on (== the HIP device's: checked in init)
+    Trace trace;
 };
 
 inline bool hsa_ok(Ctx& c, hsa_status_t s, const char* what) {
@@ -104,7 +129,11 @@ inline bool init(Ctx& c, int hip_device, const void* addr_in_library) {
     Dl_info info;
     if (!dladdr(addr_in_library, &info) || !info.dli_fname) { c.err = "dladdr failed"; return false; }
     std::string path(info.dli_fname);
+#ifdef DSG_STAMPS
+    path = path.substr(0, path.find_last_of('/') + 1) + "dsg_kernels_stamps.hsaco";
+#else
     path = path.substr(0, path.find_last_of('/') + 1) + "dsg_kernels.hsaco";
+#endif
     std::ifstream f(path, std::ios::binary);
     c.image.assign((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
     if (c.image.empty()) { c.err = "cannot read " + path + " (run make)"; return false; }
@@ -156,7 +185,7 @@ inline bool record(Ctx& c, const void* host_fn, hipStream_t stream, dim3 grid, d
     Kernel k;
     if (!lookup(c, host_fn, stream, k)) return false;
     const size_t hidden = (size + 7) & ~(size_t)7;
-    const size_t need = std::max<size_t>(k.kernarg_size, hidden + 72);
+    const size_t need = std::max<size_t>(k.kernarg_size, hidden + 144);
     const size_t off = (c.ka_host.size() + 255) & ~(size_t)255;
     c.ka_host.resize(off + ((need + 255) & ~(size_t)255), 0);
     char* p = c.ka_host.data() + off;
@@ -167,7 +196,10 @@ inline bool record(Ctx& c, const void* host_fn, hipStream_t stream, dim3 grid, d
     std::memcpy(p + hidden + 12, gs, sizeof gs);
     const uint16_t dims = 3;
     std::memcpy(p + hidden + 64, &dims, 2);
-    c.plan.push_back(Launch{k, grid.x, grid.y, grid.z, block.x, block.y, block.z, off});
+    const int no_slot = -1;                  // timeline build: "not traced" (dsg_kernels.h: DSG_TL_ARG_OFF); unused otherwise
+    std::memcpy(p + hidden + 128, &no_slot, 4);
+    const char* nm = hipKernelNameRefByPtr(host_fn, stream);
+    c.plan.push_back(Launch{k, grid.x, grid.y, grid.z, block.x, block.y, block.z, off, hidden, nm ? nm : "?"});
     return true;
 }
 
@@ -188,7 +220,8 @@ inline bool finish(Ctx& c) {
 
 // packets of one step of `c` into its queue + doorbell; `last`: the final packet releases to system scope and carries the
 // completion signal
-inline void submit_step(Ctx& c, bool first_step, bool last_step) {
+inline void submit_step(Ctx& c, bool first_step, bool last_step, int step_index = -1) {
+    const bool traced = c.trace.armed && step_index >= c.trace.first && step_index < c.trace.first + c.trace.n && !last_step;
     const uint32_t mask = c.q->size - 1;
     const size_t L = c.plan.size();
     const uint64_t first = hsa_queue_add_write_index_relaxed(c.q, L);
@@ -203,8 +236,15 @@ inline void submit_step(Ctx& c, bool first_step, bool last_step) {
         p->private_segment_size = 0; p->group_segment_size = l.k.group;
         p->kernel_object = l.k.object;
         p->kernarg_address = c.ka_dev + l.ka_off;
+#ifdef DSG_STAMPS
+        if (traced) p->kernarg_address = c.trace.ka_trace + (size_t)(step_index - c.trace.first) * c.ka_host.size() + l.ka_off;
+#endif
         p->reserved2 = 0;
+#ifdef DSG_STAMPS
         p->completion_signal.handle = last ? c.done.handle : 0;
+#else
+        p->completion_signal.handle = last ? c.done.handle : (traced ? c.trace.sig[(size_t)(step_index - c.trace.first) * L + i].handle : 0);
+#endif
         // fence-free plan: only the first packet acquires (everything the set-up kernels wrote) and only the last one releases
         // (the samples); a kernel's stores have been acknowledged when its waves end (s_endpgm waits for them) and the barrier
         // bit orders the packets
@@ -227,17 +267,110 @@ inline bool has_room(Ctx& c) {
 // the handle's state as lost.
 inline bool run(Ctx& c, int n_steps, double timeout_s) {
     hsa_signal_store_relaxed(c.done, 1);
+    Trace& tr = c.trace;
+    const size_t L = c.plan.size();
+#ifdef DSG_STAMPS
+    struct Entry { unsigned long long t0, t1; };
+    constexpr size_t TLW = 2048;             // = dsg::DSG_TL_WAVES
+#endif
+    if (tr.armed) {
+        tr.n = std::max(0, std::min(tr.n, n_steps - 1 - tr.first));      // never the last step (its last packet carries the completion signal)
+#ifdef DSG_STAMPS
+        if ((size_t)tr.n * L > 1024) tr.n = (int)(1024 / L);
+        const size_t ring_bytes = (size_t)tr.n * L * TLW * sizeof(Entry);
+        if (ring_bytes > tr.ring_cap) {
+            if (tr.ring) (void)hipFree(tr.ring);
+            tr.ring_cap = ring_bytes;
+            if (hipMalloc((void**)&tr.ring, tr.ring_cap) != hipSuccess) { tr.ring = nullptr; tr.ring_cap = 0; c.err = "trace: hipMalloc(ring)"; return false; }
+        }
+        std::vector<char> blocks((size_t)tr.n * c.ka_host.size());
+        for (int s = 0; s < tr.n; ++s) {
+            std::memcpy(blocks.data() + (size_t)s * c.ka_host.size(), c.ka_host.data(), c.ka_host.size());
+            for (size_t i = 0; i < L; ++i) {
+                const int slot = (int)(s * L + i);
+                char* hp = blocks.data() + (size_t)s * c.ka_host.size() + c.plan[i].ka_off + c.plan[i].hidden_off;
+                std::memcpy(hp + 128, &slot, 4);
+                std::memcpy(hp + 136, &tr.ring, 8);
+            }
+        }
+        if (blocks.size() > tr.ka_trace_cap) {
+            if (tr.ka_trace) (void)hipFree(tr.ka_trace);
+            tr.ka_trace_cap = blocks.size();
+            if (hipMalloc((void**)&tr.ka_trace, tr.ka_trace_cap) != hipSuccess) { tr.ka_trace = nullptr; tr.ka_trace_cap = 0; c.err = "trace: hipMalloc"; return false; }
+        }
+        if ((!blocks.empty() && hipMemcpy(tr.ka_trace, blocks.data(), blocks.size(), hipMemcpyHostToDevice) != hipSuccess) ||
+            (ring_bytes && hipMemset(tr.ring, 0, ring_bytes) != hipSuccess) || hipDeviceSynchronize() != hipSuccess) {
+            c.err = "trace: set-up copy failed"; return false;
+        }
+#else
+        tr.sig.resize((size_t)tr.n * L);
+        bool ok = hsa_amd_profiling_set_profiler_enabled(c.q, 1) == HSA_STATUS_SUCCESS;
+        for (auto& sgn : tr.sig) ok = ok && hsa_signal_create(1, 0, nullptr, &sgn) == HSA_STATUS_SUCCESS;
+        if (!ok) { c.err = "trace: cannot enable queue profiling"; return false; }
+#endif
+    }
     const auto t0 = std::chrono::steady_clock::now();
     for (int s = 0; s < n_steps; ++s) {
         while (!has_room(c)) {
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) { c.err = "queue stalled"; return false; }
         }
-        submit_step(c, s == 0, s == n_steps - 1);
+        submit_step(c, s == 0, s == n_steps - 1, s);
     }
     const uint64_t budget_ns = (uint64_t)(timeout_s * 1e9);
     const hsa_signal_value_t v = hsa_signal_wait_scacquire(c.done, HSA_SIGNAL_CONDITION_LT, 1, budget_ns, HSA_WAIT_STATE_ACTIVE);
     c.last_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (v >= 1) { c.err = "completion signal timed out"; return false; }
+#ifdef DSG_STAMPS
+    if (tr.armed) {
+        int khz = 100000;
+        (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, 0);
+        std::vector<Entry> got((size_t)tr.n * L * TLW);
+        if (!got.empty() && hipMemcpy(got.data(), tr.ring, got.size() * sizeof(Entry), hipMemcpyDeviceToHost) != hipSuccess) { c.err = "trace: read-back failed"; return false; }
+        const size_t NS = (size_t)tr.n * L;
+        std::vector<unsigned long long> t0(NS, ~0ull), t1(NS, 0ull);
+        for (size_t sl = 0; sl < NS; ++sl)
+            for (size_t w = 0; w < TLW; ++w) {
+                const Entry& en = got[sl * TLW + w];
+                if (en.t0 == 0) continue;                        // no wave wrote this entry
+                t0[sl] = std::min(t0[sl], en.t0); t1[sl] = std::max(t1[sl], en.t1);
+            }
+        tr.us.assign(NS * 2, 0.0);
+        tr.names.clear();
+        for (const Launch& l : c.plan) tr.names.push_back(l.name);
+        const unsigned long long base = NS ? t0[0] : 0ull;
+        unsigned long long last_end = base;
+        for (size_t i = 0; i < NS; ++i) {
+            tr.us[2 * i] = (double)(long long)(t0[i] - base) * 1000.0 / khz;
+            tr.us[2 * i + 1] = (double)(long long)(t1[i] - base) * 1000.0 / khz;
+            last_end = std::max(last_end, t1[i]);
+        }
+        tr.traced_span_us = (double)(last_end - base) * 1000.0 / khz;
+        tr.armed = false;
+    }
+#else
+    if (tr.armed) {
+        uint64_t freq = 0;
+        hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &freq);
+        const double to_us = freq ? 1e6 / (double)freq : 0.0;
+        tr.us.assign(tr.sig.size() * 2, 0.0);
+        tr.names.clear();
+        for (const Launch& l : c.plan) tr.names.push_back(l.name);
+        uint64_t base = 0, last_end = 0;
+        for (size_t i = 0; i < tr.sig.size(); ++i) {
+            hsa_amd_profiling_dispatch_time_t t{};
+            if (hsa_amd_profiling_get_dispatch_time(c.gpu, tr.sig[i], &t) != HSA_STATUS_SUCCESS) { c.err = "trace: no dispatch time"; return false; }
+            if (i == 0) base = t.start;
+            tr.us[2 * i] = (double)(t.start - base) * to_us;
+            tr.us[2 * i + 1] = (double)(t.end - base) * to_us;
+            last_end = std::max(last_end, t.end);
+        }
+        tr.traced_span_us = (double)(last_end - base) * to_us;
+        for (auto& sgn : tr.sig) hsa_signal_destroy(sgn);
+        tr.sig.clear();
+        hsa_amd_profiling_set_profiler_enabled(c.q, 0);
+        tr.armed = false;
+    }
+#endif
     return true;
 }
 
@@ -255,7 +388,7 @@ inline bool run_multi(Ctx** cs, const int* n_steps, int n, double timeout_s, std
         bool any = false;
         for (int i = 0; i < n; ++i) {
             if (next[i] >= n_steps[i] || !has_room(*cs[i])) continue;
-            submit_step(*cs[i], next[i] == 0, next[i] == n_steps[i] - 1);
+            submit_step(*cs[i], next[i] == 0, next[i] == n_steps[i] - 1, -1);
             if (++next[i] == n_steps[i]) --open;
             any = true;
         }
@@ -276,6 +409,8 @@ inline void destroy(Ctx& c) {
     if (c.q) hsa_queue_destroy(c.q);
     if (c.ready) { hsa_signal_destroy(c.done); hsa_executable_destroy(c.ex); }
     if (c.ka_dev) (void)hipFree(c.ka_dev);
+    if (c.trace.ka_trace) (void)hipFree(c.trace.ka_trace);
+    if (c.trace.ring) (void)hipFree(c.trace.ring);
     if (c.tried) hsa_shut_down();
     c = Ctx();
 }

@@ -70,6 +70,7 @@ __device__ __forceinline__ void ln_rows_blk(const GemmArgs& g, int m0, int tid, 
 // MFMA loop was SLOWER than the 16 x 16 tile kernels: 407 vs 321 us per batch-16 step, profiles/r02_b_*).
 template <class P, int PRO, int EPI, int DMAX, int TNW, int RT>
 __global__ __launch_bounds__(256) void k_gemm_blk(const GemmArgs g) {
+    DSG_TL_SCOPE();
     typedef typename P::elem elem;
     constexpr int ES = (int)sizeof(elem), BM = 16 * RT, CH = 8;
     static_assert(EPI != EPI_PARTIAL, "split-K partials come from k_gemm_blk_k");
@@ -215,6 +216,7 @@ __global__ __launch_bounds__(256) void k_gemm_blk(const GemmArgs g) {
 // are reduced through LDS in a fixed order; wave w finishes tile (w >> 1, w & 1).
 template <class P, int EPI, int KPW>
 __global__ __launch_bounds__(256) void k_gemm_blk_k(const GemmArgs g) {
+    DSG_TL_SCOPE();
     typedef typename P::elem elem;
     constexpr int RT = 2, CT = 2;
     static_assert(EPI == EPI_RESID || EPI == EPI_PARTIAL, "direct A operand, fp32 output");

@@ -164,7 +164,7 @@ __device__ __forceinline__ void inloc_body(const InLocArgs& g) {
     local_attn_tail<P, HD, W>(a, rot, sc, b, w, h, keep, c2, s2);
 }
 template <class P, int HD, int W>
-__global__ __launch_bounds__(256) void k_inloc(const InLocArgs g) { inloc_body<P, HD, W>(g); }
+__global__ __launch_bounds__(256) void k_inloc(const InLocArgs g) { DSG_TL_SCOPE(); inloc_body<P, HD, W>(g); }
 
 // ---------------------------------------------------------------------------------------------------------
 // k_mid: pre1 = R + attn.Wo^T + bo ; x1 = LayerNorm1(pre1) ; hidden[:, slice] = gelu(x1.W1[slice]^T + b1)
@@ -201,7 +201,6 @@ __device__ __forceinline__ void mid_tail(const MidArgs& g, f32x4 (&acc)[DT], con
     for (int t = 0; t < DT; ++t) { acc[t] = acc[t] + pbo[t] + pr[t]; s += (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]); }
     s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
     if (lg == 0) red[0][wave][lr] = s;
-    DSG_STAMP(0, 3);
     DSG_LDS_BARRIER();
     const float mean = ((red[0][0][lr] + red[0][1][lr]) + (red[0][2][lr] + red[0][3][lr])) / (float)D;
     float q = 0.f;
@@ -224,9 +223,7 @@ __device__ __forceinline__ void mid_tail(const MidArgs& g, f32x4 (&acc)[DT], con
         P::store4((elem*)(a1 + lr * XP) + n, y);
         acc[t] = y;                                   // written to X1 at the very end (keeps stores out of the vmcnt queue)
     }
-    DSG_STAMP(0, 4);
     DSG_LDS_BARRIER();
-    DSG_STAMP(0, 5);
     // ---- linear1 slice + GELU
     f32x4 c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
     if constexpr (KD <= CH) {
@@ -245,7 +242,6 @@ __device__ __forceinline__ void mid_tail(const MidArgs& g, f32x4 (&acc)[DT], con
                     c1 = P::mma(bf[c], *(const f32x4*)(a1 + lr * XP + ((kb0 + c) * P::KB + P::E * lg) * ES), c1);
         }
     }
-    DSG_STAMP(0, 6);
     if (m0 + lr < g.M) {
         f32x4 y;
 #pragma unroll
@@ -262,6 +258,7 @@ __device__ __forceinline__ void mid_tail(const MidArgs& g, f32x4 (&acc)[DT], con
 // MFMA starts after ~25 loads instead of ~57 (measured: 10.7 k vs 12.3 k cycles per kernel).
 template <class P, int DT>      // DT = D / 64 : 16-col tiles of the out_proj output per wave
 __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
+    DSG_TL_SCOPE();
     typedef typename P::elem elem;
     constexpr int ES = (int)sizeof(elem);
     constexpr int D = DT * 64;
@@ -271,9 +268,7 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
     __shared__ __attribute__((aligned(16))) char a1[16 * XP];
     __shared__ float red[2][4][16];
     __shared__ __attribute__((aligned(16))) float vecs[3][D];      // out_proj bias, LayerNorm1 scale / shift: one load per WORKGROUP
-    DSG_STAMP(0, 0);
     preload_kernargs(g);
-    DSG_STAMP_SCALAR_WAIT(0, 8);
     const int NGH = g.ff / 64;
     const int ng = xcd_ngroup<P>(), mt = blockIdx.y;
     if (ng >= NGH) return;
@@ -334,10 +329,8 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
         }
         if (kb + PD == KD) load_operands();           // all fragments requested: now the operands of the later phases
         DSG_LOADS_ISSUED();
-        if (kb == 0) DSG_STAMP(0, 1);
 #pragma unroll
         for (int t = 0; t < DT; ++t) acc[t] = P::mma(bf[kb][t], af[kb], acc[t]);      // D[n 4lg+r][row lr]
-        if (kb == 0) DSG_STAMP(0, 2);
         DSG_LOADS_ISSUED();
     }
 #pragma unroll
@@ -352,7 +345,6 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
         pbo[t] = *(const f32x4*)(&vecs[0][n]); pg[t] = *(const f32x4*)(&vecs[1][n]); pbt[t] = *(const f32x4*)(&vecs[2][n]);
     }
     mid_tail<P, DT>(g, acc, pbo, pr, pg, pbt, pb1, w1f, w1, a1, red, m0, ng, n1t, wave, lr, lg);
-    DSG_STAMP(0, 7);
 }
 
 
@@ -389,7 +381,6 @@ __device__ __forceinline__ void attn_mid_body(const AttnMidArgs& ga) {
     __shared__ __attribute__((aligned(16))) char a1[16 * XP];      // LayerNorm1 output rows
     __shared__ float red[2][4][16];
     __shared__ __attribute__((aligned(16))) float vecs[3][D];      // out_proj bias, LayerNorm1 scale / shift: one load per WORKGROUP (see k_mid)
-    DSG_STAMP(0, 0);
     preload_kernargs(ga);
     const MidArgs& g = ga.mid;
     const int NGH = g.ff / 64;
@@ -416,7 +407,6 @@ __device__ __forceinline__ void attn_mid_body(const AttnMidArgs& ga) {
         for (int kb = 0; kb < NVF; ++kb) vfr[dt][kb] = lda16<P>(ga.vt, (VT + (size_t)((dt * NVF + kb) * 64 + lane) * P::E) * ES);       // fragment-major (vt_off)
     }
     DSG_LOADS_ISSUED();
-    DSG_STAMP(0, 9);
     // ---- (2) everything the later phases need is requested WHILE the attention math runs, a few loads per slot: a wave
     //      issues in order, and a burst of ~70 loads stalls it in the issue stage for as long as the texture path needs
     //      to drain them (~100 cycles each with 4 waves loading) -- time in which no softmax instruction can run.
@@ -468,7 +458,6 @@ __device__ __forceinline__ void attn_mid_body(const AttnMidArgs& ga) {
 #pragma unroll
         for (int kb = 0; kb < KDH; ++kb) s[nt] = P::mma(kf[nt][kb], qf[kb], s[nt]);
     }
-    DSG_STAMP(0, 10);
     const float scale = 1.0f / sqrtf((float)HD);
     float mx = -DSG_FLT_MAX;
 #pragma unroll
@@ -512,7 +501,6 @@ __device__ __forceinline__ void attn_mid_body(const AttnMidArgs& ga) {
             pfr[kb] = __builtin_bit_cast(f32x4, pp);
         }
     }
-    DSG_STAMP(0, 11);
     // ---- (4) O^T = V^T P^T  -> LDS rows (the same rounding point as the global attention buffer of k_attn)
 #pragma unroll
     for (int dt = 0; dt < ND; ++dt) {
@@ -527,7 +515,6 @@ __device__ __forceinline__ void attn_mid_body(const AttnMidArgs& ga) {
     }
 #undef DSG_ISSUE_SLOT
     DSG_LDS_BARRIER();
-    DSG_STAMP(0, 12);
 
     // ---- (5) out_proj from the LDS rows, remaining weight k-blocks PD ahead
     f32x4 acc[DT];
@@ -543,7 +530,6 @@ __device__ __forceinline__ void attn_mid_body(const AttnMidArgs& ga) {
 #pragma unroll
         for (int t = 0; t < DT; ++t) acc[t] = P::mma(bf[kb][t], af, acc[t]);      // D[n 4lg+r][row lr]
     }
-    DSG_STAMP(0, 13);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int e = tid + 256 * i;
@@ -556,10 +542,9 @@ __device__ __forceinline__ void attn_mid_body(const AttnMidArgs& ga) {
         pbo[t] = *(const f32x4*)(&vecs[0][n]); pg[t] = *(const f32x4*)(&vecs[1][n]); pbt[t] = *(const f32x4*)(&vecs[2][n]);
     }
     mid_tail<P, DT>(g, acc, pbo, pr, pg, pbt, pb1, w1f, w1, a1, red, m0, ng, n1t, wave, lr, lg);
-    DSG_STAMP(0, 7);
 }
 template <class P, int DT, int NKT>
-__global__ __launch_bounds__(256) void k_attn_mid(const AttnMidArgs ga) { attn_mid_body<P, DT, NKT>(ga); }
+__global__ __launch_bounds__(256) void k_attn_mid(const AttnMidArgs ga) { DSG_TL_SCOPE(); attn_mid_body<P, DT, NKT>(ga); }
 
 // ---------------------------------------------------------------------------------------------------------
 // k_attn_op (batched step): self-attention of one (batch element, 16-query tile) for all 4 heads (wave = head), then
@@ -580,6 +565,7 @@ struct AttnOpArgs {
 
 template <class P, int DT, int NKT>      // D = 64 DT, H = 4, hd = 16 DT, Tp = 16 NKT
 __global__ __launch_bounds__(256) void k_attn_op(const AttnOpArgs g) {
+    DSG_TL_SCOPE();
     typedef typename P::elem elem;
     constexpr int ES = (int)sizeof(elem);
     constexpr int D = DT * 64, HD = DT * 16;

@@ -1239,19 +1239,6 @@ extern "C" int dsg_debug_read(dsg_handle* h, const char* name, void* out, long l
     return 0;
 }
 
-// cycle stamps of the last launch of each step kernel (only in the -DDSG_STAMPS build; zeros otherwise)
-extern "C" int dsg_debug_stamps(dsg_handle* h, long long* out, int n) {
-    if (!h || !out) return fail(DSG_E_INVALID, "null");
-    memset(out, 0, sizeof(long long) * n);
-#ifdef DSG_STAMPS
-    HIPCHK(hipStreamSynchronize(h->stream));
-    long long tmp[8 * 16];
-    HIPCHK(hipMemcpyFromSymbol(tmp, HIP_SYMBOL(dsg::g_stamps), sizeof(tmp)));
-    memcpy(out, tmp, sizeof(long long) * std::min(n, 8 * 16));
-#endif
-    return 0;
-}
-
 extern "C" int dsg_debug_chain(dsg_handle* h, int which, int n, int use_graph, int B, float* us_per_launch) {
     if (!h || !h->finalized || !h->cond_set) return fail(DSG_E_STATE, "debug_chain needs a finalized, conditioned handle");
     HIPCHK(hipSetDevice(h->cfg.device));
@@ -1277,6 +1264,38 @@ extern "C" int dsg_debug_chain(dsg_handle* h, int which, int n, int use_graph, i
     if (exec) { (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph); }
     *us_per_launch = best;
     return 0;
+}
+
+// ---- diagnostics: per-packet timeline of the AQL step loop (dsg_aql.h: Trace).  dsg_debug_trace_arm before a dsg_sample traces
+//      steps [first, first + n) of that call; dsg_debug_trace_get returns, per traced step and packet, start / end in us (relative
+//      to the first traced dispatch) + the kernel names, ';'-separated.
+extern "C" int dsg_debug_trace_arm(dsg_handle* h, int first, int n) {
+    if (!h || first < 0 || n <= 0) return fail(DSG_E_INVALID, "dsg_debug_trace_arm: bad argument");
+#ifndef DSG_EMU
+    h->aql.trace.armed = true; h->aql.trace.first = first; h->aql.trace.n = n;
+    return 0;
+#else
+    return fail(DSG_E_NOT_IMPLEMENTED, "no AQL path under emulation");
+#endif
+}
+extern "C" int dsg_debug_trace_get(dsg_handle* h, double* us, int cap, int* n_steps, int* n_packets, char* names, int names_cap) {
+    if (!h || !us || !n_steps || !n_packets) return fail(DSG_E_INVALID, "null argument");
+#ifndef DSG_EMU
+    const dsg_aql::Trace& t = h->aql.trace;
+    const int L = (int)t.names.size();
+    if (L == 0 || t.us.empty()) return fail(DSG_E_STATE, "no trace: arm it, then sample through the AQL path");
+    *n_packets = L; *n_steps = (int)(t.us.size() / 2 / L);
+    if ((int)t.us.size() > cap) return fail(DSG_E_INVALID, "trace buffer too small");
+    memcpy(us, t.us.data(), t.us.size() * sizeof(double));
+    if (names && names_cap > 0) {
+        std::string all;
+        for (const auto& n : t.names) { all += n; all += ';'; }
+        snprintf(names, (size_t)names_cap, "%s", all.c_str());
+    }
+    return 0;
+#else
+    return fail(DSG_E_NOT_IMPLEMENTED, "no AQL path under emulation");
+#endif
 }
 
 static int run_step_p(dsg_handle* h, const StepCtx& c) {
@@ -1451,6 +1470,8 @@ static bool uc_selfcheck(dsg_handle* h) {
     bool ok = hipMemset(buf, 0, (size_t)(n_wg * 256 + 64) * sizeof(unsigned)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
     UcProbeArgs a;
     a.buf = buf; a.ctl = (int*)(buf + n_wg * 256); a.err = buf + n_wg * 256 + 16; a.n_wg = n_wg;
+    const bool trace_was_armed = h->aql.trace.armed;      // (a timeline trace armed for the caller's sample is not for this run)
+    h->aql.trace.armed = false;
     if (ok) {
         dsg_aql::begin(h->aql);
         ok = dsg_aql::record(h->aql, (const void*)&k_uc_probe_w, h->stream, dim3(n_wg + 1), dim3(256), &a, sizeof a) &&
@@ -1460,6 +1481,7 @@ static bool uc_selfcheck(dsg_handle* h) {
         ok = ok && dsg_aql::run(h->aql, iters, 10.0);
         h->aql.nofence = false;
     }
+    h->aql.trace.armed = trace_was_armed;
     unsigned res[2] = {1u, 0u};
     if (ok) ok = hipMemcpy(res, a.err, sizeof res, hipMemcpyDeviceToHost) == hipSuccess;
     (void)hipFree(buf);

@@ -141,28 +141,30 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // dsg_kernels.hsaco with the library's own before it trusts the code object with the library's argument structs
 extern "C" __device__ const unsigned dsg_device_build_tag = DSG_BUILD_TAG;
 
-// Optional cycle stamps (make stamps -> libdsg_hip_stamps.so, tools/stamps.py): wave 0 of workgroup 8 records
-// s_memtime at a few phase boundaries of the step kernels.  Compiled out of the product library.
+// Timeline build (make stamps -> libdsg_hip_stamps.so + dsg_kernels_stamps.hsaco; tools/aql_timeline.py): every step kernel
+// stamps the 100 MHz steady counter (s_memrealtime) when its first wave starts and when its last wave ends, into the slot the
+// AQL submission wrote BEHIND the kernel's arguments for this particular packet (dsg_aql.h: Trace; slot < 0: an untraced
+// packet, nothing happens).  One atomic min / max per wave; compiled out of the product library.
 #ifdef DSG_STAMPS
-__device__ long long g_stamps[8][16];
-#if DSG_STAMPS == 1
-#define DSG_STAMP(k, i)                                                                               \
-    do {                                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-        if (blockIdx.x == 0 && blockIdx.y == 1 && blockIdx.z == 0 && threadIdx.x == 0) g_stamps[k][i] = __builtin_readcyclecounter(); \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-    } while (0)
-#define DSG_STAMP_SCALAR_WAIT(k, i) do { __builtin_amdgcn_s_waitcnt(0xC07F); DSG_STAMP(k, i); } while (0)
-#elif DSG_STAMPS == 2      /* experiment: only the scheduling barriers of the stamps */
-#define DSG_STAMP(k, i) __builtin_amdgcn_sched_barrier(0)
-#define DSG_STAMP_SCALAR_WAIT(k, i) __builtin_amdgcn_sched_barrier(0)
-#else                      /* experiment: only the early wait for the kernel arguments */
-#define DSG_STAMP(k, i) ((void)0)
-#define DSG_STAMP_SCALAR_WAIT(k, i) __builtin_amdgcn_s_waitcnt(0xC07F)
-#endif
+struct TlEntry { unsigned long long t0, t1; };
+constexpr int DSG_TL_WAVES = 2048, DSG_TL_ARG_OFF = 128;       // entries (waves) per traced packet; slot index + ring pointer: reserved
+                                                               // dwords 128 / 136 of the implicit-argument block
+struct TlScope {           // every wave stores its own start / end stamp (plain 8-byte stores to its own entry: no contention)
+    TlEntry* e;
+    __device__ __forceinline__ TlScope() : e(nullptr) {
+        const char* ia = (const char*)__builtin_amdgcn_implicitarg_ptr();
+        const int slot = *(const int*)(ia + DSG_TL_ARG_OFF);
+        if (slot >= 0) {
+            TlEntry* ring = *(TlEntry* const*)(ia + DSG_TL_ARG_OFF + 8);
+            const unsigned w = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * ((blockDim.x + 63) >> 6) + (threadIdx.x >> 6);
+            if (w < (unsigned)DSG_TL_WAVES && (threadIdx.x & 63) == 0) { e = ring + (size_t)slot * DSG_TL_WAVES + w; e->t0 = __builtin_readsteadycounter(); }
+        }
+    }
+    __device__ __forceinline__ ~TlScope() { if (e) e->t1 = __builtin_readsteadycounter(); }
+};
+#define DSG_TL_SCOPE() TlScope dsg_tl_scope_
 #else
-#define DSG_STAMP(k, i) ((void)0)
-#define DSG_STAMP_SCALAR_WAIT(k, i) ((void)0)
+#define DSG_TL_SCOPE() ((void)0)
 #endif
 // Workgroup barrier for LDS hand-offs only.  __syncthreads() also drains every outstanding VECTOR memory operation
 // (s_waitcnt vmcnt(0)): in-flight weight loads and the acknowledgement of global stores issued before it.  Nothing in
@@ -570,9 +572,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
     __shared__ __attribute__((aligned(16))) char lds_a[PRO == PRO_LN ? 16 * (512 * ES + 16) : 16];     // 16 rows of up to 512 elements
     __shared__ __attribute__((aligned(16))) float lds_red[WK > 1 ? (WK - 1) * WN * TNW * 64 * 4 : 4];
 
-    DSG_STAMP(1 + EPI, 0);
     preload_kernargs(g);
-    DSG_STAMP_SCALAR_WAIT(1 + EPI, 6);
     const int NG = g.NT / (WN * TNW);
     const int ng = xcd_ngroup<P>(), ks = blockIdx.z;
     const int mt_first = blockIdx.y;
@@ -680,7 +680,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
         }
         DSG_LDS_BARRIER();
     }
-    DSG_STAMP(1 + EPI, 2);
 
     for (int kb0 = kb_lo; kb0 < kb_hi; kb0 += CH) {
         f32x4 af[CH];
@@ -695,7 +694,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
             else af[c] = *(const f32x4*)(lds_a + lr * pitch + (kb * P::KB + P::E * lg) * ES);
         }
         DSG_LOADS_ISSUED();
-        if (kb0 == kb_lo) DSG_STAMP(1 + EPI, 1);
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const bool live = kb0 + c < kb_hi;              // wave-uniform; out-of-range blocks contribute zeros
@@ -703,12 +701,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
 #pragma unroll
             for (int t = 0; t < TNW; ++t)
                 acc[t] = swapped[t] ? P::mma(bf[c][t], a, acc[t]) : P::mma(a, bf[c][t], acc[t]);
-            if (c == 0 && kb0 == kb_lo) DSG_STAMP(1 + EPI, 3);
         }
         if (kb0 + CH < kb_hi) load_b(kb0 + CH);
     }
     }   // pass
-    DSG_STAMP(1 + EPI, 4);
 
     // The normalised rows go back to global memory only now: a global store issued before the MFMA phase would sit
     // in the same vmcnt queue as the weight loads (stores and loads retire out of order with each other, so the
@@ -745,20 +741,19 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
     for (int t = 0; t < TNW; ++t)
         gemm_epilogue_tile<P, EPI>(g, m0, (nt0 + t) * 16, lr, lg, ks, swapped[t], acc[t], ops[t], k1, k2, k3, k4, k5, acc_u[CFG ? t : 0]);
     }
-    DSG_STAMP(1 + EPI, 5);
 }
 
 // batched LayerNorm-GEMM: compiled for 3 waves per SIMD (<= 168 VGPRs; at 128 it spills to scratch; requesting the weights
 // only after the LayerNorm fits 5 waves per SIMD but measured slower: 370 vs 360 us/step at batch 16), see ln_rows LEAN
 template <class P, int EPI>
-__global__ __launch_bounds__(256, 3) void k_gemm_lean(const GemmArgs g) { gemm_body<P, PRO_LN, EPI, 4, 1, 1, true>(g); }
+__global__ __launch_bounds__(256, 3) void k_gemm_lean(const GemmArgs g) { DSG_TL_SCOPE(); gemm_body<P, PRO_LN, EPI, 4, 1, 1, true>(g); }
 
 // pose head with classifier-free guidance: conditional + unconditional rows per workgroup (GemmArgs::cfgB)
 template <class P>
-__global__ __launch_bounds__(256) void k_gemm_cfg(const GemmArgs g) { gemm_body<P, PRO_LN, EPI_OUT, 4, 1, 1, false, true>(g); }
+__global__ __launch_bounds__(256) void k_gemm_cfg(const GemmArgs g) { DSG_TL_SCOPE(); gemm_body<P, PRO_LN, EPI_OUT, 4, 1, 1, false, true>(g); }
 
 template <class P, int PRO, int EPI, int WN, int WK, int TNW>
-__global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) { gemm_body<P, PRO, EPI, WN, WK, TNW>(g); }
+__global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) { DSG_TL_SCOPE(); gemm_body<P, PRO, EPI, WN, WK, TNW>(g); }
 // ---------------------------------------------------------------------------------------------------------
 // k_loc: per (batch, window, local head).  h = sum_s partial_s + Cframe + TE2[t]; rotary(pos = frame);
 //        causal local attention over {previous window, own window} with q = k = v; prepend token; rotary(pos+1)
@@ -914,6 +909,7 @@ __device__ __forceinline__ void loc_body(const LocArgs& a, int h, int w, int b) 
 
 template <class P, int HD, int W>
 __global__ __launch_bounds__(256) void k_loc(const LocArgs a) {
+    DSG_TL_SCOPE();
     preload_kernargs(a);
     loc_body<P, HD, W>(a, blockIdx.x, blockIdx.y, blockIdx.z);          // grid (local heads, windows, batch)
 }
@@ -932,6 +928,7 @@ struct AttnArgs {
 
 template <class P, int HD, int NKT>
 __global__ __launch_bounds__(64) void k_attn(const AttnArgs a) {
+    DSG_TL_SCOPE();
     typedef typename P::elem elem;
     constexpr int KD = HD / P::KB;                   // k-blocks over the head dim
     preload_kernargs(a);

@@ -77,6 +77,7 @@ __host__ __device__ inline int ws_grid_x(int n_panels, int G) { return 8 * n_pan
 // ---------------------------------------------------------------------------------------------------------
 template <int KD16>
 __global__ __launch_bounds__(256, 2) void k_ws(const GemmArgs g) {
+    DSG_TL_SCOPE();
     typedef PBF16 P;
     constexpr int EPI = EPI_GELU;
     constexpr int K = 16 * KD16, KB = K / 32, BM = 64;
@@ -155,6 +156,7 @@ __global__ __launch_bounds__(256, 2) void k_ws(const GemmArgs g) {
 // ---------------------------------------------------------------------------------------------------------
 template <int KW16>
 __global__ __launch_bounds__(256, 1) void k_ws2(const GemmArgs g) {
+    DSG_TL_SCOPE();
     typedef PBF16 P;
     constexpr int K = 64 * KW16, KB = K / 32, BM = 32;
     constexpr int ABYTES = BM * K * 2;
