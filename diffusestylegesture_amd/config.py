@@ -89,4 +89,24 @@ TINY3B = DSGConfig("tiny3b", VARIANT_DSG, njoints=37, n_poses=30, n_seed=6, late
                    audio_src_dim=40, audio_dim=16, style_dim_in=3, window=15,
                    num_layers=2, num_heads=6, ff_size=128)
 
-CONFIGS = {c.name: c for c in (ZEGGS, BEAT, TWH, TINY, TINY4, TINY5, BEATPP, BEAT3, TINY3B)}
+# the remaining name x dataset pairs BEAT-TWH-main/mydiffusion_beat_twh/sample.py:299-323 accepts: TWH dims under
+# "DiffuseStyleGesture" (attention3) and "DiffuseStyleGesture++" (attention5), and BEAT "v2" (njoints = motion_dim = 1141, the
+# whole feature vector is kept: motion_feature_division = 1, sample.py:173-176)
+TWH3 = DSGConfig("twh3", VARIANT_DSG, njoints=2232, n_poses=150, n_seed=30, latent_dim=512,
+                 audio_src_dim=1435, audio_dim=128, style_dim_in=17, window=15)
+TWHPP = DSGConfig("twhpp", VARIANT_DSGPP, njoints=2232, n_poses=150, n_seed=30, latent_dim=512,
+                  audio_src_dim=1435, audio_dim=128, style_dim_in=17, window=15)
+BEATV2 = DSGConfig("beatv2", VARIANT_DSGPLUS, njoints=1141, n_poses=150, n_seed=30, latent_dim=384,
+                   audio_src_dim=1434, audio_dim=96, style_dim_in=2, window=15)
+BEATV2_3 = DSGConfig("beatv2_3", VARIANT_DSG, njoints=1141, n_poses=150, n_seed=30, latent_dim=384,
+                     audio_src_dim=1434, audio_dim=96, style_dim_in=2, window=15)
+BEATV2PP = DSGConfig("beatv2pp", VARIANT_DSGPP, njoints=1141, n_poses=150, n_seed=30, latent_dim=384,
+                     audio_src_dim=1434, audio_dim=96, style_dim_in=2, window=15)
+
+CONFIGS = {c.name: c for c in (ZEGGS, BEAT, TWH, TINY, TINY4, TINY5, BEATPP, BEAT3, TINY3B, TWH3, TWHPP, BEATV2, BEATV2_3, BEATV2PP)}
+# (name of the reference's yml, dataset, version) -> dims, as sample.py:297-323 sets them
+DSGPLUS_CONFIGS = {
+    ("DiffuseStyleGesture", "BEAT", "v0"): BEAT3, ("DiffuseStyleGesture+", "BEAT", "v0"): BEAT, ("DiffuseStyleGesture++", "BEAT", "v0"): BEATPP,
+    ("DiffuseStyleGesture", "BEAT", "v2"): BEATV2_3, ("DiffuseStyleGesture+", "BEAT", "v2"): BEATV2, ("DiffuseStyleGesture++", "BEAT", "v2"): BEATV2PP,
+    ("DiffuseStyleGesture", "TWH", "v0"): TWH3, ("DiffuseStyleGesture+", "TWH", "v0"): TWH, ("DiffuseStyleGesture++", "TWH", "v0"): TWHPP,
+}

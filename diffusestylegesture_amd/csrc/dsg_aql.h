@@ -34,7 +34,7 @@
 namespace dsg_aql {
 
 struct Kernel { uint64_t object = 0; uint32_t kernarg_size = 0, group = 0, priv = 0; };
-struct Launch { Kernel k; unsigned gx, gy, gz, bx, by, bz; size_t ka_off, hidden_off; std::string name; };
+struct Launch { Kernel k; unsigned gx, gy, gz, bx, by, bz; size_t ka_off, hidden_off; std::string name; int fence; };
 
 // Per-packet timeline of the step loop AS IT IS TIMED (diagnostics: dsg_debug_trace_arm / tools/aql_timeline.py).  rocprofv3
 // cannot see hand-written packets, so the profile of this path comes from the path itself, in one of two ways:
@@ -181,7 +181,9 @@ inline bool lookup(Ctx& c, const void* host_fn, hipStream_t stream, Kernel& out)
 // one launch of the step: explicit argument struct + the hidden arguments of code object v5 behind it
 // (llvm AMDGPUUsage "Code Object V5 Kernel Argument": block counts u32 x3 at +0, group sizes u16 x3 at +12, remainders
 // u16 x3 at +18, global offsets u64 x3 at +40, grid dims u16 at +64)
-inline bool record(Ctx& c, const void* host_fn, hipStream_t stream, dim3 grid, dim3 block, const void* args, size_t size) {
+// fence (fence-free plans only): 1 = this packet acquires at agent scope, 2 = it releases -- the two packets of a step that touch
+// the cached sampler state (dsg_hip.cpp: state_fences)
+inline bool record(Ctx& c, const void* host_fn, hipStream_t stream, dim3 grid, dim3 block, const void* args, size_t size, int fence = 0) {
     Kernel k;
     if (!lookup(c, host_fn, stream, k)) return false;
     const size_t hidden = (size + 7) & ~(size_t)7;
@@ -199,7 +201,7 @@ inline bool record(Ctx& c, const void* host_fn, hipStream_t stream, dim3 grid, d
     const int no_slot = -1;                  // timeline build: "not traced" (dsg_kernels.h: DSG_TL_ARG_OFF); unused otherwise
     std::memcpy(p + hidden + 128, &no_slot, 4);
     const char* nm = hipKernelNameRefByPtr(host_fn, stream);
-    c.plan.push_back(Launch{k, grid.x, grid.y, grid.z, block.x, block.y, block.z, off, hidden, nm ? nm : "?"});
+    c.plan.push_back(Launch{k, grid.x, grid.y, grid.z, block.x, block.y, block.z, off, hidden, nm ? nm : "?", fence});
     return true;
 }
 
@@ -249,8 +251,8 @@ inline void submit_step(Ctx& c, bool first_step, bool last_step, int step_index 
         // (the samples); a kernel's stores have been acknowledged when its waves end (s_endpgm waits for them) and the barrier
         // bit orders the packets
         const int mid_scope = c.nofence ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT;
-        const int rel = last ? HSA_FENCE_SCOPE_SYSTEM : mid_scope;
-        const int acq = first_step && i == 0 ? HSA_FENCE_SCOPE_SYSTEM : mid_scope;
+        const int rel = last ? HSA_FENCE_SCOPE_SYSTEM : (l.fence == 2 ? HSA_FENCE_SCOPE_AGENT : mid_scope);
+        const int acq = first_step && i == 0 ? HSA_FENCE_SCOPE_SYSTEM : (l.fence == 1 ? HSA_FENCE_SCOPE_AGENT : mid_scope);
         const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
                                            (acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
                                            (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));

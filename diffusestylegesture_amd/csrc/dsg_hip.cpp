@@ -166,6 +166,8 @@ struct dsg_handle {
     // packets with a warning if a hand-off through uncached memory is ever seen stale.
     int uc_mode = 1;
     bool alloc_uc = false;               // dalloc target: a loop-written buffer
+    bool state_fences = false;           // the state lives in cached memory: release on the step's last packet, acquire on its first
+    int fence_next = 0;                  // step_launch: the next recorded packet acquires (1) / releases (2) at agent scope
     int aql_mode = 1;                    // DSG_AQL: 1 (default) = AQL packets for the eager step loop, 0 = HIP launches
     bool aql_warned = false;
     bool aql_timing = false;             // the last dsg_sample was timed by the host clock around the AQL run
@@ -343,9 +345,17 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     // row buffers carry one extra padded token block: the fused attention kernel reads Tp rows per batch element
     // (+64: the block GEMMs of dsg_batched.h read and LayerNorm whole 64-row blocks)
     const size_t Min_pad = rup(B * h->T, 16) + 16 + 128, M_pad = rup(B * ntok, 16) + Tp + 128;
-    h->alloc_uc = true;                  // ---- written by the kernels of the step loop
+    // The sampler STATE (x_t fp32 + its bf16 shadow) is the one loop-written buffer that crosses a STEP boundary only: written by
+    // the last kernel of a step, read by the first (and last) kernel of the next.  It stays in cached memory and exactly those two
+    // packets carry an agent-scope release / acquire (state_fences): the timeline of the fence-free path
+    // (profiles/r03_aql_step_timeline_b16.json) showed 11.6 us between the pose head's last wave and the next step's first wave at
+    // batch 16 -- 9.8 MB of state written as uncached stores have to be acknowledged one by one -- against ~1 us for a plain
+    // boundary; a write-back of the same bytes from the L2 costs 1-2 us.  DSG_STATE_UC=1: the round-2 behaviour (state uncached).
+    h->state_fences = h->uc_mode == 1 && !(getenv("DSG_STATE_UC") && atoi(getenv("DSG_STATE_UC")));
+    h->alloc_uc = !h->state_fences;
     CHK(dalloc(h, &h->xs32, (size_t)B * h->T * h->Jp + 16 * h->Jp));
     if (h->prec == DSG_PREC_BF16) CHK(dalloc_bytes(h, &h->xsA, ((size_t)Min_pad * h->Jp) * h->es));
+    h->alloc_uc = true;                  // ---- written AND read inside one step by the kernels of the loop
     CHK(dalloc(h, &h->partial, (size_t)h->KSin * Min_pad * D));
     CHK(dalloc(h, &h->X0, M_pad * D));
     CHK(dalloc_bytes(h, &h->X0a, M_pad * D * h->es));
@@ -844,11 +854,14 @@ template <auto K, class A>
 static int step_launch(dsg_handle* h, dim3 grid, dim3 block, const A& args) {
 #ifndef DSG_EMU
     if (h->aql.recording) {
-        if (!dsg_aql::record(h->aql, (const void*)K, h->stream, grid, block, &args, sizeof(A)))
+        const int fence = h->state_fences ? h->fence_next : 0;
+        h->fence_next = 0;
+        if (!dsg_aql::record(h->aql, (const void*)K, h->stream, grid, block, &args, sizeof(A), fence))
             return fail(DSG_E_RUNTIME, "AQL plan: " + h->aql.err);
         return 0;
     }
 #endif
+    h->fence_next = 0;
     hipLaunchKernelGGL(K, grid, block, 0, h->stream, args);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1042,6 +1055,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
     la.emb1 = h->emb1; la.ctl = c.use_ctr ? h->ctl : nullptr; la.t_arr = h->t_arr;
     la.rcos = h->rcos; la.rsin = h->rsin; la.mask = h->mask; la.mb = h->mb; la.inv_mask_div = fastdiv_inv((int)((long long)B * h->Hl / h->mb)); la.B = B; la.T = T; la.D = D; la.Hl = h->Hl;
     la.hd = h->hdl; la.W = h->W; la.X0 = h->X0; la.X0a = h->X0a; la.nomask = h->nomask;
+    h->fence_next = 1;         // the first packet of a step reads the state the previous step's last packet wrote (state_fences)
     if (ks.lat) {              // pose embedding + local attention in one launch
         InLocArgs a;
         a.xs = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; a.Jp = h->Jp; a.Wp = h->Wp_in; a.KBtot = h->Jp / KB;
@@ -1140,6 +1154,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
         g.out_mode = c.out_mode; g.xs32 = h->xs32; g.xsA = h->prec == DSG_PREC_BF16 ? h->xsA : nullptr;
         g.fwd_out = h->fwd_out; g.ctl = c.use_ctr ? h->ctl : nullptr; g.st = step_tables(h); g.n_tab = h->n_run;
         g.dyn = h->dyn; g.ext_noise = c.ext_noise; g.const_noise = c.const_noise; g.clip_x0 = c.clip_x0;
+        h->fence_next = 2;     // the last packet of a step writes the state (state_fences)
         if (h->cfgB > 0) {      // guidance: one workgroup per CONDITIONAL row tile evaluates the twin rows as well (k_gemm_cfg)
             g.B = h->cfgB; g.M = h->cfgB * ntok; g.MT = cdiv(g.M, 16);
             g.cfgB = h->cfgB; g.cfg_off = h->cfgB * ntok; g.cfg_scale = h->cfg_scale;

@@ -157,7 +157,10 @@ struct TlScope {           // every wave stores its own start / end stamp (plain
         if (slot >= 0) {
             TlEntry* ring = *(TlEntry* const*)(ia + DSG_TL_ARG_OFF + 8);
             const unsigned w = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * ((blockDim.x + 63) >> 6) + (threadIdx.x >> 6);
-            if (w < (unsigned)DSG_TL_WAVES && (threadIdx.x & 63) == 0) { e = ring + (size_t)slot * DSG_TL_WAVES + w; e->t0 = __builtin_readsteadycounter(); }
+            // grids of more than 2048 waves: the first 1024 keep their own entries (-> first start), the later ones share the other
+            // 1024 round-robin; the last writers of those are the last waves of the grid (-> last end)
+            const unsigned ent = w < 1024u ? w : 1024u + (w & 1023u);
+            if ((threadIdx.x & 63) == 0) { e = ring + (size_t)slot * DSG_TL_WAVES + ent; e->t0 = __builtin_readsteadycounter(); }
         }
     }
     __device__ __forceinline__ ~TlScope() { if (e) e->t1 = __builtin_readsteadycounter(); }

@@ -155,7 +155,7 @@ def generate_clips_streams(lanes, diffusion, feats_per_lane, styles, seed=123456
 
 
 def generate_clip_dsgplus(model, diffusion, feats, style, seed0, real_n_frames, seed=123456, skip_timesteps=0,
-                          sample_fn=None, stream_id=0, seed_last=None):
+                          sample_fn=None, stream_id=0, seed_last=None, feature_division=3):
     """DSG+ window loop (BEAT-TWH sample.py:98-192), attention4: zero-padded tail, no left audio context, GT seed for
     window 0, no root shift, last window kept whole, first S frames dropped, crop, keep the first J/3 features.
     `model.cfg.variant == 3` is that tree's "DiffuseStyleGesture" (attention3 at BEAT dims): S frames of left audio context.
@@ -214,7 +214,9 @@ def generate_clip_dsgplus(model, diffusion, feats, style, seed0, real_n_frames, 
     else:
         seq = np.concatenate([o[:, :, 0, :] for o in out], axis=2).transpose(0, 2, 1)
     seq = seq[:, S:][:, :real_n_frames]
-    return np.ascontiguousarray(seq[:, :, : J // 3], dtype=np.float32)
+    # "v0" data: the model features are poses + velocities + accelerations, only the poses are kept (motion_feature_division = 3,
+    # BEAT-TWH sample.py:173-180); "v2": the whole vector (division 1)
+    return np.ascontiguousarray(seq[:, :, : J // feature_division], dtype=np.float32)
 
 
 def window_audio(audio, n_frames, n_poses=88, n_seed=8, sr=16000, fps=20):

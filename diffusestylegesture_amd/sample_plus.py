@@ -17,7 +17,7 @@ import os
 
 import numpy as np
 
-from .config import BEAT, BEAT3, BEATPP, TWH
+from .config import DSGPLUS_CONFIGS
 from .sample import generate_clip_dsgplus
 
 
@@ -65,6 +65,10 @@ def build_parser():
     p.add_argument('--seed_last_npy', default='', help='DiffuseStyleGesture++: raw poses of the closing snippet (sample.py:85-93)')
     p.add_argument('--speaker', type=int, default=0, help='index of the one-hot style / speaker entry')
     p.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    p.add_argument('--version', default='v0', choices=['v0', 'v2'],
+                   help="`version` of the reference's yml (sample.py:309-315): v0 = poses + velocities + accelerations (njoints = 3 x motion_dim), "
+                        "v2 (BEAT only) = njoints = motion_dim = 1141")
+    p.add_argument('--mean_std_npz', default='', help="v2: file with `mean` and `std` [motion_dim] (the reference's gesture_BEAT_mean_v2.npy / _std_v2.npy)")
     return p
 
 
@@ -75,16 +79,21 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     if args.wav_path or args.txt_path or args.tst_path:
         raise SystemExit("feature extraction from wav / transcript / h5 stays in the reference's pipelines: pass --features_npy")
-    if args.dataset == 'BEAT':
-        cfg = {'DiffuseStyleGesture': BEAT3, 'DiffuseStyleGesture+': BEAT, 'DiffuseStyleGesture++': BEATPP}[args.name]
-    elif args.dataset == 'TWH':
-        if args.name != 'DiffuseStyleGesture+':
-            raise NotImplementedError("TWH dims are set up for DiffuseStyleGesture+ (attention4) only")
-        cfg = TWH
+    if args.dataset not in ('BEAT', 'TWH') or (args.name, args.dataset, args.version) not in DSGPLUS_CONFIGS:
+        raise NotImplementedError(f"{args.dataset} {args.version}")          # sample.py:323-327 (TWH has no v2 branch either)
+    cfg = DSGPLUS_CONFIGS[(args.name, args.dataset, args.version)]           # every name x dataset pair of sample.py:297-323
+    if args.version == 'v2':
+        # the v2 statistics are not part of the reference tree; and its seed construction (pose + velocity + acceleration =
+        # 3 x motion_dim columns, sample.py:125-129) cannot produce njoints = motion_dim features: the seed file holds the
+        # [n_seed, njoints] feature rows themselves
+        if not args.mean_std_npz:
+            raise SystemExit("--version v2 needs --mean_std_npz (gesture_BEAT_mean_v2 / _std_v2 of the dataset)")
+        ms = np.load(args.mean_std_npz)
+        mean, std = ms["mean"], ms["std"]
     else:
-        raise NotImplementedError(args.dataset)                               # sample.py:327
-    ms = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "beat_twh_mean_std.npz"))
-    mean, std = ms[args.dataset + "_mean"], ms[args.dataset + "_std"]
+        ms = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "beat_twh_mean_std.npz"))
+        mean, std = ms[args.dataset + "_mean"], ms[args.dataset + "_std"]
+    v2_seed = lambda a: np.ascontiguousarray(((np.asarray(a, np.float64)[: cfg.n_seed] - mean) / std).astype(np.float32).T[None, :, None, :])
     dev = int(args.gpu)
     torch.cuda.set_device(dev)
     model = DSGDenoiser(cfg, precision=args.precision, max_batch=1, device=dev)
@@ -92,14 +101,15 @@ def main(argv=None):
     diffusion = create_gaussian_diffusion()
     wins, real_n = window_features(np.load(args.features_npy), args.max_len, cfg.stride)
     feats = [torch.from_numpy(w[None]).cuda(dev) for w in wins]
-    seed0 = torch.from_numpy(seed_features(np.load(args.seed_npy)[: cfg.n_seed + 2], mean, std)).cuda(dev)
+    mk_seed = v2_seed if args.version == 'v2' else (lambda a: seed_features(a[: cfg.n_seed + 2], mean, std))
+    seed0 = torch.from_numpy(mk_seed(np.load(args.seed_npy))).cuda(dev)
     seed_last = None
     if cfg.variant == 5:
-        seed_last = torch.from_numpy(seed_features(np.load(args.seed_last_npy)[: cfg.n_seed + 2], mean, std)).cuda(dev)
+        seed_last = torch.from_numpy(mk_seed(np.load(args.seed_last_npy))).cuda(dev)
     style = np.zeros(cfg.style_dim_in, np.float32)
     style[args.speaker] = 1.0
     seq = generate_clip_dsgplus(model, diffusion, feats, style, seed0, real_n, seed=123456, skip_timesteps=args.skip_timesteps,
-                                seed_last=seed_last)[0]
+                                seed_last=seed_last, feature_division=1 if args.version == 'v2' else 3)[0]
     out_poses = np.multiply(seq, std) + mean                                  # sample.py:184 (no clipping of std here)
     os.makedirs(args.save_dir, exist_ok=True)
     stem = os.path.join(args.save_dir, os.path.splitext(os.path.basename(args.features_npy))[0])

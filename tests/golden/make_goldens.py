@@ -360,6 +360,29 @@ def gen_attn3_beat():
     np.savez_compressed(os.path.join(HERE, "g14_forward_attn3_beat.npz"), **g)
 
 
+def gen_remaining_dims():
+    """G15: forward of the imported BEAT-TWH-tree MDM at the remaining name x dataset dims sample.py:297-323 accepts -- TWH under
+    "DiffuseStyleGesture" (attention3) and "DiffuseStyleGesture++" (attention5), BEAT "v2" (njoints = 1141) under attention4."""
+    sys.path[:0] = [REF + "/BEAT-TWH-main", REF + "/BEAT-TWH-main/model"]
+    from model.mdm import MDM
+    g = {"wseed": WSEED}
+    for cfg, mode, ts in ((C.TWH3, 'cross_local_attention3_style1_sample', 700), (C.TWHPP, 'cross_local_attention5_style1_sample', 12),
+                          (C.BEATV2, 'cross_local_attention4_style1_sample', 333)):
+        m = MDM(modeltype='', njoints=cfg.njoints, nfeats=1, cond_mode=mode, arch='trans_enc', latent_dim=cfg.latent_dim, n_seed=cfg.n_seed,
+                ff_size=cfg.ff_size, num_layers=cfg.num_layers, num_heads=cfg.num_heads, style_dim=cfg.style_dim_in,
+                source_audio_dim=cfg.audio_src_dim, audio_feat_dim_latent=cfg.audio_dim)
+        missing, unexpected = m.load_state_dict(_to_torch_sd(synth_state_dict(cfg, WSEED)), strict=False)
+        assert not missing and not unexpected, (missing, unexpected)
+        m.eval()
+        y = synth_window_inputs(cfg, 1, window=2, seed_pose_scale=0.1)
+        x = np.random.RandomState(77).randn(1, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+        out = m(torch.from_numpy(x), torch.tensor([ts]), y=_y_torch(y)).numpy()
+        g[cfg.name + "_out"] = out.astype(np.float32)
+        g[cfg.name + "_meta"] = np.array([1, 0.1, 77, ts], dtype=np.float64)
+        print("G15", cfg.name, out.shape, float(np.abs(out).mean()))
+    np.savez_compressed(os.path.join(HERE, "g15_forward_remaining_dims.npz"), **g)
+
+
 def gen_dsgplus_caller():
     """G11: the reference's own DSG+ caller, `inference()` of BEAT-TWH-main/mydiffusion_beat_twh/sample.py:44-192, driven for
     the three model names it knows (attention3 / 4 / 5) at BEAT dims with 3 DDPM steps per window (skip_timesteps=997) and
@@ -498,4 +521,4 @@ if __name__ == "__main__":
     {"zeggs": gen_zeggs, "dsgplus": gen_dsgplus, "clip": gen_clip, "bvh": gen_bvh, "wavlm": gen_wavlm, "dsgpp": gen_dsgpp,
      "clip1000": lambda: gen_clip(0, "g12_clip1000_zeggs.npz", f32=True),
      "bvh1000": lambda: gen_bvh("g12_clip1000_zeggs.npz", "g13_bvh1000_zeggs.npz", full=False),
-     "attn3beat": gen_attn3_beat, "dsgplus_caller": gen_dsgplus_caller}[which]()
+     "attn3beat": gen_attn3_beat, "dsgplus_caller": gen_dsgplus_caller, "remaining_dims": gen_remaining_dims}[which]()

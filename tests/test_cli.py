@@ -51,5 +51,5 @@ def test_bench_cpu_baseline_leg_runs_on_cpu():
         out = mod.cpu_baseline(20)
     finally:
         sys.argv = argv
-    assert out["kind"] == "port" and out["unit"] == "frames/s" and out["value"] > 0 and out["cores"] >= 1
+    assert out["kind"].startswith("port") and out["unit"] == "frames/s" and out["value"] > 0 and out["cores"] >= 1
     assert "20 DDPM steps" in out["sample"]

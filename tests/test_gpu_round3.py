@@ -265,3 +265,47 @@ def test_bench_one_real_rccl_rank(gpu):
     assert "HSA agent" in ranked.stderr and "rank-local HIP device 0" in ranked.stderr
     print(f"bench: plain {a['value']:.1f} frames/s, one RCCL rank {b['value']:.1f} frames/s")
     assert abs(b["value"] / a["value"] - 1.0) < 0.05
+
+
+@pytest.mark.parametrize("cfg", [C.TWH3, C.TWHPP, C.BEATV2], ids=lambda c: c.name)
+def test_remaining_name_x_dataset_dims_vs_reference(gpu, golden_dir, cfg):
+    """G15: TWH under "DiffuseStyleGesture" (attention3) / "DiffuseStyleGesture++" (attention5) and BEAT "v2" (njoints 1141): forward
+    vs the imported reference at those dims (BEAT-TWH-main/mydiffusion_beat_twh/sample.py:297-323 accepts every pair)."""
+    g = np.load(os.path.join(golden_dir, "g15_forward_remaining_dims.npz"))
+    _, sps, rs, ts = g[cfg.name + "_meta"]
+    y = synth_window_inputs(cfg, 1, window=2, seed_pose_scale=float(sps))
+    x = np.random.RandomState(int(rs)).randn(1, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+    for prec, tol in (("fp32", 2e-5), ("bf16", 1.2e-2)):
+        m = _model(cfg, prec, wseed=int(g["wseed"]))
+        e = rel_l2(m(x, np.array([int(ts)]), y), g[cfg.name + "_out"])
+        assert e < tol, (cfg.name, prec, e)
+
+
+def test_dsgplus_command_line_every_name_x_dataset(gpu, tmp_path):
+    """sample_plus.main for the pairs round 2 refused: TWH x {DiffuseStyleGesture, ++} and BEAT v2 -- checkpoint file in, poses out."""
+    import torch
+    from diffusestylegesture_amd import sample_plus
+    ms = np.load(os.path.join(ROOT, "diffusestylegesture_amd", "data", "beat_twh_mean_std.npz"))
+    rs = np.random.RandomState(4)
+    for name, dataset, version, cfg in (("DiffuseStyleGesture", "TWH", "v0", C.TWH3), ("DiffuseStyleGesture++", "TWH", "v0", C.TWHPP),
+                                        ("DiffuseStyleGesture+", "BEAT", "v2", C.BEATV2)):
+        ck = str(tmp_path / f"{cfg.name}.pt")
+        torch.save({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, 20240).items()}, ck)
+        ta = np.concatenate([synth_window_inputs(C.TWH if dataset == "TWH" else C.BEAT, 1, window=w)["audio"][0] for w in range(2)])[:170]
+        np.save(str(tmp_path / "ta.npy"), ta)
+        argv = ["--model_path", ck, "--features_npy", str(tmp_path / "ta.npy"), "--name", name, "--dataset", dataset, "--version", version,
+                "--save_dir", str(tmp_path / ("o" + cfg.name)), "--skip_timesteps", "997"]
+        if version == "v2":
+            np.savez(str(tmp_path / "ms.npz"), mean=np.zeros(1141), std=np.ones(1141))
+            np.save(str(tmp_path / "seed.npy"), 0.1 * rs.randn(cfg.n_seed, 1141))
+            argv += ["--mean_std_npz", str(tmp_path / "ms.npz")]
+            width = 1141
+        else:
+            mean, std = ms[dataset + "_mean"], ms[dataset + "_std"]
+            np.save(str(tmp_path / "seed.npy"), mean + std * 0.5 * rs.randn(cfg.n_seed + 2, mean.shape[-1]))
+            width = cfg.njoints // 3
+        argv += ["--seed_npy", str(tmp_path / "seed.npy")]
+        if cfg.variant == 5:
+            argv += ["--seed_last_npy", str(tmp_path / "seed.npy")]
+        res = np.load(sample_plus.main(argv))
+        assert res.shape == (170, width) and np.isfinite(res).all(), (name, dataset, version, res.shape)
