@@ -1,8 +1,8 @@
 # MFMA-side counters per kernel (HIP-launch path under the profiler) at batch 1 and 16: how busy are the matrix cores?
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-for B in 1 16; do
+for B in 1 16 64; do
 rm -rf gpurun_out/pmc_mfma_b$B
-timeout 200 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_BF16 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_mfma_b$B -o z -- python tools/step_timing.py --batch $B --steps 20 --reps 1 --kset $( [ $B = 1 ] && echo latency || echo block ) > gpurun_out/pmc_mfma_b$B.log 2>&1
+timeout 200 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_BF16 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_mfma_b$B -o z -- python tools/step_timing.py --batch $B --steps 20 --reps 1 --kset $( [ $B = 1 ] && echo latency || ( [ $B = 64 ] && echo stream || echo block ) ) > gpurun_out/pmc_mfma_b$B.log 2>&1
 python - <<PY
 import csv, glob, collections
 f = glob.glob("gpurun_out/pmc_mfma_b$B/*counter_collection.csv")
