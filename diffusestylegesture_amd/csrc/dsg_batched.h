@@ -197,6 +197,27 @@ __global__ __launch_bounds__(256) void k_gemm_blk(const GemmArgs g) {
         if (kb0 + CH < KBtot) load_b(kb0 + CH);
     }
     // ---- epilogue
+    if constexpr (EPI == EPI_QKV) {
+        if (!swapped[0]) {
+            // a V column group (64 TNW columns never straddle 2 D): the block's V^T goes through the retired row buffer and out in
+            // aligned token groups (vt_store_block) instead of 4 element stores per lane and row quad
+            constexpr int SP = BM + 4;
+            elem* stage = (elem*)lds_a;
+            DSG_LDS_BARRIER();                                  // every wave is done reading the A rows
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int t = 0; t < TNW; ++t) {
+                    f32x4 y;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = acc[rt][t][e] + ops[rt][t].pbs;
+                    P::store4(stage + ((wave * TNW + t) * 16 + lr) * SP + rt * 16 + 4 * lg, y);
+                }
+            DSG_LDS_BARRIER();
+            vt_store_block<P, 64 * TNW>(g, stage, SP, m0, BM, ng * 64 * TNW - 2 * (g.H * g.hd), tid);
+            return;
+        }
+    }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         const int mt = m0 + rt * 16;

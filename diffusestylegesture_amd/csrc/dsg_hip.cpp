@@ -789,7 +789,7 @@ static bool stream_set_ok(const dsg_handle* h) {
 }
 static int auto_kernel_set(const dsg_handle* h, int B, int lanes) {
     const int rows = B * h->ntok;
-    if (rows >= 2800 && stream_set_ok(h)) return DSG_KSET_STREAM;
+    if (rows >= (lanes > 1 ? 1400 : 2800) && stream_set_ok(h)) return DSG_KSET_STREAM;
     if (lanes <= 1) {
         if (B <= 2 && latency_set_ok(h)) return DSG_KSET_LATENCY;
         return rows >= 1000 ? DSG_KSET_BLOCK : DSG_KSET_TILE;
@@ -844,6 +844,7 @@ extern "C" int dsg_last_kernel_set(dsg_handle* h, int* set) {
 struct StepCtx {
     int B;                  // batch rows the kernels run on (with guidance: conditional elements + their twins)
     int out_mode; bool use_ctr; const float* ext_noise; int const_noise;
+    int no_noise = 0;       // DDIM with eta = 0: no step adds noise (the pose head skips the Philox draw)
     int clip_x0 = 0;        // clip_denoised=True
     KernelSel ks;           // what select_kernels chose for this call
 };
@@ -913,17 +914,34 @@ static int ws_groups(int n_panels, int n_blocks, int occ) {
     G = std::max(G, 8);
     return std::min(G, rup(n_blocks, 8));
 }
+template <int EPI>
 static int launch_ws(dsg_handle* h, GemmArgs g) {
     g.KS = 1; g.kb_per_split = g.KBtot;
     g.inv_ntok = fastdiv_inv(g.ntok); g.inv_hd = fastdiv_inv(g.hd);
     if (g.NT % 8) return fail(DSG_E_INVALID, "k_ws: N must be a multiple of 128");
     const int P = g.NT / 8, MB = cdiv(g.M, 64);
     g.ws_G = ws_groups(P, MB, 2);
-    const dim3 grid(ws_grid_x(P, g.ws_G));
+    const dim3 grid(ws_grid_x(P, g.ws_G) + (EPI == EPI_OUT ? 8 : 0));      // EPI_OUT: + the bookkeeping workgroup (one XCD round)
     const int K = g.KBtot * 32;
-    if (K == 256) return step_launch<&k_ws<16>>(h, grid, dim3(256), g);
-    if (K == 128) return step_launch<&k_ws<8>>(h, grid, dim3(256), g);
+    if (K == 256) return step_launch<&k_ws<EPI, 16>>(h, grid, dim3(256), g);
+    if (K == 128) return step_launch<&k_ws<EPI, 8>>(h, grid, dim3(256), g);
     return fail(DSG_E_NOT_IMPLEMENTED, "k_ws: K must be 128 or 256");
+}
+// STREAM: LayerNorm once per row (k_ln_frag) -> fragment-major bf16 rows in X1a (free between linear1 and the next attention
+// kernel) [+ fp32 rows in Xn], then the GEMM streams them like linear1.  Packet fences of the state (fence_next) belong to the GEMM.
+template <int EPI>
+static int launch_ln_ws(dsg_handle* h, GemmArgs g) {
+    const int fence = h->fence_next;
+    h->fence_next = 0;
+    GemmArgs l = g;
+    l.out = h->X1a;
+    const dim3 grid(cdiv(rup(g.M, 64), 16));
+    if (g.D == 256) CHK((step_launch<&k_ln_frag<4>>(h, grid, dim3(256), l)));
+    else if (g.D == 128) CHK((step_launch<&k_ln_frag<2>>(h, grid, dim3(256), l)));
+    else return fail(DSG_E_NOT_IMPLEMENTED, "k_ln_frag: latent_dim must be 128 or 256");
+    h->fence_next = fence;
+    g.A = h->X1a; g.lda = g.D; g.a_frag = 1; g.X = nullptr; g.Xn = nullptr;
+    return launch_ws<EPI>(h, g);
 }
 static int launch_ws2(dsg_handle* h, GemmArgs g) {
     g.KS = 1; g.kb_per_split = g.KBtot;
@@ -944,7 +962,10 @@ template <class P, int PRO, int EPI>
 static int launch_gemm_w(dsg_handle* h, const GemmArgs& g, const KernelSel& ks) {
     constexpr bool blk_wins = EPI == EPI_QKV || EPI == EPI_GELU;
     if constexpr (sizeof(typename P::elem) == 2 && PRO == PRO_DIRECT && EPI == EPI_GELU) {
-        if (ks.stream && g.a_frag) return launch_ws(h, g);      // STREAM: linear1 on the fragment-major LayerNorm1 rows of k_attn_op
+        if (ks.stream && g.a_frag) return launch_ws<EPI_GELU>(h, g);      // STREAM: linear1 on the fragment-major LayerNorm1 rows of k_attn_op
+    }
+    if constexpr (sizeof(typename P::elem) == 2 && PRO == PRO_LN && (EPI == EPI_QKV || EPI == EPI_OUT)) {
+        if (ks.stream) return launch_ln_ws<EPI>(h, g);                    // STREAM: LayerNorm once per row, then the same streaming GEMM
     }
     if constexpr (EPI != EPI_PARTIAL) {
         if (ks.blk && blk_wins && g.KBtot * P::KB <= 512) return launch_blk<P, PRO, EPI>(h, g);
@@ -1043,7 +1064,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
     GemmArgs z;
     memset(&z, 0, sizeof(z));
     z.KS = 1; z.kb_per_split = 0; z.B = B; z.ntok = ntok; z.Tp = h->Tp; z.H = h->H; z.hd = h->hd; z.T = T; z.J = h->J; z.Jp = h->Jp;
-    z.Jq = h->Jq; z.D = D;
+    z.Jq = h->Jq; z.D = D; z.inv_ntok4 = fastdiv_inv(rup(ntok, 4));
 
     LocArgs la;
     memset(&la, 0, sizeof(la));
@@ -1153,7 +1174,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
         g.X = h->pre2; g.ln_g = h->layers[h->L - 1].g2; g.ln_b = h->layers[h->L - 1].be2; g.Xn = nullptr;
         g.out_mode = c.out_mode; g.xs32 = h->xs32; g.xsA = h->prec == DSG_PREC_BF16 ? h->xsA : nullptr;
         g.fwd_out = h->fwd_out; g.ctl = c.use_ctr ? h->ctl : nullptr; g.st = step_tables(h); g.n_tab = h->n_run;
-        g.dyn = h->dyn; g.ext_noise = c.ext_noise; g.const_noise = c.const_noise; g.clip_x0 = c.clip_x0;
+        g.dyn = h->dyn; g.ext_noise = c.ext_noise; g.const_noise = c.const_noise; g.clip_x0 = c.clip_x0; g.no_noise = c.no_noise;
         h->fence_next = 2;     // the last packet of a step writes the state (state_fences)
         if (h->cfgB > 0) {      // guidance: one workgroup per CONDITIONAL row tile evaluates the twin rows as well (k_gemm_cfg)
             g.B = h->cfgB; g.M = h->cfgB * ntok; g.MT = cdiv(g.M, 16);
@@ -1179,7 +1200,7 @@ static int debug_launch(dsg_handle* h, int which, int i, int B) {
     GemmArgs z;
     memset(&z, 0, sizeof(z));
     z.KS = 1; z.B = B; z.ntok = ntok; z.Tp = h->Tp; z.H = h->H; z.hd = h->hd; z.T = T; z.J = h->J; z.Jp = h->Jp;
-    z.Jq = h->Jq; z.D = D;
+    z.Jq = h->Jq; z.D = D; z.inv_ntok4 = fastdiv_inv(rup(ntok, 4));
     const Layer& ly = h->layers[(which == 1) ? 0 : i % h->L];
     LocArgs la;
     memset(&la, 0, sizeof(la));
@@ -1557,6 +1578,7 @@ static int sample_prepare(dsg_handle* h, const dsg_sample_args* a, int B, void* 
     StepCtx& c = job.c;
     c.B = rows; c.out_mode = a->mode == DSG_MODE_DDPM ? OUT_DDPM : OUT_DDIM; c.use_ctr = true; c.ext_noise = ext;
     c.const_noise = a->const_noise; c.clip_x0 = a->clip_denoised ? 1 : 0;
+    c.no_noise = (a->mode == DSG_MODE_DDIM && a->eta == 0.f && !ext) ? 1 : 0;
     CHK(select_kernels(h, rows, c.ks));
     job.n_run = n_run; job.B = B; job.done = 0;
     job.dumping = a->n_dump > 0 && a->dump_steps && a->dump_out;
@@ -1605,7 +1627,7 @@ static int sample_run_hip(dsg_handle* h, const dsg_sample_args* a, SampleJob& jo
     if (spg > 0 && n_run >= spg && job.done == 0) {
         // everything that varies between calls (step index, coefficients, noise key, conditioning) lives in device
         // memory, so one captured graph per (batch, sampler, mask batch, const_noise, steps, flags, kernel set) serves every window and clip
-        dsg_handle::GKey key = {c.B, c.out_mode, h->mb, c.const_noise, n_run, (c.clip_x0 ? 1 : 0) | (h->cfgB ? 2 : 0) | (h->nomask ? 4 : 0) | (c.ks.attn_in_mid ? 8 : 0),
+        dsg_handle::GKey key = {c.B, c.out_mode, h->mb, c.const_noise, n_run, (c.clip_x0 ? 1 : 0) | (h->cfgB ? 2 : 0) | (h->nomask ? 4 : 0) | (c.ks.attn_in_mid ? 8 : 0) | (c.no_noise ? 16 : 0),
                                 c.ks.set};
         auto it = h->graphs.find(key);
         bool ok = true;

@@ -179,6 +179,18 @@ struct TlScope {           // every wave stores its own start / end stamp (plain
         __builtin_amdgcn_s_barrier();                                          \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");        \
     } while (0)
+// Hand-off through LDS between the lanes of ONE wave (a wave's LDS instructions execute in order, so nothing is emitted: the
+// fences only pin the compiler's order; the host emulator runs lanes as fibers and needs a real rendezvous).
+#ifndef DSG_EMU
+#define DSG_WAVE_LDS_SYNC()                                                    \
+    do {                                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");        \
+        __builtin_amdgcn_wave_barrier();                                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");        \
+    } while (0)
+#else
+#define DSG_WAVE_LDS_SYNC() ((void)__shfl_xor(0, 0))
+#endif
 // hipcc fetches kernel arguments lazily, one s_load batch (+ s_waitcnt lgkmcnt(0)) per region that first needs them;
 // the kernarg segment is freshly written for every launch, so each batch is a scalar-cache MISS -- several serial
 // misses per kernel.  Touching one dword per 64-byte line of the argument struct at the top of the kernel makes all
@@ -328,6 +340,9 @@ struct GemmArgs {
     int cfgB, cfg_off;
     const float* cfg_scale; // [cfgB]
     int clip_x0;            // EPI_OUT: clamp x0 to [-1, 1] (clip_denoised=True, gaussian_diffusion.py:377-379)
+    unsigned inv_ntok4;     // EPI_QKV block kernels: fastdiv_inv(ntok rounded up to 4) (vt_store_block)
+    int no_noise;           // EPI_OUT: the sampler adds no noise at any step of this call (DDIM with eta = 0: sigma = 0,
+                            // gaussian_diffusion.py:782-791) -- the Philox draw is skipped, x_{t-1} = mean + 0 z bit for bit
 };
 
 // Workgroup -> n-group with the n-group pinned to an XCD (workgroups are dealt round-robin to the 8 XCDs in linear
@@ -341,6 +356,58 @@ __host__ __device__ inline int xcd_grid_x(int NG) { return 8 * ((NG + 7) / 8); }
 // x / d for 0 <= x, x * d < 2^32, as one v_mul_hi_u32: inv = ceil(2^32 / d) (host: fastdiv_inv; d == 1 -> inv 0)
 __device__ __forceinline__ int fdiv(int x, unsigned inv) { return inv ? (int)__umulhi((unsigned)x, inv) : x; }
 __host__ __device__ inline unsigned fastdiv_inv(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1u) / (unsigned)d); }
+
+// V^T of a whole row block, written in ALIGNED token groups.  A GEMM lane holds 4 consecutive ROWS of the batch for one feature; the
+// fragment order stores tokens in groups of 4 per batch element, and with ntok = 89 a row quad is such a group only for every
+// fourth batch element -- the other three paid 4 element stores per quad (2-byte uncached stores: LN + QKV 16.8 -> 9.6 us at
+// 5696 rows when removed).  So V blocks go through LDS: `stage[f * SP + r]` = V(row m0 + r, feature n0 + f) in the GEMM type
+// (already with bias), and the workgroup's threads walk the (feature, aligned group) pairs the block touches: one 8- / 16-byte
+// store per group whose tokens all lie in the block (the tokens past ntok of an element's last group are written as 0 -- the
+// attention kernels multiply them by P = 0), element stores only for the two groups a block boundary cuts.
+// n0: first staged column, counted from the start of V (a multiple of 16 inside one head or spanning whole heads).
+template <class P, int NCOLS>
+__device__ __forceinline__ void vt_store_block(const GemmArgs& g, const typename P::elem* stage, int SP, int m0, int nrows, int n0, int tid) {
+    typedef typename P::elem elem;
+    typedef elem elem4 __attribute__((ext_vector_type(4)));
+    static_assert(256 % NCOLS == 0, "threads per feature");
+    const int ntok = g.ntok, ntok4 = (ntok + 3) & ~3;
+    const int m_end = min(m0 + nrows, g.M);                  // rows [m0, m_end) are this block's
+    if (m_end <= m0) return;
+    const int b_lo = fdiv(m0, g.inv_ntok);
+    const int rp_lo = (b_lo * ntok4 + (m0 - b_lo * ntok)) & ~3;          // first aligned slot in padded-row space (row' = b ntok4 + token)
+    const int b_hi = fdiv(m_end - 1, g.inv_ntok);
+    const int rp_hi = b_hi * ntok4 + (m_end - 1 - b_hi * ntok);
+    const int ngroups = ((rp_hi - rp_lo) >> 2) + 1;
+    const int nvf = P::E == 4 ? g.Tp / 16 : g.Tp / 32;
+    const int f = tid % NCOLS;                               // one feature per thread, 256 / NCOLS threads share its groups
+    const int nn = n0 + f, head = fdiv(nn, g.inv_hd), d = nn - head * g.hd;
+    const elem* col = stage + f * SP;
+    for (int j = tid / NCOLS; j < ngroups; j += 256 / NCOLS) {
+        const int rp = rp_lo + 4 * j;
+        const int b = fdiv(rp, g.inv_ntok4), s0 = rp - b * ntok4;        // tokens s0 .. s0 + 3 of batch element b
+        elem* dst = (elem*)g.vt + ((size_t)b * g.H + head) * g.hd * g.Tp;
+        const int mrow = b * ntok + s0 - m0;                 // block row of token s0
+        bool whole = true;
+        elem4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = mrow + e;
+            const bool pad = s0 + e >= ntok;
+            const bool own = !pad && r >= 0 && r < m_end - m0;
+            whole = whole && (own || pad);
+            v[e] = own ? col[r] : elem(0);
+        }
+        if (whole) {
+            *(elem4*)(dst + vt_off<P>(d, s0, nvf)) = v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = mrow + e;
+                if (s0 + e < ntok && r >= 0 && r < m_end - m0) dst[vt_off<P>(d, s0 + e, nvf)] = v[e];
+            }
+        }
+    }
+}
 
 // Exact (erf) GELU.  fp32 kernels call erff; the bf16 kernels round the result to 8 mantissa bits anyway, so they use
 // Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7 in erf, ~15 instructions with v_rcp/v_exp) instead of the ~60-instruction
@@ -445,7 +512,7 @@ __device__ __forceinline__ void gemm_prefetch_tile(const GemmArgs& g, int m0, in
                 const int bc = b < g.B ? b : g.B - 1, fc = sx > 0 ? sx - 1 : 0;
                 o.pr = lda16<P>(g.xs32, (((size_t)bc * g.T + fc) * g.Jp + j0) * sizeof(float));
             }
-            if (o.ovalid && g.out_mode != OUT_FORWARD) {
+            if (o.ovalid && g.out_mode != OUT_FORWARD && !g.no_noise) {
                 const int f = sx - 1;
                 const int bn = g.const_noise ? 0 : b;
                 if (g.ext_noise) {

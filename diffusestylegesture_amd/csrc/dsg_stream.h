@@ -35,6 +35,7 @@
 // Reference arithmetic being replaced: linear1 / linear2 of torch's TransformerEncoderLayer (main/model/mdm.py:79-86) at M = 89 B.
 #pragma once
 #include "dsg_batched.h"
+#include <type_traits>
 
 namespace dsg {
 
@@ -73,22 +74,43 @@ __device__ __forceinline__ WsId ws_id(int n_panels, int G) {
 __host__ __device__ inline int ws_grid_x(int n_panels, int G) { return 8 * n_panels * (G >> 3); }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_ws: linear1 (K = D <= 256, bias + GELU), 64 x 128 blocks, W panel stationary in registers.   KD16 = K / 16
+// k_ln_frag: LayerNorm of the fp32 residual rows ONCE per row (the block kernels redo it in each of their 12 - 18 column groups):
+// the normalised rows in fp32 (g.Xn: the attention kernel's residual; may be null) and in bf16, fragment-major (g.out) -- the A
+// operand k_ws<EPI_QKV> / k_ws<EPI_OUT> stream global -> LDS.  Same arithmetic and rounding point as the LayerNorm-on-read
+// prologue (ln_rows).  16 rows per workgroup.
 // ---------------------------------------------------------------------------------------------------------
-template <int KD16>
-__global__ __launch_bounds__(256, 2) void k_ws(const GemmArgs g) {
+template <int NCH>
+__global__ __launch_bounds__(256) void k_ln_frag(const GemmArgs g) {
     DSG_TL_SCOPE();
     typedef PBF16 P;
-    constexpr int EPI = EPI_GELU;
+    constexpr int D = 64 * NCH, PITCH = D * 2 + 16;
+    __shared__ __attribute__((aligned(16))) char img[16 * PITCH];
+    preload_kernargs(g);
+    const int m0 = (int)blockIdx.x * 16, tid = threadIdx.x, row = tid >> 4, c = tid & 15;
+    f32x4 v[8];
+    ln_rows<P, NCH>(g, m0, tid, img, PITCH, v);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int col = c * 4 + 64 * i;
+        if (g.Xn) *(f32x4*)(g.Xn + (size_t)(m0 + row) * D + col) = v[i];
+        P::store4((P::elem*)g.out + qk_off<P>(m0 + row, col, D / P::KB), v[i]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_ws: a K = D <= 256 GEMM on fragment-major bf16 rows, 64 x 128 blocks, W panel stationary in registers.   KD16 = K / 16
+//   EPI_GELU  linear1 (bias + GELU -> hidden, fragment-major)
+//   EPI_QKV   the QKV projection (a 128-column panel is Q / K or V: the operand order -- D[feature][token] for Q / K, D[token][feature]
+//             for V^T -- is a per-workgroup scalar branch OUTSIDE the MFMA loop; v_mfma ignores EXEC, a per-MFMA select compiles into a
+//             branch around every MFMA)
+//   EPI_OUT   the pose head + sampler update (8 extra workgroups: the first one does the step bookkeeping, see StepCtl)
+// ---------------------------------------------------------------------------------------------------------
+template <int EPI, int KD16, bool SW>       // SW: D[feature][token] (Q / K, linear1, pose head); !SW: D[token][feature] (V^T)
+__device__ __forceinline__ void ws_body(const GemmArgs& g, const WsId id, char* lds) {
+    typedef PBF16 P;
     constexpr int K = 16 * KD16, KB = K / 32, BM = 64;
     constexpr int ABYTES = BM * K * 2;
-    static_assert(KD16 % 4 == 0 && KD16 <= 16, "K = 64, 128, 192 or 256");
-    __shared__ __attribute__((aligned(16))) char lds[2 * ABYTES];
-    preload_kernargs(g);
-    const int n_panels = g.NT >> 3, G = g.ws_G;
-    const WsId id = ws_id(n_panels, G);
-    const int MB = (g.M + BM - 1) / BM;
-    if (!id.work || id.grp >= MB) return;
+    const int G = g.ws_G, MB = (g.M + BM - 1) / BM;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lhi = lane >> 5;
 
@@ -116,6 +138,14 @@ __global__ __launch_bounds__(256, 2) void k_ws(const GemmArgs g) {
     };
     int cur = 0;
     issue_a(id.grp, 0);
+    int step = 0;
+    float k1 = 0.f, k2 = 0.f, k3 = 0.f, k4 = 0.f, k5 = 0.f;
+    if constexpr (EPI == EPI_OUT) {
+        if (g.out_mode != OUT_FORWARD) {
+            step = ldw<P>(&g.ctl->stepB);
+            k1 = ldwf<P>(&g.ctl->k1); k2 = ldwf<P>(&g.ctl->k2); k3 = ldwf<P>(&g.ctl->k3); k4 = ldwf<P>(&g.ctl->k4); k5 = ldwf<P>(&g.ctl->k5);
+        }
+    }
 #pragma unroll 1
     for (int mb = id.grp; mb < MB; mb += G) {
         const int m0 = mb * BM;
@@ -132,22 +162,117 @@ __global__ __launch_bounds__(256, 2) void k_ws(const GemmArgs g) {
         for (int s = 0; s < KD16; ++s) {
             const f32x4 a = *(const f32x4*)(abase + ((s >> 1) * 64 + 2 * (s & 1) * 16) * 16);
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) acc[ct] = mma32(wf[ct][s], a, acc[ct]);      // D[feature][token]: 4 consecutive features per lane
-        }
-        // ---- epilogue: per column tile, the 4 accumulator quads of the lane
-        const int mw = m0 + 32 * wm;
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            TileOps ops[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) gemm_prefetch_tile<P, EPI>(g, mw, nb[ct] + 8 * q + 4 * lhi, l31, 0, 0, ops[q]);      // token mw + l31, 4 features
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 v = {acc[ct][4 * q], acc[ct][4 * q + 1], acc[ct][4 * q + 2], acc[ct][4 * q + 3]};
-                gemm_epilogue_tile<P, EPI>(g, mw, nb[ct] + 8 * q + 4 * lhi, l31, 0, 0, true, v, ops[q], 0.f, 0.f, 0.f, 0.f, 0.f);
+            for (int ct = 0; ct < 2; ++ct) {
+                if constexpr (SW) acc[ct] = mma32(wf[ct][s], a, acc[ct]);      // 4 consecutive features per lane
+                else acc[ct] = mma32(a, wf[ct][s], acc[ct]);                   // 4 consecutive tokens per lane
             }
         }
+        const int mw = m0 + 32 * wm;
+        if constexpr (EPI == EPI_QKV && !SW) {
+            // ---- V^T: the block goes through the retired activation buffer and out in aligned token groups (vt_store_block)
+            constexpr int SP = BM + 4;                             // 136-byte feature pitch: 8-byte aligned quads
+            typedef typename P::elem elem;
+            elem* stage = (elem*)(lds + cur * ABYTES);
+            DSG_LDS_BARRIER();                                     // every wave is done reading the activation block
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int f = wn * 64 + ct * 32 + l31;             // feature within the panel
+                const float bias = g.bias[id.panel * 128 + f];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = {acc[ct][4 * q] + bias, acc[ct][4 * q + 1] + bias, acc[ct][4 * q + 2] + bias, acc[ct][4 * q + 3] + bias};
+                    P::store4(stage + f * SP + 32 * wm + 8 * q + 4 * lhi, v);
+                }
+            }
+            DSG_LDS_BARRIER();
+            vt_store_block<P, 128>(g, stage, SP, m0, BM, id.panel * 128 - 2 * (g.H * g.hd), tid);
+            cur ^= 1;
+            continue;
+        }
+        if constexpr (EPI == EPI_OUT) {
+            // ---- pose head: the C layout gives a lane 4 features of ONE token per quad, i.e. a wave store touches 32 tokens x 32 bytes
+            //      of the [B][T][Jp] state -- and the x_t loads likewise.  Each wave transposes its 32 x 32 tile through its own slice of
+            //      the retired activation buffer (LDS operations of a wave execute in order: no barrier between its write and read) so
+            //      that 8 lanes cover 128 contiguous bytes of one token; the epilogue arithmetic is position-based (gemm_epilogue_tile).
+            constexpr int TP = 36;                                 // floats per token: 144-byte pitch, conflict-free both ways
+            float* st = (float*)(lds + cur * ABYTES) + wave * (32 * TP);
+            DSG_LDS_BARRIER();                                     // every wave is done reading the activation block
+            const int tok = lane >> 3, quad = lane & 7;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *(f32x4*)(st + l31 * TP + 8 * q + 4 * lhi) = (f32x4){acc[ct][4 * q], acc[ct][4 * q + 1], acc[ct][4 * q + 2], acc[ct][4 * q + 3]};
+                DSG_WAVE_LDS_SYNC();
+#pragma unroll
+                for (int i0 = 0; i0 < 4; i0 += 2) {
+                    TileOps ops[2];
+                    f32x4 v[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int t = tok + 8 * (i0 + j);
+                        v[j] = *(const f32x4*)(st + t * TP + 4 * quad);
+                        gemm_prefetch_tile<P, EPI>(g, mw + t, nb[ct] + 4 * quad, 0, 0, step, ops[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        gemm_epilogue_tile<P, EPI>(g, mw + tok + 8 * (i0 + j), nb[ct] + 4 * quad, 0, 0, 0, true, v[j], ops[j], k1, k2, k3, k4, k5);
+                }
+                DSG_WAVE_LDS_SYNC();
+            }
+            cur ^= 1;
+            continue;
+        }
+        // ---- epilogue: per column tile, the 4 accumulator quads of the lane, QG quads' operands in flight at a time
+        constexpr int QG = EPI == EPI_GELU ? 4 : (EPI == EPI_QKV ? 2 : 1);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int q0 = 0; q0 < 4; q0 += QG) {
+                TileOps ops[QG];
+#pragma unroll
+                for (int j = 0; j < QG; ++j) {
+                    const int q = q0 + j;
+                    if constexpr (SW) gemm_prefetch_tile<P, EPI>(g, mw, nb[ct] + 8 * q + 4 * lhi, l31, 0, step, ops[j]);      // token mw + l31, 4 features
+                    else gemm_prefetch_tile<P, EPI>(g, mw + 8 * q + 4 * lhi, nb[ct], l31, 0, step, ops[j]);                  // feature nb + l31, 4 tokens
+                }
+#pragma unroll
+                for (int j = 0; j < QG; ++j) {
+                    const int q = q0 + j;
+                    const f32x4 v = {acc[ct][4 * q], acc[ct][4 * q + 1], acc[ct][4 * q + 2], acc[ct][4 * q + 3]};
+                    if constexpr (SW) gemm_epilogue_tile<P, EPI>(g, mw, nb[ct] + 8 * q + 4 * lhi, l31, 0, 0, true, v, ops[j], k1, k2, k3, k4, k5);
+                    else gemm_epilogue_tile<P, EPI>(g, mw + 8 * q + 4 * lhi, nb[ct], l31, 0, 0, false, v, ops[j], k1, k2, k3, k4, k5);
+                }
+            }
         cur ^= 1;
+    }
+}
+
+template <int EPI, int KD16>
+__global__ __launch_bounds__(256, EPI == EPI_OUT ? 1 : 2) void k_ws(const GemmArgs g) {
+    DSG_TL_SCOPE();
+    typedef PBF16 P;
+    constexpr int K = 16 * KD16, BM = 64;
+    static_assert(KD16 % 4 == 0 && KD16 <= 16, "K = 64, 128, 192 or 256");
+    static_assert(EPI == EPI_GELU || EPI == EPI_QKV || EPI == EPI_OUT, "GEMMs of the step with K = D");
+    __shared__ __attribute__((aligned(16))) char lds[2 * BM * K * 2];
+    preload_kernargs(g);
+    const int n_panels = g.NT >> 3;
+    const WsId id = ws_id(n_panels, g.ws_G);
+    if constexpr (EPI == EPI_OUT) {
+        if (!id.work) {
+            if (g.ctl && (int)blockIdx.x == ws_grid_x(n_panels, g.ws_G) && threadIdx.x == 0 && g.out_mode != OUT_FORWARD) step_advance_A<P>(g.ctl, g.st, g.n_tab);
+            return;
+        }
+    }
+    if (!id.work || id.grp >= (g.M + BM - 1) / BM) return;
+    if constexpr (EPI == EPI_QKV) {
+        // a whole 128-column panel is Q / K or V: two straight-line bodies under ONE scalar branch (v_mfma ignores EXEC, so a per-MFMA
+        // select becomes a branch around every MFMA; and one body with both operand orders keeps both epilogues' registers live: spills)
+        if (id.panel * 128 >= 2 * (g.H * g.hd)) ws_body<EPI, KD16, false>(g, id, lds);
+        else ws_body<EPI, KD16, true>(g, id, lds);
+    } else {
+        ws_body<EPI, KD16, true>(g, id, lds);
     }
 }
 
