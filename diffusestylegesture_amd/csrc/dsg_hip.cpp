@@ -752,9 +752,11 @@ extern "C" int dsg_set_window_cond_cfg(dsg_handle* h, const float* style, const 
 //            (dsg_batched.h); out_proj and the pose head stay on 16 x 16 tiles                    us at 16); from 300 rows per lane when
 //                                                                                               several lanes share the CUs (4 x 4:
 //                                                                                               4691 vs 4400 frames/s, 4 x 16: 8243 vs 6447)
-//   STREAM   BLOCK with linear1 / linear2 as weight-stationary persistent GEMMs (dsg_stream.h:   3 + 4L      >= 2800 rows per lane (batch 32: 369 ->
-//            W panel in registers, activations global -> LDS, 32x32x16 MFMA)                    357 us, batch 64: 611 -> 544; 4 x 16: 510 -> 500);
-//                                                                                               slower below (batch 16: 234 -> 243 us)
+//   STREAM   weight-stationary persistent GEMMs for every K = D / K = ff product of a layer      3 + 5L      >= 2800 rows in one lane (batch 32: 372 ->
+//            (dsg_stream.h: W panel in registers, activations global -> LDS, 32x32x16 MFMA):                357 us, batch 64: 611 -> 505); >= 1400 rows per
+//            LayerNorm once per row (k_ln_frag), QKV, linear1, linear2, pose head; pose embedding         lane with several lanes (4 x 16: 10.2k -> 11.7k
+//            and layer-0 QKV as in BLOCK                                                                  frames/s, 4 x 32: 11.0k -> 13.3k); slower below
+//                                                                                                         (4 x 8: 8.3k vs 8.8k, batch 16: 316 vs 240 us)
 //   With several lanes sharing the GPU the redundant recompute of LATENCY costs from batch 2 (4 x 2: 3507 frames/s TILE vs
 //   3303 LATENCY): dsg_recommend_kernel_set(B, lanes) encodes the multi-lane column; the caller applies it to its lanes.
 //   k_attn_op (attention + out_proj + LayerNorm1 in one kernel) replaces k_attn + out_proj in TILE / BLOCK wherever an
@@ -768,7 +770,7 @@ struct KernelSel {
     bool attn_in_mid = false;   // ... with the attention inside k_mid (batch 1)
     bool blk = false;           // BLOCK: 32-row block GEMMs
     bool attn_op = false;       // k_attn_op instead of k_attn + out_proj
-    bool stream = false;        // STREAM: BLOCK with the weight-stationary persistent FFN GEMMs of dsg_stream.h (linear1, linear2)
+    bool stream = false;        // STREAM: BLOCK with the weight-stationary persistent GEMMs of dsg_stream.h (LayerNorm + QKV, linear1, linear2, pose head)
 };
 static bool have_attn_mid(const dsg_handle* h, int B) {
     return B == 1 && h->H == 4 && ((h->D == 256 && h->Tp == 96) || (h->D == 128 && h->Tp == 32));
@@ -812,7 +814,7 @@ static int select_kernels(const dsg_handle* h, int B, KernelSel& k) {
     k.lat = set == DSG_KSET_LATENCY;
     k.attn_in_mid = k.lat && h->fuse_attn_mid && have_attn_mid(h, B);
     k.stream = set == DSG_KSET_STREAM;
-    k.blk = set == DSG_KSET_BLOCK || k.stream;      // (STREAM: QKV, pose embedding and pose head as in BLOCK)
+    k.blk = set == DSG_KSET_BLOCK || k.stream;      // (STREAM: pose embedding and layer-0 QKV as in BLOCK)
     k.attn_op = !k.lat && have_attn_op(h);
     return 0;
 }

@@ -1,38 +1,47 @@
-// dsg_stream.h -- kernel set DSG_KSET_STREAM: weight-stationary, persistent FFN GEMMs for large batches (bf16).
+// dsg_stream.h -- kernel set DSG_KSET_STREAM: weight-stationary, persistent GEMMs for large batches (bf16).
 //
-// Why (round-2 profile of the BLOCK set, profiles/r02_j_b64_kernel_stats.csv): at 5696 rows linear1 took 12.8-22.9 us and linear2
-// 16.4 us while moving ~180 MB through the CUs' load paths -- 32 x 64 output blocks re-read an activation block 16 times and a
-// weight slice 178 times (16 FLOP per byte pulled into a CU), and every fragment went through VGPRs.  Here:
+// Why (round-2 profile of the BLOCK set, profiles/r02_j_b64_kernel_stats.csv): at 5696 rows LN + QKV took 23.8 us, linear1 12.8-22.9,
+// linear2 16.4 and the pose head 54.9 while moving ~180 MB per GEMM through the CUs' load paths -- 32 x 64 output blocks re-read an
+// activation block 12-18 times (normalising it each time) and a weight slice 178 times (16 FLOP per byte pulled into a CU), and
+// every fragment went through VGPRs.  Here:
 //   * WEIGHTS ARE STATIONARY IN REGISTERS.  A workgroup owns one 128-column panel of W for its whole life; each of its 4 waves
 //     (2 x 2 over a 64-row x 128-column block) keeps its 64 columns x K = 256 slice as v_mfma_f32_32x32x16_bf16 operand fragments
 //     (128 VGPRs), loaded ONCE, and walks the row blocks  mb = group, group + G, ...  (persistent: grid = panels x groups ~ 2
 //     workgroups per CU).  Per 64 x 128 block a CU pulls 32 KB of activations for 4.2 MFLOP: 128 FLOP per byte.
 //   * ACTIVATIONS GO GLOBAL -> LDS DIRECTLY (global_load_lds_dwordx4, no VGPR staging), the whole block in one batch of 8
 //     instructions per wave, DOUBLE BUFFERED: the next block's loads are issued before the current block's MFMA loop.  The A
-//     operand is stored fragment-major by its producer (k_attn_op / the GELU epilogue), so a block is one contiguous span and the
-//     LDS image is conflict-free for ds_read_b128 as it lies.
+//     operand is stored fragment-major by its producer (k_attn_op / k_ln_frag / the GELU epilogue), so a block is one contiguous
+//     span and the LDS image is conflict-free for ds_read_b128 as it lies.
+//   * LAYERNORM ONCE PER ROW (k_ln_frag): the LayerNorm-on-read GEMMs (QKV of layers > 0, pose head) get their operand from a
+//     16-rows-per-workgroup pass that writes the normalised rows in bf16, fragment-major (+ fp32 for the attention kernel's
+//     residual) -- one extra dispatch (5.5 us at 5696 rows) instead of 64 fp32 rows staged through registers per (block, panel).
 //   * 32 x 32 x 16 MFMA: half the LDS operand bytes per FLOP of the 16 x 16 x 32 form (one 1 KB A fragment feeds two MFMAs of
 //     32 K FLOP each), 4 waves x 1 KB per 64 cycles = 64 B/clk of the CU's 256 B/clk LDS read rate.
 //   * linear2 (K = ff = 1024, k_ws2): the 4 waves split K; each keeps W[64 columns x its 256-wide K quarter] in registers, the 32-row
 //     block of `hidden` (64 KB, fragment-major, contiguous) is double buffered in LDS, the four partial 32 x 64 blocks are reduced
 //     through the retired buffer in a fixed order.
+//   * V^T IN ALIGNED TOKEN GROUPS (vt_store_block, dsg_kernels.h): a V panel's block is transposed through the retired activation
+//     buffer so that every 4-token group of a batch element is one 8-byte store (ntok = 89: three of four batch elements paid 4
+//     element stores per lane and row quad -- QKV 16.8 -> 12.5 us at 5696 rows; the block kernels of dsg_batched.h do the same).
+//   * the pose head (EPI_OUT) transposes each wave's 32 x 32 tile through LDS so that 8 lanes cover 128 contiguous bytes of the
+//     [B][T][Jp] state; its registers (W 128 + accumulators + x_t / noise operands) take one workgroup per CU.
 // Epilogues are the ones of dsg_kernels.h (gemm_prefetch_tile / gemm_epilogue_tile), called per accumulator quad with the
 // (token, feature) the 32 x 32 C layout gives the lane -- same arithmetic per element; the set differs from the others only in the
 // order of the k sums.
-// Measured on MI355X (profiles/r03_c_*_kernel_stats.csv, r03_d_*, r03_e_*; per launch, HIP-launch path under rocprofv3):
-//     rows (clips)      linear1  blk -> k_ws      linear2  blk_k -> k_ws2      step (AQL), BLOCK -> STREAM
-//     5696 (1 x 64)         12.8 -> 10.1 us            16.3 -> 10.5 us            611 -> 544 us   (+12 % clips/s)
-//     2848 (1 x 32)                                                                369 -> 357 us
-//     4 x 1424 (4 x 16)                                                            510 -> 500 us
-//     1424 (1 x 16)           5.5 -> 5.95 us            6.95 -> 5.9 us            234 -> 243 us   (slower: see below)
-// i.e. it pays from ~2800 rows per lane; select_kernels() picks it there.  Below that a workgroup gets ONE block, so the register-
-// resident panel is loaded for nothing and the persistent loop has nothing to overlap; and with the fence-free loop (uncached
-// activation buffers, max_batch <= 16) the 128 KB-LDS linear2 kernel, faster on its own, makes the chain slower.
-// The same design with LayerNorm-on-read (QKV of layers > 0, pose head; 64 fp32 rows staged through registers, one workgroup per
-// CU) was built and measured SLOWER than the block kernels at every size (QKV 28.0 vs 23.0 us at 5696 rows, 17.4 vs 8.4 at 1424;
-// head 53.4 vs 52.3 / 18.5 vs 17.0) -- the synchronous fp32 staging serialises load, LayerNorm and MFMA phases -- and removed again;
-// those GEMMs stay on dsg_batched.h.
-// Reference arithmetic being replaced: linear1 / linear2 of torch's TransformerEncoderLayer (main/model/mdm.py:79-86) at M = 89 B.
+// Measured on MI355X (profiles/r03_c_*, r03_q_*_kernel_stats.csv; per launch, HIP-launch path under rocprofv3; step: AQL path):
+//     rows (clips)      LN + QKV  blk -> k_ln_frag + k_ws   linear1  blk -> k_ws   linear2  blk_k -> k_ws2   head  lean -> k_ws     step, BLOCK -> STREAM
+//     5696 (1 x 64)         23.0 -> 5.5 + 12.5 us               12.8 -> 10.1 us        16.3 -> 10.5 us        52.5 -> 51.6 us      611 -> 505 us (+21 % clips/s)
+//     2848 (1 x 32)                                                                                                               372 -> 357 us
+//     4 x 1424 (4 x 16)                                                                                                           500 -> 436 us (10.2k -> 11.7k frames/s)
+//     4 x 2848 (4 x 32)                                                                                                           933 -> 768 us (11.0k -> 13.3k frames/s)
+//     4 x 712 (4 x 8)                                                                                                             292 -> 308 us   (slower)
+//     1424 (1 x 16)                                                                                                               240 -> 316 us   (slower: see below)
+// i.e. it pays from ~2800 rows in one lane and ~1400 rows per lane with several lanes; auto_kernel_set() picks it there.  Below that a
+// workgroup gets ONE block, so the register-resident panel is loaded for nothing and the persistent loop has nothing to overlap.
+// An earlier form with LayerNorm-on-read INSIDE the weight-stationary GEMM (64 fp32 rows staged through registers, one workgroup
+// per CU) was slower than the block kernels at every size (QKV 28.0 vs 23.0 us at 5696 rows): csrc/experiments/dsg_stream_ln.h.
+// Reference arithmetic being replaced: the nn.Linear / LayerNorm calls of torch's TransformerEncoderLayer (main/model/mdm.py:79-86)
+// and the pose head (mdm.py:233-236) at M = 89 B.
 #pragma once
 #include "dsg_batched.h"
 #include <type_traits>
