@@ -271,6 +271,7 @@ static std::map<std::string, std::vector<int64_t>> expected_tensors(const dsg_ha
     return m;
 }
 
+static bool stream_set_ok(const dsg_handle* h);
 extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     if (!c || !out) return fail(DSG_E_INVALID, "dsg_create: null argument");
     if (c->variant < 3 || c->variant > 5) return fail(DSG_E_NOT_IMPLEMENTED, "variant must be 3, 4 or 5");
@@ -318,9 +319,11 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     //   DSG_AQL   0: HIP launches instead of hand-written AQL packets
     //   DSG_FUSE_ATTN_MID  0: k_attn + k_mid instead of k_attn_mid at batch 1 (bit-identical; A/B)
     if (const char* e = getenv("DSG_KSET")) h->kset_req = atoi(e);
-    // large batches re-read their activations from the L2 often enough that the uncached buffers cost what the fences save
-    // (64 clips in 4 lanes x 16: 9667 vs 9680 frames/s): cached + fenced from batch 32
-    if (c->max_batch > 16) h->uc_mode = 0;
+    // Large batches on the BLOCK set re-read their activations from the L2 often enough that the uncached buffers cost what the
+    // fences save (4 x 16: 9667 vs 9680 frames/s, 4 x 32: 10 430 vs 10 695): cached + fenced from batch 17 -- unless the handle can run
+    // the STREAM set, which large batches select and which reads an activation block once per 128-column panel: fence-free wins there
+    // at every size (1 x 64: 505 -> 479 us, 1 x 32: 356 -> 338, 4 x 32: 13.3k -> 13.8k frames/s; profiles/r03_q_uc_stream.log)
+    if (c->max_batch > 16 && !stream_set_ok(h)) h->uc_mode = 0;
     if (const char* e = getenv("DSG_UC")) h->uc_mode = atoi(e);
     if (const char* e = getenv("DSG_AQL")) h->aql_mode = atoi(e);
     else {
