@@ -925,7 +925,7 @@ static int launch_ws(dsg_handle* h, GemmArgs g) {
     g.inv_ntok = fastdiv_inv(g.ntok); g.inv_hd = fastdiv_inv(g.hd);
     if (g.NT % 8) return fail(DSG_E_INVALID, "k_ws: N must be a multiple of 128");
     const int P = g.NT / 8, MB = cdiv(g.M, 64);
-    g.ws_G = ws_groups(P, MB, 2);
+    g.ws_G = ws_groups(P, MB, EPI == EPI_OUT ? 1 : 2);      // resident workgroups per CU: the pose head's registers allow one
     const dim3 grid(ws_grid_x(P, g.ws_G) + (EPI == EPI_OUT ? 8 : 0));      // EPI_OUT: + the bookkeeping workgroup (one XCD round)
     const int K = g.KBtot * 32;
     if (K == 256) return step_launch<&k_ws<EPI, 16>>(h, grid, dim3(256), g);
@@ -1142,7 +1142,13 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                 a.X1 = h->X1; a.X1a = h->X1a; a.B = B; a.ntok = ntok; a.Tp = h->Tp;
                 const dim3 grid(cdiv(ntok, 16), B);
                 if constexpr (sizeof(typename P::elem) == 2) {
-                    if (D == 256 && h->Tp == 96) CHK((step_launch<&k_attn_op<P, 4, 6>>(h, grid, dim3(256), a)));
+                    // two query tiles per workgroup (K / V^T / W_o once per 32 rows; bit-identical) once the batch fills the GPU:
+                    // (from 4000 token rows) 1 x 64: 478 -> 463 us; 4 x 32 within noise; 4 x 16: 436 -> 442 us, block 1 x 16: 235 -> 251 (slower)
+                    if (ks.stream && M >= 4000) {
+                        const dim3 grid2(cdiv(cdiv(ntok, 16), 2), B);
+                        if (D == 256 && h->Tp == 96) CHK((step_launch<&k_attn_op2<P, 4, 6>>(h, grid2, dim3(256), a)));
+                        else CHK((step_launch<&k_attn_op2<P, 2, 2>>(h, grid2, dim3(256), a)));
+                    } else if (D == 256 && h->Tp == 96) CHK((step_launch<&k_attn_op<P, 4, 6>>(h, grid, dim3(256), a)));
                     else CHK((step_launch<&k_attn_op<P, 2, 2>>(h, grid, dim3(256), a)));
                 }
             }

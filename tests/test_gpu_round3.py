@@ -107,6 +107,33 @@ def test_config3_fence_free_soak_full_clip(gpu, monkeypatch):
     assert np.array_equal(outs["0"], outs["1"])
 
 
+def test_stream_set_fence_free_at_large_batch(gpu, monkeypatch):
+    """Handles that can run the STREAM set keep uncached loop buffers and fence-free packets at every max_batch (round 3: 1 x 64
+    505 -> 479 us/step).  2 lanes x batch 32 (2848 token rows per lane: STREAM by the automatic rule), 2 windows x 300 steps:
+    bit-identical to cached buffers + agent-scope fences, and the default really is the fence-free path."""
+    import torch
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    from diffusestylegesture_amd.model import DSGDenoiser
+    from diffusestylegesture_amd.sample import generate_clips_streams
+    cfg, NL, B, K = C.ZEGGS, 2, 32, 2
+    feats = [[torch.from_numpy(synth_window_inputs(cfg, B, window=w, clip0=ln * B)["audio"]).cuda() for w in range(K)] for ln in range(NL)]
+    outs = {}
+    for uc in ("default", "0"):
+        if uc == "default":
+            monkeypatch.delenv("DSG_UC", raising=False)
+        else:
+            monkeypatch.setenv("DSG_UC", uc)
+        m = DSGDenoiser(cfg, precision="bf16", max_batch=B)
+        m.load_state_dict(synth_state_dict(cfg, 20240))
+        lanes = [m, m.clone()]
+        d = create_gaussian_diffusion()
+        outs[uc] = generate_clips_streams(lanes, d, feats, [0, 1, 0, 0, 0, 0], seed=7, skip_timesteps=700, stream_ids=[0, 1])
+        assert all(ln.last_sample_path() == "aql" and ln.last_kernel_set() == "stream" for ln in lanes)
+        assert all(ln.last_sample_fence_free() == (uc == "default") for ln in lanes)
+    assert outs["0"].shape == (64, 152, cfg.njoints) and np.isfinite(outs["0"]).all()
+    assert np.array_equal(outs["0"], outs["default"])
+
+
 def test_twh_1000_step_chain_bf16_vs_oracle(gpu):
     """config[4] dims (TWH: latent 512, K = 2232 pose features, 151 tokens; the TILE kernel set): one whole window, 1000 DDPM
     steps in bf16 against the fp32 oracle -- the drift number config[4] (16 windows x 1000 steps) rests on.  ~40 s of CPU."""
@@ -164,11 +191,12 @@ def test_kernel_sets_are_sticky_lane_properties(gpu):
             assert lanes[i].last_kernel_set() == kset and np.array_equal(np.asarray(multi[i]), np.asarray(alone)), (kset, i)
 
 
-@pytest.mark.parametrize("B", [3, 16])
+@pytest.mark.parametrize("B", [3, 16, 48])
 def test_stream_kernel_set_vs_oracle(gpu, B):
-    """Kernel set "stream" (dsg_stream.h: weight-stationary persistent GEMMs, 32x32x16 MFMA, global->LDS staging, 64-row blocks) at
-    ZEGGS dims: a forward with ragged last blocks (267 / 1424 rows) and a 40-step DDPM chain with distinct rows against the oracle,
-    row by row; DDIM on top at batch 16 (config[2]'s shape)."""
+    """Kernel set "stream" (dsg_stream.h: weight-stationary persistent GEMMs, 32x32x16 MFMA, global->LDS staging, 64-row blocks;
+    LayerNorm once per row, V^T through LDS in aligned token groups, two query tiles per attention workgroup from 4000 rows) at
+    ZEGGS dims: a forward with ragged last blocks (267 / 1424 / 4272 rows) and a 40-step DDPM chain with distinct rows against the
+    oracle, row by row; DDIM on top at batch 16 (config[2]'s shape)."""
     from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
     from oracle import philox, sampler
     from oracle.mdm import MDMOracle

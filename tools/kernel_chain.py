@@ -14,7 +14,7 @@ from diffusestylegesture_amd.model import DSGDenoiser
 from diffusestylegesture_amd.synth import synth_state_dict, synth_window_inputs
 
 names = ["null", "oproj same-weights", "oproj cycling layers", "LN+linear1+GELU", "linear2 (K=1024)", "k_attn", "k_loc",
-         "k_in (split-K)", "pose head (LN + N=1152)", "LN+QKV", "k_mid", "k_qkv_attn", "k_inloc"]
+         "k_in (split-K)", "pose head (LN + N=1152)", "LN+QKV", "k_mid", None, "k_inloc"]      # (id 11 retired with k_qkv_attn)
 cfg = CF.ZEGGS
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 m = DSGDenoiser(cfg, precision="bf16", max_batch=B, device=0)
@@ -29,7 +29,7 @@ fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_flo
 extra = {20: "alternate oproj/linear2 (iso avg of 1,4)", 21: "cycle oproj,linear2,k_in,LN+QKV (avg of 1,4,7,9)",
          22: "cycle the 6 step kernels (avg of 12,9,5,10,4,8)"}
 for g in (1, 0):
-    for which, nm in list(enumerate(names)) + sorted(extra.items()):
+    for which, nm in [(i, n) for i, n in enumerate(names) if n] + sorted(extra.items()):
         us = C.c_float()
         rc = fn(m.handle, which, 1280, g, B, C.byref(us))
         print(f"B={B} {'graph' if g else 'eager'} {which:2d} {nm:28s}: {us.value:7.2f} us/launch" if rc == 0 else f"{nm}: rc={rc}", flush=True)

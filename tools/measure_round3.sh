@@ -20,11 +20,12 @@ $B --gpus 1 --config3 on --steps 1 --warmup 1 > $O/${TAG}_bench_with_config3_rec
 $B --config beat --steps 1 > $O/${TAG}_bench_beat.log 2>&1
 $B --config twh --steps 1 > $O/${TAG}_bench_twh.log 2>&1
 # kernel sets side by side (one process, same inputs)
-timeout 600 python tools/sweep.py --steps 150 --reps 3 --spec latency:1x1,tile:1x1,latency:4x1,latency:1x2,tile:1x2,tile:4x2,latency:4x2,tile:1x4,block:1x4,block:4x4,tile:4x4,block:1x16,tile:1x16,stream:1x16,block:4x8,block:4x16,stream:4x16,block:1x32,stream:1x32,block:1x64,stream:1x64 2>&1 | grep -v amdgpu.ids > $O/${TAG}_sweep_kernel_sets.log
+timeout 900 python tools/sweep.py --steps 150 --reps 3 --spec latency:1x1,tile:1x1,latency:4x1,latency:1x2,tile:1x2,tile:4x2,latency:4x2,tile:1x4,block:1x4,block:4x4,tile:4x4,block:1x16,tile:1x16,stream:1x16,block:4x8,stream:4x8,block:4x16,stream:4x16,block:1x32,stream:1x32,block:4x32,stream:4x32,block:1x64,stream:1x64 2>&1 | grep -v amdgpu.ids > $O/${TAG}_sweep_kernel_sets.log
 # the timed path's own timeline (in-kernel stamps; command-processor timestamps)
 python tools/aql_timeline.py --out $O/${TAG}_aql_step_timeline.json > $O/${TAG}_aql_step_timeline.log 2>&1
 python tools/aql_timeline.py --batch 16 --n 16 --out $O/${TAG}_aql_step_timeline_b16.json > /dev/null 2>&1
 python tools/aql_timeline.py --lib product --out $O/${TAG}_aql_step_timeline_cp_timestamps.json > /dev/null 2>&1
+python tools/aql_timeline.py --batch 64 --kset stream --steps 120 --first 40 --n 16 --out $O/${TAG}_aql_step_timeline_b64_stream.json > /dev/null 2>&1
 # rocprofv3 (HIP-launch path): kernel stats at batch 1 / 16 / 64, PMC traffic (separate passes), MFMA / SQ counters
 bash tools/prof.sh ${TAG}_b1 latency:1x1:hip 100 > $O/${TAG}_prof_b1.txt 2>&1
 bash tools/prof.sh ${TAG}_b16 block:1x16:hip 50 > $O/${TAG}_prof_b16.txt 2>&1
