@@ -42,15 +42,17 @@ def _model(cfg, prec, max_batch=1, wseed=20240):
 # the arrangement bench.py --clips-per-gpu 16 runs.  Every clip has its own conditioning and its own Philox rows; the
 # oracle samples a clip on its own (rows and lanes are independent), through the same window loop / stitching.
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
-def test_config3_arrangement_4_lanes_x_batch_4_vs_oracle(gpu, prec):
+@pytest.mark.parametrize("prec,NL,B,kset", [("fp32", 4, 4, "block"), ("bf16", 4, 4, "block"), ("bf16", 4, 16, "stream")])
+def test_config3_arrangement_4_lanes_x_batch_4_vs_oracle(gpu, prec, NL, B, kset):
+    """4 lanes x batch 4 = config[3]'s 16 clips per GPU (BLOCK set); 4 lanes x batch 16 = 64 clips per GPU, the arrangement
+    from which the lanes run the STREAM set (round 3)."""
     import torch
     from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
     from diffusestylegesture_amd.sample import generate_clips_streams
     from oracle import philox, sampler
     from oracle.mdm import MDMOracle
     from oracle.schedule import OracleDiffusion
-    cfg, NL, B, K, n_run = C.ZEGGS, 4, 4, 2, 60
+    cfg, K, n_run = C.ZEGGS, 2, 60
     skip = 1000 - n_run
     m = _model(cfg, prec, max_batch=B)
     lanes = [m] + [m.clone() for _ in range(NL - 1)]
@@ -61,13 +63,13 @@ def test_config3_arrangement_4_lanes_x_batch_4_vs_oracle(gpu, prec):
     sids = [7 + ln for ln in range(NL)]
     got = generate_clips_streams(lanes, d, feats, style, seed=4242, skip_timesteps=skip, stream_ids=sids)
     assert got.shape == (NL * B, K * cfg.stride - cfg.n_seed, cfg.njoints) and np.isfinite(got).all()
-    # the arrangement that ships: AQL packets on 4 queues, fence-free, the kernel set recommended for 4 lanes x 356 rows
-    assert m.recommend_kernel_set(B, NL) == "block"
-    assert all(ln.last_kernel_set() == "block" and ln.last_sample_path() == "aql" and ln.last_sample_fence_free() for ln in lanes)
+    # the arrangement that ships: AQL packets on 4 queues, fence-free, the kernel set recommended for 4 lanes x 356 / 1424 rows
+    assert m.recommend_kernel_set(B, NL) == kset
+    assert all(ln.last_kernel_set() == kset and ln.last_sample_path() == "aql" and ln.last_sample_fence_free() for ln in lanes)
     ref, od = MDMOracle(synth_state_dict(cfg, 20240), cfg), OracleDiffusion()
     shape = (B, cfg.njoints, 1, cfg.n_poses)
     worst = 0.0
-    for ln, b in ((0, 0), (0, 3), (1, 1), (2, 2), (3, 0), (3, 3)):
+    for ln, b in ((0, 0), (0, B - 1), (1, 1), (2, 2), (3, 0), (3, B - 1)):
         def sample_window(c, y, ln=ln, b=b):
             nf = lambda k: philox.normal_bj1t(shape, 4242, c * (1 + n_run) + k, sids[ln])[b:b + 1]
             return sampler.p_sample_loop(od, ref, (1,) + shape[1:], nf, {"y": y}, skip_timesteps=skip)
@@ -75,12 +77,12 @@ def test_config3_arrangement_4_lanes_x_batch_4_vs_oracle(gpu, prec):
         e = rel_l2(got[ln * B + b], want)
         worst = max(worst, e)
         assert e < TOL_CHAIN[prec], (ln, b, e)
-    print(f"config[3] arrangement {prec}: worst rel-L2 of 6 clips vs oracle = {worst:.3e}")
+    print(f"{NL} lanes x batch {B} ({kset}) {prec}: worst rel-L2 of 6 clips vs oracle = {worst:.3e}")
     assert not np.array_equal(got[0], got[1]) and not np.array_equal(got[0], got[B])
     # and a lane reproduces itself bit for bit when sampled alone (same handle = same kernel set)
     from diffusestylegesture_amd.sample import generate_clip
     alone = generate_clip(lanes[2], d, feats[2], style, seed=4242, skip_timesteps=skip, stream_id=sids[2])
-    assert lanes[2].last_kernel_set() == "block" and np.array_equal(alone, got[2 * B:3 * B])
+    assert lanes[2].last_kernel_set() == kset and np.array_equal(alone, got[2 * B:3 * B])
 
 
 def test_config3_fence_free_soak_full_clip(gpu, monkeypatch):
