@@ -43,6 +43,21 @@ for name in ("dsg_set_window_cond", "dsg_set_seed_last", "dsg_sample", "dsg_sync
             return r
         return g
     setattr(cdll, name, wrap())
+def wrap_py(obj, name):
+    f = getattr(obj, name)
+
+    def g(*a_, **k_):
+        t0 = time.perf_counter()
+        r = f(*a_, **k_)
+        acc["py:" + name] += time.perf_counter() - t0
+        cnt["py:" + name] += 1
+        return r
+    setattr(obj, name, g)
+
+
+for obj, name in ((S, "_zeggs_window_y"), (S, "_zeggs_stitch"), (S, "_zeggs_finish"), (d, "_prepare"), (m, "_alloc_out"), (m, "set_cond"), (m, "set_schedule")):
+    if hasattr(obj, name):
+        wrap_py(obj, name)
 feats = [torch.from_numpy(synth_window_inputs(cfg, a.batch, window=w)["audio"]).cuda() for w in range(4)]
 style = [1] + [0] * (cfg.style_dim_in - 1)
 sample_fn = d.ddim_sample_loop if a.sampler == "ddim50" else d.p_sample_loop
@@ -57,5 +72,6 @@ wall = time.perf_counter() - t0
 print(f"{a.sampler} batch {a.batch}: {1e3 * wall / a.passes:.2f} ms per pass of 4 windows")
 for k in sorted(acc, key=lambda k: -acc[k]):
     print(f"  {k:24s} {1e3 * acc[k] / a.passes:8.3f} ms/pass   {cnt[k] / a.passes:5.1f} calls/pass   {1e6 * acc[k] / max(cnt[k], 1):8.1f} us/call")
-print(f"  python + torch outside the C-ABI: {1e3 * (wall - sum(acc.values())) / a.passes:.3f} ms/pass")
+c_abi = sum(v for k, v in acc.items() if not k.startswith("py:"))
+print(f"  python + torch outside the C-ABI: {1e3 * (wall - c_abi) / a.passes:.3f} ms/pass  (py:* rows are inclusive of nested C-ABI calls)")
 print(f"  last window: AQL loop {d.last_step_time_us() * n_steps / 1e3:.3f} ms ({d.last_step_time_us():.2f} us/step x {n_steps})")
