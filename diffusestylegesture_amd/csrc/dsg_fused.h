@@ -135,7 +135,7 @@ __device__ __forceinline__ void inloc_body(const InLocArgs& g) {
     }
     if (w == 0 && tid < HD) {
         a.X0[(size_t)(b * ntok) * a.D + col0 + tid] = tokv;
-        ((elem*)a.X0a)[(size_t)(b * ntok) * a.D + col0 + tid] = P::cvt(tokv);
+        ((elem*)a.X0a)[a.x0a_frag ? (size_t)qk_off<P>(b * ntok, col0 + tid, a.D / P::KB) : (size_t)(b * ntok) * a.D + col0 + tid] = P::cvt(tokv);
     }
 
     // ---- (3) reduce the 4 K-slices, add the constants, apply the rotary -> rot

@@ -790,7 +790,7 @@ static bool latency_set_ok(const dsg_handle* h) {
 static bool stream_set_ok(const dsg_handle* h) {
     // k_ws keeps 64 columns x K = D of W per wave in registers (D = 128 / 256), k_ws2 a quarter of K = ff (ff = 128 / 1024);
     // linear1 reads the fragment-major LayerNorm1 rows k_attn_op writes
-    return have_attn_op(h) && (h->D == 256 || h->D == 128) && (h->ff == 1024 || h->ff == 128) && h->Jp % 128 == 0;
+    return have_attn_op(h) && (h->D == 256 || h->D == 128) && (h->ff == 1024 || h->ff == 128) && (h->Jp == 1152 || h->Jp == 128);
 }
 static int auto_kernel_set(const dsg_handle* h, int B, int lanes) {
     const int rows = B * h->ntok;
@@ -948,17 +948,23 @@ static int launch_ln_ws(dsg_handle* h, GemmArgs g) {
     g.A = h->X1a; g.lda = g.D; g.a_frag = 1; g.X = nullptr; g.Xn = nullptr;
     return launch_ws<EPI>(h, g);
 }
+template <int EPI>
 static int launch_ws2(dsg_handle* h, GemmArgs g) {
     g.KS = 1; g.kb_per_split = g.KBtot;
     g.inv_ntok = fastdiv_inv(g.ntok); g.inv_hd = fastdiv_inv(g.hd);
     if (g.NT % 4) return fail(DSG_E_INVALID, "k_ws2: N must be a multiple of 64");
     const int P = g.NT / 4, MB = cdiv(g.M, 32);
     g.ws_G = ws_groups(P, MB, 1);
-    const dim3 grid(ws_grid_x(P, g.ws_G));
+    const dim3 grid(ws_grid_x(P, g.ws_G) + (EPI == EPI_PARTIAL ? 8 : 0));      // EPI_PARTIAL: + the bookkeeping workgroup
     const int K = g.KBtot * 32;
-    if (K == 1024) return step_launch<&k_ws2<16>>(h, grid, dim3(256), g);
-    if (K == 128) return step_launch<&k_ws2<2>>(h, grid, dim3(256), g);
-    return fail(DSG_E_NOT_IMPLEMENTED, "k_ws2: K must be 128 or 1024");
+    if constexpr (EPI == EPI_RESID) {
+        if (K == 1024) return step_launch<&k_ws2<EPI, 16>>(h, grid, dim3(256), g);
+        if (K == 128) return step_launch<&k_ws2<EPI, 2>>(h, grid, dim3(256), g);
+    } else {
+        if (K == 1152) return step_launch<&k_ws2<EPI, 18>>(h, grid, dim3(256), g);
+        if (K == 128) return step_launch<&k_ws2<EPI, 2>>(h, grid, dim3(256), g);
+    }
+    return fail(DSG_E_NOT_IMPLEMENTED, "k_ws2: K must be 128 / 1024 (linear2) or 128 / 1152 (pose embedding)");
 }
 
 // a K = D GEMM of the un-fused sets: block kernel (BLOCK, the GEMMs it wins), else 16 x 16 tiles -- LayerNorm GEMMs from 512
@@ -966,8 +972,8 @@ static int launch_ws2(dsg_handle* h, GemmArgs g) {
 template <class P, int PRO, int EPI>
 static int launch_gemm_w(dsg_handle* h, const GemmArgs& g, const KernelSel& ks) {
     constexpr bool blk_wins = EPI == EPI_QKV || EPI == EPI_GELU;
-    if constexpr (sizeof(typename P::elem) == 2 && PRO == PRO_DIRECT && EPI == EPI_GELU) {
-        if (ks.stream && g.a_frag) return launch_ws<EPI_GELU>(h, g);      // STREAM: linear1 on the fragment-major LayerNorm1 rows of k_attn_op
+    if constexpr (sizeof(typename P::elem) == 2 && PRO == PRO_DIRECT && (EPI == EPI_GELU || EPI == EPI_QKV)) {
+        if (ks.stream && g.a_frag) return launch_ws<EPI>(h, g);      // STREAM: linear1 on the fragment-major LayerNorm1 rows of k_attn_op
     }
     if constexpr (sizeof(typename P::elem) == 2 && PRO == PRO_LN && (EPI == EPI_QKV || EPI == EPI_OUT)) {
         if (ks.stream) return launch_ln_ws<EPI>(h, g);                    // STREAM: LayerNorm once per row, then the same streaming GEMM
@@ -990,7 +996,7 @@ static int launch_gemm_w(dsg_handle* h, const GemmArgs& g, const KernelSel& ks) 
 template <class P>
 static int launch_gemm_k4(dsg_handle* h, const GemmArgs& g, const KernelSel& ks) {
     if constexpr (sizeof(typename P::elem) == 2) {
-        if (ks.stream && g.a_frag) return launch_ws2(h, g);
+        if (ks.stream && g.a_frag) return launch_ws2<EPI_RESID>(h, g);
     }
     if (ks.blk) return launch_blk_k<P, EPI_RESID>(h, g);
     return launch_gemm<P, PRO_DIRECT, EPI_RESID, 1, 4>(h, g);
@@ -1076,11 +1082,12 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
     // split-K of the pose-embedding GEMM across workgroups: one split per 256 pose features for the 16 x 16 tile kernel; the
     // block kernel splits K over its 4 waves already, so 2 workgroup splits keep a wave's share at <= 8 k-blocks (one batch of
     // loads) without fragmenting the work 5 ways
-    const int ks_in = ks.blk ? std::min(h->KSin, 2) : h->KSin;
+    const int ks_in = ks.stream ? 1 : (ks.blk ? std::min(h->KSin, 2) : h->KSin);      // (STREAM: K stays whole, see k_ws2)
     la.partial = h->partial; la.KS = ks_in; la.Min_pad = MTin * 16; la.Cf = h->Cf; la.TE2 = h->TE2; la.TE = h->TE;
     la.emb1 = h->emb1; la.ctl = c.use_ctr ? h->ctl : nullptr; la.t_arr = h->t_arr;
     la.rcos = h->rcos; la.rsin = h->rsin; la.mask = h->mask; la.mb = h->mb; la.inv_mask_div = fastdiv_inv((int)((long long)B * h->Hl / h->mb)); la.B = B; la.T = T; la.D = D; la.Hl = h->Hl;
     la.hd = h->hdl; la.W = h->W; la.X0 = h->X0; la.X0a = h->X0a; la.nomask = h->nomask;
+    la.x0a_frag = (ks.stream && sizeof(typename P::elem) == 2) ? 1 : 0;
     h->fence_next = 1;         // the first packet of a step reads the state the previous step's last packet wrote (state_fences)
     if (ks.lat) {              // pose embedding + local attention in one launch
         InLocArgs a;
@@ -1095,7 +1102,12 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
             g.A = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; g.lda = h->Jp;
             g.out = h->partial; g.ldo = D;
             g.ctl = c.use_ctr ? h->ctl : nullptr; g.st = step_tables(h); g.n_tab = h->n_run;
-            if (ks.blk) CHK((launch_blk_k<P, EPI_PARTIAL>(h, g)));
+            bool done = false;
+            if constexpr (sizeof(typename P::elem) == 2) {
+                if (ks.stream) { g.a_frag = 1; CHK(launch_ws2<EPI_PARTIAL>(h, g)); done = true; }      // the state shadow is fragment-major (xs_frag)
+            }
+            if (done) {}
+            else if (ks.blk) CHK((launch_blk_k<P, EPI_PARTIAL>(h, g)));
             else CHK((launch_gemm<P, PRO_DIRECT, EPI_PARTIAL, 4, 1>(h, g)));
         }
         DSG_LOC_DISPATCH(k_loc, la, dim3(h->Hl, T / h->W, B));
@@ -1107,7 +1119,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
             g.M = M; g.MT = MT; g.NT = 3 * D / 16; g.KBtot = D / KB; g.Wp = ly.Wqkv; g.bias = ly.bqkv;
             g.q = h->q; g.k = h->k; g.vt = h->vt;
             if (l == 0) {
-                g.A = h->X0a; g.lda = D;
+                g.A = h->X0a; g.lda = D; g.a_frag = la.x0a_frag;
                 CHK((launch_gemm_w<P, PRO_DIRECT, EPI_QKV>(h, g, ks)));
             } else {
                 g.X = h->pre2; g.ln_g = h->layers[l - 1].g2; g.ln_b = h->layers[l - 1].be2; g.Xn = h->Xn;
@@ -1186,6 +1198,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
         g.out_mode = c.out_mode; g.xs32 = h->xs32; g.xsA = h->prec == DSG_PREC_BF16 ? h->xsA : nullptr;
         g.fwd_out = h->fwd_out; g.ctl = c.use_ctr ? h->ctl : nullptr; g.st = step_tables(h); g.n_tab = h->n_run;
         g.dyn = h->dyn; g.ext_noise = c.ext_noise; g.const_noise = c.const_noise; g.clip_x0 = c.clip_x0; g.no_noise = c.no_noise;
+        g.xs_frag = ks.stream ? 1 : 0;
         h->fence_next = 2;     // the last packet of a step writes the state (state_fences)
         if (h->cfgB > 0) {      // guidance: one workgroup per CONDITIONAL row tile evaluates the twin rows as well (k_gemm_cfg)
             g.B = h->cfgB; g.M = h->cfgB * ntok; g.MT = cdiv(g.M, 16);
@@ -1350,9 +1363,9 @@ static int run_step_p(dsg_handle* h, const StepCtx& c) {
 }
 
 static int launch_x_in(dsg_handle* h, const float* x, const float* init, int do_q, float qa, float qb, int use_philox,
-                       NoiseKey nk, unsigned draw, int B) {
+                       NoiseKey nk, unsigned draw, int B, const KernelSel& ks) {
     XInArgs a;
-    a.dupB = h->cfgB;
+    a.dupB = h->cfgB; a.xs_frag = ks.stream ? 1 : 0;
     a.x = x; a.init = init; a.do_q = do_q; a.qa = qa; a.qb = qb; a.use_philox = use_philox; a.nkey = nk; a.draw = draw;
     a.B = B; a.J = h->J; a.Jp = h->Jp; a.Jq = h->Jq; a.T = h->T; a.xs32 = h->xs32;
     a.xsA = h->prec == DSG_PREC_BF16 ? h->xsA : nullptr;
@@ -1433,9 +1446,9 @@ extern "C" int dsg_forward(dsg_handle* h, const float* x, const int64_t* t, floa
     const float* xd = nullptr;
     CHK(to_dev(h, x, h->io_tmp, n, &xd));
     NoiseKey nk = {0, 0, 0, 0};
-    CHK(launch_x_in(h, xd, nullptr, 0, 0.f, 0.f, 0, nk, 0, B));
     StepCtx c; c.B = rows; c.out_mode = OUT_FORWARD; c.use_ctr = false; c.ext_noise = nullptr; c.const_noise = 0;
     CHK(select_kernels(h, rows, c.ks));
+    CHK(launch_x_in(h, xd, nullptr, 0, 0.f, 0.f, 0, nk, 0, B, c.ks));
     CHK(run_step_p(h, c));
     CHK(from_dev(h, out, h->fwd_out, n));
     CHK(order_before(h, stream));
@@ -1566,8 +1579,10 @@ static int sample_prepare(dsg_handle* h, const dsg_sample_args* a, int B, void* 
     CHK(to_dev(h, a->init_image, h->io_tmp2, n, &init_d));
     const int do_q = (a->skip_timesteps > 0 || a->init_image) ? 1 : 0;
     const int i0 = n_run - 1;
+    KernelSel ksel;
+    CHK(select_kernels(h, rows, ksel));      // (first: the layout of the state shadow belongs to the kernel set)
     CHK(launch_x_in(h, noise_d, init_d, do_q, (float)h->sched.sqrt_ac[i0], (float)h->sched.sqrt_1mac[i0],
-                    noise_d ? 0 : 1, nk, a->draw_base, B));
+                    noise_d ? 0 : 1, nk, a->draw_base, B, ksel));
     // replayed per-step noise
     const float* ext = nullptr;
     if (a->step_noise) {
@@ -1590,7 +1605,7 @@ static int sample_prepare(dsg_handle* h, const dsg_sample_args* a, int B, void* 
     c.B = rows; c.out_mode = a->mode == DSG_MODE_DDPM ? OUT_DDPM : OUT_DDIM; c.use_ctr = true; c.ext_noise = ext;
     c.const_noise = a->const_noise; c.clip_x0 = a->clip_denoised ? 1 : 0;
     c.no_noise = (a->mode == DSG_MODE_DDIM && a->eta == 0.f && !ext) ? 1 : 0;
-    CHK(select_kernels(h, rows, c.ks));
+    c.ks = ksel;
     job.n_run = n_run; job.B = B; job.done = 0;
     job.dumping = a->n_dump > 0 && a->dump_steps && a->dump_out;
     // steps_per_graph: 0 = default = no hipGraph.  Measured on MI355X / ROCm 7.2: hipGraph replay of the step is slower than

@@ -128,6 +128,12 @@ __device__ __forceinline__ int vt_off(int dim, int tok, int nvf) {
     if constexpr (P::E == 4) return ((((dim >> 4) * nvf + (tok >> 4)) * 64 + lg * 16 + (dim & 15)) * 4) + r;
     else return ((((dim >> 4) * nvf + (tok >> 5)) * 64 + lg * 16 + (dim & 15)) * 8) + ((tok >> 2) & 4) + r;
 }
+// element offset of (row, j .. j + 3) in the compute-dtype shadow of the sampler state: row-major [rows][Jp], or fragment-major
+// (the GEMM operand order, qk_off) when the kernel set streams it
+template <class P>
+__device__ __forceinline__ size_t xs_off(int row, int j, int Jp, int frag) {
+    return frag ? (size_t)qk_off<P>(row, j, Jp / P::KB) : (size_t)row * Jp + j;
+}
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // Load phases are written branch-free (clamped addresses, select afterwards): a load under a runtime predicate makes
 // hipcc place `s_waitcnt vmcnt(0)` at every join, which turns N independent loads into N serial memory round trips
@@ -341,6 +347,8 @@ struct GemmArgs {
     const float* cfg_scale; // [cfgB]
     int clip_x0;            // EPI_OUT: clamp x0 to [-1, 1] (clip_denoised=True, gaussian_diffusion.py:377-379)
     unsigned inv_ntok4;     // EPI_QKV block kernels: fastdiv_inv(ntok rounded up to 4) (vt_store_block)
+    int xs_frag;            // EPI_OUT: the state shadow xsA is stored fragment-major (qk_off over [B T][Jp]): the STREAM set's pose
+                            // embedding streams it like every other operand (k_ws2<EPI_PARTIAL>)
     int no_noise;           // EPI_OUT: the sampler adds no noise at any step of this call (DDIM with eta = 0: sigma = 0,
                             // gaussian_diffusion.py:782-791) -- the Philox draw is skipped, x_{t-1} = mean + 0 z bit for bit
 };
@@ -620,10 +628,10 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmArgs& g, int m0, in
                     for (int e = 0; e < 4; ++e)
                         if (j0 + e >= g.J) xn[e] = 0.f;
                     *(f32x4*)(g.xs32 + ((size_t)b * g.T + f) * g.Jp + j0) = xn;
-                    if (g.xsA) P::store4((elem*)g.xsA + ((size_t)b * g.T + f) * g.Jp + j0, xn);
+                    if (g.xsA) P::store4((elem*)g.xsA + xs_off<P>(b * g.T + f, j0, g.Jp, g.xs_frag), xn);
                     if (g.cfgB > 0) {                   // the unconditional twin advances with the same x_{t-1}
                         *(f32x4*)(g.xs32 + ((size_t)(b + g.cfgB) * g.T + f) * g.Jp + j0) = xn;
-                        if (g.xsA) P::store4((elem*)g.xsA + ((size_t)(b + g.cfgB) * g.T + f) * g.Jp + j0, xn);
+                        if (g.xsA) P::store4((elem*)g.xsA + xs_off<P>((b + g.cfgB) * g.T + f, j0, g.Jp, g.xs_frag), xn);
                     }
                 }
             }
@@ -847,6 +855,7 @@ struct LocArgs {
     int B, T, D, Hl, hd, W;   // hd / W must match the kernel's template arguments
     float* X0;              // [M_pad][D] fp32, row = b*(T+1) + 1 + f ; row b*(T+1) = token
     void* X0a;              // same in P::elem (GEMM operand copy)
+    int x0a_frag;           // ... stored fragment-major (qk_off over [rows][D]): the STREAM set streams it into the layer-0 QKV
 };
 
 // Shared tail of k_loc / k_inloc.  `rot` holds the rotary-embedded [2W][HD] tile (pad rows = -1).  Phase A: one thread
@@ -899,7 +908,12 @@ __device__ __forceinline__ void local_attn_tail(const LocArgs& a, float (&rot)[2
             const float vlo = lo * c2[i] - hi * s2[i], vhi = hi * c2[i] + lo * s2[i];
             const size_t o = (size_t)(b * ntok + 1 + w * W + q) * a.D + col0 + dd;
             a.X0[o] = vlo; a.X0[o + half] = vhi;
-            ((elem*)a.X0a)[o] = P::cvt(vlo); ((elem*)a.X0a)[o + half] = P::cvt(vhi);
+            if (a.x0a_frag) {
+                const int row = b * ntok + 1 + w * W + q, kdh = a.D / P::KB;
+                ((elem*)a.X0a)[qk_off<P>(row, col0 + dd, kdh)] = P::cvt(vlo); ((elem*)a.X0a)[qk_off<P>(row, col0 + dd + half, kdh)] = P::cvt(vhi);
+            } else {
+                ((elem*)a.X0a)[o] = P::cvt(vlo); ((elem*)a.X0a)[o + half] = P::cvt(vhi);
+            }
         }
     }
 }
@@ -961,7 +975,7 @@ __device__ __forceinline__ void loc_body(const LocArgs& a, int h, int w, int b) 
     DSG_LOADS_ISSUED();
     if (w == 0 && tid < HD) {                              // token row (position 0: rotary is the identity)
         a.X0[(size_t)(b * ntok) * a.D + col0 + tid] = tokv;
-        ((elem*)a.X0a)[(size_t)(b * ntok) * a.D + col0 + tid] = P::cvt(tokv);
+        ((elem*)a.X0a)[a.x0a_frag ? (size_t)qk_off<P>(b * ntok, col0 + tid, a.D / P::KB) : (size_t)(b * ntok) * a.D + col0 + tid] = P::cvt(tokv);
     }
 #pragma unroll
     for (int i = 0; i < NPI; ++i) {
@@ -1123,6 +1137,7 @@ struct XInArgs {
     int B, J, Jp, Jq, T;
     float* xs32; void* xsA;
     int dupB;               // classifier-free guidance: batch element b is also written to row b + dupB (its unconditional twin)
+    int xs_frag;            // xsA fragment-major (see GemmArgs::xs_frag)
 };
 template <class P>
 __global__ void k_x_in(const XInArgs a) {
@@ -1150,10 +1165,10 @@ __global__ void k_x_in(const XInArgs a) {
             for (int e = 0; e < 4; ++e) if (j0 + e >= a.J) z[e] = 0.f;
         }
         *(f32x4*)(a.xs32 + ((size_t)b * a.T + f) * a.Jp + j0) = z;
-        if (a.xsA) P::store4((elem*)a.xsA + ((size_t)b * a.T + f) * a.Jp + j0, z);
+        if (a.xsA) P::store4((elem*)a.xsA + xs_off<P>(b * a.T + f, j0, a.Jp, a.xs_frag), z);
         if (a.dupB > 0) {
             *(f32x4*)(a.xs32 + ((size_t)(b + a.dupB) * a.T + f) * a.Jp + j0) = z;
-            if (a.xsA) P::store4((elem*)a.xsA + ((size_t)(b + a.dupB) * a.T + f) * a.Jp + j0, z);
+            if (a.xsA) P::store4((elem*)a.xsA + xs_off<P>((b + a.dupB) * a.T + f, j0, a.Jp, a.xs_frag), z);
         }
     }
 }

@@ -286,12 +286,16 @@ __global__ __launch_bounds__(256, EPI == EPI_OUT ? 1 : 2) void k_ws(const GemmAr
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_ws2: linear2 (K = ff), 32 x 64 blocks, the 4 waves split K, W slice stationary in registers.   KW16 = K / 64
+// k_ws2: a large-K GEMM, 32 x 64 blocks, the 4 waves split K, W slice stationary in registers.   KW16 = K / 64
+//   EPI_RESID    linear2 (K = ff): + bias + residual rows
+//   EPI_PARTIAL  the pose embedding (K = Jp, the padded pose dimension) on the fragment-major state shadow: the plain product into
+//                `partial[0]` (k_loc adds the conditioning); 8 extra workgroups, the first one does the step bookkeeping (StepCtl)
 // ---------------------------------------------------------------------------------------------------------
-template <int KW16>
+template <int EPI, int KW16>
 __global__ __launch_bounds__(256, 1) void k_ws2(const GemmArgs g) {
     DSG_TL_SCOPE();
     typedef PBF16 P;
+    static_assert(EPI == EPI_RESID || EPI == EPI_PARTIAL, "linear2 or the pose embedding");
     constexpr int K = 64 * KW16, KB = K / 32, BM = 32;
     constexpr int ABYTES = BM * K * 2;
     constexpr int REDBYTES = 4 * 2 * 16 * 64 * 4;                 // 4 waves x 2 column tiles x 16 registers x 64 lanes, fp32
@@ -301,6 +305,12 @@ __global__ __launch_bounds__(256, 1) void k_ws2(const GemmArgs g) {
     const int n_panels = g.NT >> 2, G = g.ws_G;
     const WsId id = ws_id(n_panels, G);
     const int MB = (g.M + BM - 1) / BM;
+    if constexpr (EPI == EPI_PARTIAL) {
+        if (!id.work) {
+            if (g.ctl && (int)blockIdx.x == ws_grid_x(n_panels, G) && threadIdx.x == 0) step_advance_B<P>(g.ctl, g.st, g.n_tab);
+            return;
+        }
+    }
     if (!id.work || id.grp >= MB) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -320,7 +330,8 @@ __global__ __launch_bounds__(256, 1) void k_ws2(const GemmArgs g) {
     const int ct_f = wave >> 1, q0 = 2 * (wave & 1);
     f32x4 pbias[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) pbias[j] = *(const f32x4*)(g.bias + id.panel * 64 + ct_f * 32 + 8 * (q0 + j) + 4 * lhi);
+    for (int j = 0; j < 2; ++j)
+        pbias[j] = EPI == EPI_RESID ? *(const f32x4*)(g.bias + id.panel * 64 + ct_f * 32 + 8 * (q0 + j) + 4 * lhi) : (f32x4){0.f, 0.f, 0.f, 0.f};
     auto issue_a = [&](int mb, int buf) {
         const char* src = (const char*)g.A + (size_t)mb * ABYTES;      // fragment-major: 2 row tiles x KB k-blocks, contiguous
         char* dst = lds + buf * ABYTES;
@@ -342,7 +353,8 @@ __global__ __launch_bounds__(256, 1) void k_ws2(const GemmArgs g) {
         f32x4 pres[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            pres[j] = lda16<P>(g.R, ((size_t)(m0 + l31) * g.ldo + id.panel * 64 + ct_f * 32 + 8 * (q0 + j) + 4 * lhi) * sizeof(float));
+            pres[j] = EPI == EPI_RESID ? lda16<P>(g.R, ((size_t)(m0 + l31) * g.ldo + id.panel * 64 + ct_f * 32 + 8 * (q0 + j) + 4 * lhi) * sizeof(float))
+                                       : (f32x4){0.f, 0.f, 0.f, 0.f};
         f32x16 acc[2];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
