@@ -925,7 +925,7 @@ static int launch_ws(dsg_handle* h, GemmArgs g) {
     g.inv_ntok = fastdiv_inv(g.ntok); g.inv_hd = fastdiv_inv(g.hd);
     if (g.NT % 8) return fail(DSG_E_INVALID, "k_ws: N must be a multiple of 128");
     const int P = g.NT / 8, MB = cdiv(g.M, 64);
-    g.ws_G = ws_groups(P, MB, EPI == EPI_OUT ? 1 : 2);      // resident workgroups per CU: the pose head's registers allow one
+    g.ws_G = ws_groups(P, MB, 2);
     const dim3 grid(ws_grid_x(P, g.ws_G) + (EPI == EPI_OUT ? 8 : 0));      // EPI_OUT: + the bookkeeping workgroup (one XCD round)
     const int K = g.KBtot * 32;
     if (K == 256) return step_launch<&k_ws<EPI, 16>>(h, grid, dim3(256), g);

@@ -128,13 +128,22 @@ __device__ __forceinline__ void ws_body(const GemmArgs& g, const WsId id, char* 
     f32x4 wf[2][KD16];
     int nb[2];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        nb[ct] = id.panel * 128 + wn * 64 + ct * 32;
-        const int nt = (nb[ct] >> 4) + (l31 >> 4);
+    for (int ct = 0; ct < 2; ++ct) nb[ct] = id.panel * 128 + wn * 64 + ct * 32;
+    // lane part of a fragment address in ONE 32-bit register; tile / k-step part wave-uniform (scalar base per load)
+    const unsigned w_lane = (unsigned)((l31 >> 4) * KB * 64 + lhi * 16 + (lane & 15));
+    auto load_w = [&](int opaque_zero) {
 #pragma unroll
-        for (int s = 0; s < KD16; ++s)
-            wf[ct][s] = wbase[((size_t)nt * KB + (s >> 1)) * 64 + (2 * (s & 1) + lhi) * 16 + (lane & 15)];
-    }
+        for (int ct = 0; ct < 2; ++ct) {
+            const f32x4* wt = wbase + (size_t)__builtin_amdgcn_readfirstlane((nb[ct] >> 4) * KB * 64 + opaque_zero);
+#pragma unroll
+            for (int s = 0; s < KD16; ++s)
+                wf[ct][s] = (wt + ((s >> 1) * 64 + 2 * (s & 1) * 16))[w_lane];
+        }
+    };
+    // the pose head's epilogue (x_t, bias, Philox + Box-Muller, the sampler update) needs the registers the panel occupies: it
+    // re-reads its panel per block (64 KB from the L2) and runs 2 workgroups per CU instead of 1
+    constexpr bool W_PER_BLOCK = EPI == EPI_OUT;
+    if constexpr (!W_PER_BLOCK) load_w(0);
     // activation block mb -> LDS buffer (fragment-major operand: one contiguous 4 KB-tiles x KB span)
     auto issue_a = [&](int mb, int buf) {
         const char* src = (const char*)g.A + (size_t)mb * (BM * K * 2);
@@ -161,6 +170,13 @@ __device__ __forceinline__ void ws_body(const GemmArgs& g, const WsId id, char* 
         glds_wait();
         DSG_LDS_BARRIER();             // the block has landed for every wave; every wave is done with the other buffer
         if (mb + G < MB) issue_a(mb + G, cur ^ 1);
+        if constexpr (W_PER_BLOCK) {
+            int zero = 0;
+#ifndef DSG_EMU
+            asm volatile("" : "+s"(zero));         // keeps the (loop-invariant) panel loads inside the loop
+#endif
+            load_w(zero);
+        }
         f32x16 acc[2];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
@@ -213,19 +229,13 @@ __device__ __forceinline__ void ws_body(const GemmArgs& g, const WsId id, char* 
                 for (int q = 0; q < 4; ++q)
                     *(f32x4*)(st + l31 * TP + 8 * q + 4 * lhi) = (f32x4){acc[ct][4 * q], acc[ct][4 * q + 1], acc[ct][4 * q + 2], acc[ct][4 * q + 3]};
                 DSG_WAVE_LDS_SYNC();
-#pragma unroll
-                for (int i0 = 0; i0 < 4; i0 += 2) {
-                    TileOps ops[2];
-                    f32x4 v[2];
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int t = tok + 8 * (i0 + j);
-                        v[j] = *(const f32x4*)(st + t * TP + 4 * quad);
-                        gemm_prefetch_tile<P, EPI>(g, mw + t, nb[ct] + 4 * quad, 0, 0, step, ops[j]);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        gemm_epilogue_tile<P, EPI>(g, mw + tok + 8 * (i0 + j), nb[ct] + 4 * quad, 0, 0, 0, true, v[j], ops[j], k1, k2, k3, k4, k5);
+#pragma unroll 1
+                for (int i = 0; i < 4; ++i) {          // one (token, feature quad) per lane at a time: the register budget of 2 workgroups per CU
+                    TileOps ops;
+                    const int t = tok + 8 * i;
+                    const f32x4 v = *(const f32x4*)(st + t * TP + 4 * quad);
+                    gemm_prefetch_tile<P, EPI>(g, mw + t, nb[ct] + 4 * quad, 0, 0, step, ops);
+                    gemm_epilogue_tile<P, EPI>(g, mw + t, nb[ct] + 4 * quad, 0, 0, 0, true, v, ops, k1, k2, k3, k4, k5);
                 }
                 DSG_WAVE_LDS_SYNC();
             }
@@ -258,7 +268,7 @@ __device__ __forceinline__ void ws_body(const GemmArgs& g, const WsId id, char* 
 }
 
 template <int EPI, int KD16>
-__global__ __launch_bounds__(256, EPI == EPI_OUT ? 1 : 2) void k_ws(const GemmArgs g) {
+__global__ __launch_bounds__(256, 2) void k_ws(const GemmArgs g) {
     DSG_TL_SCOPE();
     typedef PBF16 P;
     constexpr int K = 16 * KD16, BM = 64;
