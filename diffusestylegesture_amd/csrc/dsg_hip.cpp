@@ -774,6 +774,8 @@ struct KernelSel {
     bool blk = false;           // BLOCK: 32-row block GEMMs
     bool attn_op = false;       // k_attn_op instead of k_attn + out_proj
     bool stream = false;        // STREAM: BLOCK with the weight-stationary persistent GEMMs of dsg_stream.h (LayerNorm + QKV, linear1, linear2, pose head)
+    bool xs_frag = false;       // BLOCK / STREAM (bf16, Jp 128 / 1152): the state shadow is fragment-major and the pose embedding streams it (k_ws2<EPI_PARTIAL>:
+                                // 8.9 -> 4.3 us at 1424 rows, 29.9 -> 11.0 at 5632; 3.8 -> 4.1 at 356)
 };
 static bool have_attn_mid(const dsg_handle* h, int B) {
     return B == 1 && h->H == 4 && ((h->D == 256 && h->Tp == 96) || (h->D == 128 && h->Tp == 32));
@@ -819,6 +821,7 @@ static int select_kernels(const dsg_handle* h, int B, KernelSel& k) {
     k.stream = set == DSG_KSET_STREAM;
     k.blk = set == DSG_KSET_BLOCK || k.stream;      // (STREAM: pose embedding and layer-0 QKV as in BLOCK)
     k.attn_op = !k.lat && have_attn_op(h);
+    k.xs_frag = k.blk && h->prec == DSG_PREC_BF16 && (h->Jp == 1152 || h->Jp == 128);
     return 0;
 }
 
@@ -1082,7 +1085,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
     // split-K of the pose-embedding GEMM across workgroups: one split per 256 pose features for the 16 x 16 tile kernel; the
     // block kernel splits K over its 4 waves already, so 2 workgroup splits keep a wave's share at <= 8 k-blocks (one batch of
     // loads) without fragmenting the work 5 ways
-    const int ks_in = ks.stream ? 1 : (ks.blk ? std::min(h->KSin, 2) : h->KSin);      // (STREAM: K stays whole, see k_ws2)
+    const int ks_in = ks.xs_frag ? 1 : (ks.blk ? std::min(h->KSin, 2) : h->KSin);      // (streamed embedding: K stays whole, see k_ws2)
     la.partial = h->partial; la.KS = ks_in; la.Min_pad = MTin * 16; la.Cf = h->Cf; la.TE2 = h->TE2; la.TE = h->TE;
     la.emb1 = h->emb1; la.ctl = c.use_ctr ? h->ctl : nullptr; la.t_arr = h->t_arr;
     la.rcos = h->rcos; la.rsin = h->rsin; la.mask = h->mask; la.mb = h->mb; la.inv_mask_div = fastdiv_inv((int)((long long)B * h->Hl / h->mb)); la.B = B; la.T = T; la.D = D; la.Hl = h->Hl;
@@ -1104,7 +1107,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
             g.ctl = c.use_ctr ? h->ctl : nullptr; g.st = step_tables(h); g.n_tab = h->n_run;
             bool done = false;
             if constexpr (sizeof(typename P::elem) == 2) {
-                if (ks.stream) { g.a_frag = 1; CHK(launch_ws2<EPI_PARTIAL>(h, g)); done = true; }      // the state shadow is fragment-major (xs_frag)
+                if (ks.xs_frag) { g.a_frag = 1; CHK(launch_ws2<EPI_PARTIAL>(h, g)); done = true; }      // the state shadow is fragment-major
             }
             if (done) {}
             else if (ks.blk) CHK((launch_blk_k<P, EPI_PARTIAL>(h, g)));
@@ -1198,7 +1201,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
         g.out_mode = c.out_mode; g.xs32 = h->xs32; g.xsA = h->prec == DSG_PREC_BF16 ? h->xsA : nullptr;
         g.fwd_out = h->fwd_out; g.ctl = c.use_ctr ? h->ctl : nullptr; g.st = step_tables(h); g.n_tab = h->n_run;
         g.dyn = h->dyn; g.ext_noise = c.ext_noise; g.const_noise = c.const_noise; g.clip_x0 = c.clip_x0; g.no_noise = c.no_noise;
-        g.xs_frag = ks.stream ? 1 : 0;
+        g.xs_frag = ks.xs_frag ? 1 : 0;
         h->fence_next = 2;     // the last packet of a step writes the state (state_fences)
         if (h->cfgB > 0) {      // guidance: one workgroup per CONDITIONAL row tile evaluates the twin rows as well (k_gemm_cfg)
             g.B = h->cfgB; g.M = h->cfgB * ntok; g.MT = cdiv(g.M, 16);
@@ -1365,7 +1368,7 @@ static int run_step_p(dsg_handle* h, const StepCtx& c) {
 static int launch_x_in(dsg_handle* h, const float* x, const float* init, int do_q, float qa, float qb, int use_philox,
                        NoiseKey nk, unsigned draw, int B, const KernelSel& ks) {
     XInArgs a;
-    a.dupB = h->cfgB; a.xs_frag = ks.stream ? 1 : 0;
+    a.dupB = h->cfgB; a.xs_frag = ks.xs_frag ? 1 : 0;
     a.x = x; a.init = init; a.do_q = do_q; a.qa = qa; a.qb = qb; a.use_philox = use_philox; a.nkey = nk; a.draw = draw;
     a.B = B; a.J = h->J; a.Jp = h->Jp; a.Jq = h->Jq; a.T = h->T; a.xs32 = h->xs32;
     a.xsA = h->prec == DSG_PREC_BF16 ? h->xsA : nullptr;
