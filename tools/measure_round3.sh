@@ -1,7 +1,7 @@
 #!/bin/bash
 # One measurement round on the GPU box (round 3); everything lands in gpurun_out/$TAG_* (copy what matters into profiles/).
-#   gpurun --timeout 1500 -- 'bash tools/measure_round3.sh r03_z [tests]'
-TAG=${1:-r03_z}; WITH_TESTS=${2:-}
+#   gpurun --timeout 1500 -- 'bash tools/measure_round3.sh r03_y [tests]'
+TAG=${1:-r03_y}; WITH_TESTS=${2:-}
 O=gpurun_out; mkdir -p $O
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 if [ -n "$WITH_TESTS" ]; then
