@@ -139,7 +139,7 @@ def test_classifier_free_guidance_wrapper(tiny):
 @pytest.mark.parametrize("kset", ["tile", "block", "stream"])
 def test_kernel_sets_tiny(tiny, emu_lib, golden_dir, kset):
     """Explicit kernel sets (dsg_set_kernel_set) at the tiny dims against the same goldens as the latency kernels, incl. the
-    ragged last row tile (bf16: with k_attn_op; "stream": the weight-stationary FFN GEMMs of dsg_stream.h); at batch 8 and batch 23 (529 rows: the 3-waves-per-SIMD LayerNorm GEMMs from
+    ragged last row tile (bf16: with k_attn_op; "stream": the weight-stationary GEMMs of dsg_stream.h incl. LayerNorm once per row, the streamed pose embedding and pose head); at batch 8 and batch 23 (529 rows: the 3-waves-per-SIMD LayerNorm GEMMs from
     512 rows) against the oracle; the set that ran is reported (dsg_last_kernel_set) and sticky."""
     from oracle.mdm import MDMOracle
     gt, _, y, x = tiny
