@@ -16,6 +16,8 @@ $B --clips-per-gpu 16 --lanes 1 --steps 2 --warmup 1 > $O/${TAG}_bench_16clips_l
 $B --clips-per-gpu 16 --lanes 1 --sampler ddim50 --steps 5 --warmup 1 > $O/${TAG}_bench_ddim50_b16_lockstep.log 2>&1
 $B --clips-per-gpu 64 --steps 1 --warmup 1 > $O/${TAG}_bench_64clips_l4_b16.log 2>&1
 $B --clips-per-gpu 128 --steps 1 --warmup 1 > $O/${TAG}_bench_128clips_l4_b32.log 2>&1
+$B --clips-per-gpu 192 --steps 1 --warmup 1 > $O/${TAG}_bench_192clips.log 2>&1
+$B --clips-per-gpu 256 --steps 1 --warmup 1 > $O/${TAG}_bench_256clips.log 2>&1
 $B --gpus 1 --config3 on --steps 1 --warmup 1 > $O/${TAG}_bench_with_config3_record.log 2>&1
 $B --config beat --steps 1 > $O/${TAG}_bench_beat.log 2>&1
 $B --config twh --steps 1 > $O/${TAG}_bench_twh.log 2>&1
