@@ -19,6 +19,7 @@ from tests.util import rel_l2
 
 pytestmark = pytest.mark.gpu
 
+TOL_FWD = {"fp32": 2e-5, "bf16": 1.2e-2}       # as in test_gpu_parity.py: bf16 <= 2x the measured 4.5e-3 .. 6.7e-3
 TOL_CHAIN = {"fp32": 1e-4, "bf16": 2e-2}
 
 
@@ -191,6 +192,40 @@ def test_kernel_sets_are_sticky_lane_properties(gpu):
         for i in range(2):
             alone = d.manual_seed(9, i).p_sample_loop(lanes[i], shape2, clip_denoised=False, model_kwargs=ys[i], skip_timesteps=950)
             assert lanes[i].last_kernel_set() == kset and np.array_equal(np.asarray(multi[i]), np.asarray(alone)), (kset, i)
+
+
+@pytest.mark.parametrize("cfg_name", ["beat", "twh", "beatpp"])
+def test_block_set_at_dsgplus_dims_batch_8(gpu, cfg_name):
+    """The BLOCK kernel set at DSG+ dims (latent 384 / 512, head dim 96 / 128, 151 tokens: 32-row block GEMMs with the 512-wide row
+    buffer, V^T through LDS in aligned token groups with heads that straddle a 64-column group) -- batch 8 = 1208 token rows is
+    where AUTO selects it; forward with distinct rows and timesteps against the oracle in fp32 and bf16, and a short DDPM chain."""
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    from oracle import philox, sampler
+    from oracle.mdm import MDMOracle
+    from oracle.schedule import OracleDiffusion
+    cfg, B = C.CONFIGS[cfg_name], 8
+    sd = synth_state_dict(cfg, 20240)
+    ref = MDMOracle(sd, cfg)
+    y = synth_window_inputs(cfg, B, window=1, clip0=3, seed_pose_scale=0.2)
+    shape = (B, cfg.njoints, 1, cfg.n_poses)
+    x = np.random.RandomState(8).randn(*shape).astype(np.float32)
+    ts = (np.arange(B) * 97 + 11) % 1000
+    for prec in ("fp32", "bf16"):
+        m = _model(cfg, prec, max_batch=B)
+        out = np.asarray(m(x, ts, y))
+        assert m.last_kernel_set() == "block"
+        for b in (0, 5, B - 1):
+            yb = {k: (v[b:b + 1] if k != "mask_local" and v is not None else v) for k, v in y.items()}
+            e = rel_l2(out[b], ref(x[b:b + 1], [int(ts[b])], yb)[0])
+            assert e < TOL_FWD[prec], (prec, b, e)
+    s = np.asarray(create_gaussian_diffusion().manual_seed(4, 2).p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=988))
+    assert m.last_kernel_set() == "block" and m.last_sample_path() == "aql"
+    b = 6
+    yb = {k: (v[b:b + 1] if k != "mask_local" and v is not None else v) for k, v in y.items()}
+    r = sampler.p_sample_loop(OracleDiffusion(), ref, (1,) + shape[1:], lambda k: philox.normal_bj1t(shape, 4, k, 2)[b:b + 1], {"y": yb}, skip_timesteps=988)
+    e = rel_l2(s[b], r[0])
+    print(f"{cfg_name} batch 8, BLOCK set, 12-step chain row {b}: rel-L2 {e:.3e}")
+    assert e < TOL_CHAIN["bf16"]
 
 
 @pytest.mark.parametrize("B", [3, 16, 48])
