@@ -228,6 +228,29 @@ def test_block_set_at_dsgplus_dims_batch_8(gpu, cfg_name):
     assert e < TOL_CHAIN["bf16"]
 
 
+def test_stream_and_block_sets_at_tiny_dims(gpu):
+    """The K = 128 instantiations (k_ws<.., 8>, k_ws2<.., 2>, k_ln_frag<2>, k_attn_op<.., 2, 2>) that the ZEGGS tests never launch, on the GPU:
+    tiny dims (latent 128, 23 tokens -- batch elements misaligned to the 4-token groups of V^T), batch 23, forward + 10-step chain."""
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    from oracle import philox, sampler
+    from oracle.mdm import MDMOracle
+    from oracle.schedule import OracleDiffusion
+    cfg, B = C.TINY, 23
+    sd = synth_state_dict(cfg, 77)
+    ref = MDMOracle(sd, cfg)
+    y = synth_window_inputs(cfg, B, window=1, seed_pose_scale=0.3)
+    shape = (B, cfg.njoints, 1, cfg.n_poses)
+    x = np.random.RandomState(B).randn(*shape).astype(np.float32)
+    ts = np.arange(B) * 40 + 3
+    want = ref(x, list(ts), y)
+    for kset in ("stream", "block"):
+        m = _model(cfg, "bf16", max_batch=B, wseed=77).set_kernel_set(kset)
+        assert rel_l2(np.asarray(m(x, ts, y)), want) < TOL_FWD["bf16"] and m.last_kernel_set() == kset
+        s = np.asarray(create_gaussian_diffusion().manual_seed(3, 1).p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=990))
+        r = sampler.p_sample_loop(OracleDiffusion(), ref, shape, lambda k: philox.normal_bj1t(shape, 3, k, 1), {"y": y}, skip_timesteps=990)
+        assert m.last_sample_path() == "aql" and rel_l2(s, r) < TOL_CHAIN["bf16"], kset
+
+
 @pytest.mark.parametrize("B", [3, 16, 48])
 def test_stream_kernel_set_vs_oracle(gpu, B):
     """Kernel set "stream" (dsg_stream.h: weight-stationary persistent GEMMs, 32x32x16 MFMA, global->LDS staging, 64-row blocks;
