@@ -228,6 +228,35 @@ def test_block_set_at_dsgplus_dims_batch_8(gpu, cfg_name):
     assert e < TOL_CHAIN["bf16"]
 
 
+@pytest.mark.parametrize("kset", ["block", "stream"])
+def test_guidance_in_the_batched_kernel_sets(gpu, kset):
+    """Classifier-free guidance fused into the step loop (cfg_sampler.py:8-31: conditional rows + their unconditional twins in one
+    batch, combined in the pose-head epilogue) in the BLOCK and STREAM sets, whose state shadow is fragment-major and whose pose
+    embedding streams it: 6 clips + 6 twins = 1068 token rows, 10 DDPM steps, two scales, against the oracle's two evaluations
+    per step -- rows 0 and 5."""
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    from diffusestylegesture_amd.model import ClassifierFreeSampleModel
+    from oracle import philox, sampler
+    from oracle.mdm import MDMOracle
+    from oracle.schedule import OracleDiffusion
+    cfg, B = C.ZEGGS, 6
+    m = _model(cfg, "bf16", max_batch=2 * B).set_kernel_set(kset)
+    ref = MDMOracle(synth_state_dict(cfg, 20240), cfg)
+    y = synth_window_inputs(cfg, B, window=1, clip0=2, seed_pose_scale=0.3)
+    scale = np.linspace(0.5, 2.5, B).astype(np.float32)
+    shape = (B, cfg.njoints, 1, cfg.n_poses)
+    d = create_gaussian_diffusion().manual_seed(3, 9)
+    s = np.asarray(d.p_sample_loop(ClassifierFreeSampleModel(m), shape, clip_denoised=False, model_kwargs={"y": dict(y, scale=scale)}, skip_timesteps=990))
+    assert m.last_kernel_set() == kset and m.last_sample_path() == "aql" and np.isfinite(s).all()
+    for b in (0, B - 1):
+        yb = {k: (v[b:b + 1] if k != "mask_local" else v) for k, v in y.items()}
+        yb["scale"] = scale[b:b + 1]
+        r = sampler.p_sample_loop(OracleDiffusion(), sampler.CFGModel(ref), (1,) + shape[1:], lambda k, b=b: philox.normal_bj1t(shape, 3, k, 9)[b:b + 1],
+                                  {"y": yb}, skip_timesteps=990)
+        e = rel_l2(s[b], r[0])
+        assert e < 2 * TOL_CHAIN["bf16"], (kset, b, e)
+
+
 def test_stream_and_block_sets_at_tiny_dims(gpu):
     """The K = 128 instantiations (k_ws<.., 8>, k_ws2<.., 2>, k_ln_frag<2>, k_attn_op<.., 2, 2>) that the ZEGGS tests never launch, on the GPU:
     tiny dims (latent 128, 23 tokens -- batch elements misaligned to the 4-token groups of V^T), batch 23, forward + 10-step chain."""
