@@ -192,9 +192,11 @@ def main():
         cfg = C.CONFIGS[a.config]
     NC, NL = a.clips_per_gpu, a.lanes
     streams = NL > 1
-    if streams and cfg.variant != 3:
-        raise SystemExit("sampling lanes drive the ZEGGS clip loop")
     B = NC // NL
+    # clip c -> rank c % world (parallel.shard_clips: the map gather_poses inverts): this rank's clips, dealt to its lanes in order
+    from diffusestylegesture_amd.parallel import shard_clips
+    my_clips = shard_clips(world * NC, rank, world)
+    lane_clips = [my_clips[ln * B:(ln + 1) * B] for ln in range(NL)]
     model = DSGDenoiser(cfg, precision=a.precision, max_batch=B, device=local, steps_per_graph=a.steps_per_graph, library=library)
     model.load_state_dict(synth_state_dict(cfg, 20240))
     lanes = [model] + [model.clone() for _ in range(NL - 1)]
@@ -207,28 +209,29 @@ def main():
     else:
         frames_per_clip = 1830                                                  # BEAT-TWH sample.py:56, max_len=0
         n_windows = -(-frames_per_clip // cfg.stride)                           # ceil -> 16 windows
-    # synthetic per-window audio features, resident in HBM before the clock starts (clip index = rank*NC + b)
-    to_dev = (lambda x: torch.from_numpy(x)) if emu else (lambda x: torch.from_numpy(x).cuda(local))
-    if streams:
-        feats = [[to_dev(synth_window_inputs(cfg, B, window=w, clip0=rank * NC + ln * B)["audio"]) for w in range(n_windows)]
-                 for ln in range(NL)]
-    else:
-        feats = [to_dev(synth_window_inputs(cfg, B, window=w, clip0=rank * NC)["audio"]) for w in range(n_windows)]
-    if emu:
-        feats = [[f.numpy() for f in fl] for fl in feats] if streams else [f.numpy() for f in feats]
+    # synthetic per-window audio features, resident in HBM before the clock starts; everything about a clip (features, seed
+    # poses, its Philox stream = the id of the first clip of its lane + its position in the lane's batch) is a function of its id
+    to_dev = (lambda x: x) if emu else (lambda x: torch.from_numpy(x).cuda(local))
+    feats = [[to_dev(synth_window_inputs(cfg, B, window=w, clips=lane_clips[ln])["audio"]) for w in range(n_windows)]
+             for ln in range(NL)]
+    seed0s = [to_dev(synth_window_inputs(cfg, B, window=0, clips=lane_clips[ln], seed_pose_scale=0.1)["seed"]) for ln in range(NL)]
     style = [1] + [0] * (cfg.style_dim_in - 1)
+    lane_streams = [lc[0] for lc in lane_clips]
 
     def one_pass(i):
-        if streams:
+        if streams and cfg.variant == 3:
             return generate_clips_streams(lanes, diffusion, feats, style, seed=123456 + i, smoothing=True, skip_timesteps=skip,
-                                          stream_ids=[rank * NL + ln for ln in range(NL)], ddim=a.sampler == "ddim50")
+                                          stream_ids=lane_streams, ddim=a.sampler == "ddim50")
+        if streams:
+            from diffusestylegesture_amd.sample import generate_clips_streams_dsgplus
+            return generate_clips_streams_dsgplus(lanes, diffusion, feats, style, seed0s, frames_per_clip, seed=123456 + i,
+                                                  skip_timesteps=skip, stream_ids=lane_streams, ddim=a.sampler == "ddim50")
         if cfg.variant == 3:
-            return generate_clip(model, diffusion, feats, style, seed=123456 + i, smoothing=True, sample_fn=sample_fn,
-                                 stream_id=rank, skip_timesteps=skip)
+            return generate_clip(model, diffusion, feats[0], style, seed=123456 + i, smoothing=True, sample_fn=sample_fn,
+                                 stream_id=lane_streams[0], skip_timesteps=skip)
         from diffusestylegesture_amd.sample import generate_clip_dsgplus
-        seed0 = to_dev(synth_window_inputs(cfg, B, window=0, clip0=rank * NC, seed_pose_scale=0.1)["seed"])
-        return generate_clip_dsgplus(model, diffusion, feats, style, seed0, frames_per_clip, seed=123456 + i,
-                                     sample_fn=sample_fn, stream_id=rank)
+        return generate_clip_dsgplus(model, diffusion, feats[0], style, seed0s[0], frames_per_clip, seed=123456 + i,
+                                     sample_fn=sample_fn, stream_id=lane_streams[0], skip_timesteps=skip)
 
     def sync():
         if not emu:
@@ -246,12 +249,11 @@ def main():
         m3 = DSGDenoiser(cfg, precision=a.precision, max_batch=B3, device=local, library=library)
         m3.load_state_dict(synth_state_dict(cfg, 20240))
         lanes3 = [m3] + [m3.clone() for _ in range(NL3 - 1)]
-        feats3 = [[to_dev(synth_window_inputs(cfg, B3, window=w, clip0=rank * 16 + ln * B3)["audio"]) for w in range(n_windows)]
+        clips3 = shard_clips(world * 16, rank, world)
+        feats3 = [[to_dev(synth_window_inputs(cfg, B3, window=w, clips=clips3[ln * B3:(ln + 1) * B3])["audio"]) for w in range(n_windows)]
                   for ln in range(NL3)]
-        if emu:
-            feats3 = [[f.numpy() for f in fl] for fl in feats3]
         run3 = lambda i: generate_clips_streams(lanes3, diffusion, feats3, style, seed=777 + i, smoothing=True, skip_timesteps=skip,
-                                                stream_ids=[rank * NL3 + ln for ln in range(NL3)])
+                                                stream_ids=[clips3[ln * B3] for ln in range(NL3)])
         run3(0)
         sync()
         t3 = time.perf_counter()
@@ -295,6 +297,8 @@ def main():
         dt = float(tt.item())
     want_c3 = a.config3 == "on" or (a.config3 == "auto" and a.gpus > 1 and NC == 1)
     c3 = config3_pass() if (want_c3 and cfg.variant == 3 and a.sampler == "ddpm") else None
+    if rank == 0 and os.environ.get("DSG_BENCH_DUMP"):      # TEST INFRASTRUCTURE (tests/test_bench_launch.py): the gathered poses, by clip id
+        np.save(os.environ["DSG_BENCH_DUMP"], np.asarray(gathered, np.float32))
     if rank == 0:
         n_clips = world * NC * a.steps
         value = n_clips * frames_per_clip / dt
@@ -336,7 +340,8 @@ def main():
                             "the committed rocprofv3 passes (separate runs), not of this run"}
         out = {
             "metric": (f"gesture frames/sec, {'1000-step DDPM' if a.sampler == 'ddpm' else '50-step DDIM'}, "
-                       + ("320-frame ZEGGS clip" if a.config == "zeggs" else f"1830-frame {a.config.upper()} clip (DSG+)")),
+                       + ("320-frame ZEGGS clip" if a.config == "zeggs" else f"1830-frame {a.config.upper()} clip (DSG+)")
+                       + (", 1/2/4/8 MI355X" if a.config == "zeggs" and a.sampler == "ddpm" else "")),
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1000.0 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.precision, "data": "synthetic" + (" (EMULATED ON CPU: test run, not a measurement)" if emu else ""),

@@ -24,6 +24,7 @@
 #include <hsa/hsa_ext_amd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <fstream>
@@ -119,9 +120,8 @@ inline bool init(Ctx& c, int hip_device, const void* addr_in_library) {
         }
         if (!found) { c.err = std::string("no HSA agent matches the HIP device's PCI id ") + bus; return false; }
         snprintf(c.bdf, sizeof c.bdf, "%04x:%02x:%02x.%x", dom, b, d, f);
-        static bool said[64] = {false};      // once per device and process (= once per rank)
-        if (getenv("LOCAL_RANK") && !said[hip_device & 63]) {
-            said[hip_device & 63] = true;
+        static std::atomic<bool> said[64];   // once per device and process (= once per rank)
+        if (getenv("LOCAL_RANK") && !said[hip_device & 63].exchange(true)) {
             fprintf(stderr, "libdsg_hip: rank-local HIP device %d <-> HSA agent %s: AQL queue created there (%zu GPU agent(s) visible)\n",
                     hip_device, c.bdf, pick.gpus.size());
         }
@@ -154,6 +154,17 @@ inline bool init(Ctx& c, int hip_device, const void* addr_in_library) {
         }
     }
     DSG_AQL_CK(c, hsa_queue_create(c.gpu, 4096, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &c.q));
+    if (const char* e = getenv("DSG_CU_MASK")) {      // measurement only (tools/multiproc.py): comma-separated 32-bit hex words, CU bit 0 first
+        std::vector<uint32_t> words;
+        for (const char* p = e; *p;) {
+            char* end = nullptr;
+            words.push_back((uint32_t)strtoul(p, &end, 16));
+            if (end == p) break;
+            p = *end == ',' ? end + 1 : end;
+        }
+        if (!words.empty() && hsa_amd_queue_cu_set_mask(c.q, (uint32_t)words.size() * 32, words.data()) != HSA_STATUS_SUCCESS)
+            fprintf(stderr, "libdsg_hip: DSG_CU_MASK: hsa_amd_queue_cu_set_mask failed (mask ignored)\n");
+    }
     DSG_AQL_CK(c, hsa_signal_create(1, 0, nullptr, &c.done));
     c.ready = true;
     return true;

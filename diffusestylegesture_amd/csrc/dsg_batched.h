@@ -72,7 +72,8 @@ template <class P, int PRO, int EPI, int DMAX, int TNW, int RT>
 __global__ __launch_bounds__(256) void k_gemm_blk(const GemmArgs g) {
     DSG_TL_SCOPE();
     typedef typename P::elem elem;
-    constexpr int ES = (int)sizeof(elem), BM = 16 * RT, CH = 8;
+    // CH: the whole K range in one batch of weight-fragment loads where it fits (K = 384 / 512 ran two serial load phases)
+    constexpr int ES = (int)sizeof(elem), BM = 16 * RT, KBMAX = DMAX / P::KB, CH = KBMAX > 16 ? 16 : (KBMAX < 8 ? 8 : KBMAX);
     static_assert(EPI != EPI_PARTIAL, "split-K partials come from k_gemm_blk_k");
     static_assert(RT == 2 || RT == 4, "32- or 64-row blocks");
     __shared__ __attribute__((aligned(16))) char lds_a[BM * (DMAX * ES + 16)];

@@ -8,12 +8,14 @@
 #include "dsg_aql.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -173,6 +175,9 @@ struct dsg_handle {
     bool aql_timing = false;             // the last dsg_sample was timed by the host clock around the AQL run
     double aql_ms = 0.0;
     bool fuse_attn_mid = true;           // k_attn_mid (attention inside the out_proj/LN/linear1 kernel) at batch 1; DSG_FUSE_ATTN_MID=0 to A/B
+    bool tnw2 = false;                   // DSG_TNW2=1 (A/B): 128-column workgroups for the LayerNorm GEMMs of the 16 x 16 tile kernels at K >= 384
+    bool force_attn_ph = false;          // DSG_ATTN_PH=1: the per-head attention + partial out_proj kernel (k_attn_ph) in the LATENCY set at
+                                         // every width it is instantiated for (default: latent_dim > 256 only) -- A/B runs, emulator tests
     int* st_tmodel = nullptr; float* st_c[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int st_cap = 0, n_run = 1;
     bool st_valid = false; int st_mode = -1, st_skip = -1; float st_eta = 0.f;      // what the device tables hold
@@ -318,7 +323,15 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     //   DSG_UC    0: cached loop buffers + fenced packets, 1: uncached + fence-free, 2: uncached + fenced
     //   DSG_AQL   0: HIP launches instead of hand-written AQL packets
     //   DSG_FUSE_ATTN_MID  0: k_attn + k_mid instead of k_attn_mid at batch 1 (bit-identical; A/B)
-    if (const char* e = getenv("DSG_KSET")) h->kset_req = atoi(e);
+    if (const char* e = getenv("DSG_KSET")) {
+        char* end = nullptr;
+        const long v = strtol(e, &end, 10);
+        if (end == e || *end != 0 || v < DSG_KSET_AUTO || v > DSG_KSET_STREAM) {
+            delete h;
+            return fail(DSG_E_INVALID, std::string("DSG_KSET must be 0 (auto) .. 4 (stream), got '") + e + "'");
+        }
+        h->kset_req = (int)v;
+    }
     // Large batches on the BLOCK set re-read their activations from the L2 often enough that the uncached buffers cost what the
     // fences save (4 x 16: 9667 vs 9680 frames/s, 4 x 32: 10 430 vs 10 695): cached + fenced from batch 17 -- unless the handle can run
     // the STREAM set, which large batches select and which reads an activation block once per 128-column panel: fence-free wins there
@@ -335,7 +348,8 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
         }
     }
     if (const char* e = getenv("DSG_FUSE_ATTN_MID")) h->fuse_attn_mid = atoi(e) != 0;
-    *out = h;
+    if (const char* e = getenv("DSG_ATTN_PH")) h->force_attn_ph = atoi(e) != 0;
+    if (const char* e = getenv("DSG_TNW2")) h->tnw2 = atoi(e) != 0;
     *out = h;
 
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -359,7 +373,8 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     CHK(dalloc(h, &h->xs32, (size_t)B * h->T * h->Jp + 16 * h->Jp));
     if (h->prec == DSG_PREC_BF16) CHK(dalloc_bytes(h, &h->xsA, ((size_t)Min_pad * h->Jp) * h->es));
     h->alloc_uc = true;                  // ---- written AND read inside one step by the kernels of the loop
-    CHK(dalloc(h, &h->partial, (size_t)h->KSin * Min_pad * D));
+    // (k_attn_ph reuses it between the first kernel of a step and the pose head: 4 per-head partial out_proj slabs of M_pad rows)
+    CHK(dalloc(h, &h->partial, std::max((size_t)h->KSin * Min_pad, (size_t)4 * M_pad) * D));
     CHK(dalloc(h, &h->X0, M_pad * D));
     CHK(dalloc_bytes(h, &h->X0a, M_pad * D * h->es));
     CHK(dalloc(h, &h->pre1, M_pad * D));
@@ -776,7 +791,12 @@ struct KernelSel {
     bool stream = false;        // STREAM: BLOCK with the weight-stationary persistent GEMMs of dsg_stream.h (LayerNorm + QKV, linear1, linear2, pose head)
     bool xs_frag = false;       // BLOCK / STREAM (bf16, Jp 128 / 1152): the state shadow is fragment-major and the pose embedding streams it (k_ws2<EPI_PARTIAL>:
                                 // 8.9 -> 4.3 us at 1424 rows, 29.9 -> 11.0 at 5632; 3.8 -> 4.1 at 356)
+    bool attn_ph = false;       // LATENCY at the DSG+ widths: k_attn_ph (per-head attention + partial out_proj) + linear1 with the PRO_LN4 prologue
+                                // instead of k_attn + k_mid (dsg_fused.h)
 };
+static bool have_attn_ph(const dsg_handle* h) {
+    return h->H == 4 && ((h->D == 384 && h->Tp == 160) || (h->D == 512 && h->Tp == 160) || (h->D == 256 && h->Tp == 96) || (h->D == 128 && h->Tp == 32));
+}
 static bool have_attn_mid(const dsg_handle* h, int B) {
     return B == 1 && h->H == 4 && ((h->D == 256 && h->Tp == 96) || (h->D == 128 && h->Tp == 32));
 }
@@ -786,8 +806,9 @@ static bool have_attn_op(const dsg_handle* h) {
 }
 static bool latency_set_ok(const dsg_handle* h) {
     // k_mid pulls all of W_o (2 D^2 bytes) through every CU: at D = 512 the un-fused sets win (TWH: 219 vs 238 us)
+    // (round 4: at the DSG+ widths the set runs k_attn_ph instead -- a quarter of W_o per workgroup, 4 x the workgroups)
     const int dt = h->D / 64;
-    return h->D <= 384 && (dt == 1 || dt == 2 || dt == 4 || dt == 6);
+    return (h->D <= 384 && (dt == 1 || dt == 2 || dt == 4 || dt == 6)) || have_attn_ph(h);
 }
 static bool stream_set_ok(const dsg_handle* h) {
     // k_ws keeps 64 columns x K = D of W per wave in registers (D = 128 / 256), k_ws2 a quarter of K = ff (ff = 128 / 1024);
@@ -817,7 +838,8 @@ static int select_kernels(const dsg_handle* h, int B, KernelSel& k) {
     k = KernelSel();
     k.set = set;
     k.lat = set == DSG_KSET_LATENCY;
-    k.attn_in_mid = k.lat && h->fuse_attn_mid && have_attn_mid(h, B);
+    k.attn_ph = k.lat && have_attn_ph(h) && (h->D > 256 || h->force_attn_ph);
+    k.attn_in_mid = k.lat && !k.attn_ph && h->fuse_attn_mid && have_attn_mid(h, B);
     k.stream = set == DSG_KSET_STREAM;
     k.blk = set == DSG_KSET_BLOCK || k.stream;      // (STREAM: pose embedding and layer-0 QKV as in BLOCK)
     k.attn_op = !k.lat && have_attn_op(h);
@@ -830,13 +852,28 @@ extern "C" int dsg_set_kernel_set(dsg_handle* h, int set) {
     if (set < DSG_KSET_AUTO || set > DSG_KSET_STREAM) return fail(DSG_E_INVALID, "dsg_set_kernel_set: unknown kernel set");
     if (set == DSG_KSET_LATENCY && h->D > 512) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set LATENCY: latent_dim > 512");
     if (set == DSG_KSET_STREAM && !stream_set_ok(h)) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set STREAM: bf16, latent_dim 128 / 256, 4 heads, ff 128 / 1024 only");
-    if (getenv("DSG_KSET")) return 0;          // an A/B run pinned the set for the whole process
+    if (getenv("DSG_KSET")) {                  // an A/B run pinned the set for the whole process: say so once, keep the pinned set
+        static std::atomic<bool> said{false};
+        if (set != h->kset_req && !said.exchange(true))
+            fprintf(stderr, "libdsg_hip: WARNING: DSG_KSET=%s pins the kernel set of every handle; dsg_set_kernel_set(%d) ignored "
+                            "(dsg_get_kernel_set reports the set in force)\n", getenv("DSG_KSET"), set);
+        return 0;
+    }
     h->kset_req = set;
+    return 0;
+}
+// the set in force for the handle (what dsg_set_kernel_set / DSG_KSET / dsg_clone left): callers that change it for one call
+// (sample.generate_clips_streams) restore it afterwards
+extern "C" int dsg_get_kernel_set(dsg_handle* h, int* set) {
+    if (!h || !set) return fail(DSG_E_INVALID, "null argument");
+    *set = h->kset_req;
     return 0;
 }
 extern "C" int dsg_recommend_kernel_set(dsg_handle* h, int B, int lanes, int* set) {
     if (!h || !set || B <= 0 || lanes <= 0) return fail(DSG_E_INVALID, "dsg_recommend_kernel_set: bad argument");
     *set = auto_kernel_set(h, B, lanes);
+    if (h->latency_mode == 0 && *set == DSG_KSET_LATENCY) *set = DSG_KSET_TILE;        // dsg_config.latency_mode, as select_kernels applies it
+    if (h->latency_mode == 1 && latency_set_ok(h)) *set = DSG_KSET_LATENCY;
     return 0;
 }
 extern "C" int dsg_last_kernel_set(dsg_handle* h, int* set) {
@@ -876,6 +913,16 @@ static int step_launch(dsg_handle* h, dim3 grid, dim3 block, const A& args) {
     return 0;
 }
 
+// k-blocks per fragment batch of gemm_body (CH) for a wave whose k range is `per_wave` k-blocks: the fewest batches, then the
+// fewest clamped (wasted) loads
+static int pick_ch(int per_wave) {
+    if (per_wave <= 8) return 8;
+    if (per_wave <= 12) return 12;
+    if (per_wave <= 16) return 16;
+    if (per_wave % 16 == 0) return 16;
+    if (per_wave % 12 == 0) return 12;
+    return 8;
+}
 template <class P, int PRO, int EPI, int WN, int WK>
 static int launch_gemm(dsg_handle* h, GemmArgs g) {
     if (g.KS == 1) g.kb_per_split = g.KBtot;
@@ -886,7 +933,24 @@ static int launch_gemm(dsg_handle* h, GemmArgs g) {
     // EPI_PARTIAL / EPI_OUT carry one extra grid row whose first workgroup does the step bookkeeping
     const int extra = (EPI == EPI_PARTIAL || EPI == EPI_OUT) ? 1 : 0;
     g.inv_ntok = fastdiv_inv(g.ntok); g.inv_hd = fastdiv_inv(g.hd);
-    return step_launch<&k_gemm<P, PRO, EPI, WN, WK, 1>>(h, dim3(xcd_grid_x(NG), g.MT + extra, g.KS), dim3(256), g);
+    const dim3 grid(xcd_grid_x(NG), g.MT + extra, g.KS);
+    // one batch of fragment loads per wave wherever the wave's k range allows it (gemm_body: CH)
+    if constexpr (PRO == PRO_LN && WN == 4 && WK == 1) {
+        // LayerNorm-on-read GEMMs at the DSG+ widths: 128 columns per workgroup (2 tiles per wave) -- every column group re-reads and
+        // re-normalises its 16 fp32 rows from uncached memory (18 / 16 / 34 groups x 10 row tiles x 24-32 KB), which is what bounds them
+        if (h->tnw2 && g.NT % 8 == 0) {
+            const dim3 grid2(xcd_grid_x(g.NT / 8), g.MT + extra, 1);
+            const int ch = pick_ch(g.KBtot);
+            if (ch == 16) return step_launch<&k_gemm<P, PRO, EPI, WN, WK, 2, 16>>(h, grid2, dim3(256), g);
+            if (ch == 12) return step_launch<&k_gemm<P, PRO, EPI, WN, WK, 2, 12>>(h, grid2, dim3(256), g);
+        }
+    }
+    if constexpr (EPI != EPI_PARTIAL) {
+        const int ch = pick_ch(std::min(g.kb_per_split, g.KBtot) / WK);
+        if (ch == 16) return step_launch<&k_gemm<P, PRO, EPI, WN, WK, 1, 16>>(h, grid, dim3(256), g);
+        if (ch == 12) return step_launch<&k_gemm<P, PRO, EPI, WN, WK, 1, 12>>(h, grid, dim3(256), g);
+    }
+    return step_launch<&k_gemm<P, PRO, EPI, WN, WK, 1>>(h, grid, dim3(256), g);
 }
 // 32-row x 64-column blocks, K = D whole (dsg_batched.h).  Measured per GEMM in the real batch-16 step
 // (profiles/r02_c_blk_sweep.log): QKV -13 us, linear1 -7, embedding -9.5 per step; out_proj +4 and the pose head +3.5 (few,
@@ -990,7 +1054,10 @@ static int launch_gemm_w(dsg_handle* h, const GemmArgs& g, const KernelSel& ks) 
             gl.KS = 1; gl.kb_per_split = gl.KBtot;
             gl.inv_ntok = fastdiv_inv(gl.ntok); gl.inv_hd = fastdiv_inv(gl.hd);
             if (gl.NT % 4) return fail(DSG_E_INVALID, "gemm: NT not divisible by the workgroup tile");
-            return step_launch<&k_gemm_lean<P, EPI>>(h, dim3(xcd_grid_x(gl.NT / 4), gl.MT + (EPI == EPI_OUT ? 1 : 0), 1), dim3(256), gl);
+            const dim3 grid(xcd_grid_x(gl.NT / 4), gl.MT + (EPI == EPI_OUT ? 1 : 0), 1);
+            if (pick_ch(gl.KBtot) == 16) return step_launch<&k_gemm_lean<P, EPI, 16>>(h, grid, dim3(256), gl);
+            if (pick_ch(gl.KBtot) == 12) return step_launch<&k_gemm_lean<P, EPI, 12>>(h, grid, dim3(256), gl);
+            return step_launch<&k_gemm_lean<P, EPI>>(h, grid, dim3(256), gl);
         }
     }
     return launch_gemm<P, PRO, EPI, 4, 1>(h, g);
@@ -1129,14 +1196,39 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                 CHK((launch_gemm_w<P, PRO_LN, EPI_QKV>(h, g, ks)));
             }
         }
-        if (!ks.attn_in_mid && !ks.attn_op) {   // attention
+        if (ks.attn_ph) {      // per-head attention + partial out_proj; LayerNorm1 (of residual + b_o + the 4 partials) + linear1 + GELU
+            {
+                AttnPhArgs a;
+                a.q = h->q; a.k = h->k; a.vt = h->vt; a.Wo = ly.Wo; a.part = h->partial; a.part_stride = (long long)MT * 16 * D;
+                a.B = B; a.H = h->H; a.ntok = ntok; a.Tp = h->Tp; a.D = D;
+                const dim3 grid(cdiv(ntok, 16), h->H, B);
+                if (D == 384) CHK((step_launch<&k_attn_ph<P, 96, 10, 6>>(h, grid, dim3(256), a)));
+                else if (D == 512) CHK((step_launch<&k_attn_ph<P, 128, 10, 8>>(h, grid, dim3(256), a)));
+                else if (D == 256) CHK((step_launch<&k_attn_ph<P, 64, 6, 4>>(h, grid, dim3(256), a)));
+                else CHK((step_launch<&k_attn_ph<P, 32, 2, 2>>(h, grid, dim3(256), a)));
+            }
+            {
+                GemmArgs g = z;
+                g.M = M; g.MT = MT; g.NT = h->ff / 16; g.KBtot = D / KB; g.Wp = ly.W1; g.bias = ly.b1;
+                g.X = l == 0 ? h->X0 : h->Xn; g.Xp = h->partial; g.xp_stride = (long long)MT * 16 * D; g.xp_bias = ly.bo;
+                g.ln_g = ly.g1; g.ln_b = ly.be1; g.Xn = h->X1; g.out = h->hidden; g.ldo = h->ff; g.out_frag = 1;
+                g.KS = 1; g.kb_per_split = g.KBtot; g.inv_ntok = fastdiv_inv(g.ntok); g.inv_hd = fastdiv_inv(g.hd);
+                if (g.NT % 4) return fail(DSG_E_INVALID, "gemm: NT not divisible by the workgroup tile");
+                const dim3 grid(xcd_grid_x(g.NT / 4), g.MT, 1);
+                const int ch = pick_ch(g.KBtot);
+                if (ch == 16) CHK((step_launch<&k_gemm_ln4<P, 16>>(h, grid, dim3(256), g)));
+                else if (ch == 12) CHK((step_launch<&k_gemm_ln4<P, 12>>(h, grid, dim3(256), g)));
+                else CHK((step_launch<&k_gemm_ln4<P, 8>>(h, grid, dim3(256), g)));
+            }
+        } else if (!ks.attn_in_mid && !ks.attn_op) {   // attention
             AttnArgs a;
             memset(&a, 0, sizeof(a));
             a.q = h->q; a.k = h->k; a.vt = h->vt; a.out = h->attn; a.B = B; a.H = h->H; a.ntok = ntok; a.Tp = h->Tp;
             a.D = D;
             CHK(launch_attn<P>(h, a));
         }
-        if (ks.lat) {      // [attention +] out_proj + residual + LayerNorm1 + linear1 slice + GELU
+        if (ks.attn_ph) {
+        } else if (ks.lat) {      // [attention +] out_proj + residual + LayerNorm1 + linear1 slice + GELU
             MidArgs a;
             memset(&a, 0, sizeof(a));
             a.A = h->attn; a.R = l == 0 ? h->X0 : h->Xn; a.Wo = ly.Wo; a.bo = ly.bo; a.ln_g = ly.g1; a.ln_b = ly.be1;
@@ -1208,7 +1300,10 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
             g.cfgB = h->cfgB; g.cfg_off = h->cfgB * ntok; g.cfg_scale = h->cfg_scale;
             g.KS = 1; g.kb_per_split = g.KBtot; g.inv_ntok = fastdiv_inv(g.ntok); g.inv_hd = fastdiv_inv(g.hd);
             if (g.NT % 4) return fail(DSG_E_INVALID, "gemm: NT not divisible by the workgroup tile");
-            CHK((step_launch<&k_gemm_cfg<P>>(h, dim3(xcd_grid_x(g.NT / 4), g.MT + 1, 1), dim3(256), g)));
+            const dim3 grid(xcd_grid_x(g.NT / 4), g.MT + 1, 1);
+            if (pick_ch(g.KBtot) == 16) CHK((step_launch<&k_gemm_cfg<P, 16>>(h, grid, dim3(256), g)));
+            else if (pick_ch(g.KBtot) == 12) CHK((step_launch<&k_gemm_cfg<P, 12>>(h, grid, dim3(256), g)));
+            else CHK((step_launch<&k_gemm_cfg<P>>(h, grid, dim3(256), g)));
         } else {
             CHK((launch_gemm_w<P, PRO_LN, EPI_OUT>(h, g, ks)));
         }
@@ -1519,15 +1614,18 @@ struct SampleJob {
 // step loop (device-resident iteration word, read with vector loads, advanced by an extra workgroup of the other kernel).
 // A mismatch (another ASIC / ROCm version mapping hipDeviceMallocUncached differently) turns fence-free submission off for
 // the process, with a warning; dsg_last_sample_fence_free then reports 0.
-static int g_uc_checked[64] = {0};      // per device: 0 not yet, 1 ok, 2 broken
+static std::atomic<int> g_uc_checked[64];      // per device: 0 not yet, 1 ok, 2 broken
+static std::mutex g_uc_mutex;                  // one probe at a time: two host threads creating handles on one device run it once
 static bool uc_selfcheck(dsg_handle* h) {
     const int dev = h->cfg.device & 63;
-    if (g_uc_checked[dev]) return g_uc_checked[dev] == 1;
+    if (int v = g_uc_checked[dev].load(std::memory_order_acquire)) return v == 1;
+    std::lock_guard<std::mutex> lock(g_uc_mutex);
+    if (int v = g_uc_checked[dev].load(std::memory_order_acquire)) return v == 1;
     const int n_wg = 256, iters = 64;
     unsigned* buf = nullptr;
     if (hipExtMallocWithFlags((void**)&buf, (size_t)(n_wg * 256 + 64) * sizeof(unsigned), hipDeviceMallocUncached) != hipSuccess) {
         (void)hipGetLastError();
-        g_uc_checked[dev] = 2;
+        g_uc_checked[dev].store(2, std::memory_order_release);
         return false;
     }
     bool ok = hipMemset(buf, 0, (size_t)(n_wg * 256 + 64) * sizeof(unsigned)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
@@ -1552,7 +1650,7 @@ static bool uc_selfcheck(dsg_handle* h) {
     if (!good)
         fprintf(stderr, "libdsg_hip: WARNING: uncached-memory hand-off check failed on device %d (stale words: %u, iterations seen: %u of %d); "
                         "the step loop keeps its acquire / release fences\n", h->cfg.device, res[0], res[1], iters);
-    g_uc_checked[dev] = good ? 1 : 2;
+    g_uc_checked[dev].store(good ? 1 : 2, std::memory_order_release);
     return good;
 }
 #endif
@@ -1656,7 +1754,7 @@ static int sample_run_hip(dsg_handle* h, const dsg_sample_args* a, SampleJob& jo
     if (spg > 0 && n_run >= spg && job.done == 0) {
         // everything that varies between calls (step index, coefficients, noise key, conditioning) lives in device
         // memory, so one captured graph per (batch, sampler, mask batch, const_noise, steps, flags, kernel set) serves every window and clip
-        dsg_handle::GKey key = {c.B, c.out_mode, h->mb, c.const_noise, n_run, (c.clip_x0 ? 1 : 0) | (h->cfgB ? 2 : 0) | (h->nomask ? 4 : 0) | (c.ks.attn_in_mid ? 8 : 0) | (c.no_noise ? 16 : 0),
+        dsg_handle::GKey key = {c.B, c.out_mode, h->mb, c.const_noise, n_run, (c.clip_x0 ? 1 : 0) | (h->cfgB ? 2 : 0) | (h->nomask ? 4 : 0) | (c.ks.attn_in_mid ? 8 : 0) | (c.no_noise ? 16 : 0) | (c.ks.attn_ph ? 32 : 0),
                                 c.ks.set};
         auto it = h->graphs.find(key);
         bool ok = true;

@@ -114,11 +114,20 @@ __global__ __launch_bounds__(256) void k_ln_frag(const GemmArgs g) {
 //             branch around every MFMA)
 //   EPI_OUT   the pose head + sampler update (8 extra workgroups: the first one does the step bookkeeping, see StepCtl)
 // ---------------------------------------------------------------------------------------------------------
+// bytes of LDS staging the epilogue of k_ws<EPI> needs per row block of BM rows
+__host__ __device__ constexpr int ws_stage_bytes(int epi, int bm) {
+    return epi == EPI_QKV ? 128 * (bm + 4) * 2 : (epi == EPI_OUT ? 4 * 32 * 36 * 4 : 0);
+}
 template <int EPI, int KD16, bool SW>       // SW: D[feature][token] (Q / K, linear1, pose head); !SW: D[token][feature] (V^T)
 __device__ __forceinline__ void ws_body(const GemmArgs& g, const WsId id, char* lds) {
     typedef PBF16 P;
     constexpr int K = 16 * KD16, KB = K / 32, BM = 64;
     constexpr int ABYTES = BM * K * 2;
+    // epilogue staging (V^T transposition, pose-head tile transposition): the retired activation buffer when it is large enough
+    // (K = 256), else its own region behind the two buffers (K = 128: 128 x 68 x 2 = 17408 B / 4 x 32 x 36 x 4 = 18432 B > 16384 --
+    // round-3 advisor: at tiny dims with more than one block per workgroup the stage ran into the buffer being prefetched)
+    constexpr int STAGE = ws_stage_bytes(EPI, BM);
+    constexpr bool STAGE_IN_A = STAGE <= ABYTES;
     const int G = g.ws_G, MB = (g.M + BM - 1) / BM;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -197,7 +206,8 @@ __device__ __forceinline__ void ws_body(const GemmArgs& g, const WsId id, char* 
             // ---- V^T: the block goes through the retired activation buffer and out in aligned token groups (vt_store_block)
             constexpr int SP = BM + 4;                             // 136-byte feature pitch: 8-byte aligned quads
             typedef typename P::elem elem;
-            elem* stage = (elem*)(lds + cur * ABYTES);
+            elem* stage = (elem*)(STAGE_IN_A ? lds + cur * ABYTES : lds + 2 * ABYTES);
+            static_assert(128 * SP * 2 <= (STAGE_IN_A ? ABYTES : STAGE), "V^T stage");
             DSG_LDS_BARRIER();                                     // every wave is done reading the activation block
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
@@ -220,7 +230,8 @@ __device__ __forceinline__ void ws_body(const GemmArgs& g, const WsId id, char* 
             //      the retired activation buffer (LDS operations of a wave execute in order: no barrier between its write and read) so
             //      that 8 lanes cover 128 contiguous bytes of one token; the epilogue arithmetic is position-based (gemm_epilogue_tile).
             constexpr int TP = 36;                                 // floats per token: 144-byte pitch, conflict-free both ways
-            float* st = (float*)(lds + cur * ABYTES) + wave * (32 * TP);
+            float* st = (float*)(STAGE_IN_A ? lds + cur * ABYTES : lds + 2 * ABYTES) + wave * (32 * TP);
+            static_assert(4 * 32 * TP * 4 <= (STAGE_IN_A ? ABYTES : STAGE), "pose-head stage");
             DSG_LDS_BARRIER();                                     // every wave is done reading the activation block
             const int tok = lane >> 3, quad = lane & 7;
 #pragma unroll
@@ -274,7 +285,8 @@ __global__ __launch_bounds__(256, 2) void k_ws(const GemmArgs g) {
     constexpr int K = 16 * KD16, BM = 64;
     static_assert(KD16 % 4 == 0 && KD16 <= 16, "K = 64, 128, 192 or 256");
     static_assert(EPI == EPI_GELU || EPI == EPI_QKV || EPI == EPI_OUT, "GEMMs of the step with K = D");
-    __shared__ __attribute__((aligned(16))) char lds[2 * BM * K * 2];
+    constexpr int ABYTES = BM * K * 2, STAGE = ws_stage_bytes(EPI, BM);
+    __shared__ __attribute__((aligned(16))) char lds[2 * ABYTES + (STAGE <= ABYTES ? 0 : STAGE)];
     preload_kernargs(g);
     const int n_panels = g.NT >> 3;
     const WsId id = ws_id(n_panels, g.ws_G);

@@ -54,6 +54,7 @@ SYMBOLS = {
     "dsg_sample": (_I, [_P, C.POINTER(dsg_sample_args), _P, _I, _P]),
     "dsg_sample_multi": (_I, [C.POINTER(_P), _I, C.POINTER(dsg_sample_args), C.POINTER(_P), _I, _P]),
     "dsg_set_kernel_set": (_I, [_P, _I]),
+    "dsg_get_kernel_set": (_I, [_P, C.POINTER(_I)]),
     "dsg_recommend_kernel_set": (_I, [_P, _I, _I, C.POINTER(_I)]),
     "dsg_last_kernel_set": (_I, [_P, C.POINTER(_I)]),
     "dsg_sync": (_I, [_P]),
@@ -93,7 +94,7 @@ class DSGLibrary:
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(self.cdll, name)          # AttributeError if the library does not export it
             fn.restype, fn.argtypes = res, args
-        if self.cdll.dsg_version() < 300:
+        if self.cdll.dsg_version() < 310:
             raise DSGError("libdsg_hip.so is older than this package")
 
     def check(self, rc: int):

@@ -188,6 +188,12 @@ class DSGDenoiser:
         self.lib.check(self.lib.cdll.dsg_set_kernel_set(self.handle, L.KERNEL_SETS[name]))
         return self
 
+    def kernel_set(self) -> str:
+        """The set in force for this lane ("auto" unless `set_kernel_set` / DSG_KSET chose one)."""
+        p = C.c_int()
+        self.lib.check(self.lib.cdll.dsg_get_kernel_set(self.handle, C.byref(p)))
+        return L.KERNEL_SET_NAMES[p.value]
+
     def recommend_kernel_set(self, batch: int, lanes: int = 1) -> str:
         """The set measured fastest for `lanes` lanes of `batch` clips advanced together (dsg_recommend_kernel_set)."""
         p = C.c_int()

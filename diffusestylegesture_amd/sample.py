@@ -129,29 +129,135 @@ def generate_clips_streams(lanes, diffusion, feats_per_lane, styles, seed=123456
     use_torch = L.is_torch(feats_per_lane[0][0])
     B = int(feats_per_lane[0][0].shape[0])
     stream_ids = list(range(n)) if stream_ids is None else list(stream_ids)
-    if kernel_set is not None:
-        ks = lanes[0].recommend_kernel_set(B, n) if kernel_set == "recommended" else kernel_set
-        for ln in lanes:
-            ln.set_kernel_set(ks)
-    diffusion.manual_seed(seed, 0)
-    shape = (B, J, 1, T)
-    dev = feats_per_lane[0][0].device if use_torch else None
+    with _lane_kernel_sets(lanes, B, kernel_set):
+        diffusion.manual_seed(seed, 0)
+        shape = (B, J, 1, T)
+        dev = feats_per_lane[0][0].device if use_torch else None
+        if use_torch:
+            import torch
+            mask = torch.ones(1, T, dtype=torch.bool, device=dev)
+        else:
+            mask = np.ones((1, T), bool)
+        per_lane_style = np.asarray(styles).ndim == 2 and len(styles) == n and np.asarray(styles).shape[0] == n and B == 1
+        stys = [_style_batch(styles[i] if per_lane_style else styles, B, use_torch, dev) for i in range(n)]
+        outs = [[] for _ in range(n)]
+        for c in range(K):
+            ys = [{"y": _zeggs_window_y(cfg, feats_per_lane[i][c], stys[i], outs[i][-1] if outs[i] else None, None, use_torch, mask)}
+                  for i in range(n)]
+            ss = diffusion.p_sample_loop_multi(list(lanes), shape, ys, seeds=[seed] * n, stream_ids=stream_ids,
+                                               skip_timesteps=skip_timesteps, ddim=ddim, eta=eta)
+            for i in range(n):
+                _zeggs_stitch(outs[i], ss[i], S, smoothing, use_torch)
+    return np.concatenate([_zeggs_finish(o, S, use_torch) for o in outs], axis=0)
+
+
+class _lane_kernel_sets:
+    """The kernel set of a multi-lane call: "recommended" = the set measured fastest for this many lanes x this batch (it differs
+    from what one lane alone would pick), a name forces that set, None leaves the lanes alone.  A set is a sticky
+    property of a lane (lanes[0] is normally the caller's own model), so whatever the call changes is put back on exit -- the
+    caller's later single-lane calls run the set they ran before (round-3 advisor)."""
+
+    def __init__(self, lanes, batch, kernel_set):
+        self.lanes, self.batch, self.want, self.saved = list(lanes), batch, kernel_set, None
+
+    def __enter__(self):
+        if self.want is not None:
+            self.saved = [ln.kernel_set() for ln in self.lanes]
+            ks = self.lanes[0].recommend_kernel_set(self.batch, len(self.lanes)) if self.want == "recommended" else self.want
+            for ln in self.lanes:
+                ln.set_kernel_set(ks)
+        return self
+
+    def __exit__(self, *exc):
+        if self.saved is not None:
+            for ln, ks in zip(self.lanes, self.saved):
+                ln.set_kernel_set(ks)
+        return False
+
+
+def _dsgplus_window_y(cfg, feats, c, sty, seedp, seed_last, use_torch, mask):
+    """model_kwargs['y'] of window c of a DSG+ clip (BEAT-TWH sample.py:98-140) for the three model names of that tree."""
+    S = cfg.n_seed
+    feat = feats[c]
+    seedp = seedp.contiguous() if use_torch else np.ascontiguousarray(seedp)
+    y = {"style": sty, "seed": seedp, "audio": feat, "mask_local": mask}
+    if cfg.variant == 3:
+        # name "DiffuseStyleGesture" of the BEAT-TWH tree (attention3): S frames of left context in front of the window's
+        # features -- zeros for window 0, the tail of the previous window's features afterwards (sample.py:100-102, :132-134)
+        if use_torch:
+            import torch
+            left = torch.zeros_like(feat[:, :S]) if c == 0 else feats[c - 1][:, -S:]
+            y["audio"] = torch.cat((left, feat), 1).contiguous()
+        else:
+            left = np.zeros_like(feat[:, :S]) if c == 0 else feats[c - 1][:, -S:]
+            y["audio"] = np.ascontiguousarray(np.concatenate((left, feat), 1))
+    if cfg.variant == 5:
+        if seed_last is None:
+            raise KeyError("seed_last")
+        a = feat[:, :-S]
+        y["audio"] = a.contiguous() if use_torch else np.ascontiguousarray(a)
+        y["seed_last"] = seed_last
+    return y
+
+
+def _dsgplus_stitch(out, s, S, use_torch):
+    """BEAT-TWH sample.py:150-160: cut the overlap off the previous window, the one-frame blend; no root shift."""
+    if out:
+        last = out[-1][..., -S:]
+        last = last.clone() if use_torch else last.copy()
+        out[-1] = out[-1][..., :-S]
+        s[..., 0] = last[..., 0] * 0.5 + s[..., 0] * 0.5
+    out.append(s)
+
+
+def _dsgplus_finish(out, S, J, real_n_frames, feature_division, use_torch):
     if use_torch:
         import torch
-        mask = torch.ones(1, T, dtype=torch.bool, device=dev)
+        seq = torch.cat([o[:, :, 0, :] for o in out], dim=2).permute(0, 2, 1).contiguous().cpu().numpy()
     else:
-        mask = np.ones((1, T), bool)
-    per_lane_style = np.asarray(styles).ndim == 2 and len(styles) == n and np.asarray(styles).shape[0] == n and B == 1
-    stys = [_style_batch(styles[i] if per_lane_style else styles, B, use_torch, dev) for i in range(n)]
-    outs = [[] for _ in range(n)]
-    for c in range(K):
-        ys = [{"y": _zeggs_window_y(cfg, feats_per_lane[i][c], stys[i], outs[i][-1] if outs[i] else None, None, use_torch, mask)}
-              for i in range(n)]
-        ss = diffusion.p_sample_loop_multi(list(lanes), shape, ys, seeds=[seed] * n, stream_ids=stream_ids,
-                                           skip_timesteps=skip_timesteps, ddim=ddim, eta=eta)
-        for i in range(n):
-            _zeggs_stitch(outs[i], ss[i], S, smoothing, use_torch)
-    return np.concatenate([_zeggs_finish(o, S, use_torch) for o in outs], axis=0)
+        seq = np.concatenate([o[:, :, 0, :] for o in out], axis=2).transpose(0, 2, 1)
+    seq = seq[:, S:][:, :real_n_frames]
+    # "v0" data: the model features are poses + velocities + accelerations, only the poses are kept (motion_feature_division = 3,
+    # BEAT-TWH sample.py:173-180); "v2": the whole vector (division 1)
+    return np.ascontiguousarray(seq[:, :, : J // feature_division], dtype=np.float32)
+
+
+def generate_clips_streams_dsgplus(lanes, diffusion, feats_per_lane, styles, seed0s, real_n_frames, seed=123456, skip_timesteps=0,
+                                   stream_ids=None, seed_lasts=None, feature_division=3, ddim=False, eta=0.0,
+                                   kernel_set="recommended"):
+    """`generate_clips_streams` for the DSG+ window loop (BEAT-TWH sample.py:98-192; all three model names of that tree): lane i
+    samples the B clips of feats_per_lane[i] (K per-window features), seeded by seed0s[i] [B, J, 1, S] (and seed_lasts[i] for
+    DiffuseStyleGesture++), on its own HSA queue; the lanes' step loops are interleaved by the library.  Lane i is bit-identical
+    to `generate_clip_dsgplus(lanes[i], ..., stream_id=stream_ids[i])` run alone on the same lane under the same kernel set.
+    Returns [N * B, real_n_frames, J // feature_division], lane-major."""
+    n = len(lanes)
+    cfg = lanes[0].cfg
+    S, T, J = cfg.n_seed, cfg.n_poses, cfg.njoints
+    K = len(feats_per_lane[0])
+    if any(len(f) != K for f in feats_per_lane) or len(feats_per_lane) != n or len(seed0s) != n:
+        raise ValueError("one feature list and one seed clip per lane, the same number of windows each")
+    use_torch = L.is_torch(feats_per_lane[0][0])
+    B = int(feats_per_lane[0][0].shape[0])
+    stream_ids = list(range(n)) if stream_ids is None else list(stream_ids)
+    with _lane_kernel_sets(lanes, B, kernel_set):
+        diffusion.manual_seed(seed, 0)
+        shape = (B, J, 1, T)
+        dev = feats_per_lane[0][0].device if use_torch else None
+        if use_torch:
+            import torch
+            mask = torch.ones(1, T, dtype=torch.bool, device=dev)
+        else:
+            mask = np.ones((1, T), bool)
+        sty = _style_batch(styles, B, use_torch, dev)
+        outs = [[] for _ in range(n)]
+        for c in range(K):
+            ys = [{"y": _dsgplus_window_y(cfg, feats_per_lane[i], c, sty, seed0s[i] if c == 0 else outs[i][-1][..., -S:],
+                                          None if seed_lasts is None else seed_lasts[i], use_torch, mask)} for i in range(n)]
+            ss = diffusion.p_sample_loop_multi(list(lanes), shape, ys, seeds=[seed] * n, stream_ids=stream_ids,
+                                               skip_timesteps=skip_timesteps, ddim=ddim, eta=eta)
+            for i in range(n):
+                _dsgplus_stitch(outs[i], ss[i], S, use_torch)
+    return np.concatenate([_dsgplus_finish(o, S, J, real_n_frames, feature_division, use_torch) for o in outs], axis=0)
 
 
 def generate_clip_dsgplus(model, diffusion, feats, style, seed0, real_n_frames, seed=123456, skip_timesteps=0,
@@ -180,43 +286,12 @@ def generate_clip_dsgplus(model, diffusion, feats, style, seed0, real_n_frames, 
         sty = torch.from_numpy(sty).to(dev)
     else:
         mask = np.ones((1, T), bool)
-    for c, feat in enumerate(feats):
-        seedp = seed0 if c == 0 else out[-1][..., -S:]
-        seedp = seedp.contiguous() if use_torch else np.ascontiguousarray(seedp)
-        y = {"style": sty, "seed": seedp, "audio": feat, "mask_local": mask}
-        if cfg.variant == 3:
-            # name "DiffuseStyleGesture" of the BEAT-TWH tree (attention3): S frames of left context in front of the window's
-            # features -- zeros for window 0, the tail of the previous window's features afterwards (sample.py:100-102, :132-134)
-            if use_torch:
-                import torch
-                left = torch.zeros_like(feat[:, :S]) if c == 0 else feats[c - 1][:, -S:]
-                y["audio"] = torch.cat((left, feat), 1).contiguous()
-            else:
-                left = np.zeros_like(feat[:, :S]) if c == 0 else feats[c - 1][:, -S:]
-                y["audio"] = np.ascontiguousarray(np.concatenate((left, feat), 1))
-        if cfg.variant == 5:
-            if seed_last is None:
-                raise KeyError("seed_last")
-            a = feat[:, :-S]
-            y["audio"] = a.contiguous() if use_torch else np.ascontiguousarray(a)
-            y["seed_last"] = seed_last
+    for c in range(len(feats)):
+        y = _dsgplus_window_y(cfg, feats, c, sty, seed0 if c == 0 else out[-1][..., -S:], seed_last, use_torch, mask)
         s = sample_fn(model, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=skip_timesteps,
                       init_image=None, progress=False, dump_steps=None, noise=None, const_noise=False)
-        if c > 0:
-            last = out[-1][..., -S:]
-            last = last.clone() if use_torch else last.copy()
-            out[-1] = out[-1][..., :-S]
-            s[..., 0] = last[..., 0] * 0.5 + s[..., 0] * 0.5
-        out.append(s)
-    if use_torch:
-        import torch
-        seq = torch.cat([o[:, :, 0, :] for o in out], dim=2).permute(0, 2, 1).contiguous().cpu().numpy()
-    else:
-        seq = np.concatenate([o[:, :, 0, :] for o in out], axis=2).transpose(0, 2, 1)
-    seq = seq[:, S:][:, :real_n_frames]
-    # "v0" data: the model features are poses + velocities + accelerations, only the poses are kept (motion_feature_division = 3,
-    # BEAT-TWH sample.py:173-180); "v2": the whole vector (division 1)
-    return np.ascontiguousarray(seq[:, :, : J // feature_division], dtype=np.float32)
+        _dsgplus_stitch(out, s, S, use_torch)
+    return _dsgplus_finish(out, S, J, real_n_frames, feature_division, use_torch)
 
 
 def window_audio(audio, n_frames, n_poses=88, n_seed=8, sr=16000, fps=20):

@@ -89,23 +89,26 @@ def synth_state_dict(cfg: DSGConfig, seed: int = 0) -> "OrderedDict[str, np.ndar
     return sd
 
 
-def synth_window_inputs(cfg: DSGConfig, batch: int, window: int = 0, clip0: int = 0, seed_pose_scale=0.0):
-    """Synthetic per-window conditioning: WavLM-like features, style one-hot, seed poses."""
+def synth_window_inputs(cfg: DSGConfig, batch: int, window: int = 0, clip0: int = 0, seed_pose_scale=0.0, clips=None):
+    """Synthetic per-window conditioning: WavLM-like features, style one-hot, seed poses.  Batch element b is clip
+    `clips[b]` (default: the contiguous range clip0 + b) -- everything is a function of the clip id alone."""
+    ids = [clip0 + b for b in range(batch)] if clips is None else [int(c) for c in clips]
+    assert len(ids) == batch
     audio = np.stack([
-        _feat(cfg, 1000 + 16 * (clip0 + b) + window) for b in range(batch)]).astype(np.float32)
+        _feat(cfg, 1000 + 16 * c + window) for c in ids]).astype(np.float32)
     style = np.zeros((batch, cfg.style_dim_in), dtype=np.float32)
     style[:, 0] = 1.0
     if seed_pose_scale == 0.0:
         seedp = np.zeros((batch, cfg.njoints, 1, cfg.n_seed), dtype=np.float32)
     else:
         seedp = np.stack([
-            (seed_pose_scale * np.random.RandomState(7 + clip0 + b).randn(cfg.njoints, 1, cfg.n_seed))
-            for b in range(batch)]).astype(np.float32)
+            (seed_pose_scale * np.random.RandomState(7 + c).randn(cfg.njoints, 1, cfg.n_seed))
+            for c in ids]).astype(np.float32)
     mask_local = np.ones((1, cfg.n_poses), dtype=bool)
     y = {"audio": audio, "style": style, "seed": seedp, "mask_local": mask_local}
     if cfg.variant == 5:        # DSG++: the fixed "closing" pose snippet (BEAT-TWH sample.py:85-93)
-        y["seed_last"] = np.stack([(0.2 * np.random.RandomState(70 + clip0 + b).randn(cfg.njoints, 1, cfg.n_seed))
-                                   for b in range(batch)]).astype(np.float32)
+        y["seed_last"] = np.stack([(0.2 * np.random.RandomState(70 + c).randn(cfg.njoints, 1, cfg.n_seed))
+                                   for c in ids]).astype(np.float32)
     return y
 
 

@@ -22,7 +22,7 @@
  *        GaussianDiffusion.p_sample_loop / ddim_sample_loop          main/diffusion/gaussian_diffusion.py:608-671, :889-936
  *   dsg_set_window_cond_cfg
  *        ClassifierFreeSampleModel.forward (y['scale'], y['uncond'])   main/model/cfg_sampler.py:8-31
- *   dsg_clone / dsg_sample_multi / dsg_set_kernel_set / dsg_recommend_kernel_set / dsg_last_kernel_set
+ *   dsg_clone / dsg_sample_multi / dsg_set_kernel_set / dsg_get_kernel_set / dsg_recommend_kernel_set / dsg_last_kernel_set
  *        (no reference counterpart: the reference samples one clip at a time, sample.py:418 batch_size = 1; these run
  *         several clips of one GPU concurrently over one copy of the weights -- BASELINE config[3] "one clip per stream")
  *   dsg_noise
@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define DSG_VERSION 300
+#define DSG_VERSION 310
 
 enum {
     DSG_OK = 0,
@@ -177,6 +177,7 @@ int dsg_sample_multi(dsg_handle** lanes, int n, const dsg_sample_args* args, flo
  * the CUs and prefer the throughput-shaped sets earlier; the caller applies it to each lane.  dsg_last_kernel_set: the set the
  * last dsg_forward / dsg_sample of the handle ran. */
 int dsg_set_kernel_set(dsg_handle* h, int set);
+int dsg_get_kernel_set(dsg_handle* h, int* set);      /* the set in force (DSG_KSET_*), incl. a DSG_KSET environment pin */
 int dsg_recommend_kernel_set(dsg_handle* h, int B, int lanes, int* set);
 int dsg_last_kernel_set(dsg_handle* h, int* set);
 int dsg_sync(dsg_handle* h);
