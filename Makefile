@@ -29,9 +29,9 @@ $(CSRC)/libdsg_hip_stamps.so: $(STAMPS_SRC) $(CSRC)/dsg_bvh.cpp
 $(CSRC)/dsg_kernels_stamps.hsaco: $(STAMPS_SRC)
 	$(HIPCC) --offload-arch=gfx950 --cuda-device-only --no-gpu-bundle-output -O3 -std=c++17 -Wno-pass-failed -DDSG_STAMPS=1 -DDSG_BUILD_TAG=$(TAG)u $(CSRC)/dsg_hip.cpp -o $@
 
-# the kernels that were measured slower and removed from the library: compile check only (csrc/experiments/)
-experiments: $(CSRC)/experiments/experiments.hip $(CSRC)/experiments/dsg_rejected_kernels.h $(CSRC)/experiments/dsg_stream_ln.h $(CSRC)/dsg_kernels.h $(CSRC)/dsg_batched.h $(CSRC)/dsg_stream.h
-	$(HIPCC) --offload-arch=gfx950 --cuda-device-only -O3 -std=c++17 -Wno-pass-failed -c $(CSRC)/experiments/experiments.hip -o /dev/null
+# the kernels that were measured slower and removed from the library: compile check only (experiments/, outside the package)
+experiments: experiments/experiments.hip experiments/dsg_rejected_kernels.h experiments/dsg_stream_ln.h $(CSRC)/dsg_kernels.h $(CSRC)/dsg_batched.h $(CSRC)/dsg_stream.h
+	$(HIPCC) --offload-arch=gfx950 --cuda-device-only -O3 -std=c++17 -Wno-pass-failed -I$(CSRC) -c experiments/experiments.hip -o /dev/null
 
 emu: $(EMU)
 $(EMU): $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h $(CSRC)/dsg_batched.h $(CSRC)/dsg_stream.h include/dsg.h tests/emu/shim/hip/hip_runtime.h tests/emu/emu_rt.cpp $(CSRC)/dsg_bvh.cpp

@@ -937,184 +937,4 @@ __global__ __launch_bounds__(256) void k_attn_op2(const AttnOpArgs g) {
     }
 }
 
-
-// ---------------------------------------------------------------------------------------------------------
-// k_attn_ph (round 4; the DSG+ widths at batch 1-2): self-attention of one (16-query tile, head) per workgroup + THAT HEAD'S share
-// of out_proj, written as a partial [rows][D] fp32 slab per head; the next kernel (linear1 with the PRO_LN4 prologue) forms
-// pre1 = R + b_o + sum_h partial_h, LayerNorm1, and multiplies.  Why: at D = 384 / 512 every fused form that owns whole rows
-// (k_mid / k_attn_mid / k_attn_op) pulls ALL of W_o (288 / 512 KB) + K / V of 4 heads (240 / 320 KB) through ONE CU per 16 rows --
-// k_mid<6> 7.0 us, k_mid<8> 9.3 us, 10 such workgroups at batch 1 (profiles/r04_a_timeline_*) -- while 4 x as many workgroups
-// with a quarter of the bytes each (K / V of one head + W_o[:, head slice]: 135 / 213 KB) run on otherwise idle CUs.
-//   * the 4 waves split the KEYS (PV k-blocks w, w + 4, ...): partial softmax per wave (own max m_w, sum l_w, unnormalised
-//     O_w = V^T P^T), merged through LDS with the usual exp(m_w - m) rescaling in a fixed wave order -- K / V pass through the CU once;
-//   * the merged 16 x hd rows go to LDS in the MFMA element type (the rounding point of the attention buffer of k_attn);
-//   * out_proj: wave w owns D / 64 column tiles, K = hd (the head's k-blocks of W_o), fragments requested before the attention math.
-// Reference arithmetic: nn.MultiheadAttention inside torch's TransformerEncoderLayer (main/model/mdm.py:79-86, :233); the k sums of
-// softmax / out_proj are taken in another order than k_attn + out_proj (per-wave key groups, per-head partials): a member of the
-// LATENCY set at these widths, validated against the oracle like every set.
-// ---------------------------------------------------------------------------------------------------------
-struct AttnPhArgs {
-    const void* q; const void* k; const void* vt;     // [B][H][Tp][hd] (fragment-major), V^T [B][H][hd][Tp]
-    const void* Wo;                                   // packed [D/16][D/KB][64][16 B]
-    float* part;                                      // [H][part_stride] fp32: slab h = rows x D partial out_proj of head h
-    long long part_stride;                            // elements between slabs
-    int B, H, ntok, Tp, D;
-};
-
-template <class P, int HD, int NKT, int DT>      // hd, Tp / 16, D / 64
-__global__ __launch_bounds__(256) void k_attn_ph(const AttnPhArgs a) {
-    DSG_TL_SCOPE();
-    typedef typename P::elem elem;
-    constexpr int ES = (int)sizeof(elem);
-    constexpr int KDH = HD / P::KB, ND = HD / 16, KD = DT * 64 / P::KB;
-    constexpr int NVF = P::E == 4 ? NKT : NKT / 2;   // PV k-blocks (bf16: two key tiles each)
-    constexpr int TPB = P::E == 4 ? 1 : 2;           // key tiles per PV k-block
-    constexpr int NPW = (NVF + 3) / 4;               // PV k-blocks per wave
-    constexpr int XPH = HD * ES + 16;                // LDS row pitch of the merged attention rows
-    static_assert(HD % P::KB == 0 && (P::E == 4 || NKT % 2 == 0), "shape");
-    __shared__ __attribute__((aligned(16))) float osum[4][ND][64][4];      // every wave's rescaled O_w
-    __shared__ float ml[2][4][16];
-    __shared__ __attribute__((aligned(16))) char aT[16 * XPH];
-    preload_kernargs(a);
-    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
-    const size_t bh = (size_t)b * a.H + h;
-    const size_t Qo = bh * a.Tp * HD, VTo = bh * HD * a.Tp;      // element offsets
-    // ---- loads: Q tile, this wave's key tiles and V^T k-blocks (clamped, never predicated), then the W_o fragments
-    f32x4 qf[KDH], kf[NPW][TPB][KDH], vfr[NPW][ND];
-#pragma unroll
-    for (int kb = 0; kb < KDH; ++kb) qf[kb] = lda16<P>(a.q, (Qo + (size_t)((qt * KDH + kb) * 64 + lane) * P::E) * ES);
-#pragma unroll
-    for (int i = 0; i < NPW; ++i) {
-        const int vb = min(wave + 4 * i, NVF - 1);
-#pragma unroll
-        for (int t = 0; t < TPB; ++t)
-#pragma unroll
-            for (int kb = 0; kb < KDH; ++kb)
-                kf[i][t][kb] = lda16<P>(a.k, (Qo + (size_t)(((vb * TPB + t) * KDH + kb) * 64 + lane) * P::E) * ES);
-#pragma unroll
-        for (int dt = 0; dt < ND; ++dt) vfr[i][dt] = lda16<P>(a.vt, (VTo + (size_t)((dt * NVF + vb) * 64 + lane) * P::E) * ES);
-    }
-    const f32x4* wo = (const f32x4*)a.Wo + lane;
-    f32x4 wf[DT][KDH];
-    // W_o fragments: with the attention operands when everything fits the register file (in flight during the attention math),
-    // else once K / V^T are dead (in flight during the merge) -- fp32 at hd = 128 would spill
-    constexpr bool WO_EARLY = (KDH + NPW * TPB * KDH + NPW * ND + DT * KDH + NPW * TPB + ND) * 4 <= 440;
-    auto load_wo = [&]() {
-#pragma unroll
-        for (int t = 0; t < DT; ++t)
-#pragma unroll
-            for (int kb = 0; kb < KDH; ++kb) wf[t][kb] = wo[((size_t)(wave * DT + t) * KD + h * KDH + kb) * 64];
-    };
-    if constexpr (WO_EARLY) load_wo();
-    DSG_LOADS_ISSUED();
-    // ---- S^T = K Q^T over this wave's keys (D[key = 4*lg + r][query = lr]); partial softmax
-    const float scale = 1.0f / sqrtf((float)HD);
-    f32x4 s[NPW][TPB];
-    float mx = -DSG_FLT_MAX;
-#pragma unroll
-    for (int i = 0; i < NPW; ++i) {
-        const bool own = wave + 4 * i < NVF;          // wave-uniform
-        const int vb = min(wave + 4 * i, NVF - 1);
-#pragma unroll
-        for (int t = 0; t < TPB; ++t) {
-            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kb = 0; kb < KDH; ++kb) acc = P::mma(kf[i][t][kb], qf[kb], acc);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = (vb * TPB + t) * 16 + 4 * lg + r;
-                const float v = (own && key < a.ntok) ? acc[r] * scale : -DSG_FLT_MAX;
-                acc[r] = v;
-                mx = fmaxf(mx, v);
-            }
-            s[i][t] = acc;
-        }
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < NPW; ++i)
-#pragma unroll
-        for (int t = 0; t < TPB; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v = s[i][t][r];
-                const float pv = v > -DSG_FLT_MAX ? P::exp_sm(v - mx) : 0.f;      // (a wave without a live key: everything 0)
-                s[i][t][r] = pv;
-                sum += pv;
-            }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
-    if (lg == 0) { ml[0][wave][lr] = mx; ml[1][wave][lr] = sum; }
-    // ---- O_w = V^T P^T (unnormalised), D[dim = 4*lg + r][query = lr]
-    f32x4 o[ND];
-#pragma unroll
-    for (int dt = 0; dt < ND; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < NPW; ++i) {
-        f32x4 pfr;
-        if constexpr (P::E == 4) {
-            pfr = s[i][0];
-        } else {
-            typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
-            u16x8 pp;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { pp[e] = f2bf(s[i][0][e]); pp[4 + e] = f2bf(s[i][TPB - 1][e]); }
-            pfr = __builtin_bit_cast(f32x4, pp);
-        }
-#pragma unroll
-        for (int dt = 0; dt < ND; ++dt) o[dt] = P::mma(vfr[i][dt], pfr, o[dt]);      // (P = 0 for the k-blocks this wave does not own)
-    }
-    if constexpr (!WO_EARLY) { DSG_LOADS_ISSUED(); load_wo(); DSG_LOADS_ISSUED(); }
-    DSG_LDS_BARRIER();
-    // ---- merge the 4 key groups: m = max_w m_w, L = sum_w exp(m_w - m) l_w (fixed order), O = sum_w exp(m_w - m) O_w / L
-    {
-        const float m0 = ml[0][0][lr], m1 = ml[0][1][lr], m2 = ml[0][2][lr], m3 = ml[0][3][lr];
-        const float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-        const float e0 = m0 > -DSG_FLT_MAX ? P::exp_sm(m0 - m) : 0.f, e1 = m1 > -DSG_FLT_MAX ? P::exp_sm(m1 - m) : 0.f;
-        const float e2 = m2 > -DSG_FLT_MAX ? P::exp_sm(m2 - m) : 0.f, e3 = m3 > -DSG_FLT_MAX ? P::exp_sm(m3 - m) : 0.f;
-        const float L = ((e0 * ml[1][0][lr] + e1 * ml[1][1][lr]) + e2 * ml[1][2][lr]) + e3 * ml[1][3][lr];
-        const float mine = wave == 0 ? e0 : (wave == 1 ? e1 : (wave == 2 ? e2 : e3));
-        const float f = mine / L;
-#pragma unroll
-        for (int dt = 0; dt < ND; ++dt) {
-            f32x4 y;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = o[dt][e] * f;
-            *(f32x4*)&osum[wave][dt][lane][0] = y;
-        }
-    }
-    DSG_LDS_BARRIER();
-#pragma unroll
-    for (int i = 0; i < (ND * 64 + 255) / 256; ++i) {
-        const int e = tid + 256 * i;
-        if (e < ND * 64) {
-            const int dt = e >> 6, ln = e & 63;
-            f32x4 y = *(const f32x4*)&osum[0][dt][ln][0];
-#pragma unroll
-            for (int w2 = 1; w2 < 4; ++w2) y += *(const f32x4*)&osum[w2][dt][ln][0];
-            P::store4((elem*)(aT + (ln & 15) * XPH) + dt * 16 + 4 * (ln >> 4), y);       // row = query, 4 consecutive dims
-        }
-    }
-    DSG_LDS_BARRIER();
-    // ---- this head's share of out_proj: D[n = 4*lg + r][row = lr], K = hd
-    f32x4 acc[DT];
-#pragma unroll
-    for (int t = 0; t < DT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kb = 0; kb < KDH; ++kb) {
-        const f32x4 af = *(const f32x4*)(aT + lr * XPH + (kb * P::KB + P::E * lg) * ES);
-#pragma unroll
-        for (int t = 0; t < DT; ++t) acc[t] = P::mma(wf[t][kb], af, acc[t]);
-    }
-    const int tq = qt * 16 + lr;
-    if (tq < a.ntok) {
-        float* dst = a.part + (size_t)h * a.part_stride + ((size_t)b * a.ntok + tq) * a.D;
-#pragma unroll
-        for (int t = 0; t < DT; ++t) *(f32x4*)(dst + (wave * DT + t) * 16 + 4 * lg) = acc[t];
-    }
-}
-
 }  // namespace dsg

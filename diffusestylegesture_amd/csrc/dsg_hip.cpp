@@ -175,9 +175,6 @@ struct dsg_handle {
     bool aql_timing = false;             // the last dsg_sample was timed by the host clock around the AQL run
     double aql_ms = 0.0;
     bool fuse_attn_mid = true;           // k_attn_mid (attention inside the out_proj/LN/linear1 kernel) at batch 1; DSG_FUSE_ATTN_MID=0 to A/B
-    bool tnw2 = false;                   // DSG_TNW2=1 (A/B): 128-column workgroups for the LayerNorm GEMMs of the 16 x 16 tile kernels at K >= 384
-    bool force_attn_ph = false;          // DSG_ATTN_PH=1: the per-head attention + partial out_proj kernel (k_attn_ph) in the LATENCY set at
-                                         // every width it is instantiated for (default: latent_dim > 256 only) -- A/B runs, emulator tests
     int* st_tmodel = nullptr; float* st_c[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int st_cap = 0, n_run = 1;
     bool st_valid = false; int st_mode = -1, st_skip = -1; float st_eta = 0.f;      // what the device tables hold
@@ -348,8 +345,6 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
         }
     }
     if (const char* e = getenv("DSG_FUSE_ATTN_MID")) h->fuse_attn_mid = atoi(e) != 0;
-    if (const char* e = getenv("DSG_ATTN_PH")) h->force_attn_ph = atoi(e) != 0;
-    if (const char* e = getenv("DSG_TNW2")) h->tnw2 = atoi(e) != 0;
     *out = h;
 
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -373,8 +368,7 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     CHK(dalloc(h, &h->xs32, (size_t)B * h->T * h->Jp + 16 * h->Jp));
     if (h->prec == DSG_PREC_BF16) CHK(dalloc_bytes(h, &h->xsA, ((size_t)Min_pad * h->Jp) * h->es));
     h->alloc_uc = true;                  // ---- written AND read inside one step by the kernels of the loop
-    // (k_attn_ph reuses it between the first kernel of a step and the pose head: 4 per-head partial out_proj slabs of M_pad rows)
-    CHK(dalloc(h, &h->partial, std::max((size_t)h->KSin * Min_pad, (size_t)4 * M_pad) * D));
+    CHK(dalloc(h, &h->partial, (size_t)h->KSin * Min_pad * D));
     CHK(dalloc(h, &h->X0, M_pad * D));
     CHK(dalloc_bytes(h, &h->X0a, M_pad * D * h->es));
     CHK(dalloc(h, &h->pre1, M_pad * D));
@@ -791,12 +785,7 @@ struct KernelSel {
     bool stream = false;        // STREAM: BLOCK with the weight-stationary persistent GEMMs of dsg_stream.h (LayerNorm + QKV, linear1, linear2, pose head)
     bool xs_frag = false;       // BLOCK / STREAM (bf16, Jp 128 / 1152): the state shadow is fragment-major and the pose embedding streams it (k_ws2<EPI_PARTIAL>:
                                 // 8.9 -> 4.3 us at 1424 rows, 29.9 -> 11.0 at 5632; 3.8 -> 4.1 at 356)
-    bool attn_ph = false;       // LATENCY at the DSG+ widths: k_attn_ph (per-head attention + partial out_proj) + linear1 with the PRO_LN4 prologue
-                                // instead of k_attn + k_mid (dsg_fused.h)
 };
-static bool have_attn_ph(const dsg_handle* h) {
-    return h->H == 4 && ((h->D == 384 && h->Tp == 160) || (h->D == 512 && h->Tp == 160) || (h->D == 256 && h->Tp == 96) || (h->D == 128 && h->Tp == 32));
-}
 static bool have_attn_mid(const dsg_handle* h, int B) {
     return B == 1 && h->H == 4 && ((h->D == 256 && h->Tp == 96) || (h->D == 128 && h->Tp == 32));
 }
@@ -806,9 +795,11 @@ static bool have_attn_op(const dsg_handle* h) {
 }
 static bool latency_set_ok(const dsg_handle* h) {
     // k_mid pulls all of W_o (2 D^2 bytes) through every CU: at D = 512 the un-fused sets win (TWH: 219 vs 238 us)
-    // (round 4: at the DSG+ widths the set runs k_attn_ph instead -- a quarter of W_o per workgroup, 4 x the workgroups)
+    // and at D = 384 with the K = D GEMMs in one fragment batch (round 4): BEAT 163.9 (TILE) vs 175-179 us (LATENCY) at batch 1
+    // (profiles/r04_b_timeline_beat_tile_ch12.json, r04_a_timeline_beat_latency.json).  An explicit dsg_set_kernel_set(LATENCY) still
+    // runs k_mid at every width <= 512.
     const int dt = h->D / 64;
-    return (h->D <= 384 && (dt == 1 || dt == 2 || dt == 4 || dt == 6)) || have_attn_ph(h);
+    return h->D <= 256 && (dt == 1 || dt == 2 || dt == 4);
 }
 static bool stream_set_ok(const dsg_handle* h) {
     // k_ws keeps 64 columns x K = D of W per wave in registers (D = 128 / 256), k_ws2 a quarter of K = ff (ff = 128 / 1024);
@@ -838,8 +829,7 @@ static int select_kernels(const dsg_handle* h, int B, KernelSel& k) {
     k = KernelSel();
     k.set = set;
     k.lat = set == DSG_KSET_LATENCY;
-    k.attn_ph = k.lat && have_attn_ph(h) && (h->D > 256 || h->force_attn_ph);
-    k.attn_in_mid = k.lat && !k.attn_ph && h->fuse_attn_mid && have_attn_mid(h, B);
+    k.attn_in_mid = k.lat && h->fuse_attn_mid && have_attn_mid(h, B);
     k.stream = set == DSG_KSET_STREAM;
     k.blk = set == DSG_KSET_BLOCK || k.stream;      // (STREAM: pose embedding and layer-0 QKV as in BLOCK)
     k.attn_op = !k.lat && have_attn_op(h);
@@ -935,16 +925,6 @@ static int launch_gemm(dsg_handle* h, GemmArgs g) {
     g.inv_ntok = fastdiv_inv(g.ntok); g.inv_hd = fastdiv_inv(g.hd);
     const dim3 grid(xcd_grid_x(NG), g.MT + extra, g.KS);
     // one batch of fragment loads per wave wherever the wave's k range allows it (gemm_body: CH)
-    if constexpr (PRO == PRO_LN && WN == 4 && WK == 1) {
-        // LayerNorm-on-read GEMMs at the DSG+ widths: 128 columns per workgroup (2 tiles per wave) -- every column group re-reads and
-        // re-normalises its 16 fp32 rows from uncached memory (18 / 16 / 34 groups x 10 row tiles x 24-32 KB), which is what bounds them
-        if (h->tnw2 && g.NT % 8 == 0) {
-            const dim3 grid2(xcd_grid_x(g.NT / 8), g.MT + extra, 1);
-            const int ch = pick_ch(g.KBtot);
-            if (ch == 16) return step_launch<&k_gemm<P, PRO, EPI, WN, WK, 2, 16>>(h, grid2, dim3(256), g);
-            if (ch == 12) return step_launch<&k_gemm<P, PRO, EPI, WN, WK, 2, 12>>(h, grid2, dim3(256), g);
-        }
-    }
     if constexpr (EPI != EPI_PARTIAL) {
         const int ch = pick_ch(std::min(g.kb_per_split, g.KBtot) / WK);
         if (ch == 16) return step_launch<&k_gemm<P, PRO, EPI, WN, WK, 1, 16>>(h, grid, dim3(256), g);
@@ -1196,39 +1176,14 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                 CHK((launch_gemm_w<P, PRO_LN, EPI_QKV>(h, g, ks)));
             }
         }
-        if (ks.attn_ph) {      // per-head attention + partial out_proj; LayerNorm1 (of residual + b_o + the 4 partials) + linear1 + GELU
-            {
-                AttnPhArgs a;
-                a.q = h->q; a.k = h->k; a.vt = h->vt; a.Wo = ly.Wo; a.part = h->partial; a.part_stride = (long long)MT * 16 * D;
-                a.B = B; a.H = h->H; a.ntok = ntok; a.Tp = h->Tp; a.D = D;
-                const dim3 grid(cdiv(ntok, 16), h->H, B);
-                if (D == 384) CHK((step_launch<&k_attn_ph<P, 96, 10, 6>>(h, grid, dim3(256), a)));
-                else if (D == 512) CHK((step_launch<&k_attn_ph<P, 128, 10, 8>>(h, grid, dim3(256), a)));
-                else if (D == 256) CHK((step_launch<&k_attn_ph<P, 64, 6, 4>>(h, grid, dim3(256), a)));
-                else CHK((step_launch<&k_attn_ph<P, 32, 2, 2>>(h, grid, dim3(256), a)));
-            }
-            {
-                GemmArgs g = z;
-                g.M = M; g.MT = MT; g.NT = h->ff / 16; g.KBtot = D / KB; g.Wp = ly.W1; g.bias = ly.b1;
-                g.X = l == 0 ? h->X0 : h->Xn; g.Xp = h->partial; g.xp_stride = (long long)MT * 16 * D; g.xp_bias = ly.bo;
-                g.ln_g = ly.g1; g.ln_b = ly.be1; g.Xn = h->X1; g.out = h->hidden; g.ldo = h->ff; g.out_frag = 1;
-                g.KS = 1; g.kb_per_split = g.KBtot; g.inv_ntok = fastdiv_inv(g.ntok); g.inv_hd = fastdiv_inv(g.hd);
-                if (g.NT % 4) return fail(DSG_E_INVALID, "gemm: NT not divisible by the workgroup tile");
-                const dim3 grid(xcd_grid_x(g.NT / 4), g.MT, 1);
-                const int ch = pick_ch(g.KBtot);
-                if (ch == 16) CHK((step_launch<&k_gemm_ln4<P, 16>>(h, grid, dim3(256), g)));
-                else if (ch == 12) CHK((step_launch<&k_gemm_ln4<P, 12>>(h, grid, dim3(256), g)));
-                else CHK((step_launch<&k_gemm_ln4<P, 8>>(h, grid, dim3(256), g)));
-            }
-        } else if (!ks.attn_in_mid && !ks.attn_op) {   // attention
+        if (!ks.attn_in_mid && !ks.attn_op) {   // attention
             AttnArgs a;
             memset(&a, 0, sizeof(a));
             a.q = h->q; a.k = h->k; a.vt = h->vt; a.out = h->attn; a.B = B; a.H = h->H; a.ntok = ntok; a.Tp = h->Tp;
             a.D = D;
             CHK(launch_attn<P>(h, a));
         }
-        if (ks.attn_ph) {
-        } else if (ks.lat) {      // [attention +] out_proj + residual + LayerNorm1 + linear1 slice + GELU
+        if (ks.lat) {      // [attention +] out_proj + residual + LayerNorm1 + linear1 slice + GELU
             MidArgs a;
             memset(&a, 0, sizeof(a));
             a.A = h->attn; a.R = l == 0 ? h->X0 : h->Xn; a.Wo = ly.Wo; a.bo = ly.bo; a.ln_g = ly.g1; a.ln_b = ly.be1;
@@ -1754,7 +1709,7 @@ static int sample_run_hip(dsg_handle* h, const dsg_sample_args* a, SampleJob& jo
     if (spg > 0 && n_run >= spg && job.done == 0) {
         // everything that varies between calls (step index, coefficients, noise key, conditioning) lives in device
         // memory, so one captured graph per (batch, sampler, mask batch, const_noise, steps, flags, kernel set) serves every window and clip
-        dsg_handle::GKey key = {c.B, c.out_mode, h->mb, c.const_noise, n_run, (c.clip_x0 ? 1 : 0) | (h->cfgB ? 2 : 0) | (h->nomask ? 4 : 0) | (c.ks.attn_in_mid ? 8 : 0) | (c.no_noise ? 16 : 0) | (c.ks.attn_ph ? 32 : 0),
+        dsg_handle::GKey key = {c.B, c.out_mode, h->mb, c.const_noise, n_run, (c.clip_x0 ? 1 : 0) | (h->cfgB ? 2 : 0) | (h->nomask ? 4 : 0) | (c.ks.attn_in_mid ? 8 : 0) | (c.no_noise ? 16 : 0),
                                 c.ks.set};
         auto it = h->graphs.find(key);
         bool ok = true;

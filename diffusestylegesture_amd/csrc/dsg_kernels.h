@@ -291,7 +291,7 @@ __global__ void k_ctl_init(StepCtl* c, const int* tmodel) {
 // ---------------------------------------------------------------------------------------------------------
 // GEMM  (skinny-M, weight-stationary-per-XCD):  Out[m][n] = sum_k Act[m][k] * W[n][k]  (+ epilogue)
 // ---------------------------------------------------------------------------------------------------------
-enum { PRO_DIRECT = 0, PRO_LN = 1, PRO_LN4 = 2 };      // PRO_LN4: LayerNorm of (R + bias + 4 partial slabs), see k_attn_ph
+enum { PRO_DIRECT = 0, PRO_LN = 1 };
 enum { EPI_PARTIAL = 0, EPI_QKV = 1, EPI_RESID = 2, EPI_GELU = 3, EPI_OUT = 4 };
 enum { OUT_FORWARD = 0, OUT_DDPM = 1, OUT_DDIM = 2 };
 
@@ -351,9 +351,6 @@ struct GemmArgs {
                             // embedding streams it like every other operand (k_ws2<EPI_PARTIAL>)
     int no_noise;           // EPI_OUT: the sampler adds no noise at any step of this call (DDIM with eta = 0: sigma = 0,
                             // gaussian_diffusion.py:782-791) -- the Philox draw is skipped, x_{t-1} = mean + 0 z bit for bit
-    // PRO_LN4 (linear1 behind k_attn_ph): the rows to normalise are X (the residual) + xp_bias + the 4 per-head partial out_proj
-    // slabs Xp[h * xp_stride + row * D + col]
-    const float* Xp; long long xp_stride; const float* xp_bias;
 };
 
 // Workgroup -> n-group with the n-group pinned to an XCD (workgroups are dealt round-robin to the 8 XCDs in linear
@@ -445,7 +442,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // profiles/r01_k_pmc_sq_b1_b16.log: 2 waves per SIMD at ~200 VGPRs -> 2.8 rounds of workgroups at batch 16), so scale /
 // shift are fetched chunk by chunk after the statistics instead of being held for the whole row, and the normalised rows
 // are written back at once (`xn_out`) instead of staying live across the MFMA phase.
-template <class P, int NCH, bool LEAN = false, int NPART = 0>
+template <class P, int NCH, bool LEAN = false>
 __device__ __forceinline__ void ln_rows(const GemmArgs& g, int m0, int tid, char* lds_a, int pitch, f32x4 (&v)[8], float* xn_out = nullptr) {
     typedef typename P::elem elem;
     constexpr int N = NCH > 0 ? NCH : 8;
@@ -454,30 +451,17 @@ __device__ __forceinline__ void ln_rows(const GemmArgs& g, int m0, int tid, char
     const size_t xr = (size_t)(m0 + row) * D;        // element offset of the row in g.X
     const int nch = NCH > 0 ? NCH : (D >> 6);
     f32x4 gg[LEAN ? 1 : N], bb[LEAN ? 1 : N];
-    f32x4 vp[NPART > 0 ? N : 1][NPART > 0 ? NPART + 1 : 1];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const int col = c * 4 + 64 * (i < nch ? i : 0);
         v[i] = lda16<P>(g.X, (xr + col) * sizeof(float));
-        if constexpr (NPART > 0) {
-            vp[i][NPART] = *(const f32x4*)(g.xp_bias + col);
-#pragma unroll
-            for (int p = 0; p < NPART; ++p) vp[i][p] = lda16<P>(g.Xp, ((size_t)p * g.xp_stride + xr + col) * sizeof(float));
-        }
         if constexpr (!LEAN) {
             gg[i] = *(const f32x4*)(g.ln_g + col);
             bb[i] = *(const f32x4*)(g.ln_b + col);
         }
     }
     DSG_LOADS_ISSUED();
-    if constexpr (NPART > 0) {       // pre1 = (R + b_o) + head 0 + head 1 + ... in a fixed order
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            v[i] = v[i] + vp[i][NPART];
-#pragma unroll
-            for (int p = 0; p < NPART; ++p) v[i] = v[i] + vp[i][p];
-        }
-    }
+
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -668,9 +652,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
     typedef typename P::elem elem;
     static_assert(WN * WK == 4, "4 waves");
     constexpr int ES = (int)sizeof(elem);
-    constexpr bool IS_LN = PRO == PRO_LN || PRO == PRO_LN4;
-    constexpr int NPART = PRO == PRO_LN4 ? 4 : 0;
-    static_assert(PRO != PRO_LN4 || LEAN, "the partial-slab prologue uses the lean LayerNorm (scale / shift fetched after the statistics)");
+    constexpr bool IS_LN = PRO == PRO_LN;
     __shared__ __attribute__((aligned(16))) char lds_a[IS_LN ? 16 * (512 * ES + 16) : 16];     // 16 rows of up to 512 elements
     __shared__ __attribute__((aligned(16))) float lds_red[WK > 1 ? (WK - 1) * WN * TNW * 64 * 4 : 4];
 
@@ -768,10 +750,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
         const int nch = g.D >> 6;                     // D / 64 float4 chunks per thread; one straight-line copy per width
         if constexpr (LEAN) {
             float* xn_out = wr ? g.Xn + (size_t)(mp + (tid >> 4)) * g.D : nullptr;
-            if (nch == 4) ln_rows<P, 4, true, NPART>(g, mp, tid, lds_a, pitch, v, xn_out);
-            else if (nch == 6) ln_rows<P, 6, true, NPART>(g, mp, tid, lds_a, pitch, v, xn_out);
-            else if (nch == 8) ln_rows<P, 8, true, NPART>(g, mp, tid, lds_a, pitch, v, xn_out);
-            else ln_rows<P, 0, true, NPART>(g, mp, tid, lds_a, pitch, v, xn_out);
+            if (nch == 4) ln_rows<P, 4, true>(g, mp, tid, lds_a, pitch, v, xn_out);
+            else if (nch == 6) ln_rows<P, 6, true>(g, mp, tid, lds_a, pitch, v, xn_out);
+            else if (nch == 8) ln_rows<P, 8, true>(g, mp, tid, lds_a, pitch, v, xn_out);
+            else ln_rows<P, 0, true>(g, mp, tid, lds_a, pitch, v, xn_out);
             wr = false;                               // already written
         } else {
             if (nch == 4) ln_rows<P, 4>(g, mp, tid, lds_a, pitch, v);
@@ -855,9 +837,7 @@ __global__ __launch_bounds__(256) void k_gemm_cfg(const GemmArgs g) { DSG_TL_SCO
 
 template <class P, int PRO, int EPI, int WN, int WK, int TNW, int CH = 8>
 __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) { DSG_TL_SCOPE(); gemm_body<P, PRO, EPI, WN, WK, TNW, false, false, CH>(g); }
-// linear1 behind k_attn_ph: LayerNorm1 of (residual + b_o + the 4 per-head partial out_proj slabs) on read, + GELU
-template <class P, int CH = 8>
-__global__ __launch_bounds__(256) void k_gemm_ln4(const GemmArgs g) { DSG_TL_SCOPE(); gemm_body<P, PRO_LN4, EPI_GELU, 4, 1, 1, true, false, CH>(g); }
+
 // ---------------------------------------------------------------------------------------------------------
 // k_loc: per (batch, window, local head).  h = sum_s partial_s + Cframe + TE2[t]; rotary(pos = frame);
 //        causal local attention over {previous window, own window} with q = k = v; prepend token; rotary(pos+1)

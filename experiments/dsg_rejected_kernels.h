@@ -15,7 +15,7 @@
 //   overlapped launches (DepWait, k_mid<OVL>, DSG_OVERLAP): 158 vs 144 us/step (round 1)
 //   dsg_stream_ln.h (this directory): the weight-stationary GEMM with LayerNorm-on-read, round 3
 #pragma once
-#include "../dsg_batched.h"
+#include "dsg_batched.h"
 
 namespace dsg {
 

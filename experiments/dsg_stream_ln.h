@@ -13,7 +13,7 @@
 // flight instead.  What would fix it is LayerNorm delivered by the PRODUCER (bf16 rows + row statistics out of linear2), so that
 // these GEMMs take the global -> LDS path of k_ws as well; see DESIGN.md s5 "Next".
 #pragma once
-#include "../dsg_stream.h"
+#include "dsg_stream.h"
 #include <type_traits>
 
 namespace dsg {

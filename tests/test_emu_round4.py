@@ -1,6 +1,6 @@
-"""CPU (emulator): round-4 kernels -- the per-head attention + partial out_proj kernel of the LATENCY set at the DSG+ widths
-(k_attn_ph + the PRO_LN4 prologue of linear1), the fragment batches of the K = 384 / 512 GEMMs, the STREAM set with more than one
-row block per workgroup at latent_dim 128 (round-3 advisor: LDS staging overflow), kernel-set restore after a multi-lane call."""
+"""CPU (emulator): round 4 -- the STREAM set with more than one row block per workgroup at latent_dim 128 (round-3 advisor: LDS
+staging overflow), kernel-set restore after a multi-lane call, the DSG+ multi-lane clip loop, the fragment batches of the
+K = 384 GEMMs (TINY3B)."""
 import os
 
 import numpy as np
@@ -19,48 +19,66 @@ def _g(golden_dir, name):
     return np.load(os.path.join(golden_dir, name))
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
-def test_attn_ph_tiny_vs_goldens(emu_lib, golden_dir, prec, monkeypatch):
-    """DSG_ATTN_PH=1 puts k_attn_ph (keys split over the 4 waves, flash-style merge, per-head partial out_proj slabs) + k_gemm_ln4
-    into the LATENCY set at the tiny dims too: forward with masks at batch 2 (row tiles straddling batch elements, ragged last
-    tile) and a 10-step chain against the goldens of the imported reference."""
+def test_stream_set_more_than_one_block_per_workgroup_tiny(emu_lib, golden_dir):
+    """Round-3 advisor (medium): k_ws<EPI, 8> (latent_dim 128) staged its V^T / pose-head tiles in a 16 KB activation buffer that
+    is too small for them (17 408 / 18 432 B) -- silent corruption as soon as a persistent workgroup owns a SECOND row block
+    (row blocks > ws_G = 168: batch >= 468 at the tiny dims, where `auto` picks STREAM).  Within a set a row's result does not
+    depend on the batch it rides in, so the first and last clips of a batch of 480 must equal the same clips sampled four at a
+    time, bit for bit."""
     gt = _g(golden_dir, "gt_tiny_zeggs.npz")
-    sd = synth_state_dict(C.TINY, int(gt["wseed"]))
-    y = synth_window_inputs(C.TINY, 2, window=2, seed_pose_scale=0.3)
-    x = np.random.RandomState(99).randn(2, C.TINY.njoints, 1, C.TINY.n_poses).astype(np.float32)
-    monkeypatch.setenv("DSG_ATTN_PH", "1")
-    m = DSGDenoiser(C.TINY, precision=prec, max_batch=2, library=emu_lib).set_kernel_set("latency")
-    m.load_state_dict(sd)
-    ts = np.array([998, 17])
-    assert rel_l2(m(x, ts, y), gt["fwd_allones"]) < TOL[prec]
-    assert rel_l2(m(x, ts, dict(y, mask_local=gt["mask2"])), gt["fwd_mask2"]) < TOL[prec]
-    assert m.last_kernel_set() == "latency"
+    cfg = C.TINY
+    sd = synth_state_dict(cfg, int(gt["wseed"]))
+    B = 480
+    yb = synth_window_inputs(cfg, B, window=1, seed_pose_scale=0.3)
+    xb = np.random.RandomState(5).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+    ts = (np.arange(B) * 2 + 3) % 1000
+    big = DSGDenoiser(cfg, precision="bf16", max_batch=B, library=emu_lib)          # auto
+    big.load_state_dict(sd)
+    out = np.asarray(big(xb, ts, yb))
+    assert big.last_kernel_set() == "stream" and np.isfinite(out).all()
+    small = DSGDenoiser(cfg, precision="bf16", max_batch=4, library=emu_lib).set_kernel_set("stream")
+    small.load_state_dict(sd)
+    for lo in (0, 236, B - 4):
+        ys = {k: (v[lo:lo + 4] if v.shape[0] == B else v) for k, v in yb.items()}
+        want = np.asarray(small(xb[lo:lo + 4], ts[lo:lo + 4], ys))
+        assert np.array_equal(out[lo:lo + 4], want), lo
+
+
+def test_multi_lane_call_restores_the_lanes_kernel_sets(emu_lib, golden_dir):
+    """Round-3 advisor: generate_clips_streams applies the set recommended for (lanes x batch) to every lane -- sticky -- and used
+    to leave it there: the caller's own model (lanes[0]) then no longer ran `auto`.  The sets in force are put back on exit."""
+    from diffusestylegesture_amd.sample import generate_clips_streams
+    cfg = C.TINY
+    m = DSGDenoiser(cfg, precision="fp32", max_batch=2, library=emu_lib)
+    m.load_state_dict(synth_state_dict(cfg, 20240))
+    lanes = [m, m.clone().set_kernel_set("block")]
     d = create_gaussian_diffusion(library=emu_lib)
-    s = d.manual_seed(77, 3).p_sample_loop(m, (2, C.TINY.njoints, 1, C.TINY.n_poses), clip_denoised=False, model_kwargs={"y": y},
-                                           skip_timesteps=990)
-    assert rel_l2(s, gt["ddpm_skip990"]) < TOL[prec] * (3 if prec == "fp32" else 1)
-    # batch 1 as well (the set's home): the same rows as the batch-2 call's first element
-    monkeypatch.setenv("DSG_ATTN_PH", "0")
-    m1 = DSGDenoiser(C.TINY, precision=prec, max_batch=1, library=emu_lib).set_kernel_set("latency")
-    m1.load_state_dict(sd)
-    y1 = {k: (v[:1] if v.shape[0] == 2 else v) for k, v in y.items()}
-    assert rel_l2(m1(x[:1], ts[:1], y1), gt["fwd_allones"][:1]) < TOL[prec]
+    feats = [[synth_window_inputs(cfg, 2, window=w, clip0=2 * ln)["audio"] for w in range(2)] for ln in range(2)]
+    generate_clips_streams(lanes, d, feats, [1, 0, 0, 0, 0, 0], seed=5, skip_timesteps=997)
+    assert lanes[0].last_kernel_set() == lanes[0].recommend_kernel_set(2, 2) == "tile"       # what ran
+    assert lanes[0].kernel_set() == "auto" and lanes[1].kernel_set() == "block"            # what is in force again
 
 
-@pytest.mark.parametrize("cfgname", ["beat", "twh"])
-def test_attn_ph_dsgplus_dims_vs_golden(emu_lib, golden_dir, cfgname):
-    """The DSG+ widths (hd 96 / 128, 151 tokens: 10 key tiles over 4 waves = 3 / 3 / 2 / 2 PV k-blocks in fp32, 2 / 1 / 1 / 1 in bf16;
-    12 / 16 k-blocks per K = D GEMM in one fragment batch) against G5, in the set `auto` now picks for batch 1 there."""
-    g5 = _g(golden_dir, "g5_forward_dsgplus.npz")
-    cfg = C.CONFIGS[cfgname]
-    sd = synth_state_dict(cfg, int(g5["wseed"]))
-    B, sps, rs, ts = g5[cfgname + "_meta"]
-    B, rs, ts = int(B), int(rs), int(ts)
-    y = synth_window_inputs(cfg, B, window=3, seed_pose_scale=float(sps))
-    x = np.random.RandomState(rs).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+@pytest.mark.parametrize("cfg", [C.TINY4, C.TINY5], ids=lambda c: c.name)
+def test_dsgplus_lanes_equal_single_lane_clips(emu_lib, cfg):
+    """generate_clips_streams_dsgplus (DSG+ window loop on sampling lanes; bench.py --config beat --clips-per-gpu 16): lane i of a
+    2-lane call reproduces generate_clip_dsgplus on the same lane with the same Philox stream, bit for bit (fp32 and bf16)."""
+    from diffusestylegesture_amd.sample import generate_clip_dsgplus, generate_clips_streams_dsgplus
+    sd = synth_state_dict(cfg, 20240)
+    K, B, frames = 3, 2, 60
     for prec in ("fp32", "bf16"):
-        m = DSGDenoiser(cfg, precision=prec, max_batch=B, library=emu_lib)
+        m = DSGDenoiser(cfg, precision=prec, max_batch=B, library=emu_lib).set_kernel_set("tile")
         m.load_state_dict(sd)
-        out = m(x, np.array([ts] * B), y)
-        assert m.last_kernel_set() == "latency"
-        assert rel_l2(out, g5[cfgname + "_out"]) < TOL[prec], (cfgname, prec)
+        lanes = [m, m.clone()]
+        d = create_gaussian_diffusion(library=emu_lib)
+        ins = [[synth_window_inputs(cfg, B, window=w, clips=[10 * ln, 10 * ln + 1], seed_pose_scale=0.2) for w in range(K)] for ln in range(2)]
+        feats = [[y["audio"] if cfg.variant != 5 else np.concatenate([y["audio"], y["audio"][:, :cfg.n_seed]], 1) for y in il] for il in ins]
+        seed0s = [il[0]["seed"] for il in ins]
+        lasts = [il[0]["seed_last"] for il in ins] if cfg.variant == 5 else None
+        got = generate_clips_streams_dsgplus(lanes, d, feats, [1, 0, 0], seed0s, frames, seed=9, skip_timesteps=996, stream_ids=[4, 7],
+                                             seed_lasts=lasts, kernel_set=None)
+        assert got.shape == (2 * B, frames, cfg.njoints // 3)
+        for ln in range(2):
+            want = generate_clip_dsgplus(lanes[ln], d, feats[ln], [1, 0, 0], seed0s[ln], frames, seed=9, skip_timesteps=996, stream_id=[4, 7][ln],
+                                         seed_last=None if lasts is None else lasts[ln])
+            assert np.array_equal(got[ln * B:(ln + 1) * B], want), (prec, ln)
