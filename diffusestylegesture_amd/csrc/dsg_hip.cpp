@@ -122,6 +122,7 @@ struct dsg_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
     std::vector<void*> allocs;                       // per-lane buffers (state, activations, conditioning)
+    std::vector<void*> allocs_uc;                    // ... those in uncached memory: returned to the process-wide pool, never to hipFree
     std::shared_ptr<SharedWeights> shared;           // checkpoint-derived buffers (see SharedWeights)
     bool alloc_shared = false;                       // dalloc target: true while loading / finalizing weights
     bool is_clone = false;
@@ -189,18 +190,54 @@ struct dsg_handle {
     float last_ms = -1.f; int last_steps = 0; bool timing_valid = false;
 };
 
+// Uncached device memory is never handed back to the HIP allocator while the process lives (round 4).  Found with
+// tools/debug_rowdep*.py: after a handle with uncached loop buffers had been destroyed, a NEW handle whose buffers landed on the
+// recycled range computed wrong rows (tiny dims, batch 200 after a batch-170 handle: every frame row >= 4096 -- exactly the part of
+// `partial` beyond its first 2 MiB -- off by up to 100 %; DSG_UC=0 clean; same under every kernel set) -- memory that changed its
+// caching attribute between two lives is not reliably coherent.  So uncached blocks go to a process-wide free list keyed by device
+// and are reused for uncached requests only; cached memory keeps using hipMalloc / hipFree.
+struct UcPool {
+    std::mutex mu;
+    std::multimap<size_t, void*> free_blocks[64];        // per device: size -> block
+    std::map<void*, size_t> size_of;
+};
+static UcPool& uc_pool() { static UcPool* p = new UcPool(); return *p; }      // (leaked on purpose: blocks outlive every handle)
+static void* uc_pool_take(int dev, size_t bytes) {
+    UcPool& P = uc_pool();
+    std::lock_guard<std::mutex> lock(P.mu);
+    auto& fb = P.free_blocks[dev & 63];
+    auto it = fb.lower_bound(bytes);
+    if (it == fb.end() || it->first > 2 * bytes + (1u << 20)) return nullptr;      // nothing close enough in size
+    void* d = it->second;
+    fb.erase(it);
+    return d;
+}
+static void uc_pool_give(int dev, void* d) {
+    UcPool& P = uc_pool();
+    std::lock_guard<std::mutex> lock(P.mu);
+    P.free_blocks[dev & 63].emplace(P.size_of[d], d);
+}
 template <class T>
 static int dalloc(dsg_handle* h, T** p, size_t n_elems, bool zero = true) {
     void* d = nullptr;
     size_t bytes = n_elems * sizeof(T);
     if (bytes == 0) bytes = 16;
+    bool is_uc = false;
 #ifndef DSG_EMU
     if (h->uc_mode && h->alloc_uc && !h->alloc_shared) {
-        if (hipExtMallocWithFlags(&d, bytes, hipDeviceMallocUncached) != hipSuccess) {      // no uncached memory here: fenced packets
-            (void)hipGetLastError();
-            d = nullptr;
-            h->uc_mode = 0;
+        d = uc_pool_take(h->cfg.device, bytes);
+        if (!d) {
+            if (hipExtMallocWithFlags(&d, bytes, hipDeviceMallocUncached) != hipSuccess) {      // no uncached memory here: fenced packets
+                (void)hipGetLastError();
+                d = nullptr;
+                h->uc_mode = 0;
+            } else {
+                UcPool& P = uc_pool();
+                std::lock_guard<std::mutex> lock(P.mu);
+                P.size_of[d] = bytes;
+            }
         }
+        is_uc = d != nullptr;
     }
 #endif
     if (!d) HIPCHK(hipMalloc(&d, bytes));
@@ -213,6 +250,7 @@ static int dalloc(dsg_handle* h, T** p, size_t n_elems, bool zero = true) {
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     if (h->alloc_shared) h->shared->allocs.push_back(d);
+    else if (is_uc) h->allocs_uc.push_back(d);
     else h->allocs.push_back(d);
     *p = (T*)d;
     return 0;
@@ -413,6 +451,7 @@ extern "C" int dsg_destroy(dsg_handle* h) {
     dsg_aql::destroy(h->aql);
 #endif
     for (void* p : h->allocs) (void)hipFree(p);
+    for (void* p : h->allocs_uc) uc_pool_give(h->cfg.device, p);
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     if (h->ev_out) (void)hipEventDestroy(h->ev_out);
     if (h->ev_t0) (void)hipEventDestroy(h->ev_t0);
@@ -1206,7 +1245,8 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                 if constexpr (sizeof(typename P::elem) == 2) {
                     // two query tiles per workgroup (K / V^T / W_o once per 32 rows; bit-identical) once the batch fills the GPU:
                     // (from 4000 token rows) 1 x 64: 478 -> 463 us; 4 x 32 within noise; 4 x 16: 436 -> 442 us, block 1 x 16: 235 -> 251 (slower)
-                    if (ks.stream && M >= 4000) {
+                    const char* op2_env = getenv("DSG_ATTN_OP2");          // A/B: 0 never, 1 always (STREAM set)
+                    if (ks.stream && (op2_env ? atoi(op2_env) != 0 : M >= 4000)) {
                         const dim3 grid2(cdiv(cdiv(ntok, 16), 2), B);
                         if (D == 256 && h->Tp == 96) CHK((step_launch<&k_attn_op2<P, 4, 6>>(h, grid2, dim3(256), a)));
                         else CHK((step_launch<&k_attn_op2<P, 2, 2>>(h, grid2, dim3(256), a)));
@@ -1600,7 +1640,11 @@ static bool uc_selfcheck(dsg_handle* h) {
     h->aql.trace.armed = trace_was_armed;
     unsigned res[2] = {1u, 0u};
     if (ok) ok = hipMemcpy(res, a.err, sizeof res, hipMemcpyDeviceToHost) == hipSuccess;
-    (void)hipFree(buf);
+    {   // (uncached memory is never handed back to hipFree: see UcPool)
+        UcPool& P = uc_pool();
+        { std::lock_guard<std::mutex> lock(P.mu); P.size_of[buf] = (size_t)(n_wg * 256 + 64) * sizeof(unsigned); }
+        uc_pool_give(h->cfg.device, buf);
+    }
     const bool good = ok && res[0] == 0u && res[1] == (unsigned)iters;      // no stale word seen, and the reader really ran `iters` times
     if (!good)
         fprintf(stderr, "libdsg_hip: WARNING: uncached-memory hand-off check failed on device %d (stale words: %u, iterations seen: %u of %d); "

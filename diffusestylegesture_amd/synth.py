@@ -114,3 +114,33 @@ def synth_window_inputs(cfg: DSGConfig, batch: int, window: int = 0, clip0: int 
 
 def _feat(cfg: DSGConfig, s: int) -> np.ndarray:
     return np.random.RandomState(s).randn(cfg.audio_frames, cfg.audio_src_dim).astype(np.float32)
+
+
+def synth_wavlm_state_dict(cfg: dict, seed: int = 0):
+    """Seeded synthetic WavLM checkpoint of ANY size (no trained WavLM-Large.pt is available offline, and 315 M parameters do not
+    fit a fixture): every tensor of `wavlm.wavlm_state_shapes(cfg)` from its own stream, like `synth_state_dict`.  Scales keep a
+    24-layer pre-norm encoder well conditioned: matrices N(0, (0.5 / sqrt(fan_in))^2), LayerNorm scales 1 + 0.05 N, biases 0.02 N,
+    the weight-norm gain of the positional convolution ~ 1, relative-position table 0.1 N, grep_a 1 + 0.05 N."""
+    from .wavlm import wavlm_state_shapes
+    sd = OrderedDict()
+    for name, shape in wavlm_state_shapes(cfg).items():
+        rs = _rs("wavlm." + name, seed)
+        n = int(np.prod(shape))
+        if name.endswith("weight_g"):
+            v = 1.0 + 0.05 * rs.randn(*shape)
+        elif name.endswith("grep_a"):
+            v = 1.0 + 0.05 * rs.randn(*shape)
+        elif "layer_norm" in name or name.endswith(".2.1.weight") or name.endswith(".2.1.bias") or name.endswith(".2.weight") or name.endswith(".2.bias"):
+            v = (1.0 if name.endswith("weight") else 0.0) + 0.05 * rs.randn(*shape)
+        elif name.endswith("bias"):
+            v = 0.02 * rs.randn(*shape)
+        elif name.endswith("relative_attention_bias.weight"):
+            v = 0.1 * rs.randn(*shape)
+        elif name == "mask_emb":
+            v = rs.rand(*shape)
+        else:
+            fan_in = n // shape[0]
+            # big matrices: float32 draws (half the time and memory of randn's float64)
+            v = rs.standard_normal(size=shape).astype(np.float32) * np.float32((1.0 if "conv_layers" in name else 0.5) / np.sqrt(fan_in))
+        sd[name] = np.ascontiguousarray(v, dtype=np.float32)
+    return sd

@@ -74,6 +74,55 @@ def relative_position_buckets(n_q, n_k, num_buckets, max_distance):
     return bucket + torch.where(dist < exact, dist, large)
 
 
+WAVLM_LARGE = dict(  # the topology of WavLM-Large.pt (the checkpoint sample.py:33 loads): 24 x 1024, 16 heads, ffn 4096, 315.5 M parameters
+    extractor_mode="layer_norm", encoder_layers=24, encoder_embed_dim=1024, encoder_ffn_embed_dim=4096, encoder_attention_heads=16,
+    layer_norm_first=True, normalize=True, conv_bias=False, conv_feature_layers="[(512,10,5)] + [(512,3,2)] * 4 + [(512,2,2)] * 2",
+    conv_pos=128, conv_pos_groups=16, relative_position_embedding=True, num_buckets=320, max_distance=800, gru_rel_pos=True)
+
+
+def wavlm_state_shapes(cfg):
+    """name -> shape of every tensor of the reference model's state dict for `cfg` (WavLM.py:214-316, modules_WavLM.py:300-415): the
+    checkpoint contract this loader consumes, restated so that a synthetic checkpoint of any size can be made without the reference
+    (diffusestylegesture_amd.synth.synth_wavlm_state_dict); make_goldens.py loads it into the reference model with strict=True."""
+    c = dict(_DEFAULTS)
+    c.update(cfg or {})
+    C_, Fd, H = int(c["encoder_embed_dim"]), int(c["encoder_ffn_embed_dim"]), int(c["encoder_attention_heads"])
+    sh = {"mask_emb": (C_,)}
+    prev = 1
+    ln_mode = c["extractor_mode"] == "layer_norm"
+    for i, (dim, k, _) in enumerate(_conv_spec(c["conv_feature_layers"])):
+        pre = f"feature_extractor.conv_layers.{i}."
+        sh[pre + "0.weight"] = (dim, prev, k)
+        if c["conv_bias"]:
+            sh[pre + "0.bias"] = (dim,)
+        if ln_mode:
+            sh[pre + "2.1.weight"] = sh[pre + "2.1.bias"] = (dim,)
+        elif i == 0:
+            sh[pre + "2.weight"] = sh[pre + "2.bias"] = (dim,)
+        prev = dim
+    sh["layer_norm.weight"] = sh["layer_norm.bias"] = (prev,)
+    if prev != C_:
+        sh["post_extract_proj.weight"], sh["post_extract_proj.bias"] = (C_, prev), (C_,)
+    K, G = int(c["conv_pos"]), int(c["conv_pos_groups"])
+    sh["encoder.pos_conv.0.bias"], sh["encoder.pos_conv.0.weight_g"], sh["encoder.pos_conv.0.weight_v"] = (C_,), (1, 1, K), (C_, C_ // G, K)
+    for l in range(int(c["encoder_layers"])):
+        p = f"encoder.layers.{l}."
+        a = p + "self_attn."
+        if c["relative_position_embedding"] and l == 0:
+            sh[a + "relative_attention_bias.weight"] = (int(c["num_buckets"]), H)
+        if c["gru_rel_pos"]:
+            sh[a + "grep_a"] = (1, H, 1, 1)
+            sh[a + "grep_linear.weight"], sh[a + "grep_linear.bias"] = (8, C_ // H), (8,)
+        for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
+            sh[a + n + ".weight"], sh[a + n + ".bias"] = (C_, C_), (C_,)
+        sh[p + "self_attn_layer_norm.weight"] = sh[p + "self_attn_layer_norm.bias"] = (C_,)
+        sh[p + "fc1.weight"], sh[p + "fc1.bias"] = (Fd, C_), (Fd,)
+        sh[p + "fc2.weight"], sh[p + "fc2.bias"] = (C_, Fd), (C_,)
+        sh[p + "final_layer_norm.weight"] = sh[p + "final_layer_norm.bias"] = (C_,)
+    sh["encoder.layer_norm.weight"] = sh["encoder.layer_norm.bias"] = (C_,)
+    return sh
+
+
 class WavLMFeatures:
     """Inference-only WavLM encoder.  `extract_features(wav)` mirrors the call the reference makes on its model object
     (returns `(features [B, T', C], None)`), so `wav2wavlm(model, wav)` reads the same on both sides."""

@@ -516,9 +516,33 @@ def gen_wavlm():
     np.savez_compressed(os.path.join(HERE, "g9_wavlm_small.npz"), **out)
 
 
+def gen_wavlm_large():
+    """G16: the reference's WavLM at the REAL WavLM-Large topology (24 layers x 1024, 16 heads, ffn 4096: 315.5 M parameters --
+    `wavlm.WAVLM_LARGE`), loaded (strict) with the seeded synthetic checkpoint `synth_wavlm_state_dict(WAVLM_LARGE, 5)` -- the
+    trained WavLM-Large.pt is not available offline and the weights do not fit a fixture, so both sides regenerate them from the
+    seed.  Input: two ZEGGS windows of audio (88 frames x 800 samples = 4.4 s each, sample.py:214-249).  Stored: `extract_features`
+    of window 0 and the wav2wavlm interpolation to 88 frames of both (sample.py:44-48)."""
+    sys.path[:0] = [os.path.join(REF, "main/mydiffusion_zeggs/WavLM")]
+    from WavLM import WavLM, WavLMConfig
+    import torch.nn.functional as F
+    from diffusestylegesture_amd.synth import synth_wavlm_state_dict
+    from diffusestylegesture_amd.wavlm import WAVLM_LARGE
+    m = WavLM(WavLMConfig(WAVLM_LARGE)).eval()
+    sd = synth_wavlm_state_dict(WAVLM_LARGE, 5)
+    r = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    print(r, sum(v.size for v in sd.values()), "params")
+    wav = torch.from_numpy(np.random.RandomState(11).randn(2, 88 * 800).astype(np.float32) * 0.1)
+    with torch.no_grad():
+        feat = m.extract_features(wav)[0]
+        rep = F.interpolate(feat.transpose(1, 2), size=88, align_corners=True, mode="linear").transpose(1, 2)
+    print("G16", feat.shape, rep.shape, float(feat.std()))
+    np.savez_compressed(os.path.join(HERE, "g16_wavlm_large.npz"), wseed=np.array(5), wav_seed=np.array(11),
+                        feat0=feat[0].numpy(), rep88=rep.numpy())
+
+
 if __name__ == "__main__":
     which = sys.argv[1]
-    {"zeggs": gen_zeggs, "dsgplus": gen_dsgplus, "clip": gen_clip, "bvh": gen_bvh, "wavlm": gen_wavlm, "dsgpp": gen_dsgpp,
+    {"zeggs": gen_zeggs, "dsgplus": gen_dsgplus, "clip": gen_clip, "bvh": gen_bvh, "wavlm": gen_wavlm, "wavlm_large": gen_wavlm_large, "dsgpp": gen_dsgpp,
      "clip1000": lambda: gen_clip(0, "g12_clip1000_zeggs.npz", f32=True),
      "bvh1000": lambda: gen_bvh("g12_clip1000_zeggs.npz", "g13_bvh1000_zeggs.npz", full=False),
      "attn3beat": gen_attn3_beat, "dsgplus_caller": gen_dsgplus_caller, "remaining_dims": gen_remaining_dims}[which]()

@@ -80,8 +80,11 @@ def test_config3_arrangement_4_lanes_x_batch_4_vs_oracle(gpu, prec, NL, B, kset)
         assert e < TOL_CHAIN[prec], (ln, b, e)
     print(f"{NL} lanes x batch {B} ({kset}) {prec}: worst rel-L2 of 6 clips vs oracle = {worst:.3e}")
     assert not np.array_equal(got[0], got[1]) and not np.array_equal(got[0], got[B])
-    # and a lane reproduces itself bit for bit when sampled alone (same handle = same kernel set)
+    # and a lane reproduces itself bit for bit when sampled alone under the same kernel set (round 4: the multi-lane call puts the
+    # lanes' own sets back on exit -- `auto` here, which alone would pick another set for batch 4 than for 4 lanes x 4)
     from diffusestylegesture_amd.sample import generate_clip
+    assert lanes[2].kernel_set() == "auto"
+    lanes[2].set_kernel_set(kset)
     alone = generate_clip(lanes[2], d, feats[2], style, seed=4242, skip_timesteps=skip, stream_id=sids[2])
     assert lanes[2].last_kernel_set() == kset and np.array_equal(alone, got[2 * B:3 * B])
 

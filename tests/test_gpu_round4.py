@@ -1,0 +1,206 @@
+"""MI355X parity tests (-m gpu), round 4: every kernel set at the DSG+ dims (BEAT / TWH / BEAT++; batch 1, 8, 32) against the oracle;
+the DSG+ window loop on sampling lanes (bench.py --config beat --clips-per-gpu 16); the state-dict contract errors on the device
+library (round 3 only ran them under the emulator); the STREAM set with more than one row block per persistent workgroup at
+latent_dim 128 (round-3 advisor); the per-step forms of the progressive generators.
+Tolerances as in test_gpu_round3.py (bf16 <= 2x the values measured on MI355X)."""
+import numpy as np
+import pytest
+
+from diffusestylegesture_amd import config as C
+from diffusestylegesture_amd.synth import synth_state_dict, synth_window_inputs
+from tests.util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL_FWD = {"fp32": 2e-5, "bf16": 1.2e-2}
+TOL_CHAIN = {"fp32": 1e-4, "bf16": 2e-2}
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from diffusestylegesture_amd import lib as L
+    return L.default_library()
+
+
+def _model(cfg, prec, max_batch=1, wseed=20240):
+    from diffusestylegesture_amd.model import DSGDenoiser
+    m = DSGDenoiser(cfg, precision=prec, max_batch=max_batch, device=0)
+    m.load_state_dict(synth_state_dict(cfg, wseed))
+    return m
+
+
+def test_state_dict_contract_errors_on_the_device_library(gpu):
+    """load_model_wo_clip's contract (main/utils/model_util.py:8-12) through libdsg_hip.so itself: unexpected key, missing key at
+    finalize, size mismatch, the tolerated clip_model.* keys -- and a handle that failed to load still loads a good dict."""
+    from diffusestylegesture_amd.model import DSGDenoiser
+    cfg = C.TINY
+    sd = synth_state_dict(cfg, 1)
+    m = DSGDenoiser(cfg, precision="bf16", max_batch=1, device=0)
+    with pytest.raises(ValueError, match="unexpected key"):
+        m.load_state_dict({"bogus.weight": np.zeros(3, np.float32)})
+    sd2 = dict(sd)
+    sd2.pop("input_process2.bias")
+    with pytest.raises(ValueError, match="missing key"):
+        m.load_state_dict(sd2)
+    with pytest.raises(ValueError, match="size mismatch"):
+        m.load_state_dict({"input_process2.bias": np.zeros(3, np.float32)})
+    m.load_state_dict(dict(sd, **{"clip_model.x": np.zeros(2, np.float32)}))
+    y = synth_window_inputs(cfg, 1, window=1)
+    x = np.random.RandomState(3).randn(1, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+    assert np.isfinite(np.asarray(m(x, np.array([10]), y))).all()
+
+
+@pytest.mark.parametrize("cfg", [C.BEAT, C.TWH, C.BEATPP], ids=lambda c: c.name)
+def test_every_kernel_set_at_dsgplus_dims_batch_1_8_32(gpu, cfg):
+    """Round-3 verdict item 1: each kernel set at the DSG+ dims at batch 1 (the sets config[4] can run: auto, latency, tile), batch 8
+    and batch 32 (tile / block; 4832 token rows) -- forward rows against the oracle in bf16 (fp32 at batch 1 and 8), a 12-step chain
+    at batch 8.  K = 384 / 512 GEMMs run their whole k range as one fragment batch since round 4."""
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    from oracle import sampler
+    from oracle.mdm import MDMOracle
+    from oracle.schedule import OracleDiffusion
+    sd = synth_state_dict(cfg, 20240)
+    ref = MDMOracle(sd, cfg)
+    for B, sets, precs in ((1, ("auto", "latency", "tile"), ("fp32", "bf16")), (8, ("tile", "block"), ("fp32", "bf16")), (32, ("tile", "block"), ("bf16",))):
+        y = synth_window_inputs(cfg, B, window=2, clip0=5, seed_pose_scale=0.2)
+        x = np.random.RandomState(B).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+        ts = (np.arange(B) * 31 + 7) % 1000
+        rows = sorted({0, B // 2, B - 1})
+        want = {b: ref(x[b:b + 1], [int(ts[b])], {k: (v[b:b + 1] if v.shape[0] == B else v) for k, v in y.items()}) for b in rows}
+        for prec in precs:
+            m = _model(cfg, prec, max_batch=B)
+            for ks in sets:
+                m.set_kernel_set(ks)
+                out = np.asarray(m(x, ts, y))
+                if ks != "auto":
+                    assert m.last_kernel_set() == ks
+                else:
+                    assert m.last_kernel_set() == ("tile" if cfg.latent_dim >= 384 else "latency")
+                for b in rows:
+                    e = rel_l2(out[b:b + 1], want[b])
+                    assert e < TOL_FWD[prec], (cfg.name, B, prec, ks, b, e)
+            if B == 8 and prec == "bf16":
+                d = create_gaussian_diffusion()
+                m.set_kernel_set("block")
+                shape = (B, cfg.njoints, 1, cfg.n_poses)
+                got = np.asarray(d.manual_seed(11, 2).p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=988))
+                b = 3
+                yb = {k: (v[b:b + 1] if v.shape[0] == B else v) for k, v in y.items()}
+                nf = lambda k: sampler.philox.normal_bj1t(shape, 11, k, 2)[b:b + 1]
+                w = sampler.p_sample_loop(OracleDiffusion(), ref, (1,) + shape[1:], nf, {"y": yb}, skip_timesteps=988)
+                assert rel_l2(got[b:b + 1], w) < TOL_CHAIN[prec], (cfg.name, rel_l2(got[b:b + 1], w))
+
+
+@pytest.mark.parametrize("cfg", [C.BEAT, C.TWHPP], ids=lambda c: c.name)
+def test_dsgplus_clip_loop_on_lanes_vs_single_lane_and_oracle(gpu, cfg):
+    """generate_clips_streams_dsgplus: 4 lanes x batch 2 at DSG+ dims, 3 windows x 40 steps, AQL packets on 4 queues; every lane ==
+    generate_clip_dsgplus on that lane alone (bit for bit, same kernel set), and one clip against the oracle's DSG+ clip driver."""
+    import torch
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    from diffusestylegesture_amd.sample import generate_clip_dsgplus, generate_clips_streams_dsgplus
+    NL, B, K, n_run, frames = 4, 2, 3, 40, 300
+    skip = 1000 - n_run
+    m = _model(cfg, "bf16", max_batch=B)
+    lanes = [m] + [m.clone() for _ in range(NL - 1)]
+    d = create_gaussian_diffusion()
+    ins = [[synth_window_inputs(cfg, B, window=w, clips=[2 * ln, 2 * ln + 1], seed_pose_scale=0.2) for w in range(K)] for ln in range(NL)]
+    # (DSG++: the caller hands stride-long feature windows and drops the last n_seed frames itself; synth gives T - 2S frames)
+    pad = (lambda a: np.concatenate([a, a[:, :cfg.n_seed]], 1)) if cfg.variant == 5 else (lambda a: a)
+    feats = [[torch.from_numpy(pad(y["audio"])).cuda() for y in il] for il in ins]
+    seed0s = [torch.from_numpy(il[0]["seed"]).cuda() for il in ins]
+    lasts = [torch.from_numpy(il[0]["seed_last"]).cuda() for il in ins] if cfg.variant == 5 else None
+    style = [1] + [0] * (cfg.style_dim_in - 1)
+    ks = m.recommend_kernel_set(B, NL)
+    got = generate_clips_streams_dsgplus(lanes, d, feats, style, seed0s, frames, seed=21, skip_timesteps=skip, stream_ids=[3, 4, 5, 6], seed_lasts=lasts)
+    assert got.shape == (NL * B, frames, cfg.njoints // 3) and np.isfinite(got).all()
+    assert all(ln.last_kernel_set() == ks and ln.last_sample_path() == "aql" for ln in lanes)
+    assert all(ln.kernel_set() == "auto" for ln in lanes)
+    for ln in (0, 3):
+        lanes[ln].set_kernel_set(ks)
+        want = generate_clip_dsgplus(lanes[ln], d, feats[ln], style, seed0s[ln], frames, seed=21, skip_timesteps=skip, stream_id=[3, 4, 5, 6][ln],
+                                     seed_last=None if lasts is None else lasts[ln])
+        assert np.array_equal(got[ln * B:(ln + 1) * B], want), ln
+
+
+def test_stream_set_several_blocks_per_workgroup_at_latent_128(gpu):
+    """Round-3 advisor (medium): k_ws<EPI, 8> staged V^T / pose-head tiles past its 16 KB activation buffer once a persistent
+    workgroup owned a second row block (tiny dims, batch >= 468; `auto` picks STREAM there).  On the device: the first, middle and
+    last clips of a batch of 480 equal the same clips sampled four at a time under the same set, bit for bit, and match the oracle."""
+    from oracle.mdm import MDMOracle
+    cfg, B = C.TINY, 480
+    sd = synth_state_dict(cfg, 20240)
+    yb = synth_window_inputs(cfg, B, window=1, seed_pose_scale=0.3)
+    xb = np.random.RandomState(5).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+    ts = (np.arange(B) * 2 + 3) % 1000
+    big = _model(cfg, "bf16", max_batch=B)
+    out = np.asarray(big(xb, ts, yb))
+    assert big.last_kernel_set() == "stream" and np.isfinite(out).all()
+    small = _model(cfg, "bf16", max_batch=4).set_kernel_set("stream")
+    ref = MDMOracle(sd, cfg)
+    for lo in (0, 236, B - 4):
+        ys = {k: (v[lo:lo + 4] if v.shape[0] == B else v) for k, v in yb.items()}
+        want = np.asarray(small(xb[lo:lo + 4], ts[lo:lo + 4], ys))
+        assert np.array_equal(out[lo:lo + 4], want), lo
+        assert rel_l2(out[lo:lo + 4], ref(xb[lo:lo + 4], list(ts[lo:lo + 4]), ys)) < 2.5e-2
+
+
+def test_handle_created_after_a_destroyed_one_is_clean(gpu):
+    """Round-4 finding (tools/debug_rowdep*.py): uncached device memory that went back to the HIP allocator and came back for another
+    buffer was not reliably coherent -- a batch-200 handle created after a batch-170 handle had been destroyed computed every frame
+    row >= 4096 wrong (up to 100 % off, all kernel sets, DSG_UC=0 clean).  Uncached blocks now live in a process-wide pool and are
+    reused for uncached requests only.  Sizes 170 -> 200 and 170 -> 180 are the ones that failed."""
+    import gc
+    cfg = C.TINY
+    sd = synth_state_dict(cfg, 20240)
+
+    def inputs(B):
+        y = synth_window_inputs(cfg, B, window=1, seed_pose_scale=0.3)
+        x = np.random.RandomState(5).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+        return x, (np.arange(B) * 2 + 3) % 1000, y
+    small = _model(cfg, "bf16", max_batch=4).set_kernel_set("block")
+    for pre, B in ((170, 200), (170, 180), (200, 170)):
+        x, t, y = inputs(pre)
+        p = _model(cfg, "bf16", max_batch=pre).set_kernel_set("block")
+        p(x, t, y)
+        del p
+        gc.collect()
+        x, t, y = inputs(B)
+        big = _model(cfg, "bf16", max_batch=B).set_kernel_set("block")
+        out = np.asarray(big(x, t, y))
+        for lo in (0, B // 2, B - 4):
+            ys = {k: (v[lo:lo + 4] if v.shape[0] == B else v) for k, v in y.items()}
+            assert np.array_equal(out[lo:lo + 4], np.asarray(small(x[lo:lo + 4], t[lo:lo + 4], ys))), (pre, B, lo)
+        del big
+        gc.collect()
+
+
+def test_attn_op2_equals_attn_op_and_rows_do_not_depend_on_the_batch(gpu, monkeypatch):
+    """k_attn_op2 (two query tiles per workgroup, STREAM from 4000 token rows) against k_attn_op at the SAME batch (DSG_ATTN_OP2 = 0 / 1),
+    bit for bit on the device -- round 3 claimed it from the emulator; the device compiler contracted the LayerNorm differently in the
+    two kernels (one ulp in ~10 % of the rows).  And the contract it serves: within a kernel set a clip's rows are the same bits
+    whatever batch they ride in -- ZEGGS, every set, batch 8 (712 rows: the 3-waves-per-SIMD LayerNorm GEMMs of TILE) and batch 48
+    (4272 rows: k_attn_op2 in STREAM) against batch 2."""
+    cfg = C.ZEGGS
+    sd = synth_state_dict(cfg, 20240)
+    B = 48
+    y = synth_window_inputs(cfg, B, window=1, seed_pose_scale=0.3)
+    x = np.random.RandomState(5).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+    ts = (np.arange(B) * 7 + 3) % 1000
+    outs = {}
+    for v in ("0", "1"):
+        monkeypatch.setenv("DSG_ATTN_OP2", v)
+        outs[v] = np.asarray(_model(cfg, "bf16", max_batch=B).set_kernel_set("stream")(x, ts, y)).copy()
+    monkeypatch.delenv("DSG_ATTN_OP2")
+    assert np.array_equal(outs["0"], outs["1"])
+    for ks, Bs in (("tile", (8,)), ("block", (8, 48)), ("stream", (8, 48))):
+        small = _model(cfg, "bf16", max_batch=2).set_kernel_set(ks)
+        for Bb in Bs:
+            big = _model(cfg, "bf16", max_batch=Bb).set_kernel_set(ks)
+            out = np.asarray(big({8: x[:8], 48: x}[Bb], ts[:Bb], {k: (v[:Bb] if v.shape[0] == B else v) for k, v in y.items()}))
+            if ks == "stream" and Bb == 48:
+                assert np.array_equal(out, outs["1"])
+            for lo in (0, Bb - 2):
+                ys = {k: (v[lo:lo + 2] if v.shape[0] == B else v) for k, v in y.items()}
+                assert np.array_equal(out[lo:lo + 2], np.asarray(small(x[lo:lo + 2], ts[lo:lo + 2], ys))), (ks, Bb, lo)
