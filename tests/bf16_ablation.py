@@ -34,6 +34,9 @@ from oracle import sampler                                           # noqa: E40
 from oracle.schedule import OracleDiffusion                          # noqa: E402
 
 POINTS = ["weights", "state", "x0a", "ln2", "qk", "v", "p", "attn", "ln1", "hidden"]
+# "weights" by matrix (only:w_in ... ; `weights` = all six): pose embedding (folded), in_proj, out_proj, linear1, linear2, pose head
+WPOINTS = {"w_in": (), "w_qkv": ("in_proj_weight",), "w_o": ("out_proj.weight",), "w_1": ("linear1.weight",), "w_2": ("linear2.weight",),
+           "w_out": ("poseFinal.weight",)}
 
 
 def bf16(x):
@@ -56,11 +59,12 @@ class RoundedOracle(M.MDMOracle):
         self.Wfold = (W2[:, D:2 * D] @ s["input_process.poseEmbedding.weight"].astype(np.float64)).astype(np.float32)
         self.cbase = (W2[:, D:2 * D] @ s["input_process.poseEmbedding.bias"].astype(np.float64) + s["input_process2.bias"]).astype(np.float32)
         self.W2a, self.W2c = s["input_process2.weight"][:, :D], s["input_process2.weight"][:, 2 * D:]
-        if "weights" in self.on:
+        if "weights" in self.on or "w_in" in self.on:
             self.Wfold = bf16(self.Wfold)
-            for k in list(s):
-                if any(t in k for t in ("in_proj_weight", "out_proj.weight", "linear1.weight", "linear2.weight", "poseFinal.weight")):
-                    s[k] = bf16(s[k])
+        tags = [t for w, ts in WPOINTS.items() if w in self.on or "weights" in self.on for t in ts]
+        for k in list(s):
+            if any(t in k for t in tags):
+                s[k] = bf16(s[k])
 
     def R(self, name, x):
         return bf16(x) if name in self.on else x
@@ -151,6 +155,10 @@ def main():
             variants.append(("all", POINTS))
         if "only" in a.modes:
             variants += [("only:" + p, [p]) for p in POINTS]
+        if "wsplit" in a.modes:
+            variants += [("only:" + p, [p]) for p in WPOINTS] + [("all-but-weights", [q for q in POINTS if q != "weights"]),
+                                                                 ("all, w_out+w_in fp32", [q for q in POINTS if q != "weights"] + ["w_qkv", "w_o", "w_1", "w_2"]),
+                                                                 ("all, w_1+w_2 fp32", [q for q in POINTS if q != "weights"] + ["w_qkv", "w_o", "w_in", "w_out"])]
         if "except" in a.modes:
             variants += [("except:" + p, [q for q in POINTS if q != p]) for p in POINTS]
         for name, on in variants:

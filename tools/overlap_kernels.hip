@@ -15,6 +15,9 @@ struct OvArgs {
     int shards;              // 1: one counter; 8: one per XCD (arrive on shard XCC_ID, wait for the sum)
     int sleep;               // s_sleep argument between polls
     int work;                // dependent FMA chain length between the loads and the stores (~4 cycles each): the kernel's "busy" time
+    unsigned* l2_ctr;        // two-level arrival (shards == 0): per-XCD counters in CACHED memory (agent-scope atomics execute in the XCD's L2),
+                             // 16 words apart; the last arriver of an XCD (workgroup b is assumed on XCD b % 8 -- checked, a miss arrives
+                             // directly) bumps the one uncached counter the consumers poll: 8 uncached atomics per link instead of nb
 };
 
 // one link of a dependent chain shaped like a batch-1 GEMM of the step: 32 KB of weights + 8 KB of the predecessor's output per
@@ -31,9 +34,9 @@ extern "C" __global__ __launch_bounds__(256) void k_link(const OvArgs a) {
             int spins = 0;
             for (;;) {
                 unsigned got = 0;
-                for (int s = 0; s < a.shards; ++s) got += __hip_atomic_load(a.wait_ctr + 16 * s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int s = 0; s < (a.shards ? a.shards : 1); ++s) got += __hip_atomic_load(a.wait_ctr + 16 * s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (got >= (unsigned)a.wait_target) break;
-                if (++spins > (1 << 20)) { __hip_atomic_fetch_add(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                if (++spins > (1 << 14)) { __hip_atomic_fetch_add(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                 if (a.sleep == 1) __builtin_amdgcn_s_sleep(1); else if (a.sleep == 4) __builtin_amdgcn_s_sleep(4); else if (a.sleep == 16) __builtin_amdgcn_s_sleep(16);
             }
         }
@@ -53,9 +56,21 @@ extern "C" __global__ __launch_bounds__(256) void k_link(const OvArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wave's stores have been acknowledged (uncached memory: they are visible)
         __syncthreads();
         if (t == 0) {
-            unsigned xcc = 0;
-            if (a.shards > 1) { xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7u; }      // HW_REG_XCC_ID, bits [3:0]
-            __hip_atomic_fetch_add(a.arrive_ctr + 16 * xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7u;      // HW_REG_XCC_ID, bits [3:0]
+            if (a.shards == 0) {
+                const unsigned home = (unsigned)b & 7u;                          // where dispatch order normally puts workgroup b
+                const unsigned mine = ((unsigned)a.nb + 7u - home) >> 3;         // workgroups with this home XCD
+                if (xcc != home) {                                               // displaced: arrive for my home group directly
+                    const unsigned old = __hip_atomic_fetch_add(a.l2_ctr + 16 * (8 + home), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    (void)old;
+                    __hip_atomic_fetch_add(a.arrive_ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // counted separately: [1] = displaced
+                } else {
+                    const unsigned old = __hip_atomic_fetch_add(a.l2_ctr + 16 * home, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (old + 1 == mine) __hip_atomic_fetch_add(a.arrive_ctr, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                __hip_atomic_fetch_add(a.arrive_ctr + 16 * (a.shards > 1 ? xcc : 0u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
