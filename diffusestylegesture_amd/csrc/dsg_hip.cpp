@@ -1597,7 +1597,8 @@ static int build_step_tables(dsg_handle* h, int mode, int skip, float eta, int* 
 // ---------------------------------------------------------------------------------------------------------
 struct SampleJob {
     StepCtx c;
-    int n_run = 0, B = 0, done = 0;
+    int n_run = 0, B = 0, done = 0;      // n_run: steps THIS call runs; done: how many of them have been issued
+    int first = 0;                       // absolute loop index of its first step (dsg_sample_args.first_step: a resumed chain)
     bool dumping = false, aql = false;
     int spg = -1;
 };
@@ -1668,6 +1669,11 @@ static int sample_prepare(dsg_handle* h, const dsg_sample_args* a, int B, void* 
     CHK(order_after(h, stream));
     int n_run = 0;
     CHK(build_step_tables(h, a->mode, a->skip_timesteps, a->eta, &n_run));
+    // a chain may be run in pieces (first_step / max_steps: the lazy generator forms of the loops): steps [first, first + n_iter)
+    const int first = a->first_step, n_total = n_run;
+    if (first < 0 || first >= n_total || a->max_steps < 0) return fail(DSG_E_INVALID, "first_step / max_steps out of range");
+    if (first > 0 && !a->init_noise) return fail(DSG_E_INVALID, "first_step > 0 resumes a chain: init_noise must hold x_t of that step");
+    const int n_iter = a->max_steps > 0 ? std::min(a->max_steps, n_total - first) : n_total - first;
     const size_t n = (size_t)B * h->J * h->T;
     NoiseKey nk;
     nk.k0 = (unsigned)(a->seed & 0xffffffffu); nk.k1 = (unsigned)(a->seed >> 32);
@@ -1677,7 +1683,7 @@ static int sample_prepare(dsg_handle* h, const dsg_sample_args* a, int B, void* 
     const float *noise_d = nullptr, *init_d = nullptr;
     CHK(to_dev(h, a->init_noise, h->io_tmp, n, &noise_d));
     CHK(to_dev(h, a->init_image, h->io_tmp2, n, &init_d));
-    const int do_q = (a->skip_timesteps > 0 || a->init_image) ? 1 : 0;
+    const int do_q = (first == 0 && (a->skip_timesteps > 0 || a->init_image)) ? 1 : 0;      // (a resumed chain starts from x_t as handed over)
     const int i0 = n_run - 1;
     KernelSel ksel;
     CHK(select_kernels(h, rows, ksel));      // (first: the layout of the state shadow belongs to the kernel set)
@@ -1686,7 +1692,7 @@ static int sample_prepare(dsg_handle* h, const dsg_sample_args* a, int B, void* 
     // replayed per-step noise
     const float* ext = nullptr;
     if (a->step_noise) {
-        const size_t ne = (size_t)n_run * n;
+        const size_t ne = (size_t)n_total * n;
         if (is_device_ptr(a->step_noise)) ext = a->step_noise;
         else {
             if (ne > h->ext_noise_cap) { CHK(dalloc(h, &h->ext_noise, ne, false)); h->ext_noise_cap = ne; }
@@ -1694,7 +1700,7 @@ static int sample_prepare(dsg_handle* h, const dsg_sample_args* a, int B, void* 
             ext = h->ext_noise;
         }
     }
-    hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(64), 0, h->stream, h->ctl, h->st_tmodel);
+    hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(64), 0, h->stream, h->ctl, h->st_tmodel, first);
     HIPCHK(hipGetLastError());
     {
         const unsigned dyn[5] = {nk.k0, nk.k1, nk.s0, nk.s1, a->draw_base + 1u};
@@ -1706,7 +1712,8 @@ static int sample_prepare(dsg_handle* h, const dsg_sample_args* a, int B, void* 
     c.const_noise = a->const_noise; c.clip_x0 = a->clip_denoised ? 1 : 0;
     c.no_noise = (a->mode == DSG_MODE_DDIM && a->eta == 0.f && !ext) ? 1 : 0;
     c.ks = ksel;
-    job.n_run = n_run; job.B = B; job.done = 0;
+    n_run = n_iter;                          // from here on: the steps of this call (the tables keep the whole chain: h->n_run)
+    job.n_run = n_iter; job.B = B; job.done = 0; job.first = first;
     job.dumping = a->n_dump > 0 && a->dump_steps && a->dump_out;
     // steps_per_graph: 0 = default = no hipGraph.  Measured on MI355X / ROCm 7.2: hipGraph replay of the step is slower than
     // stream-ordered HIP launches (180 vs 157 us; 151-163 us with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0), and both lose to the
@@ -1784,8 +1791,8 @@ static int sample_run_hip(dsg_handle* h, const dsg_sample_args* a, SampleJob& jo
     for (; job.done < n_run; ++job.done) {
         CHK(run_step_p(h, c));
         if (job.dumping) {
-            while (di < a->n_dump && a->dump_steps[di] < job.done) ++di;
-            if (di < a->n_dump && a->dump_steps[di] == job.done) {
+            while (di < a->n_dump && a->dump_steps[di] < job.first + job.done) ++di;
+            if (di < a->n_dump && a->dump_steps[di] == job.first + job.done) {
                 CHK(launch_x_out(h, h->fwd_out, B));
                 CHK(from_dev(h, a->dump_out + (size_t)di * n, h->fwd_out, n));
                 ++di;

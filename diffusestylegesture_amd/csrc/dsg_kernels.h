@@ -284,8 +284,9 @@ __device__ __forceinline__ void step_advance_A(StepCtl* c, const StepTables& st,
     c->stepA = s;
     c->tA = st.tmodel[s < n ? s : n - 1];
 }
-__global__ void k_ctl_init(StepCtl* c, const int* tmodel) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) { c->stepA = 0; c->tA = tmodel[0]; c->stepB = -1; c->k1 = c->k2 = c->k3 = c->k4 = c->k5 = 0.f; }
+// `first`: the loop index the call starts at (0, or where a chain run in pieces resumes)
+__global__ void k_ctl_init(StepCtl* c, const int* tmodel, int first) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { c->stepA = first; c->tA = tmodel[first]; c->stepB = first - 1; c->k1 = c->k2 = c->k3 = c->k4 = c->k5 = 0.f; }
 }
 
 // ---------------------------------------------------------------------------------------------------------

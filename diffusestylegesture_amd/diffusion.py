@@ -137,7 +137,7 @@ class DSGDiffusion:
         return None, False
 
     def _prepare(self, mode, model, guided, shape, noise, model_kwargs, skip_timesteps, init_image, dump_steps,
-                 const_noise, eta, step_noise, seed, draw_base, clip_denoised, stream_id=None):
+                 const_noise, eta, step_noise, seed, draw_base, clip_denoised, stream_id=None, first_step=0, max_steps=0):
         """Conditioning + schedule to the library and the argument block of one dsg_sample call."""
         B = int(shape[0])
         if tuple(shape) != (B, model.njoints, model.nfeats, model.cfg.n_poses):
@@ -165,6 +165,7 @@ class DSGDiffusion:
         a.stream_id = self.stream_id if stream_id is None else int(stream_id)
         a.draw_base = self._draw if draw_base is None else int(draw_base)
         a.clip_denoised = int(bool(clip_denoised))
+        a.first_step, a.max_steps = int(first_step), int(max_steps)
         dump = None
         if dump_steps is not None:
             ds = np.ascontiguousarray(sorted(int(d) for d in dump_steps), dtype=np.int32)
@@ -174,10 +175,11 @@ class DSGDiffusion:
         return a, keep, dump, use_torch
 
     def _fused(self, mode, model, guided, shape, noise, model_kwargs, skip_timesteps, init_image, dump_steps, const_noise,
-               eta, step_noise, seed, draw_base, clip_denoised):
+               eta, step_noise, seed, draw_base, clip_denoised, first_step=0, max_steps=0):
         B = int(shape[0])
         a, keep, dump, use_torch = self._prepare(mode, model, guided, shape, noise, model_kwargs, skip_timesteps, init_image,
-                                                 dump_steps, const_noise, eta, step_noise, seed, draw_base, clip_denoised)
+                                                 dump_steps, const_noise, eta, step_noise, seed, draw_base, clip_denoised,
+                                                 first_step=first_step, max_steps=max_steps)
         n_run = self.num_timesteps - skip_timesteps
         out, out_ptr = model._alloc_out(shape, use_torch)
         lib = model.lib
@@ -206,22 +208,35 @@ class DSGDiffusion:
         return self._generic_loop(False, model, shape, noise, model_kwargs, skip_timesteps, init_image, dump_steps,
                                   const_noise, 0.0, device, clip_denoised)
 
+    PROGRESSIVE_CHUNK = 50      # steps per library call of the generator forms
+
     def _progressive(self, ddim, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device, skip_timesteps,
                      init_image, randomize_class, cond_fn_with_grad, const_noise, eta):
-        """Generator form of the loops: one {"sample": x_{t-1}} per denoising step, in loop order.  The steps run inside the
-        library in ONE call (every step's sample is dumped: the eager HIP-launch path), then are handed out one by one -- the
-        reference computes them lazily, which only matters to a caller that abandons the generator early."""
+        """Generator form of the loops: one {"sample": x_{t-1}} per denoising step, in loop order -- LAZY like the reference's
+        (gaussian_diffusion.py:673-740): the chain runs inside the library PROGRESSIVE_CHUNK steps per call (dsg_sample_args.first_step
+        / max_steps: a chain in pieces, every step of the piece dumped), so the host holds one chunk of samples at a time (round-3
+        advisor: the whole chain used to be materialised, 0.4 GB at ZEGGS dims and batch 1) and a caller that abandons the generator
+        stops the work.  Same samples, bit for bit, as the one-call loops: draw indices are those of the whole chain."""
         self._check_unsupported(denoised_fn, cond_fn, randomize_class, cond_fn_with_grad)
         inner, guided = self._library_model(model, shape[0])
         n_run = self.num_timesteps - skip_timesteps
-        if inner is not None:
-            outs = self._fused(L.MODE_DDIM if ddim else L.MODE_DDPM, inner, guided, shape, noise, model_kwargs, skip_timesteps,
-                               init_image, list(range(n_run)), const_noise, eta, None, None, None, clip_denoised)
-        else:
+        if inner is None:
             outs = self._generic_loop(ddim, model, shape, noise, model_kwargs, skip_timesteps, init_image, list(range(n_run)),
                                       const_noise, eta, device, clip_denoised)
-        for o in outs:
-            yield {"sample": o}
+            for o in outs:
+                yield {"sample": o}
+            return
+        mode = L.MODE_DDIM if ddim else L.MODE_DDPM
+        draw0 = self._draw
+        self._draw += 1 + n_run                      # the generator owns these draw indices from the moment it is created
+        x, first = noise, 0
+        while first < n_run:
+            k = min(self.PROGRESSIVE_CHUNK, n_run - first)
+            outs = self._fused(mode, inner, guided, shape, x, model_kwargs, skip_timesteps, init_image if first == 0 else None,
+                               list(range(first, first + k)), const_noise, eta, None, None, draw0, clip_denoised, first_step=first, max_steps=k)
+            for o in outs:
+                yield {"sample": o}
+            x, first = outs[-1], first + k
 
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                                   model_kwargs=None, device=None, progress=False, skip_timesteps=0, init_image=None,

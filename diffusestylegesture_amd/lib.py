@@ -32,7 +32,7 @@ class dsg_sample_args(C.Structure):
         ("mode", C.c_int32), ("skip_timesteps", C.c_int32), ("eta", C.c_float), ("const_noise", C.c_int32),
         ("init_noise", C.c_void_p), ("step_noise", C.c_void_p), ("init_image", C.c_void_p),
         ("seed", C.c_uint64), ("stream_id", C.c_uint64), ("draw_base", C.c_uint32), ("n_dump", C.c_int32),
-        ("dump_steps", C.c_void_p), ("dump_out", C.c_void_p), ("clip_denoised", C.c_int32), ("reserved", C.c_int32 * 3)]
+        ("dump_steps", C.c_void_p), ("dump_out", C.c_void_p), ("clip_denoised", C.c_int32), ("first_step", C.c_int32), ("max_steps", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 # every symbol include/dsg.h declares: name -> (restype, argtypes)

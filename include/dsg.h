@@ -159,7 +159,9 @@ typedef struct dsg_sample_args {
     const int32_t* dump_steps;/* host int32[n_dump], ascending loop indices */
     float* dump_out;          /* [n_dump,B,J,1,T] */
     int32_t clip_denoised;    /* != 0: x0 clamped to [-1, 1] before the update (clip_denoised=True, gaussian_diffusion.py:377-379) */
-    int32_t reserved[3];
+    int32_t first_step;       /* ABI 310: run the chain in pieces (the lazy p_sample_loop_progressive, gaussian_diffusion.py:673-740): loop */
+    int32_t max_steps;        /* index this call starts at (> 0: init_noise is x_t of that step, taken as it is) and how many steps it runs */
+    int32_t reserved[1];      /* (0 = to the end); draw indices, dump_steps and step_noise stay those of the whole chain */
 } dsg_sample_args;
 
 /* runs num_timesteps - skip_timesteps denoising steps for the conditioning set by dsg_set_window_cond;

@@ -82,3 +82,32 @@ def test_dsgplus_lanes_equal_single_lane_clips(emu_lib, cfg):
             want = generate_clip_dsgplus(lanes[ln], d, feats[ln], [1, 0, 0], seed0s[ln], frames, seed=9, skip_timesteps=996, stream_id=[4, 7][ln],
                                          seed_last=None if lasts is None else lasts[ln])
             assert np.array_equal(got[ln * B:(ln + 1) * B], want), (prec, ln)
+
+
+def test_progressive_generators_are_lazy_and_chunked(emu_lib):
+    """p_sample_loop_progressive / ddim_sample_loop_progressive run the chain in pieces inside the library (dsg_sample_args.first_step /
+    max_steps; round-3 advisor: the whole chain used to be materialised): 60 steps = 2 pieces here, every sample equal to the
+    one-call loop's dump, bit for bit -- with a q_sample start (skip_timesteps + init_image), DDPM and DDIM (eta > 0)."""
+    cfg = C.TINY
+    m = DSGDenoiser(cfg, precision="bf16", max_batch=1, library=emu_lib)
+    m.load_state_dict(synth_state_dict(cfg, 20240))
+    y = synth_window_inputs(cfg, 1, window=1, seed_pose_scale=0.3)
+    shape = (1, cfg.njoints, 1, cfg.n_poses)
+    init = np.random.RandomState(8).randn(*shape).astype(np.float32)
+    d = create_gaussian_diffusion(library=emu_lib)
+    want = d.manual_seed(4, 1).p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=940, init_image=init,
+                                             dump_steps=[0, 49, 50, 59])
+    gen = d.manual_seed(4, 1).p_sample_loop_progressive(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=940, init_image=init)
+    got = [np.asarray(o["sample"]) for o in gen]
+    assert len(got) == 60
+    for i, s in enumerate((0, 49, 50, 59)):
+        assert np.array_equal(got[s], np.asarray(want[i])), s
+    # the next call draws after the generator's indices, like after a plain loop
+    a = d.p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=997)
+    d.manual_seed(4, 1).p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=940, init_image=init)
+    b = d.p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=997)
+    assert np.array_equal(np.asarray(a), np.asarray(b))
+    d100 = create_gaussian_diffusion("ddim100", library=emu_lib)
+    full = d100.manual_seed(4, 2).ddim_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, eta=0.5)
+    steps = [np.asarray(o["sample"]) for o in d100.manual_seed(4, 2).ddim_sample_loop_progressive(m, shape, clip_denoised=False, model_kwargs={"y": y}, eta=0.5)]
+    assert len(steps) == 100 and np.array_equal(steps[-1], np.asarray(full))
