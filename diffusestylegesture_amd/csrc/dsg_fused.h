@@ -940,4 +940,195 @@ __global__ __launch_bounds__(256) void k_attn_op2(const AttnOpArgs g) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// k_attn_op_w (round 4): k_attn_op for the shapes whose W_o does not fit the register file next to the attention -- the DSG+ widths
+// in bf16 (D = 384 / 512: 12 / 16 k-blocks x 6 / 8 column tiles per wave) and fp32 at the ZEGGS / tiny widths (16 / 8 k-blocks of 4
+// values).  Same arithmetic, rounding points and k order as k_attn_op; W_o streams through two register buffers of KC k-blocks:
+// chunk 0 is requested once K is dead (in flight during the softmax and PV), chunk 1 once V^T is dead, chunk c + 2 right after the
+// MFMAs of chunk c.  The batched sets (TILE / BLOCK) at these shapes lose one dispatch and one LayerNorm recompute per layer, as
+// the ZEGGS bf16 path did in round 2 (1 x 16: 292 -> 254 us).
+// ---------------------------------------------------------------------------------------------------------
+template <class P, int DT, int NKT>      // D = 64 DT, H = 4, hd = 16 DT, Tp = 16 NKT
+__global__ __launch_bounds__(256) void k_attn_op_w(const AttnOpArgs g) {
+    DSG_TL_SCOPE();
+    typedef typename P::elem elem;
+    constexpr int ES = (int)sizeof(elem);
+    constexpr int D = DT * 64, HD = DT * 16;
+    constexpr int KD = D / P::KB, KDH = HD / P::KB;
+    constexpr int XP = D * ES + 16;
+    constexpr int ND = HD / 16;
+    constexpr int NVF = P::E == 4 ? NKT : NKT / 2;   // PV k-blocks
+    constexpr int KC = 4, NC = KD / KC;              // W_o chunk: KC k-blocks x DT column tiles per wave
+    static_assert(KDH >= 1 && KD % KC == 0 && NC >= 2, "shape");
+    static_assert(P::E == 4 || (NKT % 2) == 0, "bf16 pairs key tiles");
+    __shared__ __attribute__((aligned(16))) char aT[16 * XP];      // attention output rows (MFMA element type)
+    __shared__ float red[2][4][16];
+    __shared__ __attribute__((aligned(16))) float vecs[3][D];
+    preload_kernargs(g);
+    const int qt = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
+    const int h = wave;
+    const size_t bh = (size_t)b * 4 + h;
+    const elem* Q = (const elem*)g.q + bh * g.Tp * HD;
+    const elem* K = (const elem*)g.k + bh * g.Tp * HD;
+    const elem* VT = (const elem*)g.vt + bh * HD * g.Tp;
+    const f32x4* wo = (const f32x4*)g.Wo + lane;
+    f32x4 qf[KDH], kf[NKT][KDH], vfr[ND][NVF];
+#pragma unroll
+    for (int kb = 0; kb < KDH; ++kb) qf[kb] = *(const f32x4*)(Q + (size_t)((qt * KDH + kb) * 64 + lane) * P::E);
+#pragma unroll
+    for (int nt = 0; nt < NKT; ++nt)
+#pragma unroll
+        for (int kb = 0; kb < KDH; ++kb) kf[nt][kb] = *(const f32x4*)(K + (size_t)((nt * KDH + kb) * 64 + lane) * P::E);
+    // V^T with the other operands when the register file holds everything (one round trip), else once K is dead (D = 512)
+    constexpr bool V_EARLY = (KDH + NKT * KDH + ND * NVF + DT + 4) * 4 <= 340;
+    auto load_v = [&]() {
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+            for (int kb = 0; kb < NVF; ++kb) vfr[dt][kb] = *(const f32x4*)(VT + (size_t)((dt * NVF + kb) * 64 + lane) * P::E);
+    };
+    if constexpr (V_EARLY) load_v();
+    const int tq = qt * 16 + lr;
+    const bool rowok = tq < g.ntok;
+    const size_t m = (size_t)b * g.ntok + (rowok ? tq : g.ntok - 1);      // clamped: unconditional loads, predicated stores
+    f32x4 pr[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) pr[t] = *(const f32x4*)(g.R + m * D + (wave * DT + t) * 16 + 4 * lg);
+    constexpr int NV = (3 * D / 4 + 255) / 256;
+    f32x4 vload[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int e = min(tid + 256 * i, 3 * D / 4 - 1), vsel = e / (D / 4), vidx = e % (D / 4);
+        vload[i] = ((const f32x4*)(vsel == 0 ? g.bo : (vsel == 1 ? g.ln_g : g.ln_b)))[vidx];
+    }
+    DSG_LOADS_ISSUED();
+    // ---- S^T = K Q^T (D[key = 4*lg + r][query = lr])
+    f32x4 s[NKT];
+#pragma unroll
+    for (int nt = 0; nt < NKT; ++nt) {
+        s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KDH; ++kb) s[nt] = P::mma(kf[nt][kb], qf[kb], s[nt]);
+    }
+    f32x4 bf[2][KC][DT];
+    auto load_wo = [&](int c, int buf) {
+#pragma unroll
+        for (int k = 0; k < KC; ++k)
+#pragma unroll
+            for (int t = 0; t < DT; ++t) bf[buf][k][t] = wo[((size_t)(wave * DT + t) * KD + c * KC + k) * 64];
+    };
+    if constexpr (!V_EARLY) load_v();
+    load_wo(0, 0);                                     // K is dead: chunk 0 in flight during the softmax and PV
+    DSG_LOADS_ISSUED();
+    const float scale = 1.0f / sqrtf((float)HD);
+    float mx = -DSG_FLT_MAX;
+#pragma unroll
+    for (int nt = 0; nt < NKT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = nt * 16 + 4 * lg + r;
+            const float v = key < g.ntok ? s[nt][r] * scale : -DSG_FLT_MAX;
+            s[nt][r] = v;
+            mx = fmaxf(mx, v);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NKT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = nt * 16 + 4 * lg + r;
+            const float pv = key < g.ntok ? P::exp_sm(s[nt][r] - mx) : 0.f;
+            s[nt][r] = pv;
+            sum += pv;
+        }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    f32x4 pfr[NVF];
+#pragma unroll
+    for (int kb = 0; kb < NVF; ++kb) {
+        if constexpr (P::E == 4) {
+            pfr[kb] = s[kb];
+        } else {
+            typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+            u16x8 pp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pp[e] = f2bf(s[2 * kb][e]); pp[4 + e] = f2bf(s[2 * kb + 1][e]); }
+            pfr[kb] = __builtin_bit_cast(f32x4, pp);
+        }
+    }
+    // ---- O^T = V^T P^T -> LDS rows (the rounding point of the attention buffer of k_attn)
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) {
+        f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < NVF; ++kb) o = P::mma(vfr[dt][kb], pfr[kb], o);
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = o[e] * inv;
+        P::store4((elem*)(aT + lr * XP) + h * HD + dt * 16 + 4 * lg, y);
+    }
+    DSG_LOADS_ISSUED();
+    load_wo(1, 1);                                     // V^T is dead
+    DSG_LOADS_ISSUED();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int e = tid + 256 * i;
+        if (e < 3 * D / 4) *(f32x4*)(&vecs[0][0] + e * 4) = vload[i];
+    }
+    DSG_LDS_BARRIER();
+    // ---- out_proj from the LDS rows, W_o chunk by chunk (k order 0 .. KD - 1 as in k_attn_op)
+    f32x4 acc[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const f32x4 af = *(const f32x4*)(aT + lr * XP + ((c * KC + k) * P::KB + P::E * lg) * ES);
+#pragma unroll
+            for (int t = 0; t < DT; ++t) acc[t] = P::mma(bf[c & 1][k][t], af, acc[t]);      // D[n 4lg+r][row lr]
+        }
+        if (c + 2 < NC) { DSG_LOADS_ISSUED(); load_wo(c + 2, c & 1); DSG_LOADS_ISSUED(); }
+    }
+    // ---- residual + LayerNorm1 over whole rows (row lr: 4 lane groups x 4 waves hold its D values); fma sites as in k_attn_op
+    float sm = 0.f;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+        const f32x4 pbo = *(const f32x4*)(&vecs[0][(wave * DT + t) * 16 + 4 * lg]);
+        acc[t] = acc[t] + pbo + pr[t];
+        sm += (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
+    }
+    sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
+    if (lg == 0) red[0][wave][lr] = sm;
+    DSG_LDS_BARRIER();
+    const float mean = ((red[0][0][lr] + red[0][1][lr]) + (red[0][2][lr] + red[0][3][lr])) / (float)D;
+    float qv = 0.f;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = acc[t][e] - mean; qv = __builtin_fmaf(d, d, qv); }
+    qv += __shfl_xor(qv, 16); qv += __shfl_xor(qv, 32);
+    if (lg == 0) red[1][wave][lr] = qv;
+    DSG_LDS_BARRIER();
+    const float var = ((red[1][0][lr] + red[1][1][lr]) + (red[1][2][lr] + red[1][3][lr])) / (float)D;
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    if (rowok) {
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            const int n = (wave * DT + t) * 16 + 4 * lg;
+            const f32x4 pg = *(const f32x4*)(&vecs[1][n]), pbt = *(const f32x4*)(&vecs[2][n]);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = __builtin_fmaf((acc[t][e] - mean) * rstd, pg[e], pbt[e]);
+            *(f32x4*)(g.X1 + m * D + n) = y;
+            P::store4((elem*)g.X1a + qk_off<P>((int)m, n, D / P::KB), y);
+        }
+    }
+}
+
 }  // namespace dsg

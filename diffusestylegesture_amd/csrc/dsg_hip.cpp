@@ -828,10 +828,17 @@ struct KernelSel {
 static bool have_attn_mid(const dsg_handle* h, int B) {
     return B == 1 && h->H == 4 && ((h->D == 256 && h->Tp == 96) || (h->D == 128 && h->Tp == 32));
 }
-static bool have_attn_op(const dsg_handle* h) {
-    // bf16 only: in fp32 W_o is 16 k-blocks x DT tiles per wave and does not fit the register file next to the attention
+// k_attn_op with all of W_o in registers: bf16 at the ZEGGS / tiny widths (the STREAM set and k_attn_op2 build on it)
+static bool have_attn_op_narrow(const dsg_handle* h) {
     return h->prec == DSG_PREC_BF16 && h->H == 4 && ((h->D == 256 && h->Tp == 96) || (h->D == 128 && h->Tp == 32));
 }
+// ... or k_attn_op_w (W_o streamed in chunks, round 4): the DSG+ widths in bf16, the ZEGGS / tiny widths in fp32
+static bool have_attn_op_wide(const dsg_handle* h) {
+    if (h->H != 4) return false;
+    if (h->prec == DSG_PREC_BF16) return (h->D == 384 || h->D == 512) && h->Tp == 160;
+    return (h->D == 256 && h->Tp == 96) || (h->D == 128 && h->Tp == 32);
+}
+static bool have_attn_op(const dsg_handle* h) { return have_attn_op_narrow(h) || have_attn_op_wide(h); }
 static bool latency_set_ok(const dsg_handle* h) {
     // k_mid pulls all of W_o (2 D^2 bytes) through every CU: at D = 512 the un-fused sets win (TWH: 219 vs 238 us)
     // and at D = 384 with the K = D GEMMs in one fragment batch (round 4): BEAT 163.9 (TILE) vs 175-179 us (LATENCY) at batch 1
@@ -843,7 +850,7 @@ static bool latency_set_ok(const dsg_handle* h) {
 static bool stream_set_ok(const dsg_handle* h) {
     // k_ws keeps 64 columns x K = D of W per wave in registers (D = 128 / 256), k_ws2 a quarter of K = ff (ff = 128 / 1024);
     // linear1 reads the fragment-major LayerNorm1 rows k_attn_op writes
-    return have_attn_op(h) && (h->D == 256 || h->D == 128) && (h->ff == 1024 || h->ff == 128) && (h->Jp == 1152 || h->Jp == 128);
+    return have_attn_op_narrow(h) && (h->D == 256 || h->D == 128) && (h->ff == 1024 || h->ff == 128) && (h->Jp == 1152 || h->Jp == 128);
 }
 static int auto_kernel_set(const dsg_handle* h, int B, int lanes) {
     const int rows = B * h->ntok;
@@ -871,7 +878,9 @@ static int select_kernels(const dsg_handle* h, int B, KernelSel& k) {
     k.attn_in_mid = k.lat && h->fuse_attn_mid && have_attn_mid(h, B);
     k.stream = set == DSG_KSET_STREAM;
     k.blk = set == DSG_KSET_BLOCK || k.stream;      // (STREAM: pose embedding and layer-0 QKV as in BLOCK)
-    k.attn_op = !k.lat && have_attn_op(h);
+    // the wide form (W_o streamed: DSG+ widths, fp32) belongs to BLOCK / STREAM only -- a set's arithmetic never depends on the batch,
+    // and at batch 1 its 10 workgroups per layer lose to k_attn + out_proj (BEAT: 200 vs 163 us/step; 16 clips: 3371 vs 2904 frames/s)
+    k.attn_op = !k.lat && (have_attn_op_narrow(h) || (k.blk && have_attn_op_wide(h)));
     k.xs_frag = k.blk && h->prec == DSG_PREC_BF16 && (h->Jp == 1152 || h->Jp == 128);
     return 0;
 }
@@ -1251,7 +1260,12 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                         if (D == 256 && h->Tp == 96) CHK((step_launch<&k_attn_op2<P, 4, 6>>(h, grid2, dim3(256), a)));
                         else CHK((step_launch<&k_attn_op2<P, 2, 2>>(h, grid2, dim3(256), a)));
                     } else if (D == 256 && h->Tp == 96) CHK((step_launch<&k_attn_op<P, 4, 6>>(h, grid, dim3(256), a)));
-                    else CHK((step_launch<&k_attn_op<P, 2, 2>>(h, grid, dim3(256), a)));
+                    else if (D == 128 && h->Tp == 32) CHK((step_launch<&k_attn_op<P, 2, 2>>(h, grid, dim3(256), a)));
+                    else if (D == 384) CHK((step_launch<&k_attn_op_w<P, 6, 10>>(h, grid, dim3(256), a)));
+                    else CHK((step_launch<&k_attn_op_w<P, 8, 10>>(h, grid, dim3(256), a)));
+                } else {
+                    if (D == 256) CHK((step_launch<&k_attn_op_w<P, 4, 6>>(h, grid, dim3(256), a)));
+                    else CHK((step_launch<&k_attn_op_w<P, 2, 2>>(h, grid, dim3(256), a)));
                 }
             }
             {   // linear1 + GELU -> hidden
