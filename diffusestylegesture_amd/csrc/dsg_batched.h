@@ -236,14 +236,11 @@ __global__ __launch_bounds__(256) void k_gemm_blk(const GemmArgs g) {
 // its K range in four chunks took 10 us for linear2 against 7.8 us for the 16 x 16 tile kernel; profiles/r02_c_*).  Each
 // fragment pair feeds 4 MFMAs (the 16 x 16 kernel: 1), halving the bytes pulled through L2 per output.  The 4 partial blocks
 // are reduced through LDS in a fixed order; wave w finishes tile (w >> 1, w & 1).
-// CT: 16-column tiles per workgroup.  2 (32 x 32 blocks) for the latency-shaped sizes; 4 (32 x 64, round 4) halves the re-reads of
-// the A rows from uncached memory -- linear2's `hidden` is the largest activation of a layer -- once the batch makes the kernel
-// bandwidth-shaped; the k sums of an output element are the same 4 ranges in the same order either way (bit-identical).
-template <class P, int EPI, int KPW, int CT = 2>
+template <class P, int EPI, int KPW>
 __global__ __launch_bounds__(256) void k_gemm_blk_k(const GemmArgs g) {
     DSG_TL_SCOPE();
     typedef typename P::elem elem;
-    constexpr int RT = 2;
+    constexpr int RT = 2, CT = 2;
     static_assert(EPI == EPI_RESID || EPI == EPI_PARTIAL, "direct A operand, fp32 output");
     __shared__ __attribute__((aligned(16))) float red[4][RT * CT][64][4];      // every wave's partial 32 x 32 block
     preload_kernargs(g);
@@ -270,13 +267,9 @@ __global__ __launch_bounds__(256) void k_gemm_blk_k(const GemmArgs g) {
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int t = 0; t < CT; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // this wave finishes tiles (rt, t) = (wave >> 1, (wave & 1) + 2 j), j < CT / 2: their bias / residual operands travel with the fragments
-    constexpr int NF = CT / 2;
-    static_assert(CT == 2 || CT == 4, "2 or 4 column tiles");
-    TileOps ops[NF];
-#pragma unroll
-    for (int j = 0; j < NF; ++j)
-        gemm_prefetch_tile<P, EPI>(g, min(m0 + (wave >> 1) * 16, mt_last * 16), (nt0 + (wave & 1) + 2 * j) * 16, lr, lg, 0, ops[j]);
+    // this wave finishes tile (wave >> 1, wave & 1): its bias / residual operands travel with the fragments
+    TileOps ops;
+    gemm_prefetch_tile<P, EPI>(g, min(m0 + (wave >> 1) * 16, mt_last * 16), (nt0 + (wave & 1)) * 16, lr, lg, 0, ops);
     for (int kb0 = kb_lo; kb0 < kb_hi; kb0 += KPW) {       // one pass when the wave's share fits (the sizes of the path)
         f32x4 af[KPW][RT], bf[KPW][CT];
 #pragma unroll
@@ -310,17 +303,13 @@ __global__ __launch_bounds__(256) void k_gemm_blk_k(const GemmArgs g) {
 #pragma unroll
         for (int t = 0; t < CT; ++t) *(f32x4*)&red[wave][rt * CT + t][lane][0] = acc[rt][t];
     DSG_LDS_BARRIER();
-    const int rt = wave >> 1;
+    const int rt = wave >> 1, t = wave & 1;
     const int mt = m0 + rt * 16;
     if (mt >= g.MT * 16) return;
+    f32x4 sum = *(const f32x4*)&red[0][rt * CT + t][lane][0];
 #pragma unroll
-    for (int j = 0; j < NF; ++j) {
-        const int t = (wave & 1) + 2 * j;
-        f32x4 sum = *(const f32x4*)&red[0][rt * CT + t][lane][0];
-#pragma unroll
-        for (int w2 = 1; w2 < 4; ++w2) sum += *(const f32x4*)&red[w2][rt * CT + t][lane][0];
-        gemm_epilogue_tile<P, EPI>(g, mt, (nt0 + t) * 16, lr, lg, ks, true, sum, ops[j], 0.f, 0.f, 0.f, 0.f, 0.f);
-    }
+    for (int w2 = 1; w2 < 4; ++w2) sum += *(const f32x4*)&red[w2][rt * CT + t][lane][0];
+    gemm_epilogue_tile<P, EPI>(g, mt, (nt0 + t) * 16, lr, lg, ks, true, sum, ops, 0.f, 0.f, 0.f, 0.f, 0.f);
 }
 
 }  // namespace dsg

@@ -175,8 +175,6 @@ struct dsg_handle {
     bool aql_warned = false;
     bool aql_timing = false;             // the last dsg_sample was timed by the host clock around the AQL run
     double aql_ms = 0.0;
-    bool lean_tnw2 = false;              // DSG_LEAN_TNW2=1 (A/B): the batched pose head on 16 x 128 tiles
-    bool blk_k_ct4 = false;              // DSG_BLK_K_CT4=1 (A/B): linear2 of the BLOCK set on 32 x 64 blocks
     bool fuse_attn_mid = true;           // k_attn_mid (attention inside the out_proj/LN/linear1 kernel) at batch 1; DSG_FUSE_ATTN_MID=0 to A/B
     int* st_tmodel = nullptr; float* st_c[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int st_cap = 0, n_run = 1;
@@ -385,8 +383,6 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
         }
     }
     if (const char* e = getenv("DSG_FUSE_ATTN_MID")) h->fuse_attn_mid = atoi(e) != 0;
-    if (const char* e = getenv("DSG_BLK_K_CT4")) h->blk_k_ct4 = atoi(e) != 0;
-    if (const char* e = getenv("DSG_LEAN_TNW2")) h->lean_tnw2 = atoi(e) != 0;
     *out = h;
 
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -1004,14 +1000,9 @@ static int launch_blk_k(dsg_handle* h, GemmArgs g) {
     g.inv_ntok = fastdiv_inv(g.ntok); g.inv_hd = fastdiv_inv(g.hd);
     if (g.NT % 2) return fail(DSG_E_INVALID, "gemm: NT not divisible by the workgroup tile");
     const int extra = EPI == EPI_PARTIAL ? 1 : 0;
+    const dim3 grid(xcd_grid_x(g.NT / 2), cdiv(g.MT, 2) + extra, g.KS);
     // k-blocks per wave in one pass: 8 when the wave's share of the K range is that long (linear2 at ff = 1024 in bf16), else 4
     const int per = cdiv(std::min(g.kb_per_split, g.KBtot), 4);
-    if constexpr (EPI == EPI_RESID) {
-        // linear2, 32 x 64 blocks (round 4): `hidden` is read by half as many column groups; same sums in the same order
-        if (h->blk_k_ct4 && per > 4 && per <= 8 && g.NT % 4 == 0)
-            return step_launch<&k_gemm_blk_k<P, EPI, 8, 4>>(h, dim3(xcd_grid_x(g.NT / 4), cdiv(g.MT, 2), 1), dim3(256), g);
-    }
-    const dim3 grid(xcd_grid_x(g.NT / 2), cdiv(g.MT, 2) + extra, g.KS);
     if (per > 4) return step_launch<&k_gemm_blk_k<P, EPI, 8>>(h, grid, dim3(256), g);
     return step_launch<&k_gemm_blk_k<P, EPI, 4>>(h, grid, dim3(256), g);
 }
@@ -1091,11 +1082,6 @@ static int launch_gemm_w(dsg_handle* h, const GemmArgs& g, const KernelSel& ks) 
             gl.KS = 1; gl.kb_per_split = gl.KBtot;
             gl.inv_ntok = fastdiv_inv(gl.ntok); gl.inv_hd = fastdiv_inv(gl.hd);
             if (gl.NT % 4) return fail(DSG_E_INVALID, "gemm: NT not divisible by the workgroup tile");
-            if constexpr (EPI == EPI_OUT) {
-                // pose head, 128 columns per workgroup (A/B, DSG_LEAN_TNW2): half the column groups re-normalising the uncached fp32 rows
-                if (h->lean_tnw2 && gl.NT % 8 == 0 && pick_ch(gl.KBtot) == 8)
-                    return step_launch<&k_gemm_lean<P, EPI, 8, 2>>(h, dim3(xcd_grid_x(gl.NT / 8), gl.MT + 1, 1), dim3(256), gl);
-            }
             const dim3 grid(xcd_grid_x(gl.NT / 4), gl.MT + (EPI == EPI_OUT ? 1 : 0), 1);
             if (pick_ch(gl.KBtot) == 16) return step_launch<&k_gemm_lean<P, EPI, 16>>(h, grid, dim3(256), gl);
             if (pick_ch(gl.KBtot) == 12) return step_launch<&k_gemm_lean<P, EPI, 12>>(h, grid, dim3(256), gl);

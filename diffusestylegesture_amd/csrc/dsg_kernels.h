@@ -829,8 +829,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
 
 // batched LayerNorm-GEMM: compiled for 3 waves per SIMD (<= 168 VGPRs; at 128 it spills to scratch; requesting the weights
 // only after the LayerNorm fits 5 waves per SIMD but measured slower: 370 vs 360 us/step at batch 16), see ln_rows LEAN
-template <class P, int EPI, int CH = 8, int TNW = 1>
-__global__ __launch_bounds__(256, (CH > 8 || TNW > 1) ? 2 : 3) void k_gemm_lean(const GemmArgs g) { DSG_TL_SCOPE(); gemm_body<P, PRO_LN, EPI, 4, 1, TNW, true, false, CH>(g); }
+template <class P, int EPI, int CH = 8>
+__global__ __launch_bounds__(256, CH > 8 ? 2 : 3) void k_gemm_lean(const GemmArgs g) { DSG_TL_SCOPE(); gemm_body<P, PRO_LN, EPI, 4, 1, 1, true, false, CH>(g); }
 
 // pose head with classifier-free guidance: conditional + unconditional rows per workgroup (GemmArgs::cfgB)
 template <class P, int CH = 8>
