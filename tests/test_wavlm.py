@@ -103,6 +103,7 @@ def test_features_match_reference_on_gpu_wavlm_large(golden_dir):
     assert rel_l2(clip.cpu().numpy(), rep88) < 1e-4
     one = wav2wavlm(m, torch.from_numpy(wav[1:2])).cpu().numpy()
     assert rel_l2(one, rep88[1:2]) < 1e-4
+    m.clip_features([wav[0], wav[1], wav[0], wav[1]])          # warm-up at the timed shape (MIOpen / hipBLASLt heuristics)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(3):
@@ -111,6 +112,7 @@ def test_features_match_reference_on_gpu_wavlm_large(golden_dir):
     ms32 = (time.perf_counter() - t0) / 3 * 1e3
     mb = WavLMFeatures(cfg, sd, device="cuda:0", compute_dtype=torch.bfloat16)
     e16 = rel_l2(mb.clip_features([wav[0], wav[1]]).cpu().numpy(), rep88)
+    mb.clip_features([wav[0], wav[1], wav[0], wav[1]])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(3):
