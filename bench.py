@@ -151,7 +151,7 @@ def cpu_baseline(n_steps, one_core_steps=None):
         dt = time.perf_counter() - t0
     ms_step = 1000.0 * dt / n_steps
     fps = lambda ms: round(320.0 / (4000 * ms / 1000.0), 3)
-    out = {"value": fps(ms_step), "unit": "frames/s", "cores": int(cores), "kind": "port, 1 window x 4",
+    out = {"value": fps(ms_step), "unit": "frames/s", "cores": int(cores), "kind": "port",
            "ms_per_denoise_step": round(ms_step, 3), "host": host_cpu(),
            "sample": f"{n_steps} DDPM steps of one 88-frame ZEGGS window (batch 1, fp32 numpy oracle, {cores} BLAS threads); "
                      f"a 320-frame clip is 4 such windows of 1000 steps"}
