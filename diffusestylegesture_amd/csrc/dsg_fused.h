@@ -169,6 +169,9 @@ __global__ __launch_bounds__(256) void k_inloc(const InLocArgs g) { DSG_TL_SCOPE
 // ---------------------------------------------------------------------------------------------------------
 // k_mid: pre1 = R + attn.Wo^T + bo ; x1 = LayerNorm1(pre1) ; hidden[:, slice] = gelu(x1.W1[slice]^T + b1)
 // ---------------------------------------------------------------------------------------------------------
+// linear1 fragments per wave held in registers by k_mid / k_attn_mid (and the out_proj chunk of k_mid): all KD of them up to 16
+// (fp32 at D = 256 used to stream them in two serial chunks: round 4), 4 at the widths whose W_o share already fills the file
+__host__ __device__ constexpr int mid_ch(int dt, int kd) { return dt >= 6 ? 4 : (kd > 8 ? 16 : 8); }
 struct MidArgs {
     const void* A;          // attention output rows P::elem [rows][D]
     const float* R;         // residual rows fp32 [rows][D]
@@ -186,7 +189,7 @@ struct MidArgs {
 template <class P, int DT>
 __device__ __forceinline__ void mid_tail(const MidArgs& g, f32x4 (&acc)[DT], const f32x4 (&pbo)[DT], const f32x4 (&pr)[DT],
                                          const f32x4 (&pg)[DT], const f32x4 (&pbt)[DT], const f32x4 pb1,
-                                         const f32x4 (&w1f)[(DT * 64 / P::KB) <= (DT >= 6 ? 4 : 8) ? (DT * 64 / P::KB) : 1],
+                                         const f32x4 (&w1f)[(DT * 64 / P::KB) <= mid_ch(DT, DT * 64 / P::KB) ? (DT * 64 / P::KB) : 1],
                                          const f32x4* w1, char* a1, float (&red)[2][4][16], int m0, int ng, int n1t, int wave,
                                          int lr, int lg) {
     typedef typename P::elem elem;
@@ -194,7 +197,7 @@ __device__ __forceinline__ void mid_tail(const MidArgs& g, f32x4 (&acc)[DT], con
     constexpr int D = DT * 64;
     constexpr int KD = D / P::KB;
     constexpr int XP = D * ES + 16;
-    constexpr int CH = DT >= 6 ? 4 : 8;
+    constexpr int CH = mid_ch(DT, KD);
     // ---- residual + LayerNorm1 over whole rows (row lr: 4 lane groups x 4 waves hold its D values)
     float s = 0.f;
 #pragma unroll
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
     constexpr int D = DT * 64;
     constexpr int KD = D / P::KB;
     constexpr int XP = D * ES + 16;
-    constexpr int CH = DT >= 6 ? 4 : 8;              // fragments in flight per chunk (DT tiles each): bounded by the register file
+    constexpr int CH = mid_ch(DT, KD);               // fragments in flight per chunk (DT tiles each): bounded by the register file
     __shared__ __attribute__((aligned(16))) char a1[16 * XP];
     __shared__ float red[2][4][16];
     __shared__ __attribute__((aligned(16))) float vecs[3][D];      // out_proj bias, LayerNorm1 scale / shift: one load per WORKGROUP
@@ -370,7 +373,7 @@ __device__ __forceinline__ void attn_mid_body(const AttnMidArgs& ga) {
     constexpr int KD = D / P::KB;                    // k-blocks of the out_proj / linear1 reductions
     constexpr int KDH = HD / P::KB;                  // k-blocks over the head dim
     constexpr int XP = D * ES + 16;
-    constexpr int CH = DT >= 6 ? 4 : 8;
+    constexpr int CH = mid_ch(DT, KD);
     constexpr int ND = HD / 16;
     constexpr int NVF = P::E == 4 ? NKT : NKT / 2;   // PV k-blocks
     constexpr int PD = 4;                            // out_proj k-blocks in flight ahead of the MFMA
@@ -514,6 +517,16 @@ __device__ __forceinline__ void attn_mid_body(const AttnMidArgs& ga) {
         DSG_ISSUE_SLOT(2 * NKT + dt);
     }
 #undef DSG_ISSUE_SLOT
+    // fp32 (KD = 16 at D = 256): K / V^T are dead now -- ALL remaining W_o k-blocks in one batch instead of a PD-deep pipeline of
+    // exposed L2 round trips inside the out_proj loop (round 4: k_attn_mid<PF32, 4, 6> 20.4 us, 62 % of the fp32 step)
+    constexpr bool ALL_AFTER = KD > PDA && (KD - PDA) * DT <= 64;
+    if constexpr (ALL_AFTER) {
+#pragma unroll
+        for (int kb = PDA; kb < KD; ++kb)
+#pragma unroll
+            for (int t = 0; t < DT; ++t) bf[kb][t] = wo[((size_t)(wave * DT + t) * KD + kb) * 64];
+        DSG_LOADS_ISSUED();
+    }
     DSG_LDS_BARRIER();
 
     // ---- (5) out_proj from the LDS rows, remaining weight k-blocks PD ahead
@@ -522,7 +535,7 @@ __device__ __forceinline__ void attn_mid_body(const AttnMidArgs& ga) {
     for (int t = 0; t < DT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < KD; ++kb) {
-        if (kb + PD >= PDA && kb + PD < KD) {
+        if (!ALL_AFTER && kb + PD >= PDA && kb + PD < KD) {
 #pragma unroll
             for (int t = 0; t < DT; ++t) bf[kb + PD][t] = wo[((size_t)(wave * DT + t) * KD + kb + PD) * 64];
         }

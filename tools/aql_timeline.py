@@ -32,6 +32,7 @@ p.add_argument("--steps", type=int, default=600)
 p.add_argument("--first", type=int, default=200)
 p.add_argument("--n", type=int, default=32)
 p.add_argument("--config", default="zeggs")
+p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
 p.add_argument("--out", default="")
 p.add_argument("--lib", default="stamps", choices=["stamps", "product"],
                help="stamps: libdsg_hip_stamps.so (`make stamps`): in-kernel first-wave / last-wave stamps, ~1 %% overhead; "
@@ -40,7 +41,7 @@ a = p.parse_args()
 if a.lib == "stamps":
     os.environ["DSG_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "diffusestylegesture_amd", "csrc", "libdsg_hip_stamps.so")
 cfg = CFG.CONFIGS[a.config]
-m = DSGDenoiser(cfg, precision="bf16", max_batch=a.batch, device=0).set_kernel_set(a.kset)
+m = DSGDenoiser(cfg, precision=a.precision, max_batch=a.batch, device=0).set_kernel_set(a.kset)
 m.load_state_dict(synth_state_dict(cfg, 20240))
 d = create_gaussian_diffusion()
 shape = (a.batch, cfg.njoints, 1, cfg.n_poses)
