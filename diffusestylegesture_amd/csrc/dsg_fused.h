@@ -1144,4 +1144,192 @@ __global__ __launch_bounds__(256) void k_attn_op_w(const AttnOpArgs g) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// k_ffn (round 4, BLOCK set): the whole feed-forward half of an encoder layer for a block of RT x 16 rows in ONE kernel --
+//   hidden = gelu(x1 . W1^T + b1)   (hidden stays in LDS, in the GEMM type: the rounding point of the `hidden` buffer)
+//   pre2   = x1 + hidden . W2^T + b2
+//   xn     = LayerNorm2(pre2)        -> fp32 rows (the next attention kernel's residual) + GEMM-type fragment-major rows (the next
+//                                       QKV projection's / the pose head's operand: they become DIRECT GEMMs, no LayerNorm-on-read)
+// replacing linear1, linear2 and the LayerNorm prologue of the next kernel: one dispatch instead of two, the largest activation of
+// a layer never crosses the fabric, and the 12 - 18 column groups of the next GEMM stop re-normalising the same fp32 rows.  The
+// price: every workgroup streams ALL of W1 and W2 (1 MB in bf16 at D = 256, ff = 1024) through one CU for 16 RT rows.
+// Wave w owns hidden columns [w ff/4, (w+1) ff/4) in phase 1 and output columns [w D/4, (w+1) D/4) in phase 2; weight fragments
+// are double-buffered two column tiles (phase 1) / KC k-blocks (phase 2) ahead.  The k sums of linear2 run 0 .. ff - 1 in one
+// chain (k_gemm_blk_k: four ranges, then summed), LayerNorm2 as in k_attn_op (explicit fma sites).
+// Reference arithmetic: linear1 / activation / linear2 / norm2 of torch's TransformerEncoderLayer (main/model/mdm.py:79-86).
+// ---------------------------------------------------------------------------------------------------------
+struct FfnArgs {
+    const void* A;          // LayerNorm1 rows in the GEMM type, fragment-major (k_attn_op's X1a)
+    const float* R;         // the same rows in fp32 (residual)
+    const void* W1; const float* b1;
+    const void* W2; const float* b2;
+    const float* ln_g; const float* ln_b;
+    float* Xn;              // LayerNorm2 rows fp32 [rows][D]
+    void* Xa;               // ... in the GEMM type, fragment-major
+    int M, MT;
+};
+
+template <class P, int DT, int FT, int RT, int NW, int LA = 2>      // D = 64 DT, ff = 64 FT, RT row tiles per workgroup, NW waves, LA tiles / 2 LA k-blocks of look-ahead
+__global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {
+    DSG_TL_SCOPE();
+    typedef typename P::elem elem;
+    constexpr int ES = (int)sizeof(elem);
+    constexpr int D = 64 * DT, FF = 64 * FT, KD = D / P::KB, KF = FF / P::KB;
+    constexpr int FW = FF / 16 / NW, DW = D / 16 / NW;            // column tiles per wave in phase 1 / phase 2
+    constexpr int HP = FF * ES + 16;                 // LDS pitch of a hidden row
+    constexpr int KC0 = (DW >= 4 ? 2 : 4) * LA, KC = KC0 < KF ? KC0 : KF, NC = KF / KC;   // phase 2: k-blocks per weight chunk (8 LA fragments in flight)
+    constexpr int NT = 64 * NW;
+    static_assert(FW >= LA && FW % LA == 0 && DW >= 1 && KF % KC == 0 && (FF / 16) % NW == 0 && (D / 16) % NW == 0, "shape");
+    __shared__ __attribute__((aligned(16))) char hid[RT * 16 * HP];
+    __shared__ float red[RT][2][NW][16];
+    __shared__ __attribute__((aligned(16))) float vecs[3][D];      // b2, LayerNorm2 scale / shift
+    preload_kernargs(g);
+    const int mb = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
+    const int m0 = mb * 16 * RT, mt_last = g.MT - 1;
+    // ---- loads that do not depend on phase 1: A fragments, first W1 tiles, residual rows, the per-column vectors
+    f32x4 af[RT][KD];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int mt = min(mb * RT + rt, mt_last);           // clamped (rows past the end are computed and dropped)
+#pragma unroll
+        for (int kb = 0; kb < KD; ++kb) af[rt][kb] = lda16<P>(g.A, ((size_t)(mt * KD + kb) * 64 + lane) * P::E * ES);
+    }
+    const f32x4* w1 = (const f32x4*)g.W1 + lane;
+    const f32x4* w2 = (const f32x4*)g.W2 + lane;
+    f32x4 wb1[2][LA][KD], pb1[2][LA];                // [buffer][tile of the group][k-block]
+    auto load1 = [&](int buf, int tp) {
+#pragma unroll
+        for (int j = 0; j < LA; ++j) {
+            const int nt = wave * FW + LA * tp + j;
+#pragma unroll
+            for (int kb = 0; kb < KD; ++kb) wb1[buf][j][kb] = w1[((size_t)nt * KD + kb) * 64];
+            pb1[buf][j] = *(const f32x4*)(g.b1 + nt * 16 + 4 * lg);
+        }
+    };
+    load1(0, 0);
+    f32x4 pr[RT][DW];
+    bool rowok[RT];
+    size_t mrow[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int m = m0 + rt * 16 + lr;
+        rowok[rt] = m < g.M;
+        mrow[rt] = (size_t)(rowok[rt] ? m : g.M - 1);
+#pragma unroll
+        for (int t = 0; t < DW; ++t) pr[rt][t] = lda16<P>(g.R, (mrow[rt] * D + (wave * DW + t) * 16 + 4 * lg) * sizeof(float));
+    }
+    constexpr int NV = (3 * D / 4 + NT - 1) / NT;
+    f32x4 vload[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int e = min(tid + NT * i, 3 * D / 4 - 1), vsel = e / (D / 4), vidx = e % (D / 4);
+        vload[i] = ((const f32x4*)(vsel == 0 ? g.b2 : (vsel == 1 ? g.ln_g : g.ln_b)))[vidx];
+    }
+    DSG_LOADS_ISSUED();
+    // ---- phase 1: hidden tiles of this wave, LA at a time, the next group's fragments in flight
+#pragma unroll
+    for (int tp = 0; tp < FW / LA; ++tp) {
+        if (tp + 1 < FW / LA) { load1((tp + 1) & 1, tp + 1); DSG_LOADS_ISSUED(); }
+#pragma unroll
+        for (int j = 0; j < LA; ++j) {
+            const int nt = wave * FW + LA * tp + j;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < KD; ++kb) c = P::mma(wb1[tp & 1][j][kb], af[rt][kb], c);      // D[n 4lg+r][row lr]
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = gelu_erf<P>(c[e] + pb1[tp & 1][j][e]);
+                P::store4((elem*)(hid + (rt * 16 + lr) * HP) + nt * 16 + 4 * lg, y);
+            }
+        }
+    }
+    // ---- phase 2: first W2 chunk requested before the barrier
+    f32x4 wb2[2][KC][DW];
+    auto load2 = [&](int buf, int c) {
+#pragma unroll
+        for (int k = 0; k < KC; ++k)
+#pragma unroll
+            for (int t = 0; t < DW; ++t) wb2[buf][k][t] = w2[((size_t)(wave * DW + t) * KF + c * KC + k) * 64];
+    };
+    load2(0, 0);
+    DSG_LOADS_ISSUED();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int e = tid + NT * i;
+        if (e < 3 * D / 4) *(f32x4*)(&vecs[0][0] + e * 4) = vload[i];
+    }
+    DSG_LDS_BARRIER();
+    f32x4 acc[RT][DW];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int t = 0; t < DW; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (c + 1 < NC) { load2((c + 1) & 1, c + 1); DSG_LOADS_ISSUED(); }
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const f32x4 a = *(const f32x4*)(hid + (rt * 16 + lr) * HP + ((c * KC + k) * P::KB + P::E * lg) * ES);
+#pragma unroll
+                for (int t = 0; t < DW; ++t) acc[rt][t] = P::mma(wb2[c & 1][k][t], a, acc[rt][t]);
+            }
+        }
+    }
+    // ---- + bias + residual, LayerNorm2 over whole rows (row lr: 4 lane groups x NW waves hold its D values)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        float sm = 0.f;
+#pragma unroll
+        for (int t = 0; t < DW; ++t) {
+            const f32x4 pb = *(const f32x4*)(&vecs[0][(wave * DW + t) * 16 + 4 * lg]);
+            acc[rt][t] = acc[rt][t] + pb + pr[rt][t];
+            sm += (acc[rt][t][0] + acc[rt][t][1]) + (acc[rt][t][2] + acc[rt][t][3]);
+        }
+        sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
+        if (lg == 0) red[rt][0][wave][lr] = sm;
+    }
+    DSG_LDS_BARRIER();
+    float mean[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w2_ = 0; w2_ < NW; ++w2_) tot += red[rt][0][w2_][lr];
+        mean[rt] = tot / (float)D;
+        float qv = 0.f;
+#pragma unroll
+        for (int t = 0; t < DW; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = acc[rt][t][e] - mean[rt]; qv = __builtin_fmaf(d, d, qv); }
+        qv += __shfl_xor(qv, 16); qv += __shfl_xor(qv, 32);
+        if (lg == 0) red[rt][1][wave][lr] = qv;
+    }
+    DSG_LDS_BARRIER();
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w2_ = 0; w2_ < NW; ++w2_) tot += red[rt][1][w2_][lr];
+        const float rstd = 1.0f / sqrtf(tot / (float)D + 1e-5f);
+        if (rowok[rt]) {
+#pragma unroll
+            for (int t = 0; t < DW; ++t) {
+                const int n = (wave * DW + t) * 16 + 4 * lg;
+                const f32x4 pg = *(const f32x4*)(&vecs[1][n]), pbt = *(const f32x4*)(&vecs[2][n]);
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = __builtin_fmaf((acc[rt][t][e] - mean[rt]) * rstd, pg[e], pbt[e]);
+                *(f32x4*)(g.Xn + mrow[rt] * D + n) = y;
+                P::store4((elem*)g.Xa + qk_off<P>((int)mrow[rt], n, KD), y);
+            }
+        }
+    }
+}
+
 }  // namespace dsg

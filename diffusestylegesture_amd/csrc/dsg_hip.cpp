@@ -361,9 +361,9 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     if (const char* e = getenv("DSG_KSET")) {
         char* end = nullptr;
         const long v = strtol(e, &end, 10);
-        if (end == e || *end != 0 || v < DSG_KSET_AUTO || v > DSG_KSET_STREAM) {
+        if (end == e || *end != 0 || v < DSG_KSET_AUTO || v > DSG_KSET_FFN) {
             delete h;
-            return fail(DSG_E_INVALID, std::string("DSG_KSET must be 0 (auto) .. 4 (stream), got '") + e + "'");
+            return fail(DSG_E_INVALID, std::string("DSG_KSET must be 0 (auto) .. 5 (ffn), got '") + e + "'");
         }
         h->kset_req = (int)v;
     }
@@ -822,6 +822,8 @@ struct KernelSel {
     bool blk = false;           // BLOCK: 32-row block GEMMs
     bool attn_op = false;       // k_attn_op instead of k_attn + out_proj
     bool stream = false;        // STREAM: BLOCK with the weight-stationary persistent GEMMs of dsg_stream.h (LayerNorm + QKV, linear1, linear2, pose head)
+    bool ffn = false;           // FFN set: BLOCK with linear1 + GELU + linear2 + residual + LayerNorm2 in one kernel (k_ffn); QKV of the next
+                                // layer and the pose head then read normalised rows: DIRECT GEMMs
     bool xs_frag = false;       // BLOCK / STREAM (bf16, Jp 128 / 1152): the state shadow is fragment-major and the pose embedding streams it (k_ws2<EPI_PARTIAL>:
                                 // 8.9 -> 4.3 us at 1424 rows, 29.9 -> 11.0 at 5632; 3.8 -> 4.1 at 356)
 };
@@ -852,8 +854,15 @@ static bool stream_set_ok(const dsg_handle* h) {
     // linear1 reads the fragment-major LayerNorm1 rows k_attn_op writes
     return have_attn_op_narrow(h) && (h->D == 256 || h->D == 128) && (h->ff == 1024 || h->ff == 128) && (h->Jp == 1152 || h->Jp == 128);
 }
+static bool ffn_set_ok(const dsg_handle* h) {
+    return have_attn_op_narrow(h) && ((h->D == 256 && h->ff == 1024) || (h->D == 128 && h->ff == 128));
+}
 static int auto_kernel_set(const dsg_handle* h, int B, int lanes) {
     const int rows = B * h->ntok;
+    // several lanes of 1000 .. 3500 rows each: BLOCK with the fused feed-forward kernel (round 4, profiles/r04_m_*): 4 x 12 clips
+    // 333 vs 383 us (BLOCK), 4 x 16: 379 vs 407 (STREAM) / 485, 4 x 32: 635 vs 687 / 900; 4 x 64 ties with STREAM (1256 vs 1227-1267);
+    // one lane alone never (1 x 16: 273 vs 230 BLOCK; 1 x 32: 331 vs 316 STREAM; 1 x 64: 435 vs 422)
+    if (lanes > 1 && rows >= 1000 && rows < 4000 && ffn_set_ok(h)) return DSG_KSET_FFN;
     if (rows >= (lanes > 1 ? 1400 : 2800) && stream_set_ok(h)) return DSG_KSET_STREAM;
     if (lanes <= 1) {
         if (B <= 2 && latency_set_ok(h)) return DSG_KSET_LATENCY;
@@ -871,23 +880,27 @@ static int select_kernels(const dsg_handle* h, int B, KernelSel& k) {
     }
     if (set == DSG_KSET_LATENCY && h->D > 512) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set LATENCY: latent_dim > 512");
     if (set == DSG_KSET_STREAM && !stream_set_ok(h)) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set STREAM: bf16, latent_dim 128 / 256, 4 heads, ff 128 / 1024 only");
-    if (set < DSG_KSET_LATENCY || set > DSG_KSET_STREAM) return fail(DSG_E_INVALID, "unknown kernel set");
+    if (set == DSG_KSET_FFN && !ffn_set_ok(h)) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set FFN: bf16, latent_dim 128 / 256, 4 heads, ff 128 / 1024 only");
+    if (set < DSG_KSET_LATENCY || set > DSG_KSET_FFN) return fail(DSG_E_INVALID, "unknown kernel set");
     k = KernelSel();
     k.set = set;
     k.lat = set == DSG_KSET_LATENCY;
     k.attn_in_mid = k.lat && h->fuse_attn_mid && have_attn_mid(h, B);
     k.stream = set == DSG_KSET_STREAM;
-    k.blk = set == DSG_KSET_BLOCK || k.stream;      // (STREAM: pose embedding and layer-0 QKV as in BLOCK)
+    k.ffn = set == DSG_KSET_FFN;
+    k.blk = set == DSG_KSET_BLOCK || k.stream || k.ffn;      // (STREAM: pose embedding and layer-0 QKV as in BLOCK; FFN: BLOCK + k_ffn)
     // the wide form (W_o streamed: DSG+ widths, fp32) belongs to BLOCK / STREAM only -- a set's arithmetic never depends on the batch,
     // and at batch 1 its 10 workgroups per layer lose to k_attn + out_proj (BEAT: 200 vs 163 us/step; 16 clips: 3371 vs 2904 frames/s)
     k.attn_op = !k.lat && (have_attn_op_narrow(h) || (k.blk && have_attn_op_wide(h)));
     k.xs_frag = k.blk && h->prec == DSG_PREC_BF16 && (h->Jp == 1152 || h->Jp == 128);
+
     return 0;
 }
 
 extern "C" int dsg_set_kernel_set(dsg_handle* h, int set) {
     if (!h) return fail(DSG_E_INVALID, "null handle");
-    if (set < DSG_KSET_AUTO || set > DSG_KSET_STREAM) return fail(DSG_E_INVALID, "dsg_set_kernel_set: unknown kernel set");
+    if (set < DSG_KSET_AUTO || set > DSG_KSET_FFN) return fail(DSG_E_INVALID, "dsg_set_kernel_set: unknown kernel set");
+    if (set == DSG_KSET_FFN && !ffn_set_ok(h)) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set FFN: bf16, latent_dim 128 / 256, 4 heads, ff 128 / 1024 only");
     if (set == DSG_KSET_LATENCY && h->D > 512) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set LATENCY: latent_dim > 512");
     if (set == DSG_KSET_STREAM && !stream_set_ok(h)) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set STREAM: bf16, latent_dim 128 / 256, 4 heads, ff 128 / 1024 only");
     if (getenv("DSG_KSET")) {                  // an A/B run pinned the set for the whole process: say so once, keep the pinned set
@@ -1219,6 +1232,9 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
             if (l == 0) {
                 g.A = h->X0a; g.lda = D; g.a_frag = la.x0a_frag;
                 CHK((launch_gemm_w<P, PRO_DIRECT, EPI_QKV>(h, g, ks)));
+            } else if (ks.ffn) {      // k_ffn left LayerNorm2(previous layer) in X0a, fragment-major
+                g.A = h->X0a; g.lda = D; g.a_frag = 1;
+                CHK((launch_gemm_w<P, PRO_DIRECT, EPI_QKV>(h, g, ks)));
             } else {
                 g.X = h->pre2; g.ln_g = h->layers[l - 1].g2; g.ln_b = h->layers[l - 1].be2; g.Xn = h->Xn;
                 CHK((launch_gemm_w<P, PRO_LN, EPI_QKV>(h, g, ks)));
@@ -1268,6 +1284,18 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                     else CHK((step_launch<&k_attn_op_w<P, 2, 2>>(h, grid, dim3(256), a)));
                 }
             }
+            // (guidance: the last layer leaves pre2 to the two-pass pose head k_gemm_cfg, which normalises on read)
+            if (ks.ffn && !(h->cfgB > 0 && l == h->L - 1)) {      // linear1 + GELU + linear2 + residual + LayerNorm2 (k_ffn): Xn fp32 + X0a in the GEMM type
+                FfnArgs a;
+                a.A = h->X1a; a.R = h->X1; a.W1 = ly.W1; a.b1 = ly.b1; a.W2 = ly.W2; a.b2 = ly.b2; a.ln_g = ly.g2; a.ln_b = ly.be2;
+                a.Xn = h->Xn; a.Xa = h->X0a; a.M = M; a.MT = MT;
+                if constexpr (sizeof(typename P::elem) == 2) {
+                    const dim3 grid(cdiv(MT, 2));
+                    if (D == 256) CHK((step_launch<&k_ffn<P, 4, 16, 2, 4>>(h, grid, dim3(256), a)));
+                    else CHK((step_launch<&k_ffn<P, 2, 2, 2, 4>>(h, grid, dim3(256), a)));
+                }
+                continue;
+            }
             {   // linear1 + GELU -> hidden
                 GemmArgs g = z;
                 g.M = M; g.MT = MT; g.NT = h->ff / 16; g.KBtot = D / KB; g.Wp = ly.W1; g.bias = ly.b1;
@@ -1313,6 +1341,9 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
             if (pick_ch(g.KBtot) == 16) CHK((step_launch<&k_gemm_cfg<P, 16>>(h, grid, dim3(256), g)));
             else if (pick_ch(g.KBtot) == 12) CHK((step_launch<&k_gemm_cfg<P, 12>>(h, grid, dim3(256), g)));
             else CHK((step_launch<&k_gemm_cfg<P>>(h, grid, dim3(256), g)));
+        } else if (ks.ffn) {      // the rows are normalised already (k_ffn of the last layer; cfgB == 0 here)
+            g.X = nullptr; g.ln_g = nullptr; g.ln_b = nullptr; g.A = h->X0a; g.lda = D; g.a_frag = 1;
+            CHK((launch_gemm_w<P, PRO_DIRECT, EPI_OUT>(h, g, ks)));
         } else {
             CHK((launch_gemm_w<P, PRO_LN, EPI_OUT>(h, g, ks)));
         }
