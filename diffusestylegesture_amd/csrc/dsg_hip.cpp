@@ -361,9 +361,9 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     if (const char* e = getenv("DSG_KSET")) {
         char* end = nullptr;
         const long v = strtol(e, &end, 10);
-        if (end == e || *end != 0 || v < DSG_KSET_AUTO || v > DSG_KSET_FFN) {
+        if (end == e || *end != 0 || v < DSG_KSET_AUTO || v > DSG_KSET_STREAM) {
             delete h;
-            return fail(DSG_E_INVALID, std::string("DSG_KSET must be 0 (auto) .. 5 (ffn), got '") + e + "'");
+            return fail(DSG_E_INVALID, std::string("DSG_KSET must be 0 (auto) .. 4 (stream), got '") + e + "'");
         }
         h->kset_req = (int)v;
     }
@@ -822,8 +822,8 @@ struct KernelSel {
     bool blk = false;           // BLOCK: 32-row block GEMMs
     bool attn_op = false;       // k_attn_op instead of k_attn + out_proj
     bool stream = false;        // STREAM: BLOCK with the weight-stationary persistent GEMMs of dsg_stream.h (LayerNorm + QKV, linear1, linear2, pose head)
-    bool ffn = false;           // FFN set: BLOCK with linear1 + GELU + linear2 + residual + LayerNorm2 in one kernel (k_ffn); QKV of the next
-                                // layer and the pose head then read normalised rows: DIRECT GEMMs
+    bool ffn = false;           // STREAM (round 4): linear1 + GELU + linear2 + residual + LayerNorm2 in one kernel (k_ffn); QKV of the next layer
+                                // and the pose head then read normalised rows: direct streaming GEMMs, no k_ln_frag
     bool xs_frag = false;       // BLOCK / STREAM (bf16, Jp 128 / 1152): the state shadow is fragment-major and the pose embedding streams it (k_ws2<EPI_PARTIAL>:
                                 // 8.9 -> 4.3 us at 1424 rows, 29.9 -> 11.0 at 5632; 3.8 -> 4.1 at 356)
 };
@@ -854,16 +854,11 @@ static bool stream_set_ok(const dsg_handle* h) {
     // linear1 reads the fragment-major LayerNorm1 rows k_attn_op writes
     return have_attn_op_narrow(h) && (h->D == 256 || h->D == 128) && (h->ff == 1024 || h->ff == 128) && (h->Jp == 1152 || h->Jp == 128);
 }
-static bool ffn_set_ok(const dsg_handle* h) {
-    return have_attn_op_narrow(h) && ((h->D == 256 && h->ff == 1024) || (h->D == 128 && h->ff == 128));
-}
 static int auto_kernel_set(const dsg_handle* h, int B, int lanes) {
     const int rows = B * h->ntok;
-    // several lanes of 1000 .. 3500 rows each: BLOCK with the fused feed-forward kernel (round 4, profiles/r04_m_*): 4 x 12 clips
-    // 333 vs 383 us (BLOCK), 4 x 16: 379 vs 407 (STREAM) / 485, 4 x 32: 635 vs 687 / 900; 4 x 64 ties with STREAM (1256 vs 1227-1267);
-    // one lane alone never (1 x 16: 273 vs 230 BLOCK; 1 x 32: 331 vs 316 STREAM; 1 x 64: 435 vs 422)
-    if (lanes > 1 && rows >= 1000 && rows < 4000 && ffn_set_ok(h)) return DSG_KSET_FFN;
-    if (rows >= (lanes > 1 ? 1400 : 2800) && stream_set_ok(h)) return DSG_KSET_STREAM;
+    // (round 4, STREAM with k_ffn; profiles/r04_n_sweep_sets.log: 4 x 12 clips 319 vs 383 us BLOCK, 4 x 8: 299 vs 286; 1 x 24: 295 vs 301,
+    // 1 x 16: 282 vs 230)
+    if (rows >= (lanes > 1 ? 1000 : 2000) && stream_set_ok(h)) return DSG_KSET_STREAM;
     if (lanes <= 1) {
         if (B <= 2 && latency_set_ok(h)) return DSG_KSET_LATENCY;
         return rows >= 1000 ? DSG_KSET_BLOCK : DSG_KSET_TILE;
@@ -880,15 +875,14 @@ static int select_kernels(const dsg_handle* h, int B, KernelSel& k) {
     }
     if (set == DSG_KSET_LATENCY && h->D > 512) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set LATENCY: latent_dim > 512");
     if (set == DSG_KSET_STREAM && !stream_set_ok(h)) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set STREAM: bf16, latent_dim 128 / 256, 4 heads, ff 128 / 1024 only");
-    if (set == DSG_KSET_FFN && !ffn_set_ok(h)) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set FFN: bf16, latent_dim 128 / 256, 4 heads, ff 128 / 1024 only");
-    if (set < DSG_KSET_LATENCY || set > DSG_KSET_FFN) return fail(DSG_E_INVALID, "unknown kernel set");
+    if (set < DSG_KSET_LATENCY || set > DSG_KSET_STREAM) return fail(DSG_E_INVALID, "unknown kernel set");
     k = KernelSel();
     k.set = set;
     k.lat = set == DSG_KSET_LATENCY;
     k.attn_in_mid = k.lat && h->fuse_attn_mid && have_attn_mid(h, B);
     k.stream = set == DSG_KSET_STREAM;
-    k.ffn = set == DSG_KSET_FFN;
-    k.blk = set == DSG_KSET_BLOCK || k.stream || k.ffn;      // (STREAM: pose embedding and layer-0 QKV as in BLOCK; FFN: BLOCK + k_ffn)
+    k.ffn = k.stream;           // (round 4: k_ffn instead of k_ws<GELU> + k_ws2<RESID> + k_ln_frag)
+    k.blk = set == DSG_KSET_BLOCK || k.stream;      // (STREAM: pose embedding and layer-0 QKV as in BLOCK)
     // the wide form (W_o streamed: DSG+ widths, fp32) belongs to BLOCK / STREAM only -- a set's arithmetic never depends on the batch,
     // and at batch 1 its 10 workgroups per layer lose to k_attn + out_proj (BEAT: 200 vs 163 us/step; 16 clips: 3371 vs 2904 frames/s)
     k.attn_op = !k.lat && (have_attn_op_narrow(h) || (k.blk && have_attn_op_wide(h)));
@@ -899,8 +893,7 @@ static int select_kernels(const dsg_handle* h, int B, KernelSel& k) {
 
 extern "C" int dsg_set_kernel_set(dsg_handle* h, int set) {
     if (!h) return fail(DSG_E_INVALID, "null handle");
-    if (set < DSG_KSET_AUTO || set > DSG_KSET_FFN) return fail(DSG_E_INVALID, "dsg_set_kernel_set: unknown kernel set");
-    if (set == DSG_KSET_FFN && !ffn_set_ok(h)) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set FFN: bf16, latent_dim 128 / 256, 4 heads, ff 128 / 1024 only");
+    if (set < DSG_KSET_AUTO || set > DSG_KSET_STREAM) return fail(DSG_E_INVALID, "dsg_set_kernel_set: unknown kernel set");
     if (set == DSG_KSET_LATENCY && h->D > 512) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set LATENCY: latent_dim > 512");
     if (set == DSG_KSET_STREAM && !stream_set_ok(h)) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set STREAM: bf16, latent_dim 128 / 256, 4 heads, ff 128 / 1024 only");
     if (getenv("DSG_KSET")) {                  // an A/B run pinned the set for the whole process: say so once, keep the pinned set
@@ -1080,7 +1073,7 @@ static int launch_ws2(dsg_handle* h, GemmArgs g) {
 template <class P, int PRO, int EPI>
 static int launch_gemm_w(dsg_handle* h, const GemmArgs& g, const KernelSel& ks) {
     constexpr bool blk_wins = EPI == EPI_QKV || EPI == EPI_GELU;
-    if constexpr (sizeof(typename P::elem) == 2 && PRO == PRO_DIRECT && (EPI == EPI_GELU || EPI == EPI_QKV)) {
+    if constexpr (sizeof(typename P::elem) == 2 && PRO == PRO_DIRECT && (EPI == EPI_GELU || EPI == EPI_QKV || EPI == EPI_OUT)) {
         if (ks.stream && g.a_frag) return launch_ws<EPI>(h, g);      // STREAM: linear1 on the fragment-major LayerNorm1 rows of k_attn_op
     }
     if constexpr (sizeof(typename P::elem) == 2 && PRO == PRO_LN && (EPI == EPI_QKV || EPI == EPI_OUT)) {

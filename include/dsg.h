@@ -65,17 +65,14 @@ enum { DSG_PREC_FP32 = 0, DSG_PREC_BF16 = 1 };
  * grouping / tiling, i.e. last-bit differences between sets in bf16 -- which is why the set is an explicit, sticky property of
  * a handle and never depends on how a call is issued. */
 enum {
-    DSG_KSET_AUTO = 0,      /* by batch: LATENCY for batch <= 2, TILE below 1000 token rows, BLOCK from there, STREAM from 2800 */
+    DSG_KSET_AUTO = 0,      /* by batch: LATENCY for batch <= 2, TILE below 1000 token rows, BLOCK from there, STREAM from 2000 */
     DSG_KSET_LATENCY = 1,   /* fused redundant-compute kernels, 2 + 3L dispatches: one clip in flight */
     DSG_KSET_TILE = 2,      /* one 16 x 16 MFMA tile per wave: small batches */
     DSG_KSET_BLOCK = 3,     /* 32-row block GEMMs + fused attention/out_proj/LayerNorm: large batches, several lanes */
-    DSG_KSET_STREAM = 4,    /* weight-stationary persistent GEMMs (32x32x16 MFMA, global->LDS staging, 64-row blocks) for every
+    DSG_KSET_STREAM = 4     /* weight-stationary persistent GEMMs (32x32x16 MFMA, global->LDS staging, 64-row blocks) for every
                                Linear of a layer and the pose head, LayerNorm once per row: >= 32 clips in one lane, >= 16 per
                                lane with several lanes.  bf16, latent_dim 128 / 256, 4 heads -- the ZEGGS model;
                                DSG_E_NOT_IMPLEMENTED elsewhere */
-    DSG_KSET_FFN = 5        /* ABI 310: BLOCK with the feed-forward half of a layer in ONE kernel (linear1 + GELU + linear2 + residual +
-                               LayerNorm2, the hidden activations never leave LDS; the next QKV / the pose head are direct GEMMs): several
-                               lanes of 12 .. 32 clips each (48 .. 128 clips per GPU).  bf16, the ZEGGS model; DSG_E_NOT_IMPLEMENTED elsewhere */
 };
 enum { DSG_MODE_DDPM = 0, DSG_MODE_DDIM = 1 };
 

@@ -136,7 +136,7 @@ def test_classifier_free_guidance_wrapper(tiny):
         w(x, ts, y)
 
 
-@pytest.mark.parametrize("kset", ["tile", "block", "stream", "ffn"])
+@pytest.mark.parametrize("kset", ["tile", "block", "stream"])
 def test_kernel_sets_tiny(tiny, emu_lib, golden_dir, kset):
     """Explicit kernel sets (dsg_set_kernel_set) at the tiny dims against the same goldens as the latency kernels, incl. the
     ragged last row tile (bf16: with k_attn_op; "stream": the weight-stationary GEMMs of dsg_stream.h incl. LayerNorm once per row, the streamed pose embedding and pose head); at batch 8 and batch 23 (529 rows: the 3-waves-per-SIMD LayerNorm GEMMs from
@@ -144,8 +144,8 @@ def test_kernel_sets_tiny(tiny, emu_lib, golden_dir, kset):
     from oracle.mdm import MDMOracle
     gt, _, y, x = tiny
     sd = synth_state_dict(C.TINY, int(gt["wseed"]))
-    all_precs = ("bf16",) if kset in ("stream", "ffn") else ("fp32", "bf16")       # "stream" (dsg_stream.h) and "ffn" (k_ffn) are bf16 sets
-    if kset in ("stream", "ffn"):
+    all_precs = ("bf16",) if kset == "stream" else ("fp32", "bf16")       # "stream" (dsg_stream.h, k_ffn) is a bf16 set
+    if kset == "stream":
         with pytest.raises(NotImplementedError):
             DSGDenoiser(C.TINY, precision="fp32", max_batch=2, library=emu_lib).set_kernel_set(kset)
     for prec in all_precs:

@@ -231,7 +231,7 @@ def test_block_set_at_dsgplus_dims_batch_8(gpu, cfg_name):
     assert e < TOL_CHAIN["bf16"]
 
 
-@pytest.mark.parametrize("kset", ["block", "stream", "ffn"])
+@pytest.mark.parametrize("kset", ["block", "stream"])
 def test_guidance_in_the_batched_kernel_sets(gpu, kset):
     """Classifier-free guidance fused into the step loop (cfg_sampler.py:8-31: conditional rows + their unconditional twins in one
     batch, combined in the pose-head epilogue) in the BLOCK and STREAM sets, whose state shadow is fragment-major and whose pose

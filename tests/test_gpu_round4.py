@@ -194,7 +194,7 @@ def test_attn_op2_equals_attn_op_and_rows_do_not_depend_on_the_batch(gpu, monkey
         outs[v] = np.asarray(_model(cfg, "bf16", max_batch=B).set_kernel_set("stream")(x, ts, y)).copy()
     monkeypatch.delenv("DSG_ATTN_OP2")
     assert np.array_equal(outs["0"], outs["1"])
-    for ks, Bs in (("tile", (8,)), ("block", (8, 48)), ("stream", (8, 48)), ("ffn", (8, 48))):
+    for ks, Bs in (("tile", (8,)), ("block", (8, 48)), ("stream", (8, 48))):
         small = _model(cfg, "bf16", max_batch=2).set_kernel_set(ks)
         for Bb in Bs:
             big = _model(cfg, "bf16", max_batch=Bb).set_kernel_set(ks)
@@ -206,10 +206,11 @@ def test_attn_op2_equals_attn_op_and_rows_do_not_depend_on_the_batch(gpu, monkey
                 assert np.array_equal(out[lo:lo + 2], np.asarray(small(x[lo:lo + 2], ts[lo:lo + 2], ys))), (ks, Bb, lo)
 
 
-def test_ffn_kernel_set_vs_oracle_and_lanes(gpu):
-    """Kernel set `ffn` (round 4: BLOCK with linear1 + GELU + linear2 + residual + LayerNorm2 in ONE kernel, k_ffn; the next QKV and the
-    pose head are direct GEMMs): forward rows at batch 3 / 16 / 40 and a 30-step chain at batch 16 against the oracle; the arrangement
-    it is recommended for -- 4 lanes x batch 16 -- runs it fence-free on 4 queues and a lane reproduces itself alone, bit for bit."""
+def test_stream_set_with_fused_ffn_vs_oracle_and_lanes(gpu):
+    """Round 4: the STREAM set runs the feed-forward half of a layer as ONE kernel (k_ffn: linear1 + GELU + linear2 + residual +
+    LayerNorm2, the hidden activations never leave LDS; the next QKV and the pose head are direct streaming GEMMs, no k_ln_frag):
+    forward rows at batch 3 / 16 / 40 and a 30-step chain at batch 16 against the oracle; 4 lanes x batch 16 (the arrangement of
+    bench.py --clips-per-gpu 64) fence-free on 4 queues, a lane reproduces itself alone bit for bit; the recommendation thresholds."""
     import torch
     from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
     from diffusestylegesture_amd.sample import generate_clip, generate_clips_streams
@@ -223,9 +224,9 @@ def test_ffn_kernel_set_vs_oracle_and_lanes(gpu):
         y = synth_window_inputs(cfg, B, window=2, clip0=1, seed_pose_scale=0.2)
         x = np.random.RandomState(B).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
         ts = (np.arange(B) * 23 + 5) % 1000
-        m = _model(cfg, "bf16", max_batch=B).set_kernel_set("ffn")
+        m = _model(cfg, "bf16", max_batch=B).set_kernel_set("stream")
         out = np.asarray(m(x, ts, y))
-        assert m.last_kernel_set() == "ffn"
+        assert m.last_kernel_set() == "stream"
         for b in sorted({0, B // 2, B - 1}):
             yb = {k: (v[b:b + 1] if v.shape[0] == B else v) for k, v in y.items()}
             e = rel_l2(out[b:b + 1], ref(x[b:b + 1], [int(ts[b])], yb))
@@ -239,16 +240,15 @@ def test_ffn_kernel_set_vs_oracle_and_lanes(gpu):
             yb = {k: (v[b:b + 1] if v.shape[0] == B else v) for k, v in y.items()}
             w = sampler.p_sample_loop(OracleDiffusion(), ref, (1,) + shape[1:], lambda k: sampler.philox.normal_bj1t(shape, 11, k, 2)[b:b + 1], {"y": yb}, skip_timesteps=970)
             assert rel_l2(got[b:b + 1], w) < TOL_CHAIN["bf16"]
-    with pytest.raises(NotImplementedError):
-        _model(C.BEAT, "bf16").set_kernel_set("ffn")
     NL, B, K = 4, 16, 2
     m = _model(cfg, "bf16", max_batch=B)
     lanes = [m] + [m.clone() for _ in range(NL - 1)]
-    assert m.recommend_kernel_set(16, 4) == "ffn" and m.recommend_kernel_set(16, 1) == "block" and m.recommend_kernel_set(64, 4) == "stream"
+    assert m.recommend_kernel_set(12, 4) == "stream" and m.recommend_kernel_set(8, 4) == "block"
+    assert m.recommend_kernel_set(16, 1) == "block" and m.recommend_kernel_set(24, 1) == "stream"
     d = create_gaussian_diffusion()
     feats = [[torch.from_numpy(synth_window_inputs(cfg, B, window=w, clip0=ln * B)["audio"]).cuda() for w in range(K)] for ln in range(NL)]
     got = generate_clips_streams(lanes, d, feats, [1, 0, 0, 0, 0, 0], seed=5, skip_timesteps=960, stream_ids=[0, 1, 2, 3])
-    assert all(ln.last_kernel_set() == "ffn" and ln.last_sample_path() == "aql" for ln in lanes) and np.isfinite(got).all()
-    lanes[1].set_kernel_set("ffn")
+    assert all(ln.last_kernel_set() == "stream" and ln.last_sample_path() == "aql" for ln in lanes) and np.isfinite(got).all()
+    lanes[1].set_kernel_set("stream")
     alone = generate_clip(lanes[1], d, feats[1], [1, 0, 0, 0, 0, 0], seed=5, skip_timesteps=960, stream_id=1)
     assert np.array_equal(alone, got[B:2 * B])
