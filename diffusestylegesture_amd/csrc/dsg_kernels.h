@@ -501,8 +501,15 @@ __device__ __forceinline__ void ln_rows(const GemmArgs& g, int m0, int tid, char
 // Epilogue operands of one 16 x 16 output tile (bias, residual rows, x_t, noise): requested early, they do not depend on
 // the main loop
 struct TileOps { f32x4 pb, pr, pz; float pbs; bool ovalid; };
+// x_t of (row m, features j0 .. j0 + 3) for the sampler epilogue: unconditional load from a clamped (always valid) row
+template <class P>
+__device__ __forceinline__ f32x4 out_xt_load(const GemmArgs& g, int m, int j0) {
+    const int b = fdiv(m, g.inv_ntok), sx = m - b * g.ntok;
+    const int bc = b < g.B ? b : g.B - 1, fc = sx > 0 ? sx - 1 : 0;
+    return lda16<P>(g.xs32, (((size_t)bc * g.T + fc) * g.Jp + j0) * sizeof(float));
+}
 template <class P, int EPI>
-__device__ __forceinline__ void gemm_prefetch_tile(const GemmArgs& g, int m0, int n0, int lr, int lg, int step, TileOps& o) {
+__device__ __forceinline__ void gemm_prefetch_tile(const GemmArgs& g, int m0, int n0, int lr, int lg, int step, TileOps& o, const f32x4* xt_ready = nullptr) {
         o.pb = o.pr = o.pz = (f32x4){0.f, 0.f, 0.f, 0.f};
         o.pbs = 0.f; o.ovalid = false;
         if constexpr (EPI == EPI_RESID) {
@@ -518,10 +525,8 @@ __device__ __forceinline__ void gemm_prefetch_tile(const GemmArgs& g, int m0, in
             const int b = fdiv(m, g.inv_ntok), sx = m - b * g.ntok;
             o.ovalid = m < g.M && sx > 0 && j0 < g.J;
             o.pb = *(const f32x4*)(g.bias + j0);
-            {   // x_t: unconditional load from a clamped (always valid) row; unused when the lane is not `ovalid`
-                const int bc = b < g.B ? b : g.B - 1, fc = sx > 0 ? sx - 1 : 0;
-                o.pr = lda16<P>(g.xs32, (((size_t)bc * g.T + fc) * g.Jp + j0) * sizeof(float));
-            }
+            // x_t: unconditional load from a clamped (always valid) row; unused when the lane is not `ovalid`
+            o.pr = xt_ready ? *xt_ready : out_xt_load<P>(g, m, j0);
             if (o.ovalid && g.out_mode != OUT_FORWARD && !g.no_noise) {
                 const int f = sx - 1;
                 const int bn = g.const_noise ? 0 : b;

@@ -240,12 +240,18 @@ __device__ __forceinline__ void ws_body(const GemmArgs& g, const WsId id, char* 
                 for (int q = 0; q < 4; ++q)
                     *(f32x4*)(st + l31 * TP + 8 * q + 4 * lhi) = (f32x4){acc[ct][4 * q], acc[ct][4 * q + 1], acc[ct][4 * q + 2], acc[ct][4 * q + 3]};
                 DSG_WAVE_LDS_SYNC();
-#pragma unroll 1
-                for (int i = 0; i < 4; ++i) {          // one (token, feature quad) per lane at a time: the register budget of 2 workgroups per CU
+                // x_t of the lane's 4 (token, feature quad) items up front: ONE memory round trip per column tile instead of four
+                // dependent load -> update -> store sequences (round 4); the Philox draw and the update stay one item at a time
+                // (the register budget of 2 workgroups per CU)
+                f32x4 xt[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xt[i] = out_xt_load<P>(g, mw + tok + 8 * i, nb[ct] + 4 * quad);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
                     TileOps ops;
                     const int t = tok + 8 * i;
                     const f32x4 v = *(const f32x4*)(st + t * TP + 4 * quad);
-                    gemm_prefetch_tile<P, EPI>(g, mw + t, nb[ct] + 4 * quad, 0, 0, step, ops);
+                    gemm_prefetch_tile<P, EPI>(g, mw + t, nb[ct] + 4 * quad, 0, 0, step, ops, &xt[i]);
                     gemm_epilogue_tile<P, EPI>(g, mw + t, nb[ct] + 4 * quad, 0, 0, 0, true, v, ops, k1, k2, k3, k4, k5);
                 }
                 DSG_WAVE_LDS_SYNC();
