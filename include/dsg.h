@@ -69,9 +69,10 @@ enum {
     DSG_KSET_LATENCY = 1,   /* fused redundant-compute kernels, 2 + 3L dispatches: one clip in flight */
     DSG_KSET_TILE = 2,      /* one 16 x 16 MFMA tile per wave: small batches */
     DSG_KSET_BLOCK = 3,     /* 32-row block GEMMs + fused attention/out_proj/LayerNorm: large batches, several lanes */
-    DSG_KSET_STREAM = 4     /* weight-stationary persistent GEMMs (32x32x16 MFMA, global->LDS staging, 64-row blocks) for every
-                               Linear of a layer and the pose head, LayerNorm once per row: >= 32 clips in one lane, >= 16 per
-                               lane with several lanes.  bf16, latent_dim 128 / 256, 4 heads -- the ZEGGS model;
+    DSG_KSET_STREAM = 4     /* weight-stationary persistent GEMMs (32x32x16 MFMA, global->LDS staging, 64-row blocks) for the pose
+                               embedding, QKV and the pose head; linear1 + GELU + linear2 + residual + LayerNorm2 of a layer as one
+                               kernel (3 + 3L dispatches per step): >= 2000 token rows (23 ZEGGS clips) in one lane, >= 1000 rows
+                               (12 clips) per lane with several lanes.  bf16, latent_dim 128 / 256, 4 heads -- the ZEGGS model;
                                DSG_E_NOT_IMPLEMENTED elsewhere */
 };
 enum { DSG_MODE_DDPM = 0, DSG_MODE_DDIM = 1 };
