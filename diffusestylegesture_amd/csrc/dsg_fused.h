@@ -1332,4 +1332,164 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k_ffn_part + k_ffn_ln (round 4, BLOCK set below the STREAM threshold): k_ffn split S ways over the hidden dimension.
+// k_ffn pulls all of W1 and W2 (1 MB) through one CU per 32 rows -- 17 us whatever the batch, which loses to linear1 + linear2 at
+// 1424 rows (45 workgroups).  Here workgroup (row block mb, split s) computes  hidden[:, s ff/S .. (s+1) ff/S) = gelu(x1 W1^T + b1)
+// for RT x 16 rows into LDS and multiplies it with the matching k-range of W2: a PARTIAL linear2 result, written as an fp32 slab
+// part[s][row][D].  Its weights (ff/S columns of W1, the same k-range of W2: 128 KB at S = 8) are requested in ONE batch at kernel
+// start, next to the A fragments -- one memory round trip, then 2 x FWS x RT x KD MFMAs per wave.  k_ffn_ln sums the S slabs in the
+// fixed order 0 .. S-1, adds bias + residual, applies LayerNorm2 (two-pass, fp32) and writes what k_ffn writes: the fp32 rows and
+// the GEMM-type fragment-major rows, so the next QKV projection is a DIRECT GEMM.  A row's result depends on S (a template constant
+// of the set), never on the batch.
+// Reference arithmetic: linear1 / activation / linear2 / norm2 of torch's TransformerEncoderLayer (main/model/mdm.py:79-86).
+// ---------------------------------------------------------------------------------------------------------
+struct FfnPartArgs {
+    const void* A;          // LayerNorm1 rows in the GEMM type, fragment-major (k_attn_op's X1a)
+    const void* W1; const float* b1;
+    const void* W2;
+    float* part;            // [S][slab] fp32, slab >= M * D
+    size_t slab;            // floats per slab
+    int M, MT;
+};
+
+template <class P, int DT, int FT, int RT, int NW, int S>
+__global__ __launch_bounds__(64 * NW) void k_ffn_part(const FfnPartArgs g) {
+    DSG_TL_SCOPE();
+    typedef typename P::elem elem;
+    constexpr int ES = (int)sizeof(elem);
+    constexpr int D = 64 * DT, FF = 64 * FT, KD = D / P::KB, KF = FF / P::KB;
+    constexpr int FS = FF / S, FWS = FS / 16 / NW, KFS = FS / P::KB, DW = D / 16 / NW;
+    constexpr int HP = FS * ES + 16;                 // LDS pitch of a hidden row
+    static_assert(FF % S == 0 && FS % (16 * NW) == 0 && FS % P::KB == 0 && (D / 16) % NW == 0 && FWS >= 1 && KFS >= 1, "shape");
+    __shared__ __attribute__((aligned(16))) char hid[RT * 16 * HP];
+    preload_kernargs(g);
+    const int mb = blockIdx.x / S, s = blockIdx.x - mb * S;
+    const int lane = threadIdx.x & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
+    const int m0 = mb * 16 * RT, mt_last = g.MT - 1;
+    // ---- every global load of the workgroup in one batch
+    f32x4 af[RT][KD];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int mt = min(mb * RT + rt, mt_last);           // clamped (rows past the end are computed and dropped)
+#pragma unroll
+        for (int kb = 0; kb < KD; ++kb) af[rt][kb] = lda16<P>(g.A, ((size_t)(mt * KD + kb) * 64 + lane) * P::E * ES);
+    }
+    const f32x4* w1 = (const f32x4*)g.W1 + lane;
+    const f32x4* w2 = (const f32x4*)g.W2 + lane;
+    f32x4 wb1[FWS][KD], pb1[FWS];
+#pragma unroll
+    for (int j = 0; j < FWS; ++j) {
+        const int nt = s * (FS / 16) + wave * FWS + j;
+#pragma unroll
+        for (int kb = 0; kb < KD; ++kb) wb1[j][kb] = w1[((size_t)nt * KD + kb) * 64];
+        pb1[j] = *(const f32x4*)(g.b1 + nt * 16 + 4 * lg);
+    }
+    f32x4 wb2[KFS][DW];
+#pragma unroll
+    for (int k = 0; k < KFS; ++k)
+#pragma unroll
+        for (int t = 0; t < DW; ++t) wb2[k][t] = w2[((size_t)(wave * DW + t) * KF + s * KFS + k) * 64];
+    DSG_LOADS_ISSUED();
+    // ---- phase 1: this wave's hidden tiles of the split
+#pragma unroll
+    for (int j = 0; j < FWS; ++j) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < KD; ++kb) c = P::mma(wb1[j][kb], af[rt][kb], c);      // D[n 4lg+r][row lr]
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = gelu_erf<P>(c[e] + pb1[j][e]);
+            P::store4((elem*)(hid + (rt * 16 + lr) * HP) + (wave * FWS + j) * 16 + 4 * lg, y);
+        }
+    }
+    DSG_LDS_BARRIER();
+    // ---- phase 2: partial linear2 over the split's k-range, all D columns (wave w: columns [w D/NW, (w+1) D/NW))
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        f32x4 acc[DW];
+#pragma unroll
+        for (int t = 0; t < DW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KFS; ++k) {
+            const f32x4 a = *(const f32x4*)(hid + (rt * 16 + lr) * HP + (k * P::KB + P::E * lg) * ES);
+#pragma unroll
+            for (int t = 0; t < DW; ++t) acc[t] = P::mma(wb2[k][t], a, acc[t]);
+        }
+        const int m = m0 + rt * 16 + lr;
+        if (m < g.M) {
+            float* o = g.part + (size_t)s * g.slab + (size_t)m * D + wave * DW * 16 + 4 * lg;
+#pragma unroll
+            for (int t = 0; t < DW; ++t) *(f32x4*)(o + t * 16) = acc[t];
+        }
+    }
+}
+
+struct FfnLnArgs {
+    const float* part; size_t slab;
+    const float* R;         // LayerNorm1 rows fp32 (residual)
+    const float* b2; const float* ln_g; const float* ln_b;
+    float* Xn;              // LayerNorm2 rows fp32 [rows][D]
+    void* Xa;               // ... in the GEMM type, fragment-major
+    int M;
+};
+
+// RW rows per workgroup, 16 lanes per row; lane c of a row owns columns 64 q + 4 c .. + 3 (q < DT): 256 contiguous bytes per (row, q)
+template <class P, int DT, int S, int RW = 16>
+__global__ __launch_bounds__(16 * RW) void k_ffn_ln(const FfnLnArgs g) {
+    DSG_TL_SCOPE();
+    typedef typename P::elem elem;
+    constexpr int D = 64 * DT, KD = D / P::KB;
+    preload_kernargs(g);
+    const int tid = threadIdx.x, c = tid & 15;
+    const int m = blockIdx.x * RW + (tid >> 4);
+    const bool ok = m < g.M;
+    const size_t mr = (size_t)(ok ? m : g.M - 1);
+    f32x4 p[S][DT], r[DT], pb[DT], pg[DT], pt[DT];
+#pragma unroll
+    for (int q = 0; q < DT; ++q) {
+        const int n = 64 * q + 4 * c;
+#pragma unroll
+        for (int s = 0; s < S; ++s) p[s][q] = lda16<P>(g.part, ((size_t)s * g.slab + mr * D + n) * sizeof(float));
+        r[q] = lda16<P>(g.R, (mr * D + n) * sizeof(float));
+        pb[q] = *(const f32x4*)(g.b2 + n); pg[q] = *(const f32x4*)(g.ln_g + n); pt[q] = *(const f32x4*)(g.ln_b + n);
+    }
+    DSG_LOADS_ISSUED();
+    f32x4 v[DT];
+    float sm = 0.f;
+#pragma unroll
+    for (int q = 0; q < DT; ++q) {
+        f32x4 a = p[0][q];
+#pragma unroll
+        for (int s = 1; s < S; ++s) a = a + p[s][q];
+        v[q] = a + pb[q] + r[q];
+        sm += (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) sm += __shfl_xor(sm, o);
+    const float mean = sm / (float)D;
+    float qv = 0.f;
+#pragma unroll
+    for (int q = 0; q < DT; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[q][e] - mean; qv = __builtin_fmaf(d, d, qv); }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) qv += __shfl_xor(qv, o);
+    const float rstd = 1.0f / sqrtf(qv / (float)D + 1e-5f);
+    if (ok) {
+#pragma unroll
+        for (int q = 0; q < DT; ++q) {
+            const int n = 64 * q + 4 * c;
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = __builtin_fmaf((v[q][e] - mean) * rstd, pg[q][e], pt[q][e]);
+            *(f32x4*)(g.Xn + mr * D + n) = y;
+            P::store4((elem*)g.Xa + qk_off<P>((int)mr, n, KD), y);
+        }
+    }
+}
+
+
 }  // namespace dsg

@@ -149,6 +149,7 @@ struct dsg_handle {
           *X1 = nullptr, *fwd_out = nullptr, *io_tmp = nullptr, *io_tmp2 = nullptr, *ext_noise = nullptr;
     size_t ext_noise_cap = 0;
     void *xsA = nullptr, *X0a = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *attn = nullptr, *hidden = nullptr;
+    float* ffn_part = nullptr; size_t ffn_slab = 0;      // [4][ffn_slab] partial linear2 results of k_ffn_part
     void* X1a = nullptr;                 // LayerNorm1 rows in the GEMM type, fragment-major (k_attn_op -> linear1)
     int* ctr = nullptr;                  // scratch counter for diagnostics
     StepCtl* ctl = nullptr;              // device-resident step control (dsg_kernels.h: StepCtl)
@@ -416,6 +417,8 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     CHK(dalloc_bytes(h, &h->attn, M_pad * D * h->es));
     CHK(dalloc_bytes(h, &h->X1a, M_pad * D * h->es));
     CHK(dalloc_bytes(h, &h->hidden, M_pad * (size_t)h->ff * h->es));
+    h->ffn_slab = M_pad * D;
+    if (stream_set_ok(h)) CHK(dalloc(h, &h->ffn_part, 4 * h->ffn_slab));      // partial linear2 slabs of k_ffn_part (BLOCK set)
     const size_t qkv_elems = (size_t)B * h->H * Tp * hd;
     CHK(dalloc_bytes(h, &h->q, qkv_elems * h->es));
     CHK(dalloc_bytes(h, &h->k, qkv_elems * h->es));
@@ -824,6 +827,7 @@ struct KernelSel {
     bool stream = false;        // STREAM: BLOCK with the weight-stationary persistent GEMMs of dsg_stream.h (LayerNorm + QKV, linear1, linear2, pose head)
     bool ffn = false;           // STREAM (round 4): linear1 + GELU + linear2 + residual + LayerNorm2 in one kernel (k_ffn); QKV of the next layer
                                 // and the pose head then read normalised rows: direct streaming GEMMs, no k_ln_frag
+    bool ffn_split = false;     // BLOCK (round 4, bf16 ZEGGS / tiny dims): k_ffn split over the hidden dimension (k_ffn_part + k_ffn_ln); direct QKV / pose head
     bool xs_frag = false;       // BLOCK / STREAM (bf16, Jp 128 / 1152): the state shadow is fragment-major and the pose embedding streams it (k_ws2<EPI_PARTIAL>:
                                 // 8.9 -> 4.3 us at 1424 rows, 29.9 -> 11.0 at 5632; 3.8 -> 4.1 at 356)
 };
@@ -887,6 +891,10 @@ static int select_kernels(const dsg_handle* h, int B, KernelSel& k) {
     // and at batch 1 its 10 workgroups per layer lose to k_attn + out_proj (BEAT: 200 vs 163 us/step; 16 clips: 3371 vs 2904 frames/s)
     k.attn_op = !k.lat && (have_attn_op_narrow(h) || (k.blk && have_attn_op_wide(h)));
     k.xs_frag = k.blk && h->prec == DSG_PREC_BF16 && (h->Jp == 1152 || h->Jp == 128);
+    if (set == DSG_KSET_BLOCK && stream_set_ok(h) && h->ffn_part) {
+        const char* e = getenv("DSG_FFN_SPLIT");          // A/B: 0 = linear1 + linear2 + LayerNorm-on-read (round 3)
+        k.ffn_split = e ? (atoi(e) != 0) : 1;
+    }
 
     return 0;
 }
@@ -1225,7 +1233,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
             if (l == 0) {
                 g.A = h->X0a; g.lda = D; g.a_frag = la.x0a_frag;
                 CHK((launch_gemm_w<P, PRO_DIRECT, EPI_QKV>(h, g, ks)));
-            } else if (ks.ffn) {      // k_ffn left LayerNorm2(previous layer) in X0a, fragment-major
+            } else if (ks.ffn || ks.ffn_split) {      // k_ffn / k_ffn_ln left LayerNorm2(previous layer) in X0a, fragment-major
                 g.A = h->X0a; g.lda = D; g.a_frag = 1;
                 CHK((launch_gemm_w<P, PRO_DIRECT, EPI_QKV>(h, g, ks)));
             } else {
@@ -1289,6 +1297,25 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                 }
                 continue;
             }
+            // BLOCK below the STREAM threshold (round 4): k_ffn split 4 ways over the hidden dimension + the slab sum / LayerNorm2 pass; the
+            // next QKV projection and the pose head become direct GEMMs.  (Guidance: the last layer leaves pre2 to k_gemm_cfg, which
+            // normalises on read.)  profiles/r04_q_*: 1 x 16 230.9 -> 218.8 us, 4 x 4 222.4 -> 214.4, 4 x 8 288.9 -> 240.8.
+            if (ks.ffn_split && (l < h->L - 1 || h->cfgB == 0)) {
+                if constexpr (sizeof(typename P::elem) == 2) {
+                    FfnPartArgs a;
+                    a.A = h->X1a; a.W1 = ly.W1; a.b1 = ly.b1; a.W2 = ly.W2; a.part = h->ffn_part; a.slab = h->ffn_slab; a.M = M; a.MT = MT;
+                    FfnLnArgs b;
+                    b.part = h->ffn_part; b.slab = h->ffn_slab; b.R = h->X1; b.b2 = ly.b2; b.ln_g = ly.g2; b.ln_b = ly.be2; b.Xn = h->Xn; b.Xa = h->X0a; b.M = M;
+                    if (D == 256) {
+                        CHK((step_launch<&k_ffn_part<P, 4, 16, 2, 4, 4>>(h, dim3(cdiv(MT, 2) * 4), dim3(256), a)));
+                        CHK((step_launch<&k_ffn_ln<P, 4, 4, 8>>(h, dim3(cdiv(M, 8)), dim3(128), b)));
+                    } else {
+                        CHK((step_launch<&k_ffn_part<P, 2, 2, 2, 4, 2>>(h, dim3(cdiv(MT, 2) * 2), dim3(256), a)));
+                        CHK((step_launch<&k_ffn_ln<P, 2, 2, 8>>(h, dim3(cdiv(M, 8)), dim3(128), b)));
+                    }
+                }
+                continue;
+            }
             {   // linear1 + GELU -> hidden
                 GemmArgs g = z;
                 g.M = M; g.MT = MT; g.NT = h->ff / 16; g.KBtot = D / KB; g.Wp = ly.W1; g.bias = ly.b1;
@@ -1334,7 +1361,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
             if (pick_ch(g.KBtot) == 16) CHK((step_launch<&k_gemm_cfg<P, 16>>(h, grid, dim3(256), g)));
             else if (pick_ch(g.KBtot) == 12) CHK((step_launch<&k_gemm_cfg<P, 12>>(h, grid, dim3(256), g)));
             else CHK((step_launch<&k_gemm_cfg<P>>(h, grid, dim3(256), g)));
-        } else if (ks.ffn) {      // the rows are normalised already (k_ffn of the last layer; cfgB == 0 here)
+        } else if (ks.ffn || ks.ffn_split) {      // the rows are normalised already (k_ffn / k_ffn_ln of the last layer; cfgB == 0 here)
             g.X = nullptr; g.ln_g = nullptr; g.ln_b = nullptr; g.A = h->X0a; g.lda = D; g.a_frag = 1;
             CHK((launch_gemm_w<P, PRO_DIRECT, EPI_OUT>(h, g, ks)));
         } else {

@@ -252,3 +252,45 @@ def test_stream_set_with_fused_ffn_vs_oracle_and_lanes(gpu):
     lanes[1].set_kernel_set("stream")
     alone = generate_clip(lanes[1], d, feats[1], [1, 0, 0, 0, 0, 0], seed=5, skip_timesteps=960, stream_id=1)
     assert np.array_equal(alone, got[B:2 * B])
+
+
+def test_block_set_with_the_ffn_split_over_hidden_vs_oracle(gpu, monkeypatch):
+    """Round 4: below the STREAM threshold the BLOCK set runs the feed-forward half of a layer as k_ffn_part (4 workgroups per
+    32-row block, each a quarter of ff: partial linear2 slabs in fp32) + k_ffn_ln (slab sum in a fixed order + bias + residual +
+    LayerNorm2), and the next QKV projection / the pose head as direct GEMMs.  Forward rows at batch 1 / 16 / 23 (1 x 23 needs a
+    second round of k_ffn_part workgroups) and a 30-step chain at batch 16 against the oracle; the round-3 kernels
+    (DSG_FFN_SPLIT=0: linear1, linear2, LayerNorm-on-read) agree to bf16 noise; a row does not depend on the batch."""
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    from oracle import sampler
+    from oracle.mdm import MDMOracle
+    from oracle.schedule import OracleDiffusion
+    cfg = C.ZEGGS
+    sd = synth_state_dict(cfg, 20240)
+    ref = MDMOracle(sd, cfg)
+    for B in (1, 16, 23):
+        y = synth_window_inputs(cfg, B, window=1, clip0=3, seed_pose_scale=0.2)
+        x = np.random.RandomState(100 + B).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+        ts = (np.arange(B) * 41 + 7) % 1000
+        m = _model(cfg, "bf16", max_batch=B).set_kernel_set("block")
+        out = np.asarray(m(x, ts, y))
+        assert m.last_kernel_set() == "block"
+        for b in sorted({0, B // 2, B - 1}):
+            yb = {k: (v[b:b + 1] if v.shape[0] == B else v) for k, v in y.items()}
+            e = rel_l2(out[b:b + 1], ref(x[b:b + 1], [int(ts[b])], yb))
+            assert e < TOL_FWD["bf16"], (B, b, e)
+        if B == 16:
+            monkeypatch.setenv("DSG_FFN_SPLIT", "0")
+            old = np.asarray(m(x, ts, y))
+            monkeypatch.delenv("DSG_FFN_SPLIT")
+            assert 0 < rel_l2(out, old) < TOL_FWD["bf16"]            # a different set of kernels ran, same function
+            small = _model(cfg, "bf16", max_batch=2).set_kernel_set("block")
+            ys = {k: (v[5:7] if v.shape[0] == B else v) for k, v in y.items()}
+            assert np.array_equal(out[5:7], np.asarray(small(x[5:7], ts[5:7], ys)))
+            d = create_gaussian_diffusion()
+            shape = (B, cfg.njoints, 1, cfg.n_poses)
+            got = np.asarray(d.manual_seed(13, 1).p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=970))
+            assert m.last_sample_path() == "aql" and m.last_kernel_set() == "block"
+            b = 9
+            yb = {k: (v[b:b + 1] if v.shape[0] == B else v) for k, v in y.items()}
+            w = sampler.p_sample_loop(OracleDiffusion(), ref, (1,) + shape[1:], lambda k: sampler.philox.normal_bj1t(shape, 13, k, 1)[b:b + 1], {"y": yb}, skip_timesteps=970)
+            assert rel_l2(got[b:b + 1], w) < TOL_CHAIN["bf16"]
