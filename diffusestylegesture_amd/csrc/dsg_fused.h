@@ -1154,8 +1154,11 @@ __global__ __launch_bounds__(256) void k_attn_op_w(const AttnOpArgs g) {
 // replacing linear1, linear2 and the LayerNorm prologue of the next kernel: one dispatch instead of two, the largest activation of
 // a layer never crosses the fabric, and the 12 - 18 column groups of the next GEMM stop re-normalising the same fp32 rows.  The
 // price: every workgroup streams ALL of W1 and W2 (1 MB in bf16 at D = 256, ff = 1024) through one CU for 16 RT rows.
-// Wave w owns hidden columns [w ff/4, (w+1) ff/4) in phase 1 and output columns [w D/4, (w+1) D/4) in phase 2; weight fragments
-// are double-buffered two column tiles (phase 1) / KC k-blocks (phase 2) ahead.  The k sums of linear2 run 0 .. ff - 1 in one
+// Wave w owns hidden columns [w ff/NW, (w+1) ff/NW) in phase 1 and output columns [w D/NW, (w+1) D/NW) in phase 2; weight fragments
+// are double-buffered two column tiles (phase 1) / KC k-blocks (phase 2) ahead.  At the ZEGGS widths the workgroup is 8 waves (244 VGPRs with
+// the residual rows requested after phase 1, LATE_R): twice the weight bytes in flight per CU -- 18.1 -> 16.4 us per launch at 5696 rows
+// (profiles/r04_u_*, r04_v_*; walking the hidden-column groups in a per-workgroup rotated order, in case every CU of an XCD asking
+// the same L2 channel for the same fragment at the same moment was the limit, changed nothing: 16.35 vs 16.32).  The k sums of linear2 run 0 .. ff - 1 in one
 // chain (k_gemm_blk_k: four ranges, then summed), LayerNorm2 as in k_attn_op (explicit fma sites).
 // Reference arithmetic: linear1 / activation / linear2 / norm2 of torch's TransformerEncoderLayer (main/model/mdm.py:79-86).
 // ---------------------------------------------------------------------------------------------------------
@@ -1170,7 +1173,7 @@ struct FfnArgs {
     int M, MT;
 };
 
-template <class P, int DT, int FT, int RT, int NW, int LA = 2>      // D = 64 DT, ff = 64 FT, RT row tiles per workgroup, NW waves, LA tiles / 2 LA k-blocks of look-ahead
+template <class P, int DT, int FT, int RT, int NW, int LA = 2, bool LATE_R = false>      // D = 64 DT, ff = 64 FT, RT row tiles per workgroup, NW waves, LA tiles / 2 LA k-blocks of look-ahead
 __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {
     DSG_TL_SCOPE();
     typedef typename P::elem elem;
@@ -1217,8 +1220,10 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {
         const int m = m0 + rt * 16 + lr;
         rowok[rt] = m < g.M;
         mrow[rt] = (size_t)(rowok[rt] ? m : g.M - 1);
+        if constexpr (!LATE_R) {
 #pragma unroll
-        for (int t = 0; t < DW; ++t) pr[rt][t] = lda16<P>(g.R, (mrow[rt] * D + (wave * DW + t) * 16 + 4 * lg) * sizeof(float));
+            for (int t = 0; t < DW; ++t) pr[rt][t] = lda16<P>(g.R, (mrow[rt] * D + (wave * DW + t) * 16 + 4 * lg) * sizeof(float));
+        }
     }
     constexpr int NV = (3 * D / 4 + NT - 1) / NT;
     f32x4 vload[NV];
@@ -1256,6 +1261,12 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {
             for (int t = 0; t < DW; ++t) wb2[buf][k][t] = w2[((size_t)(wave * DW + t) * KF + c * KC + k) * 64];
     };
     load2(0, 0);
+    if constexpr (LATE_R) {      // (8 waves: the residual rows are requested only now -- the register budget of phase 1)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < DW; ++t) pr[rt][t] = lda16<P>(g.R, (mrow[rt] * D + (wave * DW + t) * 16 + 4 * lg) * sizeof(float));
+    }
     DSG_LOADS_ISSUED();
 #pragma unroll
     for (int i = 0; i < NV; ++i) {

@@ -1292,7 +1292,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                 a.Xn = h->Xn; a.Xa = h->X0a; a.M = M; a.MT = MT;
                 if constexpr (sizeof(typename P::elem) == 2) {
                     const dim3 grid(cdiv(MT, 2));
-                    if (D == 256) CHK((step_launch<&k_ffn<P, 4, 16, 2, 4>>(h, grid, dim3(256), a)));
+                    if (D == 256) CHK((step_launch<&k_ffn<P, 4, 16, 2, 8, 2, true>>(h, grid, dim3(512), a)));
                     else CHK((step_launch<&k_ffn<P, 2, 2, 2, 4>>(h, grid, dim3(256), a)));
                 }
                 continue;

@@ -39,8 +39,8 @@
 // i.e. it paid from ~2800 rows in one lane and ~1400 rows per lane with several lanes.  Below that a workgroup gets ONE block, so the
 // register-resident panel is loaded for nothing and the persistent loop has nothing to overlap.
 // ROUND 4: the step no longer launches k_ln_frag, k_ws<EPI_GELU> and k_ws2<EPI_RESID> per layer -- k_ffn (dsg_fused.h) does linear1 + GELU
-// + linear2 + residual + LayerNorm2 in one kernel and writes the next QKV's / the pose head's operand (1 x 64: 422 -> 385-391 us, 256 clips
-// 16.4k -> 19.9k frames/s; auto_kernel_set() picks the set from 2000 rows, 1000 per lane with several lanes).  Those three kernels remain
+// + linear2 + residual + LayerNorm2 in one kernel and writes the next QKV's / the pose head's operand (1 x 64: 422 -> 375 us, 256 clips
+// 16.4k -> 20.2k frames/s; auto_kernel_set() picks the set from 2000 rows, 1000 per lane with several lanes).  Those three kernels remain
 // for the last layer under fused classifier-free guidance and as the measured alternative (profiles/r04_l..o_*).
 // An earlier form with LayerNorm-on-read INSIDE the weight-stationary GEMM (64 fp32 rows staged through registers, one workgroup
 // per CU) was slower than the block kernels at every size (QKV 28.0 vs 23.0 us at 5696 rows): csrc/experiments/dsg_stream_ln.h.

@@ -113,3 +113,29 @@ def test_progressive_generators_are_lazy_and_chunked(emu_lib):
     full = d100.manual_seed(4, 2).ddim_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, eta=0.5)
     steps = [np.asarray(o["sample"]) for o in d100.manual_seed(4, 2).ddim_sample_loop_progressive(m, shape, clip_denoised=False, model_kwargs={"y": y}, eta=0.5)]
     assert len(steps) == 100 and np.array_equal(steps[-1], np.asarray(full))
+
+
+def test_fused_feed_forward_kernels_at_zeggs_dims(emu_lib):
+    """Round 4: the feed-forward half of a layer as one kernel at the ZEGGS widths -- k_ffn (STREAM: 8 waves per workgroup, hidden in
+    LDS) and k_ffn_part + k_ffn_ln (BLOCK: the same split 4 ways over ff, fp32 partial slabs summed in a fixed order), the next QKV /
+    the pose head as direct GEMMs -- forward rows against the oracle; the round-3 kernels (DSG_FFN_SPLIT=0) agree to bf16 noise."""
+    from oracle.mdm import MDMOracle
+    cfg = C.ZEGGS
+    sd = synth_state_dict(cfg, 20240)
+    B = 2
+    m = DSGDenoiser(cfg, precision="bf16", max_batch=B, library=emu_lib)
+    m.load_state_dict(sd)
+    y = synth_window_inputs(cfg, B, window=1)
+    x = np.random.RandomState(0).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+    ts = [10, 500]
+    ref = MDMOracle(sd, cfg)(x, ts, y)
+    outs = {}
+    for ks in ("stream", "block"):
+        outs[ks] = np.asarray(m.set_kernel_set(ks)(x, ts, y))
+        assert m.last_kernel_set() == ks and rel_l2(outs[ks], ref) < 1.2e-2, ks
+    os.environ["DSG_FFN_SPLIT"] = "0"
+    try:
+        old = np.asarray(m(x, ts, y))
+    finally:
+        del os.environ["DSG_FFN_SPLIT"]
+    assert 0 < rel_l2(outs["block"], old) < 1.2e-2 and rel_l2(old, ref) < 1.2e-2
