@@ -122,12 +122,12 @@ def test_fused_feed_forward_kernels_at_zeggs_dims(emu_lib):
     from oracle.mdm import MDMOracle
     cfg = C.ZEGGS
     sd = synth_state_dict(cfg, 20240)
-    B = 2
+    B = 3                                                 # 267 token rows = 17 row tiles: the last 32-row block is half empty
     m = DSGDenoiser(cfg, precision="bf16", max_batch=B, library=emu_lib)
     m.load_state_dict(sd)
     y = synth_window_inputs(cfg, B, window=1)
     x = np.random.RandomState(0).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
-    ts = [10, 500]
+    ts = [10, 500, 999]
     ref = MDMOracle(sd, cfg)(x, ts, y)
     outs = {}
     for ks in ("stream", "block"):
