@@ -149,6 +149,7 @@ struct dsg_handle {
           *X1 = nullptr, *fwd_out = nullptr, *io_tmp = nullptr, *io_tmp2 = nullptr, *ext_noise = nullptr;
     size_t ext_noise_cap = 0;
     void *xsA = nullptr, *X0a = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *attn = nullptr, *hidden = nullptr;
+    int lanes_now = 1;                               // lanes of the dsg_sample_multi call in progress (1: dsg_sample / dsg_forward)
     float* ffn_part = nullptr; size_t ffn_slab = 0;      // [4][ffn_slab] partial linear2 results of k_ffn_part
     void* X1a = nullptr;                 // LayerNorm1 rows in the GEMM type, fragment-major (k_attn_op -> linear1)
     int* ctr = nullptr;                  // scratch counter for diagnostics
@@ -827,6 +828,8 @@ struct KernelSel {
     bool stream = false;        // STREAM: BLOCK with the weight-stationary persistent GEMMs of dsg_stream.h (LayerNorm + QKV, linear1, linear2, pose head)
     bool ffn = false;           // STREAM (round 4): linear1 + GELU + linear2 + residual + LayerNorm2 in one kernel (k_ffn); QKV of the next layer
                                 // and the pose head then read normalised rows: direct streaming GEMMs, no k_ln_frag
+    bool ffn_rt4 = false;       // ... on 64-row blocks: 4 lanes x >= 4000 token rows (4 x 64 clips: 981 -> 903 us per step of the 4 lanes; 1 x 64: 376 -> 432,
+                                // 4 x 16: 334 -> 392, 4 x 32 even -- profiles/r04_y2_sweep_ffn_rt4_*.log).  Bit-identical to the 32-row form.
     bool ffn_split = false;     // BLOCK (round 4, bf16 ZEGGS / tiny dims): k_ffn split over the hidden dimension (k_ffn_part + k_ffn_ln); direct QKV / pose head
     bool xs_frag = false;       // BLOCK / STREAM (bf16, Jp 128 / 1152): the state shadow is fragment-major and the pose embedding streams it (k_ws2<EPI_PARTIAL>:
                                 // 8.9 -> 4.3 us at 1424 rows, 29.9 -> 11.0 at 5632; 3.8 -> 4.1 at 356)
@@ -886,6 +889,11 @@ static int select_kernels(const dsg_handle* h, int B, KernelSel& k) {
     k.attn_in_mid = k.lat && h->fuse_attn_mid && have_attn_mid(h, B);
     k.stream = set == DSG_KSET_STREAM;
     k.ffn = k.stream;           // (round 4: k_ffn instead of k_ws<GELU> + k_ws2<RESID> + k_ln_frag)
+    {
+        const char* e = getenv("DSG_FFN_RT4");          // test hook / A/B: 64-row blocks from this many token rows at any lane count (0: never)
+        const int rows = B * h->ntok;
+        k.ffn_rt4 = k.ffn && (e ? (atoi(e) > 0 && rows >= atoi(e)) : (h->lanes_now >= 4 && rows >= 4000));
+    }
     k.blk = set == DSG_KSET_BLOCK || k.stream;      // (STREAM: pose embedding and layer-0 QKV as in BLOCK)
     // the wide form (W_o streamed: DSG+ widths, fp32) belongs to BLOCK / STREAM only -- a set's arithmetic never depends on the batch,
     // and at batch 1 its 10 workgroups per layer lose to k_attn + out_proj (BEAT: 200 vs 163 us/step; 16 clips: 3371 vs 2904 frames/s)
@@ -1292,7 +1300,10 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                 a.Xn = h->Xn; a.Xa = h->X0a; a.M = M; a.MT = MT;
                 if constexpr (sizeof(typename P::elem) == 2) {
                     const dim3 grid(cdiv(MT, 2));
-                    if (D == 256) CHK((step_launch<&k_ffn<P, 4, 16, 2, 8, 2, true>>(h, grid, dim3(512), a)));
+                    // 64 rows per workgroup (bit-identical: same waves, same k order) when several lanes fill the GPU with large batches:
+                    // half the weight bytes through the CUs' load paths per row, half the workgroups (ffn_rt4 in select_kernels)
+                    if (D == 256 && ks.ffn_rt4) CHK((step_launch<&k_ffn<P, 4, 16, 4, 8, 1, true>>(h, dim3(cdiv(MT, 4)), dim3(512), a)));
+                    else if (D == 256) CHK((step_launch<&k_ffn<P, 4, 16, 2, 8, 2, true>>(h, grid, dim3(512), a)));
                     else CHK((step_launch<&k_ffn<P, 2, 2, 2, 4>>(h, grid, dim3(256), a)));
                 }
                 continue;
@@ -1908,6 +1919,11 @@ extern "C" int dsg_sample_multi(dsg_handle** hs, int n, const dsg_sample_args* a
     }
     if (n > 16) return fail(DSG_E_INVALID, "dsg_sample_multi: at most 16 lanes (4 overlap on the hardware; put further clips into the lanes' batches)");
     std::vector<SampleJob> jobs(n);
+    struct LanesNow {          // how many lanes share the GPU during this call (select_kernels: block shape of k_ffn; never the arithmetic)
+        dsg_handle** hs; int n;
+        LanesNow(dsg_handle** hs_, int n_) : hs(hs_), n(n_) { for (int i = 0; i < n; ++i) hs[i]->lanes_now = n; }
+        ~LanesNow() { for (int i = 0; i < n; ++i) hs[i]->lanes_now = 1; }
+    } lanes_now(hs, n);
     for (int i = 0; i < n; ++i) CHK(sample_prepare(hs[i], &args[i], B, stream, jobs[i]));
     bool all_aql = true;
     for (int i = 0; i < n; ++i) all_aql = all_aql && jobs[i].aql;

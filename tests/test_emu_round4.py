@@ -133,6 +133,12 @@ def test_fused_feed_forward_kernels_at_zeggs_dims(emu_lib):
     for ks in ("stream", "block"):
         outs[ks] = np.asarray(m.set_kernel_set(ks)(x, ts, y))
         assert m.last_kernel_set() == ks and rel_l2(outs[ks], ref) < 1.2e-2, ks
+    os.environ["DSG_FFN_RT4"] = "1"                      # k_ffn on 64-row blocks (what 4 large lanes run): same waves, same k order
+    try:
+        assert np.array_equal(np.asarray(m.set_kernel_set("stream")(x, ts, y)), outs["stream"])
+    finally:
+        del os.environ["DSG_FFN_RT4"]
+    m.set_kernel_set("block")
     os.environ["DSG_FFN_SPLIT"] = "0"
     try:
         old = np.asarray(m(x, ts, y))

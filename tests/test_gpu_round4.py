@@ -294,3 +294,34 @@ def test_block_set_with_the_ffn_split_over_hidden_vs_oracle(gpu, monkeypatch):
             yb = {k: (v[b:b + 1] if v.shape[0] == B else v) for k, v in y.items()}
             w = sampler.p_sample_loop(OracleDiffusion(), ref, (1,) + shape[1:], lambda k: sampler.philox.normal_bj1t(shape, 13, k, 1)[b:b + 1], {"y": yb}, skip_timesteps=970)
             assert rel_l2(got[b:b + 1], w) < TOL_CHAIN["bf16"]
+
+
+def test_ffn_64_row_blocks_with_four_large_lanes_bit_identical(gpu, monkeypatch):
+    """Round 4: with 4 lanes of >= 4000 token rows each (bench.py --clips-per-gpu 192 / 256) k_ffn runs on 64-row blocks -- half the
+    weight bytes per row through the CUs' load paths.  Same waves, same k order: a lane's clips are bit-identical to the lane run
+    alone (32-row blocks), and so is a forward with the block shape forced (DSG_FFN_RT4)."""
+    import torch
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    from diffusestylegesture_amd.sample import generate_clip, generate_clips_streams
+    cfg = C.ZEGGS
+    NL, B = 4, 48
+    m = _model(cfg, "bf16", max_batch=B)
+    y = synth_window_inputs(cfg, B, window=1, clip0=2, seed_pose_scale=0.2)
+    x = np.random.RandomState(5).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+    ts = (np.arange(B) * 19 + 3) % 1000
+    m.set_kernel_set("stream")
+    monkeypatch.setenv("DSG_FFN_RT4", "0")
+    a = np.asarray(m(x, ts, y))
+    monkeypatch.setenv("DSG_FFN_RT4", "1")
+    b = np.asarray(m(x, ts, y))
+    monkeypatch.delenv("DSG_FFN_RT4")
+    assert np.array_equal(a, b) and np.isfinite(a).all()
+    m.set_kernel_set("auto")
+    lanes = [m] + [m.clone() for _ in range(NL - 1)]
+    d = create_gaussian_diffusion()
+    feats = [[torch.from_numpy(synth_window_inputs(cfg, B, window=0, clip0=ln * B)["audio"]).cuda()] for ln in range(NL)]
+    got = generate_clips_streams(lanes, d, feats, [1, 0, 0, 0, 0, 0], seed=9, skip_timesteps=985, stream_ids=[0, 1, 2, 3])
+    assert all(ln.last_kernel_set() == "stream" and ln.last_sample_path() == "aql" for ln in lanes) and np.isfinite(got).all()
+    lanes[2].set_kernel_set("stream")
+    alone = generate_clip(lanes[2], d, feats[2], [1, 0, 0, 0, 0, 0], seed=9, skip_timesteps=985, stream_id=2)
+    assert np.array_equal(alone, got[2 * B:3 * B])
