@@ -18,6 +18,14 @@ Clips are independent, so N GPUs run N x clips-per-gpu clips (weak scaling, no c
 poses are gathered to rank 0 with one RCCL gather inside the timed region.  Inputs (synthetic WavLM features, synthetic
 weights) are resident in HBM when the clock starts.  De-normalisation + .bvh writing (C++, rank 0) is timed separately
 (`postprocess_ms_per_clip`, `value_end_to_end`).  Prints ONE JSON line on rank 0.
+
+The default line (`python bench.py`, 1 GPU, config[1]) also carries time-bounded SUB-RECORDS for the other BASELINE configs
+(`--sub-records off` drops them; each has its own value / us_per_denoise_step / kernel_set / roofline, about 25 s in all):
+    config2   50-step DDIM, batch 16 in lock step                      (BASELINE config[2])
+    config3   16 clips as 4 lanes x batch 4 = config[3]'s per-GPU share (with --gpus N: N x 16 clips gathered over RCCL)
+    config4   DiffuseStyleGesture+ BEAT and TWH denoisers, batch 1, 2 of the 16 windows of an 1830-frame clip (config[4])
+    stream    256 clips per GPU as 4 lanes x batch 64 (the STREAM kernel set), 1 pass
+Top-level `value` / `config` stay config[1].
 """
 import argparse
 import json
@@ -56,6 +64,8 @@ def parse(argv=None):
     p.add_argument("--config3", default="auto", choices=["auto", "on", "off"],
                    help="second timed pass at config[3]'s per-GPU share (16 clips: 4 lanes x batch 4) reported as `config3` "
                         "(auto: whenever --gpus > 1 runs the default 1-clip-per-GPU workload)")
+    p.add_argument("--sub-records", default="auto", choices=["auto", "on", "off"],
+                   help="config2 / config3 / config4 / stream sub-records in the JSON line (auto: the default 1-GPU config[1] run)")
     a = p.parse_args(argv)
     if a.batch and not a.clips_per_gpu:
         a.clips_per_gpu, a.mode = a.batch, "lockstep"
@@ -160,6 +170,115 @@ def cpu_baseline(n_steps, one_core_steps=None):
     return out
 
 
+# algorithmic work per denoising step of ONE clip (SURVEY s8d / DESIGN.md s4): per-step weight parameters, fp32 state bytes
+# (x_t in, noise in, x_{t-1} out) and GFLOP
+ALGO = {"zeggs": (7.183e6, 1.205e6, 1.3152), "beat": (13.25e6, 3.694e6, 4.183), "twh": (20.23e6, 4.018e6, 6.311)}
+
+
+def roofline_record(config, precision, NC, NL, B, us, with_traffic=False):
+    """The roofline object of one workload: `us` = time in which all NC clips in flight advance one denoising step."""
+    wparams, sbytes, gflop = ALGO[config]
+    wbytes = wparams * (2 if precision == "bf16" else 4)
+    abytes = wbytes + sbytes * NC           # the NC clips in flight share one pass over the weights
+    if NC >= 8:
+        # SURVEY s8d: from 8 clips in flight (>= 712 token rows) the path is a dense contraction -> MFMA roofline
+        ach = gflop * NC / (us * 1e-6) / 1e3
+        peak = 2500.0 if precision == "bf16" else 157.3
+        return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 5),
+                "traffic": None, "algorithmic_gflop_per_denoise_step": gflop * NC,
+                "note": f"{NC} clips in flight ({NL} lane(s) x batch {B}): achieved = {gflop} GFLOP x {NC} clips / time in which all of them "
+                        "advance one denoising step; peak = dense MFMA " + ("bf16" if precision == "bf16" else "fp32")}
+    achieved = abytes / (us * 1e-6) / 1e9
+    # HBM-side traffic per step from the rocprofv3 PMC passes (tools/pmc_traffic.py; FETCH_SIZE doubled as the MI355X guide
+    # prescribes for wide coalesced reads), measured for the headline configuration only
+    traffic, tsrc = None, None
+    if with_traffic:
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_zeggs_b1_bf16.json")))   # newest round last
+        if config == "zeggs" and precision == "bf16" and NC == 1 and cands:
+            traffic = json.load(open(cands[-1]))["traffic_bytes_per_step_fetch_x2"]
+            tsrc = os.path.basename(cands[-1])
+    return {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": tsrc,
+            "algorithmic_bytes_per_denoise_step": abytes,
+            "note": "one denoising step = a chain of dependent kernel dispatches (2 + 3*L in the batch-1 latency set); achieved = "
+                    "algorithmic bytes / time per step, timed from the first doorbell to the completion signal of "
+                    "the last AQL packet (HIP events around the loop on the HIP-launch path); traffic = PMC bytes of "
+                    "the committed rocprofv3 passes (separate runs), not of this run"}
+
+
+class Workload:
+    """One arrangement of clips on this rank's GPU: NC clips as NL sampling lanes x batch B, synthetic inputs resident in HBM.
+    `one_pass(i)` samples every clip once (all windows); `step_us()` = device time in which all NC clips advanced one denoising
+    step during the last pass."""
+
+    def __init__(self, a, config, NC, NL, sampler, local, rank, world, library, emu, n_windows=None, precision=None):
+        import torch
+        from diffusestylegesture_amd import config as C
+        from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+        from diffusestylegesture_amd.model import DSGDenoiser
+        from diffusestylegesture_amd.parallel import shard_clips
+        from diffusestylegesture_amd.synth import synth_state_dict, synth_window_inputs
+        self.config, self.NC, self.NL, self.B, self.sampler, self.emu = config, NC, NL, NC // NL, sampler, emu
+        self.precision = precision or a.precision
+        self.cfg = cfg = C.TINY if emu else C.CONFIGS[config]
+        B = self.B
+        # clip c -> rank c % world (parallel.shard_clips: the map gather_poses inverts): this rank's clips, dealt to its lanes in order
+        my_clips = shard_clips(world * NC, rank, world)
+        lane_clips = [my_clips[ln * B:(ln + 1) * B] for ln in range(NL)]
+        self.model = DSGDenoiser(cfg, precision=self.precision, max_batch=B, device=local, steps_per_graph=a.steps_per_graph, library=library)
+        self.model.load_state_dict(synth_state_dict(cfg, 20240))
+        self.lanes = [self.model] + [self.model.clone() for _ in range(NL - 1)]
+        self.diffusion = create_gaussian_diffusion("ddim50" if sampler == "ddim50" else "", library=library)
+        self.sample_fn = self.diffusion.ddim_sample_loop if sampler == "ddim50" else self.diffusion.p_sample_loop
+        self.skip = int(os.environ.get("DSG_BENCH_SKIP", "0")) if emu else 0
+        if cfg.variant == 3:
+            full_windows = 2 if emu else 4
+            self.n_windows = n_windows or full_windows
+            self.frames_per_clip = self.n_windows * cfg.stride                      # 320 nominal (312 emitted)
+        else:
+            full = 1830                                                             # BEAT-TWH sample.py:56, max_len=0
+            full_windows = -(-full // cfg.stride)                                   # ceil -> 16 windows
+            self.n_windows = n_windows or full_windows
+            self.frames_per_clip = full if self.n_windows == full_windows else self.n_windows * cfg.stride
+        # synthetic per-window audio features, resident in HBM before the clock starts; everything about a clip (features, seed
+        # poses, its Philox stream = the id of the first clip of its lane + its position in the lane's batch) is a function of its id
+        to_dev = (lambda x: x) if emu else (lambda x: torch.from_numpy(x).cuda(local))
+        self.feats = [[to_dev(synth_window_inputs(cfg, B, window=w, clips=lane_clips[ln])["audio"]) for w in range(self.n_windows)]
+                      for ln in range(NL)]
+        self.seed0s = [to_dev(synth_window_inputs(cfg, B, window=0, clips=lane_clips[ln], seed_pose_scale=0.1)["seed"]) for ln in range(NL)]
+        self.style = [1] + [0] * (cfg.style_dim_in - 1)
+        self.lane_streams = [lc[0] for lc in lane_clips]
+        self.n_denoise = self.diffusion.num_timesteps - self.skip
+
+    def one_pass(self, i, skip=None):
+        from diffusestylegesture_amd.sample import (generate_clip, generate_clip_dsgplus, generate_clips_streams,
+                                                    generate_clips_streams_dsgplus)
+        skip = self.skip if skip is None else skip
+        ddim = self.sampler == "ddim50"
+        if self.NL > 1 and self.cfg.variant == 3:
+            return generate_clips_streams(self.lanes, self.diffusion, self.feats, self.style, seed=123456 + i, smoothing=True,
+                                          skip_timesteps=skip, stream_ids=self.lane_streams, ddim=ddim)
+        if self.NL > 1:
+            return generate_clips_streams_dsgplus(self.lanes, self.diffusion, self.feats, self.style, self.seed0s, self.frames_per_clip,
+                                                  seed=123456 + i, skip_timesteps=skip, stream_ids=self.lane_streams, ddim=ddim)
+        if self.cfg.variant == 3:
+            return generate_clip(self.model, self.diffusion, self.feats[0], self.style, seed=123456 + i, smoothing=True,
+                                 sample_fn=self.sample_fn, stream_id=self.lane_streams[0], skip_timesteps=skip)
+        return generate_clip_dsgplus(self.model, self.diffusion, self.feats[0], self.style, self.seed0s[0], self.frames_per_clip,
+                                     seed=123456 + i, sample_fn=self.sample_fn, stream_id=self.lane_streams[0], skip_timesteps=skip)
+
+    def step_us(self):
+        if self.NL > 1:       # all lanes advance one step in: (slowest lane's time) / steps
+            return max(1000.0 * ln.last_sample_ms()[0] / max(ln.last_sample_ms()[1], 1) for ln in self.lanes)
+        return self.diffusion.last_step_time_us()
+
+    def describe(self):
+        arr = f"{self.NL} lane(s) x batch {self.B}" if self.NC > 1 else "batch 1"
+        return (f"{self.NC} clip(s) in flight per GPU ({arr}), {self.frames_per_clip}-frame {self.config.upper()} clip "
+                f"({self.n_windows} windows x {self.n_denoise} denoising steps), {self.sampler.upper()} {self.precision}")
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -177,61 +296,14 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo" if emu else "nccl")          # "nccl" = RCCL on ROCm
-    from diffusestylegesture_amd import config as C
     from diffusestylegesture_amd import lib as L
-    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
-    from diffusestylegesture_amd.model import DSGDenoiser
-    from diffusestylegesture_amd.sample import generate_clip, generate_clips_streams
-    from diffusestylegesture_amd.synth import synth_state_dict, synth_window_inputs
 
-    library = None
-    if emu:
-        library = L.DSGLibrary(os.path.join(ROOT, "tests", "emu", "_build", "libdsg_emu.so"))
-        cfg = C.TINY
-    else:
-        cfg = C.CONFIGS[a.config]
+    library = L.DSGLibrary(os.path.join(ROOT, "tests", "emu", "_build", "libdsg_emu.so")) if emu else None
     NC, NL = a.clips_per_gpu, a.lanes
-    streams = NL > 1
     B = NC // NL
-    # clip c -> rank c % world (parallel.shard_clips: the map gather_poses inverts): this rank's clips, dealt to its lanes in order
-    from diffusestylegesture_amd.parallel import shard_clips
-    my_clips = shard_clips(world * NC, rank, world)
-    lane_clips = [my_clips[ln * B:(ln + 1) * B] for ln in range(NL)]
-    model = DSGDenoiser(cfg, precision=a.precision, max_batch=B, device=local, steps_per_graph=a.steps_per_graph, library=library)
-    model.load_state_dict(synth_state_dict(cfg, 20240))
-    lanes = [model] + [model.clone() for _ in range(NL - 1)]
-    diffusion = create_gaussian_diffusion("ddim50" if a.sampler == "ddim50" else "", library=library)
-    sample_fn = diffusion.ddim_sample_loop if a.sampler == "ddim50" else diffusion.p_sample_loop
-    skip = int(os.environ.get("DSG_BENCH_SKIP", "0")) if emu else 0
-    if cfg.variant == 3:
-        n_windows = 2 if emu else 4
-        frames_per_clip = n_windows * cfg.stride                                # 320 nominal (312 emitted)
-    else:
-        frames_per_clip = 1830                                                  # BEAT-TWH sample.py:56, max_len=0
-        n_windows = -(-frames_per_clip // cfg.stride)                           # ceil -> 16 windows
-    # synthetic per-window audio features, resident in HBM before the clock starts; everything about a clip (features, seed
-    # poses, its Philox stream = the id of the first clip of its lane + its position in the lane's batch) is a function of its id
-    to_dev = (lambda x: x) if emu else (lambda x: torch.from_numpy(x).cuda(local))
-    feats = [[to_dev(synth_window_inputs(cfg, B, window=w, clips=lane_clips[ln])["audio"]) for w in range(n_windows)]
-             for ln in range(NL)]
-    seed0s = [to_dev(synth_window_inputs(cfg, B, window=0, clips=lane_clips[ln], seed_pose_scale=0.1)["seed"]) for ln in range(NL)]
-    style = [1] + [0] * (cfg.style_dim_in - 1)
-    lane_streams = [lc[0] for lc in lane_clips]
-
-    def one_pass(i):
-        if streams and cfg.variant == 3:
-            return generate_clips_streams(lanes, diffusion, feats, style, seed=123456 + i, smoothing=True, skip_timesteps=skip,
-                                          stream_ids=lane_streams, ddim=a.sampler == "ddim50")
-        if streams:
-            from diffusestylegesture_amd.sample import generate_clips_streams_dsgplus
-            return generate_clips_streams_dsgplus(lanes, diffusion, feats, style, seed0s, frames_per_clip, seed=123456 + i,
-                                                  skip_timesteps=skip, stream_ids=lane_streams, ddim=a.sampler == "ddim50")
-        if cfg.variant == 3:
-            return generate_clip(model, diffusion, feats[0], style, seed=123456 + i, smoothing=True, sample_fn=sample_fn,
-                                 stream_id=lane_streams[0], skip_timesteps=skip)
-        from diffusestylegesture_amd.sample import generate_clip_dsgplus
-        return generate_clip_dsgplus(model, diffusion, feats[0], style, seed0s[0], frames_per_clip, seed=123456 + i,
-                                     sample_fn=sample_fn, stream_id=lane_streams[0], skip_timesteps=skip)
+    wl = Workload(a, a.config, NC, NL, a.sampler, local, rank, world, library, emu)
+    cfg, diffusion, model = wl.cfg, wl.diffusion, wl.model
+    frames_per_clip, n_windows, skip = wl.frames_per_clip, wl.n_windows, wl.skip
 
     def sync():
         if not emu:
@@ -241,50 +313,49 @@ def main():
             if not emu:
                 torch.cuda.synchronize()
 
-    def config3_pass():
-        """BASELINE config[3]'s per-GPU share -- 16 clips as 4 lanes x batch 4 -- timed like the main region (barrier + synchronize on
-        both sides, max over ranks), so that the multi-GPU runs the driver launches (1 clip per GPU by default, to agree with the
-        1-GPU bench line) ALSO carry the 16-clips-per-GPU number: N GPUs x 16 clips, 128 at N = 8."""
-        NL3, B3 = 4, 4
-        m3 = DSGDenoiser(cfg, precision=a.precision, max_batch=B3, device=local, library=library)
-        m3.load_state_dict(synth_state_dict(cfg, 20240))
-        lanes3 = [m3] + [m3.clone() for _ in range(NL3 - 1)]
-        clips3 = shard_clips(world * 16, rank, world)
-        feats3 = [[to_dev(synth_window_inputs(cfg, B3, window=w, clips=clips3[ln * B3:(ln + 1) * B3])["audio"]) for w in range(n_windows)]
-                  for ln in range(NL3)]
-        run3 = lambda i: generate_clips_streams(lanes3, diffusion, feats3, style, seed=777 + i, smoothing=True, skip_timesteps=skip,
-                                                stream_ids=[clips3[ln * B3] for ln in range(NL3)])
-        run3(0)
+    def timed(w, passes, gather_total=0, warm_skip=None):
+        """Warm-up pass, then `passes` passes between barrier + synchronize on both sides (+ the gather to rank 0, max over ranks)."""
+        w.one_pass(0, skip=warm_skip)
         sync()
-        t3 = time.perf_counter()
-        p3 = run3(1)
-        if dist is not None:
+        t = time.perf_counter()
+        us = []
+        for i in range(passes):
+            p = w.one_pass(1 + i)
+            us.append(w.step_us())
+        if dist is not None and gather_total:
             from diffusestylegesture_amd.parallel import gather_poses
-            gather_poses(p3, world * 16, dist, dst=0, device=None if emu else f"cuda:{local}")
+            gather_poses(p, gather_total, dist, dst=0, device=None if emu else f"cuda:{local}")
         sync()
-        dt3 = time.perf_counter() - t3
+        dt = time.perf_counter() - t
         if dist is not None:
-            tt3 = torch.tensor([dt3], dtype=torch.float64, device="cpu" if emu else f"cuda:{local}")
-            dist.all_reduce(tt3, op=dist.ReduceOp.MAX)
-            dt3 = float(tt3.item())
-        us3 = max(1000.0 * ln.last_sample_ms()[0] / max(ln.last_sample_ms()[1], 1) for ln in lanes3)
-        return {"workload": f"{world} GPU(s) x 16 clips (4 lanes x batch 4), {frames_per_clip}-frame ZEGGS clips, DDPM {a.precision}",
-                "clips": world * 16, "value": round(world * 16 * frames_per_clip / dt3, 2), "unit": "frames/s", "passes": 1,
-                "ms_per_pass": round(1000.0 * dt3, 3), "us_per_denoise_step_16_clips": round(us3, 2),
-                "kernel_set": lanes3[0].last_kernel_set(), "sample_path": lanes3[0].last_sample_path()}
+            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if emu else f"cuda:{local}")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, float(np.mean(us))
+
+    def sub_record(label, config, NC_, NL_, sampler, passes, n_windows=None, warm_skip=None, gather=False):
+        """One BASELINE configuration other than the headline's, timed like the main region on a bounded sample."""
+        w = Workload(a, config, NC_, NL_, sampler, local, rank, world, library, emu, n_windows=n_windows)
+        dt, us = timed(w, passes, gather_total=world * NC_ if gather else 0, warm_skip=warm_skip)
+        rec = {"baseline_config": label, "workload": f"{world} GPU(s) x " + w.describe(), "clips": world * NC_,
+               "value": round(world * NC_ * passes * w.frames_per_clip / dt, 2), "unit": "frames/s", "passes": passes,
+               "ms_per_pass": round(1000.0 * dt / passes, 3), "us_per_denoise_step": round(us, 2),
+               "kernel_set": w.lanes[0].last_kernel_set(), "sample_path": w.lanes[0].last_sample_path(),
+               "roofline": roofline_record(config, w.precision, NC_, NL_, w.B, us) if us > 0 else None}
+        if NC_ > 1:
+            rec["us_per_denoise_step_all_clips"] = rec["us_per_denoise_step"]
+        del w
+        return rec
 
     for i in range(a.warmup):
-        one_pass(i)
+        wl.one_pass(i)
     sync()
     step_us = []
     t0 = time.perf_counter()
     poses = None
     for i in range(a.steps):
-        poses = one_pass(a.warmup + i)
-        if streams:       # all lanes advance one step in: (slowest lane's time) / steps
-            step_us.append(max(1000.0 * ln.last_sample_ms()[0] / max(ln.last_sample_ms()[1], 1) for ln in lanes))
-        else:
-            step_us.append(diffusion.last_step_time_us())
+        poses = wl.one_pass(a.warmup + i)
+        step_us.append(wl.step_us())
     gathered = poses
     if dist is not None:        # the only exchange of the path: finished poses -> rank 0 (RCCL over xGMI)
         from diffusestylegesture_amd.parallel import gather_poses
@@ -295,49 +366,35 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if emu else f"cuda:{local}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    want_c3 = a.config3 == "on" or (a.config3 == "auto" and a.gpus > 1 and NC == 1)
-    c3 = config3_pass() if (want_c3 and cfg.variant == 3 and a.sampler == "ddpm") else None
+    # ---- sub-records: the other BASELINE configurations, bounded (module docstring).  config3 is also what a multi-GPU run of the
+    #      default workload carries (N x 16 clips gathered over RCCL); the single-GPU-only records run on one rank only.
+    headline = cfg.variant == 3 and a.sampler == "ddpm" and NC == 1 and a.config == "zeggs"
+    want_sub = a.sub_records == "on" or (a.sub_records == "auto" and headline and world == 1 and not emu)
+    want_c3 = a.config3 == "on" or (a.config3 == "auto" and headline and (a.gpus > 1 or want_sub))
+    subs = {}
+    if want_c3 and cfg.variant == 3 and a.sampler == "ddpm":
+        # "one clip per stream" is realised as 4 HSA queues x batch 4: four compute queues overlap on this GPU, a fifth collapses the
+        # rate (16 x 1: 726 frames/s vs 5817 for 4 x 4; DESIGN.md s7, profiles/r04_b_multiproc_lanes.log)
+        subs["config3"] = sub_record("config[3] per-GPU share: 16 clips, one clip per stream realised as 4 queues x batch 4 (a 5th "
+                                     "queue collapses the rate)", "zeggs", 16, 4, "ddpm", 1, gather=True)
+    if want_sub and world == 1:
+        subs["config2"] = sub_record("config[2]: 50-step DDIM, batch 16 in lock step", "zeggs", 16, 1, "ddim50", 3)
+        subs["config4"] = {
+            name: sub_record(f"config[4]: DiffuseStyleGesture+ {name.upper()} denoiser, batch 1, 2 of the 16 windows of an 1830-frame clip",
+                             name, 1, 1, "ddpm", 1, n_windows=2, warm_skip=900)
+            for name in ("beat", "twh")}
+        subs["stream"] = sub_record("256 clips per GPU (4 lanes x batch 64, STREAM kernel set)", "zeggs", 256, 4, "ddpm", 1, warm_skip=960)
     if rank == 0 and os.environ.get("DSG_BENCH_DUMP"):      # TEST INFRASTRUCTURE (tests/test_bench_launch.py): the gathered poses, by clip id
         np.save(os.environ["DSG_BENCH_DUMP"], np.asarray(gathered, np.float32))
     if rank == 0:
         n_clips = world * NC * a.steps
         value = n_clips * frames_per_clip / dt
         emitted = int(poses.shape[1])
-        n_denoise = diffusion.num_timesteps - skip
+        n_denoise = wl.n_denoise
         us = float(np.mean(step_us))
         if not us > 0:      # no device timer (emulated test run): wall clock per denoising step
             us = 1e6 * dt / (a.steps * n_windows * n_denoise)
-        # algorithmic work per denoising step of ONE clip (SURVEY s8d / DESIGN.md): per-step weight parameters, fp32 state
-        # bytes (x_t in, noise in, x_{t-1} out) and FLOPs
-        wparams, sbytes, gflop = {"zeggs": (7.183e6, 1.205e6, 1.3152), "beat": (13.25e6, 3.694e6, 4.183),
-                                  "twh": (20.23e6, 4.018e6, 6.311)}[a.config]
-        wbytes = wparams * (2 if a.precision == "bf16" else 4)
-        abytes = wbytes + sbytes * NC           # the NC clips in flight share one pass over the weights
-        if NC >= 8:
-            # from 8 clips in flight (>= 712 token rows) the path is a dense contraction -> MFMA roofline
-            ach = gflop * NC / (us * 1e-6) / 1e3
-            peak = 2500.0 if a.precision == "bf16" else 157.3
-            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 5),
-                    "traffic": None, "algorithmic_gflop_per_denoise_step": gflop * NC,
-                    "note": f"{NC} clips in flight ({NL} lane(s) x batch {B}): achieved = {gflop} GFLOP x {NC} clips / time in which all of them "
-                            "advance one denoising step; peak = dense MFMA " + ("bf16" if a.precision == "bf16" else "fp32")}
-        else:
-            achieved = abytes / (us * 1e-6) / 1e9
-            # HBM-side traffic per step from the rocprofv3 PMC passes (tools/pmc_traffic.py; FETCH_SIZE doubled as the
-            # MI355X guide prescribes for wide coalesced reads), measured for the headline configuration only
-            traffic, tsrc = None, None
-            import glob
-            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_zeggs_b1_bf16.json")))   # newest round last
-            if a.config == "zeggs" and a.precision == "bf16" and NC == 1 and cands:
-                traffic = json.load(open(cands[-1]))["traffic_bytes_per_step_fetch_x2"]
-                tsrc = os.path.basename(cands[-1])
-            roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": tsrc,
-                    "algorithmic_bytes_per_denoise_step": abytes,
-                    "note": "one denoising step = 2 + 3*L dependent kernel dispatches (batch-1 latency mode); achieved = "
-                            "algorithmic bytes / time per step, timed from the first doorbell to the completion signal of "
-                            "the last AQL packet (HIP events around the loop on the HIP-launch path); traffic = PMC bytes of "
-                            "the committed rocprofv3 passes (separate runs), not of this run"}
+        roof = roofline_record(a.config, a.precision, NC, NL, B, us, with_traffic=True)
         out = {
             "metric": (f"gesture frames/sec, {'1000-step DDPM' if a.sampler == 'ddpm' else '50-step DDIM'}, "
                        + ("320-frame ZEGGS clip" if a.config == "zeggs" else f"1830-frame {a.config.upper()} clip (DSG+)")
@@ -345,9 +402,9 @@ def main():
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1000.0 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.precision, "data": "synthetic" + (" (EMULATED ON CPU: test run, not a measurement)" if emu else ""),
-            "config": {"workload": f"1xMI355X per rank, {NC} clip(s) in flight per GPU ({f'{NL} lane(s) x batch {B}' if NC > 1 else 'batch 1'}), "
-                                   f"{frames_per_clip}-frame {a.config.upper()} clip ({n_windows} windows x {n_denoise} denoising steps), "
-                                   f"{a.sampler.upper()} {a.precision}",
+            "config": {"workload": "1xMI355X per rank, " + wl.describe()
+                                   + (" -- more than one clip per GPU: 'one clip per stream' is realised as <= 4 HSA queues x a batch per queue, "
+                                      "because the 5th compute queue of a GPU collapses the rate" if NC > 1 and NL > 1 else ""),
                        "clips_per_gpu": NC, "lanes": NL, "batch_per_lane": B, "mode": a.mode if NC > 1 else "batch1",
                        "frames_nominal_per_clip": frames_per_clip,
                        "frames_emitted_per_clip": emitted, "denoise_steps_per_window": n_denoise, "parallelism": f"clips x{world}"},
@@ -375,8 +432,7 @@ def main():
             out["postprocess_ms_per_clip"] = round(1000.0 * post / g.shape[0], 3)
             out["postprocess_ms_per_pass"] = round(1000.0 * post, 3)
             out["value_end_to_end"] = round(n_clips * frames_per_clip / (dt + post * a.steps), 2)
-        if c3 is not None:
-            out["config3"] = c3
+        out.update(subs)
         if world == 1 and not a.no_cpu_baseline and a.config == "zeggs" and a.sampler == "ddpm" and not emu:
             out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_steps)
         print(json.dumps(out), flush=True)

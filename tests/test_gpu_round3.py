@@ -372,7 +372,7 @@ def test_bench_one_real_rccl_rank(gpu):
     HIP device (printed once per rank) -- what every rank of the 8-GPU run does, on the one GPU a lease has.  The rate must
     agree with the un-launched run."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    args = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-postprocess"]
+    args = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-postprocess", "--sub-records", "off"]
     plain = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args, capture_output=True, text=True, timeout=600, env=env)
     assert plain.returncode == 0, plain.stderr[-2000:]
     ranked = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
