@@ -216,10 +216,21 @@ class DSGDiffusion:
         (gaussian_diffusion.py:673-740): the chain runs inside the library PROGRESSIVE_CHUNK steps per call (dsg_sample_args.first_step
         / max_steps: a chain in pieces, every step of the piece dumped), so the host holds one chunk of samples at a time (round-3
         advisor: the whole chain used to be materialised, 0.4 GB at ZEGGS dims and batch 1) and a caller that abandons the generator
-        stops the work.  Same samples, bit for bit, as the one-call loops: draw indices are those of the whole chain."""
+        stops the work.  Same samples, bit for bit, as the one-call loops: draw indices are those of the whole chain, reserved HERE,
+        when the generator is created (round-4 advisor: a generator body runs at the first next(), so reserving them inside it let a
+        loop started between creation and first use draw the same noise)."""
         self._check_unsupported(denoised_fn, cond_fn, randomize_class, cond_fn_with_grad)
         inner, guided = self._library_model(model, shape[0])
         n_run = self.num_timesteps - skip_timesteps
+        draw0 = None
+        if inner is not None:
+            draw0 = self._draw
+            self._draw += 1 + n_run                  # the generator owns these draw indices from the moment it is created
+        return self._progressive_gen(ddim, model, inner, guided, shape, noise, clip_denoised, model_kwargs, device, skip_timesteps,
+                                     init_image, const_noise, eta, n_run, draw0)
+
+    def _progressive_gen(self, ddim, model, inner, guided, shape, noise, clip_denoised, model_kwargs, device, skip_timesteps,
+                         init_image, const_noise, eta, n_run, draw0):
         if inner is None:
             outs = self._generic_loop(ddim, model, shape, noise, model_kwargs, skip_timesteps, init_image, list(range(n_run)),
                                       const_noise, eta, device, clip_denoised)
@@ -227,8 +238,6 @@ class DSGDiffusion:
                 yield {"sample": o}
             return
         mode = L.MODE_DDIM if ddim else L.MODE_DDPM
-        draw0 = self._draw
-        self._draw += 1 + n_run                      # the generator owns these draw indices from the moment it is created
         x, first = noise, 0
         while first < n_run:
             k = min(self.PROGRESSIVE_CHUNK, n_run - first)

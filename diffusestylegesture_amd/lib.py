@@ -61,6 +61,7 @@ SYMBOLS = {
     "dsg_last_sample_ms": (_I, [_P, C.POINTER(C.c_float), C.POINTER(_I)]),
     "dsg_last_sample_path": (_I, [_P, C.POINTER(_I)]),
     "dsg_last_sample_fence_free": (_I, [_P, C.POINTER(_I)]),
+    "dsg_trim": (_I, [_I, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "dsg_noise": (_I, [_P, _I, _I, _I, C.c_uint64, C.c_uint64, C.c_uint32, _P]),
     "dsg_pose2bvh": (_I, [_P, _I, _I, _P, _P, _I, C.c_char_p]),
     "dsg_pose2bvh_channels": (_I, [_P, _I, _I, _P, _P, _I, _P, _P]),
@@ -94,7 +95,7 @@ class DSGLibrary:
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(self.cdll, name)          # AttributeError if the library does not export it
             fn.restype, fn.argtypes = res, args
-        if self.cdll.dsg_version() < 310:
+        if self.cdll.dsg_version() < 320:
             raise DSGError("libdsg_hip.so is older than this package")
 
     def check(self, rc: int):
@@ -106,6 +107,14 @@ class DSGLibrary:
         if rc == E_NOT_IMPLEMENTED:
             raise NotImplementedError(msg)
         raise DSGError(f"[{rc}] {msg}")
+
+
+def trim(device: int = -1, library: "DSGLibrary | None" = None):
+    """dsg_trim: hand the uncached arenas that hold no live block back to HIP; returns (bytes released, bytes still held)."""
+    lib = library or default_library()
+    rel, held = C.c_longlong(0), C.c_longlong(0)
+    lib.check(lib.cdll.dsg_trim(device, C.byref(rel), C.byref(held)))
+    return int(rel.value), int(held.value)
 
 
 _default = None

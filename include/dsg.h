@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define DSG_VERSION 310
+#define DSG_VERSION 320
 
 enum {
     DSG_OK = 0,
@@ -65,7 +65,8 @@ enum { DSG_PREC_FP32 = 0, DSG_PREC_BF16 = 1 };
  * grouping / tiling, i.e. last-bit differences between sets in bf16 -- which is why the set is an explicit, sticky property of
  * a handle and never depends on how a call is issued. */
 enum {
-    DSG_KSET_AUTO = 0,      /* by batch: LATENCY for batch <= 2, TILE below 1000 token rows, BLOCK from there, STREAM from 2000 */
+    DSG_KSET_AUTO = 0,      /* by batch: LATENCY for batch <= 2 (latent_dim <= 256; the wider DSG+ models run TILE there), TILE below 1000
+                               token rows, BLOCK from there, STREAM from 2000 */
     DSG_KSET_LATENCY = 1,   /* fused redundant-compute kernels, 2 + 3L dispatches: one clip in flight */
     DSG_KSET_TILE = 2,      /* one 16 x 16 MFMA tile per wave: small batches */
     DSG_KSET_BLOCK = 3,     /* 32-row block GEMMs + fused attention/out_proj/LayerNorm: large batches, several lanes */
@@ -97,7 +98,8 @@ typedef struct dsg_config {
     int32_t precision;      /* DSG_PREC_* */
     int32_t device;         /* HIP device ordinal */
     int32_t steps_per_graph;/* > 0: denoising steps captured per hipGraph replay; 0 = default (eager: measured faster), -1 = eager */
-    int32_t latency_mode;   /* DSG_KSET_AUTO only: 0 = by batch, 1 = never the LATENCY set, 2 = always */
+    int32_t latency_mode;   /* DSG_KSET_AUTO only: 0 = by batch, 1 = never the LATENCY set, 2 = always (where AUTO can pick it at all:
+                               latent_dim <= 256; dsg_recommend_kernel_set and the handle itself apply the same rule) */
     int32_t reserved[4];
 } dsg_config;
 
@@ -193,6 +195,14 @@ int dsg_last_sample_path(dsg_handle* h, int* path);
  * memory (default for handles of max_batch <= 16; DSG_UC=0 selects cached buffers + agent-scope fences) and the one-time
  * hand-off self-check of the device passed */
 int dsg_last_sample_fence_free(dsg_handle* h, int* fence_free);
+/* ABI 320.  The loop buffers of fence-free handles are sub-allocated from per-device arenas of uncached memory that the library
+ * keeps across handles (a range that changed its caching attribute between two lives proved incoherent on MI355X / ROCm 7.2, so a
+ * destroyed handle's blocks go back to the arena, not to hipFree).  dsg_trim hands every arena of `device` (< 0: all devices)
+ * without a live block back to the HIP allocator -- for a long-lived service between bursts of work -- and reports the bytes
+ * released / still held (either pointer may be null).  DSG_UC_POOL_CAP_MB (default 16384) bounds the arenas of a device; a handle
+ * created past the cap gets cached loop buffers + fenced packets (dsg_last_sample_fence_free reports 0).  No reference counterpart
+ * (torch's caching allocator: torch.cuda.empty_cache()). */
+int dsg_trim(int device, long long* bytes_released, long long* bytes_held);
 /* the framework's noise stream as a tensor: out [B, J, 1, T] (device) = draw `draw` of (seed, stream_id), i.e. exactly the
  * noise the fused sampler uses for that draw index (x_T is draw_base, step i is draw_base + 1 + i).  Stands in for
  * th.randn / th.randn_like of gaussian_diffusion.py:704, :542 in the generic loop. */

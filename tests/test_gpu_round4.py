@@ -122,6 +122,24 @@ def test_dsgplus_clip_loop_on_lanes_vs_single_lane_and_oracle(gpu, cfg):
         want = generate_clip_dsgplus(lanes[ln], d, feats[ln], style, seed0s[ln], frames, seed=21, skip_timesteps=skip, stream_id=[3, 4, 5, 6][ln],
                                      seed_last=None if lasts is None else lasts[ln])
         assert np.array_equal(got[ln * B:(ln + 1) * B], want), ln
+    # ... and the oracle's DSG+ clip driver (round-4 verdict 8a: the docstring promised it): clip 7 = batch element 1 of lane 3, every
+    # window's chain on the noise rows of that element (draw index of window c, step k: c (1 + n_run) + k of stream 6)
+    from oracle import philox, sampler
+    from oracle.mdm import MDMOracle
+    from oracle.schedule import OracleDiffusion
+    ln, b = 3, 1
+    ref, od = MDMOracle(synth_state_dict(cfg, 20240), cfg), OracleDiffusion()
+    shape = (B, cfg.njoints, 1, cfg.n_poses)
+
+    def sample_window(c, yy):
+        nf = lambda k: philox.normal_bj1t(shape, 21, c * (1 + n_run) + k, 6)[b:b + 1]
+        return sampler.p_sample_loop(od, ref, (1,) + shape[1:], nf, {"y": yy}, skip_timesteps=skip)
+    feats_np = [pad(il["audio"])[b:b + 1] for il in ins[ln]]
+    want = sampler.dsgplus_clip(sample_window, cfg, feats_np, style, ins[ln][0]["seed"][b:b + 1], frames,
+                                seed_last=ins[ln][0]["seed_last"][b:b + 1] if cfg.variant == 5 else None)
+    e = rel_l2(got[ln * B + b], want)
+    print(f"{cfg.name}: lane {ln} clip {b} of the 4 x 2 DSG+ call vs the oracle clip driver: rel-L2 {e:.2e}")
+    assert e < TOL_CHAIN["bf16"], e
 
 
 def test_stream_set_several_blocks_per_workgroup_at_latent_128(gpu):
@@ -279,8 +297,8 @@ def test_block_set_with_the_ffn_split_over_hidden_vs_oracle(gpu, monkeypatch):
             e = rel_l2(out[b:b + 1], ref(x[b:b + 1], [int(ts[b])], yb))
             assert e < TOL_FWD["bf16"], (B, b, e)
         if B == 16:
-            monkeypatch.setenv("DSG_FFN_SPLIT", "0")
-            old = np.asarray(m(x, ts, y))
+            monkeypatch.setenv("DSG_FFN_SPLIT", "0")          # (read once, at dsg_create: a handle created under the switch)
+            old = np.asarray(_model(cfg, "bf16", max_batch=B).set_kernel_set("block")(x, ts, y))
             monkeypatch.delenv("DSG_FFN_SPLIT")
             assert 0 < rel_l2(out, old) < TOL_FWD["bf16"]            # a different set of kernels ran, same function
             small = _model(cfg, "bf16", max_batch=2).set_kernel_set("block")
@@ -309,11 +327,10 @@ def test_ffn_64_row_blocks_with_four_large_lanes_bit_identical(gpu, monkeypatch)
     y = synth_window_inputs(cfg, B, window=1, clip0=2, seed_pose_scale=0.2)
     x = np.random.RandomState(5).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
     ts = (np.arange(B) * 19 + 3) % 1000
-    m.set_kernel_set("stream")
-    monkeypatch.setenv("DSG_FFN_RT4", "0")
-    a = np.asarray(m(x, ts, y))
+    monkeypatch.setenv("DSG_FFN_RT4", "0")              # (read once, at dsg_create: handles created under the switch)
+    a = np.asarray(_model(cfg, "bf16", max_batch=B).set_kernel_set("stream")(x, ts, y))
     monkeypatch.setenv("DSG_FFN_RT4", "1")
-    b = np.asarray(m(x, ts, y))
+    b = np.asarray(_model(cfg, "bf16", max_batch=B).set_kernel_set("stream")(x, ts, y))
     monkeypatch.delenv("DSG_FFN_RT4")
     assert np.array_equal(a, b) and np.isfinite(a).all()
     m.set_kernel_set("auto")

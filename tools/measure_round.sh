@@ -1,7 +1,7 @@
 #!/bin/bash
-# One measurement round on the GPU box (round 4); everything lands in gpurun_out/$TAG_* (copy what matters into profiles/).
-#   gpurun --timeout 1500 -- 'bash tools/measure_round4.sh r04_y [tests]'
-TAG=${1:-r04_y}; WITH_TESTS=${2:-}
+# One measurement round on the GPU box (any round: the tag names it); everything lands in gpurun_out/$TAG_* (copy what matters into profiles/).
+#   gpurun --timeout 1500 -- 'bash tools/measure_round.sh r05_z [tests]'
+TAG=${1:-r05_z}; WITH_TESTS=${2:-}
 O=gpurun_out; mkdir -p $O
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 if [ -n "$WITH_TESTS" ]; then
