@@ -98,7 +98,8 @@ __device__ __forceinline__ void inloc_body(const InLocArgs& g) {
     const f32x4* wbase = (const f32x4*)g.Wp + lane;
     constexpr int CH = 9;
     const int kb_last = g.KBtot - 1;
-    f32x4 af[CH][2], bf[CH][NL];
+    f32x4 af[CH][2];
+    typename P::wfrag bf[CH][NL];
     auto load_chunk = [&](int kb0) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -106,7 +107,7 @@ __device__ __forceinline__ void inloc_body(const InLocArgs& g) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) af[c][mt] = lda16<P>(g.xs, (arow[mt] + (size_t)kb * P::KB) * ES);
 #pragma unroll
-            for (int nt = 0; nt < NL; ++nt) bf[c][nt] = wbase[((size_t)(ntile0 + nt) * g.KBtot + kb) * 64];
+            for (int nt = 0; nt < NL; ++nt) bf[c][nt] = P::wload(wbase, (size_t)(ntile0 + nt) * g.KBtot + kb);
         }
     };
     load_chunk(kb_lo);
@@ -128,7 +129,7 @@ __device__ __forceinline__ void inloc_body(const InLocArgs& g) {
             for (int mt = 0; mt < 2; ++mt) {
                 const f32x4 av = live ? af[c][mt] : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int nt = 0; nt < NL; ++nt) acc[mt][nt] = P::mma(av, bf[c][nt], acc[mt][nt]);   // D[row 4lg+r][col lr]
+                for (int nt = 0; nt < NL; ++nt) acc[mt][nt] = P::mma_a(av, bf[c][nt], acc[mt][nt]);   // D[row 4lg+r][col lr]
             }
         }
         if (kb0 + CH < kb_hi) load_chunk(kb0 + CH);
@@ -189,7 +190,7 @@ struct MidArgs {
 template <class P, int DT>
 __device__ __forceinline__ void mid_tail(const MidArgs& g, f32x4 (&acc)[DT], const f32x4 (&pbo)[DT], const f32x4 (&pr)[DT],
                                          const f32x4 (&pg)[DT], const f32x4 (&pbt)[DT], const f32x4 pb1,
-                                         const f32x4 (&w1f)[(DT * 64 / P::KB) <= mid_ch(DT, DT * 64 / P::KB) ? (DT * 64 / P::KB) : 1],
+                                         const typename P::wfrag (&w1f)[(DT * 64 / P::KB) <= mid_ch(DT, DT * 64 / P::KB) ? (DT * 64 / P::KB) : 1],
                                          const f32x4* w1, char* a1, float (&red)[2][4][16], int m0, int ng, int n1t, int wave,
                                          int lr, int lg) {
     typedef typename P::elem elem;
@@ -232,17 +233,17 @@ __device__ __forceinline__ void mid_tail(const MidArgs& g, f32x4 (&acc)[DT], con
     if constexpr (KD <= CH) {
 #pragma unroll
         for (int kb = 0; kb < KD; ++kb)
-            c1 = P::mma(w1f[kb], *(const f32x4*)(a1 + lr * XP + (kb * P::KB + P::E * lg) * ES), c1);
+            c1 = P::mma_w(w1f[kb], *(const f32x4*)(a1 + lr * XP + (kb * P::KB + P::E * lg) * ES), c1);
     } else {
 #pragma unroll
         for (int kb0 = 0; kb0 < KD; kb0 += CH) {
-            f32x4 bf[CH];
+            typename P::wfrag bf[CH];
 #pragma unroll
-            for (int c = 0; c < CH; ++c) if (kb0 + c < KD) bf[c] = w1[((size_t)n1t * KD + kb0 + c) * 64];
+            for (int c = 0; c < CH; ++c) if (kb0 + c < KD) bf[c] = P::wload(w1, (size_t)n1t * KD + kb0 + c);
 #pragma unroll
             for (int c = 0; c < CH; ++c)
                 if (kb0 + c < KD)
-                    c1 = P::mma(bf[c], *(const f32x4*)(a1 + lr * XP + ((kb0 + c) * P::KB + P::E * lg) * ES), c1);
+                    c1 = P::mma_w(bf[c], *(const f32x4*)(a1 + lr * XP + ((kb0 + c) * P::KB + P::E * lg) * ES), c1);
         }
     }
     if (m0 + lr < g.M) {
@@ -298,15 +299,16 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
     //      LayerNorm scale/shift, linear1 fragments) last, in the order they are needed.
     constexpr int PD0 = DT >= 6 ? 2 : 4;             // k-blocks in flight ahead of the MFMA (register budget)
     constexpr int PD = PD0 < KD ? PD0 : KD;
-    f32x4 af[KD], bf[KD][DT];
+    f32x4 af[KD];
+    typename P::wfrag bf[KD][DT];
     f32x4 pbo[DT], pr[DT], pg[DT], pbt[DT], pb1;
-    f32x4 w1f[KD <= CH ? KD : 1];
+    typename P::wfrag w1f[KD <= CH ? KD : 1];
     const int n1t = ng * 4 + wave;                   // this wave's 16-col tile of the hidden layer
 #pragma unroll
     for (int kb = 0; kb < PD; ++kb) {
         af[kb] = *(const f32x4*)(arow + (size_t)kb * 64 * P::E);
 #pragma unroll
-        for (int t = 0; t < DT; ++t) bf[kb][t] = wo[((size_t)(wave * DT + t) * KD + kb) * 64];
+        for (int t = 0; t < DT; ++t) bf[kb][t] = P::wload(wo, (size_t)(wave * DT + t) * KD + kb);
     }
     auto load_operands = [&]() {
 #pragma unroll
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
         }
         if constexpr (KD <= CH) {
 #pragma unroll
-            for (int k2 = 0; k2 < KD; ++k2) w1f[k2] = w1[((size_t)n1t * KD + k2) * 64];
+            for (int k2 = 0; k2 < KD; ++k2) w1f[k2] = P::wload(w1, (size_t)n1t * KD + k2);
         }
         pb1 = *(const f32x4*)(g.b1 + n1t * 16 + 4 * lg);
     };
@@ -328,12 +330,12 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
         if (kb + PD < KD) {
             af[kb + PD] = *(const f32x4*)(arow + (size_t)(kb + PD) * 64 * P::E);
 #pragma unroll
-            for (int t = 0; t < DT; ++t) bf[kb + PD][t] = wo[((size_t)(wave * DT + t) * KD + kb + PD) * 64];
+            for (int t = 0; t < DT; ++t) bf[kb + PD][t] = P::wload(wo, (size_t)(wave * DT + t) * KD + kb + PD);
         }
         if (kb + PD == KD) load_operands();           // all fragments requested: now the operands of the later phases
         DSG_LOADS_ISSUED();
 #pragma unroll
-        for (int t = 0; t < DT; ++t) acc[t] = P::mma(bf[kb][t], af[kb], acc[t]);      // D[n 4lg+r][row lr]
+        for (int t = 0; t < DT; ++t) acc[t] = P::mma_w(bf[kb][t], af[kb], acc[t]);      // D[n 4lg+r][row lr]
         DSG_LOADS_ISSUED();
     }
 #pragma unroll
@@ -377,7 +379,8 @@ __device__ __forceinline__ void attn_mid_body(const AttnMidArgs& ga) {
     constexpr int ND = HD / 16;
     constexpr int NVF = P::E == 4 ? NKT : NKT / 2;   // PV k-blocks
     constexpr int PD = 4;                            // out_proj k-blocks in flight ahead of the MFMA
-    constexpr int PDA = KD <= 8 ? KD : PD;           // ... of which this many are requested before the attention math
+    constexpr int PDA = KD * P::WF <= 8 ? KD : PD;   // ... of which this many are requested before the attention math (register budget: fp32 and the
+                                                     // two-register weight fragments of bf16w2 hold half as many k-blocks)
     static_assert(KDH >= 1 && PDA >= PD && PDA <= KD, "shape");
     static_assert(P::E == 4 || (NKT % 2) == 0, "bf16 pairs key tiles");
     __shared__ __attribute__((aligned(16))) char aT[16 * XP];      // attention output rows (MFMA element type)
@@ -414,9 +417,9 @@ __device__ __forceinline__ void attn_mid_body(const AttnMidArgs& ga) {
     //      issues in order, and a burst of ~70 loads stalls it in the issue stage for as long as the texture path needs
     //      to drain them (~100 cycles each with 4 waves loading) -- time in which no softmax instruction can run.
     //      Spread between the softmax stages the same loads cost nothing and have arrived when out_proj starts.
-    f32x4 bf[KD][DT];
+    typename P::wfrag bf[KD][DT];
     f32x4 pbo[DT], pr[DT], pg[DT], pbt[DT], pb1;
-    f32x4 w1f[KD <= CH ? KD : 1];
+    typename P::wfrag w1f[KD <= CH ? KD : 1];
     const int n1t = ng * 4 + wave;                   // this wave's 16-col tile of the hidden layer
     constexpr int G = PDA + 4;                       // load groups: PDA weight k-blocks, bias+residual, LN scale+shift, linear1 fragments, linear1 bias
     constexpr int S = 2 * NKT + ND;                  // slots: after each key tile of the max pass, of the exp pass, after each PV tile
@@ -425,7 +428,7 @@ __device__ __forceinline__ void attn_mid_body(const AttnMidArgs& ga) {
     auto issue_group = [&](int gi) {
         if (gi < PDA) {
 #pragma unroll
-            for (int t = 0; t < DT; ++t) bf[gi][t] = wo[((size_t)(wave * DT + t) * KD + gi) * 64];
+            for (int t = 0; t < DT; ++t) bf[gi][t] = P::wload(wo, (size_t)(wave * DT + t) * KD + gi);
         } else if (gi == PDA) {
 #pragma unroll
             for (int t = 0; t < DT; ++t) {
@@ -441,7 +444,7 @@ __device__ __forceinline__ void attn_mid_body(const AttnMidArgs& ga) {
         } else if (gi == PDA + 2) {
             if constexpr (KD <= CH) {
 #pragma unroll
-                for (int k2 = 0; k2 < KD; ++k2) w1f[k2] = w1[((size_t)n1t * KD + k2) * 64];
+                for (int k2 = 0; k2 < KD; ++k2) w1f[k2] = P::wload(w1, (size_t)n1t * KD + k2);
             }
         } else {
             pb1 = *(const f32x4*)(g.b1 + n1t * 16 + 4 * lg);
@@ -519,12 +522,12 @@ __device__ __forceinline__ void attn_mid_body(const AttnMidArgs& ga) {
 #undef DSG_ISSUE_SLOT
     // fp32 (KD = 16 at D = 256): K / V^T are dead now -- ALL remaining W_o k-blocks in one batch instead of a PD-deep pipeline of
     // exposed L2 round trips inside the out_proj loop (round 4: k_attn_mid<PF32, 4, 6> 20.4 us, 62 % of the fp32 step)
-    constexpr bool ALL_AFTER = KD > PDA && (KD - PDA) * DT <= 64;
+    constexpr bool ALL_AFTER = KD > PDA && (KD - PDA) * DT * P::WF <= 64;
     if constexpr (ALL_AFTER) {
 #pragma unroll
         for (int kb = PDA; kb < KD; ++kb)
 #pragma unroll
-            for (int t = 0; t < DT; ++t) bf[kb][t] = wo[((size_t)(wave * DT + t) * KD + kb) * 64];
+            for (int t = 0; t < DT; ++t) bf[kb][t] = P::wload(wo, (size_t)(wave * DT + t) * KD + kb);
         DSG_LOADS_ISSUED();
     }
     DSG_LDS_BARRIER();
@@ -537,11 +540,11 @@ __device__ __forceinline__ void attn_mid_body(const AttnMidArgs& ga) {
     for (int kb = 0; kb < KD; ++kb) {
         if (!ALL_AFTER && kb + PD >= PDA && kb + PD < KD) {
 #pragma unroll
-            for (int t = 0; t < DT; ++t) bf[kb + PD][t] = wo[((size_t)(wave * DT + t) * KD + kb + PD) * 64];
+            for (int t = 0; t < DT; ++t) bf[kb + PD][t] = P::wload(wo, (size_t)(wave * DT + t) * KD + kb + PD);
         }
         const f32x4 af = *(const f32x4*)(aT + lr * XP + (kb * P::KB + P::E * lg) * ES);
 #pragma unroll
-        for (int t = 0; t < DT; ++t) acc[t] = P::mma(bf[kb][t], af, acc[t]);      // D[n 4lg+r][row lr]
+        for (int t = 0; t < DT; ++t) acc[t] = P::mma_w(bf[kb][t], af, acc[t]);      // D[n 4lg+r][row lr]
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {

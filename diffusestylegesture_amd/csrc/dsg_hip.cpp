@@ -199,6 +199,9 @@ struct dsg_handle {
     float last_ms = -1.f; int last_steps = 0; bool timing_valid = false;
 };
 
+// bf16 activations (DSG_PREC_BF16, DSG_PREC_BF16W2): the compute-dtype shadows / fragment layouts of the bf16 kernels
+static inline bool is_bf16(const dsg_handle* h) { return h->prec != DSG_PREC_FP32; }
+
 // Uncached device memory is never handed back to the HIP allocator while a handle may still be created (round 4).  Found with
 // tools/debug_rowdep*.py: after a handle with uncached loop buffers had been destroyed, a NEW handle whose buffers landed on the
 // recycled range computed wrong rows (tiny dims, batch 200 after a batch-170 handle: every frame row >= 4096 -- exactly the part of
@@ -220,9 +223,9 @@ struct UcPool {
     std::mutex mu;
     std::vector<UcArena> arenas[64];     // per device
     std::map<void*, std::pair<char*, size_t>> live;    // block -> (base of its arena, length)
-    size_t cap_bytes = (size_t)16384 << 20;
     size_t trimmed = 0;                  // arenas returned by dsg_trim so far (diagnostics)
-    UcPool() { if (const char* e = getenv("DSG_UC_POOL_CAP_MB")) cap_bytes = (size_t)std::max(atoll(e), 0ll) << 20; }
+    // (allocation time only -- handle creation, never the step loop -- so the cap is read where it is applied)
+    static size_t cap_bytes() { const char* e = getenv("DSG_UC_POOL_CAP_MB"); return (size_t)(e ? std::max(atoll(e), 0ll) : 16384ll) << 20; }
 };
 static UcPool& uc_pool() { static UcPool* p = new UcPool(); return *p; }      // (leaked on purpose: arenas outlive every handle)
 constexpr size_t UC_ALIGN = 4096, UC_ARENA_MIN = (size_t)32 << 20, UC_ARENA_GRAN = (size_t)2 << 20;
@@ -283,7 +286,7 @@ static void* uc_pool_take(int dev, size_t bytes) {
         size_t total = 0;
         for (const UcArena& A : av) total += A.size;
         const size_t want = std::max(UC_ARENA_MIN, (bytes + UC_ARENA_GRAN - 1) / UC_ARENA_GRAN * UC_ARENA_GRAN);
-        if (total + want > P.cap_bytes) return nullptr;
+        if (total + want > UcPool::cap_bytes()) return nullptr;
         void* d = nullptr;
         if (hipExtMallocWithFlags(&d, want, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         UcArena A;
@@ -447,7 +450,7 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     if (c->audio_dim % 4) return fail(DSG_E_INVALID, "audio_dim must be a multiple of 4");
     if (c->max_batch <= 0 || c->njoints <= 0 || c->n_seed < 0 || c->n_seed >= c->n_poses)
         return fail(DSG_E_INVALID, "bad dims");
-    if (c->precision != DSG_PREC_FP32 && c->precision != DSG_PREC_BF16) return fail(DSG_E_INVALID, "precision");
+    if (c->precision != DSG_PREC_FP32 && c->precision != DSG_PREC_BF16 && c->precision != DSG_PREC_BF16W2) return fail(DSG_E_INVALID, "precision");
     const int ntok = c->n_poses + 1, Tp = rup(ntok, 32);
     if (!(Tp == 32 || Tp == 96 || Tp == 160))
         return fail(DSG_E_NOT_IMPLEMENTED, "attention kernel is instantiated for n_poses+1 padded to 32, 96 or 160 tokens");
@@ -457,8 +460,8 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     h->shared = std::make_shared<SharedWeights>();
     h->cfg = *c;
     h->prec = c->precision;
-    h->es = h->prec == DSG_PREC_BF16 ? 2 : 4;
-    h->kbk = h->prec == DSG_PREC_BF16 ? 32 : 16;
+    h->es = is_bf16(h) ? 2 : 4;
+    h->kbk = is_bf16(h) ? 32 : 16;
     h->J = c->njoints; h->T = c->n_poses; h->S = c->n_seed; h->D = c->latent_dim; h->As = c->audio_src_dim;
     h->A = c->audio_dim; h->W = c->window; h->L = c->num_layers; h->H = c->num_heads; h->hd = hd; h->ff = c->ff_size;
     h->Hl = c->local_heads; h->hdl = hdl; h->ntok = ntok; h->Tp = Tp;
@@ -523,7 +526,7 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     h->state_fences = h->uc_mode == 1 && !(getenv("DSG_STATE_UC") && atoi(getenv("DSG_STATE_UC")));
     h->alloc_uc = !h->state_fences;
     CHK(dalloc(h, &h->xs32, (size_t)B * h->T * h->Jp + 16 * h->Jp));
-    if (h->prec == DSG_PREC_BF16) CHK(dalloc_bytes(h, &h->xsA, ((size_t)Min_pad * h->Jp) * h->es));
+    if (is_bf16(h)) CHK(dalloc_bytes(h, &h->xsA, ((size_t)Min_pad * h->Jp) * h->es));
     h->alloc_uc = true;                  // ---- written AND read inside one step by the kernels of the loop
     CHK(dalloc(h, &h->partial, (size_t)h->KSin * Min_pad * D));
     CHK(dalloc(h, &h->X0, M_pad * D));
@@ -661,7 +664,7 @@ static int launch_mm(dsg_handle* h, float* C, int ldc, const float* A, long long
 template <class P>
 static int launch_pack(dsg_handle* h, void** dst, const float* W, long long ldw, int N, int K, int NT, int KBtot) {
     const size_t n = (size_t)NT * KBtot * 64 * P::E;
-    CHK(dalloc_bytes(h, dst, n * sizeof(typename P::elem)));
+    CHK(dalloc_bytes(h, dst, n * sizeof(typename P::elem) * P::WF));
     const int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
     hipLaunchKernelGGL((k_pack_w<P>), dim3(grid), dim3(256), 0, h->stream, *dst, W, ldw, N, K, NT, KBtot);
     HIPCHK(hipGetLastError());
@@ -669,6 +672,7 @@ static int launch_pack(dsg_handle* h, void** dst, const float* W, long long ldw,
 }
 static int pack(dsg_handle* h, void** dst, const float* W, long long ldw, int N, int K, int Npad, int Kpad) {
     if (h->prec == DSG_PREC_BF16) return launch_pack<PBF16>(h, dst, W, ldw, N, K, Npad / 16, Kpad / 32);
+    if (h->prec == DSG_PREC_BF16W2) return launch_pack<PBF16W2>(h, dst, W, ldw, N, K, Npad / 16, Kpad / 32);
     return launch_pack<PF32>(h, dst, W, ldw, N, K, Npad / 16, Kpad / 16);
 }
 static int padded_vec(dsg_handle* h, float** dst, const float* src, int n, int npad) {
@@ -959,7 +963,7 @@ static bool have_attn_op_narrow(const dsg_handle* h) {
 }
 // ... or k_attn_op_w (W_o streamed in chunks, round 4): the DSG+ widths in bf16, the ZEGGS / tiny widths in fp32
 static bool have_attn_op_wide(const dsg_handle* h) {
-    if (h->H != 4) return false;
+    if (h->H != 4 || h->prec == DSG_PREC_BF16W2) return false;
     if (h->prec == DSG_PREC_BF16) return (h->D == 384 || h->D == 512) && h->Tp == 160;
     return (h->D == 256 && h->Tp == 96) || (h->D == 128 && h->Tp == 32);
 }
@@ -996,6 +1000,7 @@ static int resolve_auto_set(const dsg_handle* h, int B, int lanes) {
     int set = auto_kernel_set(h, B, lanes);
     if (h->latency_mode == 0 && set == DSG_KSET_LATENCY) set = DSG_KSET_TILE;
     if (h->latency_mode == 1 && latency_set_ok(h)) set = DSG_KSET_LATENCY;
+    if (h->prec == DSG_PREC_BF16W2 && set > DSG_KSET_TILE) set = DSG_KSET_TILE;      // bf16w2: LATENCY and TILE only (16 x 16 tiles at every batch size)
     return set;
 }
 // k_ffn_part + k_ffn_ln exist for the shapes the STREAM set exists for
@@ -1006,6 +1011,8 @@ static int select_kernels(const dsg_handle* h, int B, KernelSel& k) {
     if (set == DSG_KSET_LATENCY && h->D > 512) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set LATENCY: latent_dim > 512");
     if (set == DSG_KSET_STREAM && !stream_set_ok(h)) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set STREAM: bf16, latent_dim 128 / 256, 4 heads, ff 128 / 1024 only");
     if (set < DSG_KSET_LATENCY || set > DSG_KSET_STREAM) return fail(DSG_E_INVALID, "unknown kernel set");
+    if (h->prec == DSG_PREC_BF16W2 && (set > DSG_KSET_TILE || (set == DSG_KSET_LATENCY && h->D > 256)))
+        return fail(DSG_E_NOT_IMPLEMENTED, "precision bf16w2: kernel sets LATENCY (latent_dim <= 256) and TILE only");
     k = KernelSel();
     k.set = set;
     k.lat = set == DSG_KSET_LATENCY;
@@ -1044,6 +1051,7 @@ extern "C" int dsg_set_kernel_set(dsg_handle* h, int set) {
     if (set < DSG_KSET_AUTO || set > DSG_KSET_STREAM) return fail(DSG_E_INVALID, "dsg_set_kernel_set: unknown kernel set");
     if (set == DSG_KSET_LATENCY && h->D > 512) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set LATENCY: latent_dim > 512");
     if (set == DSG_KSET_STREAM && !stream_set_ok(h)) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set STREAM: bf16, latent_dim 128 / 256, 4 heads, ff 128 / 1024 only");
+    if (h->prec == DSG_PREC_BF16W2 && set > DSG_KSET_TILE) return fail(DSG_E_NOT_IMPLEMENTED, "precision bf16w2: kernel sets LATENCY and TILE only");
     if (getenv("DSG_KSET")) {                  // an A/B run pinned the set for the whole process: say so once, keep the pinned set
         static std::atomic<bool> said{false};
         if (set != h->kset_req && !said.exchange(true))
@@ -1219,13 +1227,13 @@ static int launch_ws2(dsg_handle* h, GemmArgs g) {
 template <class P, int PRO, int EPI>
 static int launch_gemm_w(dsg_handle* h, const GemmArgs& g, const KernelSel& ks) {
     constexpr bool blk_wins = EPI == EPI_QKV || EPI == EPI_GELU;
-    if constexpr (sizeof(typename P::elem) == 2 && PRO == PRO_DIRECT && (EPI == EPI_GELU || EPI == EPI_QKV || EPI == EPI_OUT)) {
+    if constexpr (sizeof(typename P::elem) == 2 && !P::W2 && PRO == PRO_DIRECT && (EPI == EPI_GELU || EPI == EPI_QKV || EPI == EPI_OUT)) {
         if (ks.stream && g.a_frag) return launch_ws<EPI>(h, g);      // STREAM: linear1 on the fragment-major LayerNorm1 rows of k_attn_op
     }
-    if constexpr (sizeof(typename P::elem) == 2 && PRO == PRO_LN && (EPI == EPI_QKV || EPI == EPI_OUT)) {
+    if constexpr (sizeof(typename P::elem) == 2 && !P::W2 && PRO == PRO_LN && (EPI == EPI_QKV || EPI == EPI_OUT)) {
         if (ks.stream) return launch_ln_ws<EPI>(h, g);                    // STREAM: LayerNorm once per row, then the same streaming GEMM
     }
-    if constexpr (EPI != EPI_PARTIAL) {
+    if constexpr (EPI != EPI_PARTIAL && !P::W2) {
         if (ks.blk && blk_wins && g.KBtot * P::KB <= 512) return launch_blk<P, PRO, EPI>(h, g);
     }
     if constexpr (PRO == PRO_LN) {
@@ -1245,10 +1253,12 @@ static int launch_gemm_w(dsg_handle* h, const GemmArgs& g, const KernelSel& ks) 
 // linear2: K = ff split over the 4 waves of the workgroup
 template <class P>
 static int launch_gemm_k4(dsg_handle* h, const GemmArgs& g, const KernelSel& ks) {
-    if constexpr (sizeof(typename P::elem) == 2) {
+    if constexpr (sizeof(typename P::elem) == 2 && !P::W2) {
         if (ks.stream && g.a_frag) return launch_ws2<EPI_RESID>(h, g);
     }
-    if (ks.blk) return launch_blk_k<P, EPI_RESID>(h, g);
+    if constexpr (!P::W2) {
+        if (ks.blk) return launch_blk_k<P, EPI_RESID>(h, g);
+    }
     return launch_gemm<P, PRO_DIRECT, EPI_RESID, 1, 4>(h, g);
 }
 
@@ -1291,10 +1301,13 @@ static int launch_mid(dsg_handle* h, const MidArgs& a) {
         case 1: return step_launch<&k_mid<P, 1>>(h, grid, dim3(256), a);
         case 2: return step_launch<&k_mid<P, 2>>(h, grid, dim3(256), a);
         case 4: return step_launch<&k_mid<P, 4>>(h, grid, dim3(256), a);
-        case 6: return step_launch<&k_mid<P, 6>>(h, grid, dim3(256), a);
-        case 8: return step_launch<&k_mid<P, 8>>(h, grid, dim3(256), a);
-        default: return fail(DSG_E_NOT_IMPLEMENTED, "k_mid: latent_dim / 64 must be 1, 2, 4, 6 or 8");
+        default: break;
     }
+    if constexpr (!P::W2) {      // (bf16w2: two-register weight fragments, LATENCY up to latent_dim 256 -- select_kernels)
+        if (h->D == 384) return step_launch<&k_mid<P, 6>>(h, grid, dim3(256), a);
+        if (h->D == 512) return step_launch<&k_mid<P, 8>>(h, grid, dim3(256), a);
+    }
+    return fail(DSG_E_NOT_IMPLEMENTED, "k_mid: latent_dim / 64 must be 1, 2, 4, 6 or 8 (bf16w2: 1, 2 or 4)");
 }
 // Attention fused into k_mid: one batch element, 4 heads (wave = head), D <= 256.  Bit-identical to k_attn + k_mid and
 // one dispatch less per layer.  With HIP launches it does not pay (152.4 vs 151.3 us/step): the four heads' strided
@@ -1341,7 +1354,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
     h->fence_next = 1;         // the first packet of a step reads the state the previous step's last packet wrote (state_fences)
     if (ks.lat) {              // pose embedding + local attention in one launch
         InLocArgs a;
-        a.xs = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; a.Jp = h->Jp; a.Wp = h->Wp_in; a.KBtot = h->Jp / KB;
+        a.xs = is_bf16(h) ? h->xsA : (void*)h->xs32; a.Jp = h->Jp; a.Wp = h->Wp_in; a.KBtot = h->Jp / KB;
         a.loc = la; a.ctl_upd = c.use_ctr ? h->ctl : nullptr; a.st = step_tables(h); a.n_tab = h->n_run;
         DSG_LOC_DISPATCH(k_inloc, a, dim3(h->Hl, T / h->W, B + 1));
     } else {
@@ -1349,16 +1362,17 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
             GemmArgs g = z;
             g.M = Min; g.MT = MTin; g.NT = D / 16; g.KBtot = h->Jp / KB; g.KS = ks_in; g.Wp = h->Wp_in;
             g.kb_per_split = cdiv(g.KBtot, g.KS);
-            g.A = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; g.lda = h->Jp;
+            g.A = is_bf16(h) ? h->xsA : (void*)h->xs32; g.lda = h->Jp;
             g.out = h->partial; g.ldo = D;
             g.ctl = c.use_ctr ? h->ctl : nullptr; g.st = step_tables(h); g.n_tab = h->n_run;
             bool done = false;
-            if constexpr (sizeof(typename P::elem) == 2) {
+            if constexpr (sizeof(typename P::elem) == 2 && !P::W2) {
                 if (ks.xs_frag) { g.a_frag = 1; CHK(launch_ws2<EPI_PARTIAL>(h, g)); done = true; }      // the state shadow is fragment-major
             }
-            if (done) {}
-            else if (ks.blk) CHK((launch_blk_k<P, EPI_PARTIAL>(h, g)));
-            else CHK((launch_gemm<P, PRO_DIRECT, EPI_PARTIAL, 4, 1>(h, g)));
+            if constexpr (!P::W2) {
+                if (!done && ks.blk) { CHK((launch_blk_k<P, EPI_PARTIAL>(h, g))); done = true; }
+            }
+            if (!done) CHK((launch_gemm<P, PRO_DIRECT, EPI_PARTIAL, 4, 1>(h, g)));
         }
         DSG_LOC_DISPATCH(k_loc, la, dim3(h->Hl, T / h->W, B));
     }
@@ -1399,6 +1413,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                 CHK(launch_mid<P>(h, a));
             }
         } else if (ks.attn_op) {
+          if constexpr (!P::W2) {        // (bf16w2 runs LATENCY / TILE without k_attn_op: select_kernels)
             // attention + out_proj + residual + LayerNorm1 in one kernel per (query tile, batch element); linear1 reads the
             // normalised rows in the GEMM type
             {
@@ -1462,6 +1477,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                 g.A = h->X1a; g.lda = D; g.a_frag = 1; g.out = h->hidden; g.ldo = h->ff; g.out_frag = 1;
                 CHK((launch_gemm_w<P, PRO_DIRECT, EPI_GELU>(h, g, ks)));
             }
+          }
         } else {
             {   // out_proj + residual -> pre1
                 GemmArgs g = z;
@@ -1487,7 +1503,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
         GemmArgs g = z;
         g.M = M; g.MT = MT; g.NT = h->Jp / 16; g.KBtot = D / KB; g.Wp = h->Wp_out; g.bias = h->b_out;
         g.X = h->pre2; g.ln_g = h->layers[h->L - 1].g2; g.ln_b = h->layers[h->L - 1].be2; g.Xn = nullptr;
-        g.out_mode = c.out_mode; g.xs32 = h->xs32; g.xsA = h->prec == DSG_PREC_BF16 ? h->xsA : nullptr;
+        g.out_mode = c.out_mode; g.xs32 = h->xs32; g.xsA = is_bf16(h) ? h->xsA : nullptr;
         g.fwd_out = h->fwd_out; g.ctl = c.use_ctr ? h->ctl : nullptr; g.st = step_tables(h); g.n_tab = h->n_run;
         g.dyn = h->dyn; g.ext_noise = c.ext_noise; g.const_noise = c.const_noise; g.clip_x0 = c.clip_x0; g.no_noise = c.no_noise;
         g.xs_frag = ks.xs_frag ? 1 : 0;
@@ -1553,7 +1569,7 @@ static int debug_launch(dsg_handle* h, int which, int i, int B) {
         case 6: DSG_LOC_DISPATCH(k_loc, la, dim3(h->Hl, T / h->W, B)); return 0;
         case 7: {
             GemmArgs g = z; g.M = Min; g.MT = MTin; g.NT = D / 16; g.KBtot = h->Jp / KB; g.KS = h->KSin; g.Wp = h->Wp_in;
-            g.kb_per_split = cdiv(g.KBtot, g.KS); g.A = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; g.lda = h->Jp;
+            g.kb_per_split = cdiv(g.KBtot, g.KS); g.A = is_bf16(h) ? h->xsA : (void*)h->xs32; g.lda = h->Jp;
             g.out = h->partial; g.ldo = D; return launch_gemm<P, PRO_DIRECT, EPI_PARTIAL, 4, 1>(h, g); }
         case 8: {
             GemmArgs g = z; g.M = M; g.MT = MT; g.NT = h->Jp / 16; g.KBtot = D / KB; g.Wp = h->Wp_out; g.bias = h->b_out;
@@ -1569,7 +1585,7 @@ static int debug_launch(dsg_handle* h, int which, int i, int B) {
             a.W1 = ly.W1; a.b1 = ly.b1; a.X1 = h->X1; a.hidden = h->hidden; a.M = M; a.MT = MT; a.ff = h->ff;
             return launch_mid<P>(h, a); }
         case 12: {
-            InLocArgs a; a.xs = h->prec == DSG_PREC_BF16 ? h->xsA : (void*)h->xs32; a.Jp = h->Jp; a.Wp = h->Wp_in;
+            InLocArgs a; a.xs = is_bf16(h) ? h->xsA : (void*)h->xs32; a.Jp = h->Jp; a.Wp = h->Wp_in;
             a.KBtot = h->Jp / KB; a.loc = la; a.ctl_upd = nullptr; a.st = step_tables(h); a.n_tab = 1;
             DSG_LOC_DISPATCH(k_inloc, a, dim3(h->Hl, T / h->W, B + 1)); return 0; }
         default: return fail(DSG_E_INVALID, "debug_chain: unknown kernel id");
@@ -1600,6 +1616,7 @@ extern "C" int dsg_debug_read(dsg_handle* h, const char* name, void* out, long l
 extern "C" int dsg_debug_chain(dsg_handle* h, int which, int n, int use_graph, int B, float* us_per_launch) {
     if (!h || !h->finalized || !h->cond_set) return fail(DSG_E_STATE, "debug_chain needs a finalized, conditioned handle");
     HIPCHK(hipSetDevice(h->cfg.device));
+    if (h->prec == DSG_PREC_BF16W2) return fail(DSG_E_NOT_IMPLEMENTED, "dsg_debug_chain: precision bf16w2");
     auto one = [&](int i) { return h->prec == DSG_PREC_BF16 ? debug_launch<PBF16>(h, which, i, B) : debug_launch<PF32>(h, which, i, B); };
     const int G = 64;
     hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
@@ -1657,6 +1674,7 @@ extern "C" int dsg_debug_trace_get(dsg_handle* h, double* us, int cap, int* n_st
 }
 
 static int run_step_p(dsg_handle* h, const StepCtx& c) {
+    if (h->prec == DSG_PREC_BF16W2) return run_step<PBF16W2>(h, c);
     return h->prec == DSG_PREC_BF16 ? run_step<PBF16>(h, c) : run_step<PF32>(h, c);
 }
 
@@ -1666,10 +1684,10 @@ static int launch_x_in(dsg_handle* h, const float* x, const float* init, int do_
     a.dupB = h->cfgB; a.xs_frag = ks.xs_frag ? 1 : 0;
     a.x = x; a.init = init; a.do_q = do_q; a.qa = qa; a.qb = qb; a.use_philox = use_philox; a.nkey = nk; a.draw = draw;
     a.B = B; a.J = h->J; a.Jp = h->Jp; a.Jq = h->Jq; a.T = h->T; a.xs32 = h->xs32;
-    a.xsA = h->prec == DSG_PREC_BF16 ? h->xsA : nullptr;
+    a.xsA = is_bf16(h) ? h->xsA : nullptr;
     const size_t n = (size_t)B * h->T * (h->Jp / 4);
     const int grid = (int)std::min<size_t>((n + 255) / 256, 2048);
-    if (h->prec == DSG_PREC_BF16) hipLaunchKernelGGL((k_x_in<PBF16>), dim3(grid), dim3(256), 0, h->stream, a);
+    if (is_bf16(h)) hipLaunchKernelGGL((k_x_in<PBF16>), dim3(grid), dim3(256), 0, h->stream, a);
     else hipLaunchKernelGGL((k_x_in<PF32>), dim3(grid), dim3(256), 0, h->stream, a);
     HIPCHK(hipGetLastError());
     return 0;

@@ -79,6 +79,13 @@ struct PF32 {                       // fp32 storage, v_mfma_f32_16x16x4_f32
         return c;
     }
     static __device__ __forceinline__ void store4(elem* p, f32x4 v) { *(f32x4*)p = v; }
+    // weight fragments (see PBF16W2): one 16-byte fragment per k-block
+    typedef f32x4 wfrag;
+    static constexpr int WF = 1;    // 16-byte registers per weight fragment
+    static constexpr bool W2 = false;
+    static __device__ __forceinline__ wfrag wload(const f32x4* base, size_t frag) { return base[frag * 64]; }      // base = packed weights + lane
+    static __device__ __forceinline__ f32x4 mma_w(const wfrag& w, f32x4 a, f32x4 c) { return mma(w, a, c); }     // D = W_tile . Act_tile^T
+    static __device__ __forceinline__ f32x4 mma_a(f32x4 a, const wfrag& w, f32x4 c) { return mma(a, w, c); }     // D = Act_tile . W_tile^T
 };
 struct PBF16 {                      // bf16 storage, v_mfma_f32_16x16x32_bf16, fp32 accumulate
     typedef bf16_t elem;
@@ -95,6 +102,26 @@ struct PBF16 {                      // bf16 storage, v_mfma_f32_16x16x32_bf16, f
         typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
         *(bf16x4v*)p = __builtin_convertvector(v, bf16x4v);
     }
+    typedef f32x4 wfrag;
+    static constexpr int WF = 1;
+    static constexpr bool W2 = false;
+    static __device__ __forceinline__ wfrag wload(const f32x4* base, size_t frag) { return base[frag * 64]; }
+    static __device__ __forceinline__ f32x4 mma_w(const wfrag& w, f32x4 a, f32x4 c) { return mma(w, a, c); }
+    static __device__ __forceinline__ f32x4 mma_a(f32x4 a, const wfrag& w, f32x4 c) { return mma(a, w, c); }
+};
+// "bf16w2" (round 5): bf16 activations, every WEIGHT as the sum of two bf16 numbers -- hi = bf16(w), lo = bf16(w - hi): 16 mantissa
+// bits instead of 8 -- two v_mfma_f32_16x16x32_bf16 per fragment, fp32 accumulate.  The bf16 drift of a 1000-step chain is the
+// weights' 8-bit mantissa (tests/bf16_ablation.py: 5.9e-3 of 6.2e-3), and at batch 1 the MFMA pipe is ~1 % busy; what the mode costs
+// is the fp32-sized weight traffic.  Everything that is not a weight (activations, Q / K / V, softmax, the state shadow) is exactly
+// PBF16.  Packed layout: fragment f of the PBF16 order becomes the two consecutive 1 KB blocks 2f (hi) and 2f + 1 (lo), so every
+// fragment INDEX of the kernels stays what it is; a weight fragment is two registers quads (wfrag) loaded by wload.
+struct PBF16W2 : PBF16 {
+    struct wfrag { f32x4 h, l; };
+    static constexpr int WF = 2;
+    static constexpr bool W2 = true;
+    static __device__ __forceinline__ wfrag wload(const f32x4* base, size_t frag) { wfrag w; w.h = base[frag * 128]; w.l = base[frag * 128 + 64]; return w; }
+    static __device__ __forceinline__ f32x4 mma_w(const wfrag& w, f32x4 a, f32x4 c) { return PBF16::mma(w.l, a, PBF16::mma(w.h, a, c)); }
+    static __device__ __forceinline__ f32x4 mma_a(f32x4 a, const wfrag& w, f32x4 c) { return PBF16::mma(a, w.l, PBF16::mma(a, w.h, c)); }
 };
 
 // Loads of data another kernel of the step loop wrote.  The loop-written buffers live in uncached device memory (dsg_hip.cpp:
@@ -700,14 +727,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
     // All fragment loads of a chunk are issued before its first MFMA, and the NEXT chunk's weight fragments are
     // requested while the current chunk's MFMAs run: at these sizes a kernel is a latency chain, so every load that
     // does not depend on the prologue (weights, bias, residual, x_t, noise) is in flight before the LayerNorm starts.
-    f32x4 bf[CH][TNW];
+    typename P::wfrag bf[CH][TNW];
     const int kb_last = g.KBtot - 1;
     auto load_b = [&](int kb0) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const int kb = min(kb0 + c, kb_last);           // clamped, never predicated
 #pragma unroll
-            for (int t = 0; t < TNW; ++t) bf[c][t] = wbase[((size_t)(nt0 + t) * g.KBtot + kb) * 64];
+            for (int t = 0; t < TNW; ++t) bf[c][t] = P::wload(wbase, (size_t)(nt0 + t) * g.KBtot + kb);
         }
     };
     load_b(kb_lo);
@@ -789,7 +816,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
             const f32x4 a = live ? af[c] : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < TNW; ++t)
-                acc[t] = swapped[t] ? P::mma(bf[c][t], a, acc[t]) : P::mma(a, bf[c][t], acc[t]);
+                acc[t] = swapped[t] ? P::mma_w(bf[c][t], a, acc[t]) : P::mma_a(a, bf[c][t], acc[t]);
         }
         if (kb0 + CH < kb_hi) load_b(kb0 + CH);
     }
@@ -1321,7 +1348,14 @@ __global__ void k_pack_w(void* dst, const float* W, long long ldw, int N, int K,
         const int nn = nt * 16 + (lane & 15);
         const int k = kb * P::KB + P::E * (lane >> 4) + j;
         const float v = (nn < N && k < K) ? W[(long long)nn * ldw + k] : 0.f;
-        ((elem*)dst)[i] = P::cvt(v);
+        if constexpr (P::W2) {           // fragment f -> blocks 2f (hi) and 2f + 1 (lo) of 64 lanes x E elements
+            const size_t frag = i / (64 * P::E), in = i % (64 * P::E);
+            const elem hi = P::cvt(v);
+            ((elem*)dst)[(2 * frag) * 64 * P::E + in] = hi;
+            ((elem*)dst)[(2 * frag + 1) * 64 * P::E + in] = P::cvt(v - P::up(hi));
+        } else {
+            ((elem*)dst)[i] = P::cvt(v);
+        }
     }
 }
 __global__ void k_fill_f32(float* p, float v, size_t n) {

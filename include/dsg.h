@@ -60,7 +60,11 @@ enum {
     DSG_E_STATE = -6          /* call order (e.g. sample before finalize / set_window_cond) */
 };
 
-enum { DSG_PREC_FP32 = 0, DSG_PREC_BF16 = 1 };
+/* DSG_PREC_BF16W2 (ABI 320): bf16 activations, every weight as hi + lo bf16 (16 mantissa bits), two MFMAs per weight fragment --
+ * the precision mode between bf16 and fp32 (the bf16 drift of a 1000-step chain is the weights' 8-bit mantissa).  Kernel sets
+ * LATENCY and TILE (every batch size); BLOCK / STREAM are DSG_E_NOT_IMPLEMENTED.  The reference computes in fp32
+ * (main/train/training_loop.py:39: no autocast): DSG_PREC_FP32 is its arithmetic, the other two trade accuracy for speed. */
+enum { DSG_PREC_FP32 = 0, DSG_PREC_BF16 = 1, DSG_PREC_BF16W2 = 2 };
 /* kernel sets (dsg_set_kernel_set): which hand-written kernels one denoising step is made of.  Same arithmetic, different
  * grouping / tiling, i.e. last-bit differences between sets in bf16 -- which is why the set is an explicit, sticky property of
  * a handle and never depends on how a call is issued. */

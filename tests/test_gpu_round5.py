@@ -1,0 +1,94 @@
+"""GPU parity tests added in round 5 (all through the C ABI / ctypes shim)."""
+import gc
+import os
+
+import numpy as np
+import pytest
+
+from diffusestylegesture_amd import config as C
+from diffusestylegesture_amd.synth import synth_state_dict, synth_window_inputs
+from tests.util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL_FWD = {"fp32": 2e-5, "bf16": 1.2e-2}
+TOL_CHAIN = {"fp32": 1e-4, "bf16": 2e-2}
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from diffusestylegesture_amd import lib as L
+    return L.default_library()
+
+
+def _model(cfg, prec, max_batch=1, wseed=20240, **kw):
+    from diffusestylegesture_amd.model import DSGDenoiser
+    m = DSGDenoiser(cfg, precision=prec, max_batch=max_batch, device=0, **kw)
+    m.load_state_dict(synth_state_dict(cfg, wseed))
+    return m
+
+
+def test_uncached_pool_reuse_trim_and_cap(gpu, monkeypatch):
+    """Round-4 verdict 8c / advisor: the pool of uncached loop buffers is a sub-allocator over arenas (ABI 320).  (1) A handle with
+    CACHED loop buffers (DSG_UC=0) destroyed before an uncached one is created -- the case the round-4 test did not cover; (2) dsg_trim
+    between two generations of handles: whatever it hands back to HIP, the next handle's rows are the bits a small handle computes;
+    (3) past DSG_UC_POOL_CAP_MB a handle gets cached buffers + fenced packets and still computes the same bits."""
+    from diffusestylegesture_amd import lib as L
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    cfg = C.TINY
+
+    def inputs(B):
+        y = synth_window_inputs(cfg, B, window=1, seed_pose_scale=0.3)
+        x = np.random.RandomState(5).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+        return x, (np.arange(B) * 2 + 3) % 1000, y
+
+    small = _model(cfg, "bf16", max_batch=4).set_kernel_set("block")
+
+    def check(B, tag):
+        x, t, y = inputs(B)
+        big = _model(cfg, "bf16", max_batch=B).set_kernel_set("block")
+        out = np.asarray(big(x, t, y))
+        for lo in (0, B // 2, B - 4):
+            ys = {k: (v[lo:lo + 4] if v.shape[0] == B else v) for k, v in y.items()}
+            assert np.array_equal(out[lo:lo + 4], np.asarray(small(x[lo:lo + 4], t[lo:lo + 4], ys))), (tag, B, lo)
+        return big
+
+    monkeypatch.setenv("DSG_UC", "0")                    # (1) cached loop buffers, handed back to hipFree at destroy
+    x, t, y = inputs(170)
+    p = _model(cfg, "bf16", max_batch=170).set_kernel_set("block")
+    p(x, t, y)
+    del p
+    gc.collect()
+    monkeypatch.delenv("DSG_UC")
+    b = check(200, "after a cached handle")
+    del b
+    gc.collect()
+    rel, held = L.trim(0)                                # (2)
+    print(f"dsg_trim: {rel >> 20} MB released, {held >> 20} MB held")
+    assert rel >= 0 and held >= 0
+    b = check(180, "after dsg_trim")
+    b2 = check(200, "second generation")
+    del b, b2
+    gc.collect()
+    # (3) a handle that cannot fit under the cap (ZEGGS dims, 48 clips: ~150 MB of loop buffers against a 1 MB cap) gets cached buffers
+    # and fenced packets -- same bits as the fence-free handle created without the cap
+    zc = C.ZEGGS
+    B = 48
+    y = synth_window_inputs(zc, B, window=1, seed_pose_scale=0.2)
+    shape = (B, zc.njoints, 1, zc.n_poses)
+    d = create_gaussian_diffusion()
+    monkeypatch.setenv("DSG_UC_POOL_CAP_MB", "1")
+    m = _model(zc, "bf16", max_batch=B)
+    s1 = np.asarray(d.manual_seed(3, 1).p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=990))
+    assert np.isfinite(s1).all() and m.last_sample_path() == "aql" and not m.last_sample_fence_free()
+    monkeypatch.delenv("DSG_UC_POOL_CAP_MB")
+    m2 = _model(zc, "bf16", max_batch=B)
+    s2 = np.asarray(d.manual_seed(3, 1).p_sample_loop(m2, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=990))
+    assert m2.last_sample_fence_free() and m2.last_kernel_set() == m.last_kernel_set() and np.array_equal(s1, s2)
+    del m, m2
+    gc.collect()
+    rel, held = L.trim(0)
+    print(f"dsg_trim: {rel >> 20} MB released, {held >> 20} MB held")
+    assert rel >= (32 << 20)                             # at least one arena of the 48-clip handle holds no live block any more
