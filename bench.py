@@ -46,7 +46,7 @@ def parse(argv=None):
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=3, help="passes (clips per lane / batch element) inside the timed region")
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--precision", default="bf16", choices=["bf16", "bf16w2", "fp32"])
     p.add_argument("--sampler", default="ddpm", choices=["ddpm", "ddim50"])
     p.add_argument("--clips-per-gpu", type=int, default=0, help="clips in flight per GPU (default 1; 16 = config[3]'s per-GPU share)")
     p.add_argument("--mode", default="auto", choices=["auto", "streams", "lockstep"],
@@ -178,16 +178,16 @@ ALGO = {"zeggs": (7.183e6, 1.205e6, 1.3152), "beat": (13.25e6, 3.694e6, 4.183), 
 def roofline_record(config, precision, NC, NL, B, us, with_traffic=False):
     """The roofline object of one workload: `us` = time in which all NC clips in flight advance one denoising step."""
     wparams, sbytes, gflop = ALGO[config]
-    wbytes = wparams * (2 if precision == "bf16" else 4)
+    wbytes = wparams * {"bf16": 2, "bf16w2": 4, "fp32": 4}[precision]      # (bf16w2: hi + lo bf16 per weight)
     abytes = wbytes + sbytes * NC           # the NC clips in flight share one pass over the weights
     if NC >= 8:
         # SURVEY s8d: from 8 clips in flight (>= 712 token rows) the path is a dense contraction -> MFMA roofline
         ach = gflop * NC / (us * 1e-6) / 1e3
-        peak = 2500.0 if precision == "bf16" else 157.3
+        peak = 157.3 if precision == "fp32" else 2500.0
         return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 5),
                 "traffic": None, "algorithmic_gflop_per_denoise_step": gflop * NC,
                 "note": f"{NC} clips in flight ({NL} lane(s) x batch {B}): achieved = {gflop} GFLOP x {NC} clips / time in which all of them "
-                        "advance one denoising step; peak = dense MFMA " + ("bf16" if precision == "bf16" else "fp32")}
+                        "advance one denoising step; peak = dense MFMA " + ("fp32" if precision == "fp32" else "bf16")}
     achieved = abytes / (us * 1e-6) / 1e9
     # HBM-side traffic per step from the rocprofv3 PMC passes (tools/pmc_traffic.py; FETCH_SIZE doubled as the MI355X guide
     # prescribes for wide coalesced reads), measured for the headline configuration only

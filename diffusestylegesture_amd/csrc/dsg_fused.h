@@ -224,7 +224,7 @@ __device__ __forceinline__ void mid_tail(const MidArgs& g, f32x4 (&acc)[DT], con
         f32x4 y;
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[e] = (acc[t][e] - mean) * rstd * pg[t][e] + pbt[t][e];
-        P::store4((elem*)(a1 + lr * XP) + n, y);
+        P::store4_a((elem*)(a1 + lr * XP) + n, 16 * XP, y);
         acc[t] = y;                                   // written to X1 at the very end (keeps stores out of the vmcnt queue)
     }
     DSG_LDS_BARRIER();
@@ -233,7 +233,7 @@ __device__ __forceinline__ void mid_tail(const MidArgs& g, f32x4 (&acc)[DT], con
     if constexpr (KD <= CH) {
 #pragma unroll
         for (int kb = 0; kb < KD; ++kb)
-            c1 = P::mma_w(w1f[kb], *(const f32x4*)(a1 + lr * XP + (kb * P::KB + P::E * lg) * ES), c1);
+            c1 = P::mma_w(w1f[kb], P::aload(a1 + lr * XP + (kb * P::KB + P::E * lg) * ES, 16 * XP), c1);
     } else {
 #pragma unroll
         for (int kb0 = 0; kb0 < KD; kb0 += CH) {
@@ -243,14 +243,14 @@ __device__ __forceinline__ void mid_tail(const MidArgs& g, f32x4 (&acc)[DT], con
 #pragma unroll
             for (int c = 0; c < CH; ++c)
                 if (kb0 + c < KD)
-                    c1 = P::mma_w(bf[c], *(const f32x4*)(a1 + lr * XP + ((kb0 + c) * P::KB + P::E * lg) * ES), c1);
+                    c1 = P::mma_w(bf[c], P::aload(a1 + lr * XP + ((kb0 + c) * P::KB + P::E * lg) * ES, 16 * XP), c1);
         }
     }
     if (m0 + lr < g.M) {
         f32x4 y;
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[e] = gelu_erf<P>(c1[e] + pb1[e]);
-        P::store4((elem*)g.hidden + qk_off<P>(m0 + lr, n1t * 16 + 4 * lg, g.ff / P::KB), y);       // fragment-major: linear2's A operand
+        P::store4_afrag((elem*)g.hidden, (size_t)qk_off<P>(m0 + lr, n1t * 16 + 4 * lg, g.ff / P::KB), y);       // fragment-major: linear2's A operand
     }
     if (wr) {
 #pragma unroll
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
     constexpr int KD = D / P::KB;
     constexpr int XP = D * ES + 16;
     constexpr int CH = mid_ch(DT, KD);               // fragments in flight per chunk (DT tiles each): bounded by the register file
-    __shared__ __attribute__((aligned(16))) char a1[16 * XP];
+    __shared__ __attribute__((aligned(16))) char a1[16 * XP * P::AF];     // (PBF16W2: + the lo image)
     __shared__ float red[2][4][16];
     __shared__ __attribute__((aligned(16))) float vecs[3][D];      // out_proj bias, LayerNorm1 scale / shift: one load per WORKGROUP
     preload_kernargs(g);
@@ -280,7 +280,6 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
     const f32x4* wo = (const f32x4*)g.Wo + lane;
     const f32x4* w1 = (const f32x4*)g.W1 + lane;
-    const elem* arow = (const elem*)g.A + ((size_t)mt * KD * 64 + lane) * P::E;      // attention rows, fragment-major: k-block kb at + kb * 64 * E
     // The three per-column vectors are the same for every wave and row tile: fetched once per workgroup (one 16-byte load
     // by 3 D / 4 lanes) and read back from LDS, instead of 12 wave-wide loads per wave through the CU's load path, which
     // bounds this kernel (measured: -1060 cycles per kernel without those loads).
@@ -299,14 +298,14 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
     //      LayerNorm scale/shift, linear1 fragments) last, in the order they are needed.
     constexpr int PD0 = DT >= 6 ? 2 : 4;             // k-blocks in flight ahead of the MFMA (register budget)
     constexpr int PD = PD0 < KD ? PD0 : KD;
-    f32x4 af[KD];
+    typename P::afrag af[KD];
     typename P::wfrag bf[KD][DT];
     f32x4 pbo[DT], pr[DT], pg[DT], pbt[DT], pb1;
     typename P::wfrag w1f[KD <= CH ? KD : 1];
     const int n1t = ng * 4 + wave;                   // this wave's 16-col tile of the hidden layer
 #pragma unroll
     for (int kb = 0; kb < PD; ++kb) {
-        af[kb] = *(const f32x4*)(arow + (size_t)kb * 64 * P::E);
+        af[kb] = P::aload_frag(g.A, (size_t)mt * KD + kb, lane);
 #pragma unroll
         for (int t = 0; t < DT; ++t) bf[kb][t] = P::wload(wo, (size_t)(wave * DT + t) * KD + kb);
     }
@@ -328,7 +327,7 @@ __global__ __launch_bounds__(256) void k_mid(const MidArgs g) {
 #pragma unroll
     for (int kb = 0; kb < KD; ++kb) {
         if (kb + PD < KD) {
-            af[kb + PD] = *(const f32x4*)(arow + (size_t)(kb + PD) * 64 * P::E);
+            af[kb + PD] = P::aload_frag(g.A, (size_t)mt * KD + kb + PD, lane);
 #pragma unroll
             for (int t = 0; t < DT; ++t) bf[kb + PD][t] = P::wload(wo, (size_t)(wave * DT + t) * KD + kb + PD);
         }
@@ -383,8 +382,8 @@ __device__ __forceinline__ void attn_mid_body(const AttnMidArgs& ga) {
                                                      // two-register weight fragments of bf16w2 hold half as many k-blocks)
     static_assert(KDH >= 1 && PDA >= PD && PDA <= KD, "shape");
     static_assert(P::E == 4 || (NKT % 2) == 0, "bf16 pairs key tiles");
-    __shared__ __attribute__((aligned(16))) char aT[16 * XP];      // attention output rows (MFMA element type)
-    __shared__ __attribute__((aligned(16))) char a1[16 * XP];      // LayerNorm1 output rows
+    __shared__ __attribute__((aligned(16))) char aT[16 * XP * P::AF];     // attention output rows (MFMA element type; PBF16W2: + the lo image)
+    __shared__ __attribute__((aligned(16))) char a1[16 * XP * P::AF];     // LayerNorm1 output rows
     __shared__ float red[2][4][16];
     __shared__ __attribute__((aligned(16))) float vecs[3][D];      // out_proj bias, LayerNorm1 scale / shift: one load per WORKGROUP (see k_mid)
     preload_kernargs(ga);
@@ -516,7 +515,7 @@ __device__ __forceinline__ void attn_mid_body(const AttnMidArgs& ga) {
         f32x4 y;
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[e] = o[e] * inv;
-        P::store4((elem*)(aT + lr * XP) + h * HD + dt * 16 + 4 * lg, y);
+        P::store4_a((elem*)(aT + lr * XP) + h * HD + dt * 16 + 4 * lg, 16 * XP, y);
         DSG_ISSUE_SLOT(2 * NKT + dt);
     }
 #undef DSG_ISSUE_SLOT
@@ -542,7 +541,7 @@ __device__ __forceinline__ void attn_mid_body(const AttnMidArgs& ga) {
 #pragma unroll
             for (int t = 0; t < DT; ++t) bf[kb + PD][t] = P::wload(wo, (size_t)(wave * DT + t) * KD + kb + PD);
         }
-        const f32x4 af = *(const f32x4*)(aT + lr * XP + (kb * P::KB + P::E * lg) * ES);
+        const typename P::afrag af = P::aload(aT + lr * XP + (kb * P::KB + P::E * lg) * ES, 16 * XP);
 #pragma unroll
         for (int t = 0; t < DT; ++t) acc[t] = P::mma_w(bf[kb][t], af, acc[t]);      // D[n 4lg+r][row lr]
     }

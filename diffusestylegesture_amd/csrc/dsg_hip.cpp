@@ -535,9 +535,9 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     CHK(dalloc(h, &h->pre2, M_pad * D));
     CHK(dalloc(h, &h->Xn, M_pad * D));
     CHK(dalloc(h, &h->X1, M_pad * D));
-    CHK(dalloc_bytes(h, &h->attn, M_pad * D * h->es));
+    CHK(dalloc_bytes(h, &h->attn, M_pad * D * h->es * (h->prec == DSG_PREC_BF16W2 ? 2 : 1)));      // (bf16w2: hi + lo images)
     CHK(dalloc_bytes(h, &h->X1a, M_pad * D * h->es));
-    CHK(dalloc_bytes(h, &h->hidden, M_pad * (size_t)h->ff * h->es));
+    CHK(dalloc_bytes(h, &h->hidden, M_pad * (size_t)h->ff * h->es * (h->prec == DSG_PREC_BF16W2 ? 2 : 1)));      // (bf16w2: hi + lo images)
     h->ffn_slab = M_pad * D;             // (the partial linear2 slabs of k_ffn_part are allocated on the first BLOCK call: ensure_set_buffers)
     const size_t qkv_elems = (size_t)B * h->H * Tp * hd;
     CHK(dalloc_bytes(h, &h->q, qkv_elems * h->es));
@@ -999,8 +999,10 @@ static int auto_kernel_set(const dsg_handle* h, int B, int lanes) {
 static int resolve_auto_set(const dsg_handle* h, int B, int lanes) {
     int set = auto_kernel_set(h, B, lanes);
     if (h->latency_mode == 0 && set == DSG_KSET_LATENCY) set = DSG_KSET_TILE;
+    // bf16w2: 16 x 16 tiles at every batch size.  Its weight fragments are twice the bytes, so the redundant W_o of the fused LATENCY
+    // kernels costs more than the dispatches it saves: 168 vs 155 us per batch-1 step (profiles/r05_e_*); LATENCY stays selectable
+    if (h->prec == DSG_PREC_BF16W2) set = DSG_KSET_TILE;
     if (h->latency_mode == 1 && latency_set_ok(h)) set = DSG_KSET_LATENCY;
-    if (h->prec == DSG_PREC_BF16W2 && set > DSG_KSET_TILE) set = DSG_KSET_TILE;      // bf16w2: LATENCY and TILE only (16 x 16 tiles at every batch size)
     return set;
 }
 // k_ffn_part + k_ffn_ln exist for the shapes the STREAM set exists for
@@ -1243,7 +1245,9 @@ static int launch_gemm_w(dsg_handle* h, const GemmArgs& g, const KernelSel& ks) 
             gl.inv_ntok = fastdiv_inv(gl.ntok); gl.inv_hd = fastdiv_inv(gl.hd);
             if (gl.NT % 4) return fail(DSG_E_INVALID, "gemm: NT not divisible by the workgroup tile");
             const dim3 grid(xcd_grid_x(gl.NT / 4), gl.MT + (EPI == EPI_OUT ? 1 : 0), 1);
-            if (pick_ch(gl.KBtot) == 16) return step_launch<&k_gemm_lean<P, EPI, 16>>(h, grid, dim3(256), gl);
+            if constexpr (!P::W2) {      // (bf16w2: 16 k-blocks of two-register weight + activation fragments do not fit: two batches of 8)
+                if (pick_ch(gl.KBtot) == 16) return step_launch<&k_gemm_lean<P, EPI, 16>>(h, grid, dim3(256), gl);
+            }
             if (pick_ch(gl.KBtot) == 12) return step_launch<&k_gemm_lean<P, EPI, 12>>(h, grid, dim3(256), gl);
             return step_launch<&k_gemm_lean<P, EPI>>(h, grid, dim3(256), gl);
         }

@@ -26,6 +26,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace dsg {
 
@@ -86,6 +87,16 @@ struct PF32 {                       // fp32 storage, v_mfma_f32_16x16x4_f32
     static __device__ __forceinline__ wfrag wload(const f32x4* base, size_t frag) { return base[frag * 64]; }      // base = packed weights + lane
     static __device__ __forceinline__ f32x4 mma_w(const wfrag& w, f32x4 a, f32x4 c) { return mma(w, a, c); }     // D = W_tile . Act_tile^T
     static __device__ __forceinline__ f32x4 mma_a(f32x4 a, const wfrag& w, f32x4 c) { return mma(a, w, c); }     // D = Act_tile . W_tile^T
+    // GEMM A operands that a kernel of the step produces itself (LayerNorm rows / attention rows in LDS, `hidden`): one image here,
+    // a hi + lo pair in PBF16W2.  lo_off: byte distance of the lo image (LDS) / ignored
+    typedef f32x4 afrag;
+    static constexpr int AF = 1;
+    static __device__ __forceinline__ afrag azero() { return (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    static __device__ __forceinline__ void store4_a(elem* p, int lo_off, f32x4 v) { (void)lo_off; store4(p, v); }
+    static __device__ __forceinline__ afrag aload(const char* p, int lo_off) { (void)lo_off; return *(const f32x4*)p; }
+    // fragment-major global A operand written by one kernel and read by the next (`hidden`): element offset of the PBF16 order -> here
+    static __device__ __forceinline__ void store4_afrag(elem* base, size_t off, f32x4 v) { store4(base + off, v); }
+    static __device__ __forceinline__ afrag aload_frag(const void* base, size_t frag, int lane) { return *(const f32x4*)((const char*)base + (frag * 64 + lane) * 16); }
 };
 struct PBF16 {                      // bf16 storage, v_mfma_f32_16x16x32_bf16, fp32 accumulate
     typedef bf16_t elem;
@@ -108,6 +119,16 @@ struct PBF16 {                      // bf16 storage, v_mfma_f32_16x16x32_bf16, f
     static __device__ __forceinline__ wfrag wload(const f32x4* base, size_t frag) { return base[frag * 64]; }
     static __device__ __forceinline__ f32x4 mma_w(const wfrag& w, f32x4 a, f32x4 c) { return mma(w, a, c); }
     static __device__ __forceinline__ f32x4 mma_a(f32x4 a, const wfrag& w, f32x4 c) { return mma(a, w, c); }
+    // GEMM A operands that a kernel of the step produces itself (LayerNorm rows / attention rows in LDS, `hidden`): one image here,
+    // a hi + lo pair in PBF16W2.  lo_off: byte distance of the lo image (LDS) / ignored
+    typedef f32x4 afrag;
+    static constexpr int AF = 1;
+    static __device__ __forceinline__ afrag azero() { return (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    static __device__ __forceinline__ void store4_a(elem* p, int lo_off, f32x4 v) { (void)lo_off; store4(p, v); }
+    static __device__ __forceinline__ afrag aload(const char* p, int lo_off) { (void)lo_off; return *(const f32x4*)p; }
+    // fragment-major global A operand written by one kernel and read by the next (`hidden`): element offset of the PBF16 order -> here
+    static __device__ __forceinline__ void store4_afrag(elem* base, size_t off, f32x4 v) { store4(base + off, v); }
+    static __device__ __forceinline__ afrag aload_frag(const void* base, size_t frag, int lane) { return *(const f32x4*)((const char*)base + (frag * 64 + lane) * 16); }
 };
 // "bf16w2" (round 5): bf16 activations, every WEIGHT as the sum of two bf16 numbers -- hi = bf16(w), lo = bf16(w - hi): 16 mantissa
 // bits instead of 8 -- two v_mfma_f32_16x16x32_bf16 per fragment, fp32 accumulate.  The bf16 drift of a 1000-step chain is the
@@ -122,6 +143,33 @@ struct PBF16W2 : PBF16 {
     static __device__ __forceinline__ wfrag wload(const f32x4* base, size_t frag) { wfrag w; w.h = base[frag * 128]; w.l = base[frag * 128 + 64]; return w; }
     static __device__ __forceinline__ f32x4 mma_w(const wfrag& w, f32x4 a, f32x4 c) { return PBF16::mma(w.l, a, PBF16::mma(w.h, a, c)); }
     static __device__ __forceinline__ f32x4 mma_a(f32x4 a, const wfrag& w, f32x4 c) { return PBF16::mma(a, w.l, PBF16::mma(a, w.h, c)); }
+    // ... and the A operands the step's kernels hand to each other through LDS (LayerNorm1 / LayerNorm2 rows, the attention rows of
+    // k_attn_mid) or as `hidden`: hi + lo as well, three MFMAs per fragment (w.h a.h + w.l a.h + w.h a.l; the lo x lo term is below
+    // fp32 rounding).  The ablation (tests/bf16_ablation.py): with all weights exact the chain still drifts 3.1e-3 from exactly these
+    // rounding points; what stays single bf16 is Q / K / V / P, x_t and the embedding output (1.4e-4 ... 4.1e-4 each).
+    struct afrag { f32x4 h, l; };
+    static constexpr int AF = 2;
+    static __device__ __forceinline__ afrag azero() { afrag a; a.h = a.l = (f32x4){0.f, 0.f, 0.f, 0.f}; return a; }
+    static __device__ __forceinline__ void split4(f32x4 v, u16x4& hi, u16x4& lo) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { hi[e] = f2bf(v[e]); lo[e] = f2bf(v[e] - bf2f(hi[e])); }
+    }
+    static __device__ __forceinline__ void store4_a(elem* p, int lo_off, f32x4 v) {
+        u16x4 hi, lo; split4(v, hi, lo);
+        *(u16x4*)p = hi; *(u16x4*)((char*)p + lo_off) = lo;
+    }
+    static __device__ __forceinline__ afrag aload(const char* p, int lo_off) { afrag a; a.h = *(const f32x4*)p; a.l = *(const f32x4*)(p + lo_off); return a; }
+    // fragment f of the PBF16 order -> 1 KB blocks 2f (hi) and 2f + 1 (lo), like the weights
+    static __device__ __forceinline__ void store4_afrag(elem* base, size_t off, f32x4 v) {
+        u16x4 hi, lo; split4(v, hi, lo);
+        const size_t o2 = off + (off / (64 * E)) * (64 * E);
+        *(u16x4*)(base + o2) = hi; *(u16x4*)(base + o2 + 64 * E) = lo;
+    }
+    static __device__ __forceinline__ afrag aload_frag(const void* base, size_t frag, int lane) {
+        afrag a; a.h = *(const f32x4*)((const char*)base + (frag * 128 + lane) * 16); a.l = *(const f32x4*)((const char*)base + (frag * 128 + 64 + lane) * 16); return a;
+    }
+    static __device__ __forceinline__ f32x4 mma_w(const wfrag& w, const afrag& a, f32x4 c) { return PBF16::mma(w.h, a.l, PBF16::mma(w.l, a.h, PBF16::mma(w.h, a.h, c))); }
+    static __device__ __forceinline__ f32x4 mma_a(const afrag& a, const wfrag& w, f32x4 c) { return PBF16::mma(a.l, w.h, PBF16::mma(a.h, w.l, PBF16::mma(a.h, w.h, c))); }
 };
 
 // Loads of data another kernel of the step loop wrote.  The loop-written buffers live in uncached device memory (dsg_hip.cpp:
@@ -471,7 +519,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // shift are fetched chunk by chunk after the statistics instead of being held for the whole row, and the normalised rows
 // are written back at once (`xn_out`) instead of staying live across the MFMA phase.
 template <class P, int NCH, bool LEAN = false>
-__device__ __forceinline__ void ln_rows(const GemmArgs& g, int m0, int tid, char* lds_a, int pitch, f32x4 (&v)[8], float* xn_out = nullptr) {
+__device__ __forceinline__ void ln_rows(const GemmArgs& g, int m0, int tid, char* lds_a, int pitch, f32x4 (&v)[8], float* xn_out = nullptr, int lo_off = 0) {
     typedef typename P::elem elem;
     constexpr int N = NCH > 0 ? NCH : 8;
     const int D = g.D;
@@ -521,7 +569,7 @@ __device__ __forceinline__ void ln_rows(const GemmArgs& g, int m0, int tid, char
                 for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * gg[i][e] + bb[i][e];
                 v[i] = y;
             }
-            P::store4((elem*)(lds_a + row * pitch) + c * 4 + 64 * i, y);
+            P::store4_a((elem*)(lds_a + row * pitch) + c * 4 + 64 * i, lo_off, y);
         }
 }
 
@@ -588,7 +636,8 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmArgs& g, int m0, in
                 f32x4 y;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] = gelu_erf<P>(acc[e] + o.pb[e]);
-                P::store4((elem*)g.out + (g.out_frag ? (size_t)qk_off<P>(m, n, g.ldo / P::KB) : (size_t)m * g.ldo + n), y);
+                if (g.out_frag) P::store4_afrag((elem*)g.out, (size_t)qk_off<P>(m, n, g.ldo / P::KB), y);      // `hidden` (PBF16W2: hi + lo)
+                else P::store4((elem*)g.out + (size_t)m * g.ldo + n, y);
             }
         } else if constexpr (EPI == EPI_QKV) {
             const int Dm = g.H * g.hd;
@@ -686,7 +735,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
     static_assert(WN * WK == 4, "4 waves");
     constexpr int ES = (int)sizeof(elem);
     constexpr bool IS_LN = PRO == PRO_LN;
-    __shared__ __attribute__((aligned(16))) char lds_a[IS_LN ? 16 * (512 * ES + 16) : 16];     // 16 rows of up to 512 elements
+    constexpr int LDS_A = 16 * (512 * ES + 16);      // 16 rows of up to 512 elements (PBF16W2: a second image of the same size, the lo halves)
+    __shared__ __attribute__((aligned(16))) char lds_a[IS_LN ? LDS_A * P::AF : 16];
+    // PBF16W2: the A operand is a hi + lo pair where a kernel of the step produced it for this GEMM -- the LayerNorm rows (LDS) and
+    // the two direct GEMMs with the residual epilogue: out_proj (k_attn's rows) and linear2 (`hidden`), both fragment-major
+    constexpr bool A2 = P::W2 && (IS_LN || (PRO == PRO_DIRECT && EPI == EPI_RESID));
+    typedef typename std::conditional<A2, typename P::afrag, f32x4>::type AFrag;
     __shared__ __attribute__((aligned(16))) float lds_red[WK > 1 ? (WK - 1) * WN * TNW * 64 * 4 : 4];
 
     preload_kernargs(g);
@@ -783,37 +837,40 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
         const int nch = g.D >> 6;                     // D / 64 float4 chunks per thread; one straight-line copy per width
         if constexpr (LEAN) {
             float* xn_out = wr ? g.Xn + (size_t)(mp + (tid >> 4)) * g.D : nullptr;
-            if (nch == 4) ln_rows<P, 4, true>(g, mp, tid, lds_a, pitch, v, xn_out);
-            else if (nch == 6) ln_rows<P, 6, true>(g, mp, tid, lds_a, pitch, v, xn_out);
-            else if (nch == 8) ln_rows<P, 8, true>(g, mp, tid, lds_a, pitch, v, xn_out);
-            else ln_rows<P, 0, true>(g, mp, tid, lds_a, pitch, v, xn_out);
+            if (nch == 4) ln_rows<P, 4, true>(g, mp, tid, lds_a, pitch, v, xn_out, LDS_A);
+            else if (nch == 6) ln_rows<P, 6, true>(g, mp, tid, lds_a, pitch, v, xn_out, LDS_A);
+            else if (nch == 8) ln_rows<P, 8, true>(g, mp, tid, lds_a, pitch, v, xn_out, LDS_A);
+            else ln_rows<P, 0, true>(g, mp, tid, lds_a, pitch, v, xn_out, LDS_A);
             wr = false;                               // already written
         } else {
-            if (nch == 4) ln_rows<P, 4>(g, mp, tid, lds_a, pitch, v);
-            else if (nch == 6) ln_rows<P, 6>(g, mp, tid, lds_a, pitch, v);
-            else if (nch == 8) ln_rows<P, 8>(g, mp, tid, lds_a, pitch, v);
-            else ln_rows<P, 0>(g, mp, tid, lds_a, pitch, v);
+            if (nch == 4) ln_rows<P, 4>(g, mp, tid, lds_a, pitch, v, nullptr, LDS_A);
+            else if (nch == 6) ln_rows<P, 6>(g, mp, tid, lds_a, pitch, v, nullptr, LDS_A);
+            else if (nch == 8) ln_rows<P, 8>(g, mp, tid, lds_a, pitch, v, nullptr, LDS_A);
+            else ln_rows<P, 0>(g, mp, tid, lds_a, pitch, v, nullptr, LDS_A);
         }
         DSG_LDS_BARRIER();
     }
 
     for (int kb0 = kb_lo; kb0 < kb_hi; kb0 += CH) {
-        f32x4 af[CH];
+        AFrag af[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const int kb = min(kb0 + c, kb_last);
-            if constexpr (PRO == PRO_DIRECT) {
+            if constexpr (PRO == PRO_DIRECT && A2) {
+                af[c] = P::aload_frag(g.A, (size_t)(mt_first * g.KBtot + kb), lane);       // (attention rows / `hidden`: always fragment-major)
+            } else if constexpr (PRO == PRO_DIRECT) {
                 // fragment-major A: one contiguous 1 KB block per wave load (8 cache lines instead of 16 half-used ones)
                 const size_t ao = g.a_frag ? ((size_t)(mt_first * g.KBtot + kb) * 64 + lane) * P::E : arow_off + (size_t)kb * P::KB;
                 af[c] = lda16<P>(g.A, ao * ES);
             }
-            else af[c] = *(const f32x4*)(lds_a + lr * pitch + (kb * P::KB + P::E * lg) * ES);      // (IS_LN)
+            else af[c] = P::aload(lds_a + lr * pitch + (kb * P::KB + P::E * lg) * ES, LDS_A);      // (IS_LN)
         }
         DSG_LOADS_ISSUED();
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const bool live = kb0 + c < kb_hi;              // wave-uniform; out-of-range blocks contribute zeros
-            const f32x4 a = live ? af[c] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            AFrag a = af[c];
+            if (!live) { if constexpr (A2) a = P::azero(); else a = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
             for (int t = 0; t < TNW; ++t)
                 acc[t] = swapped[t] ? P::mma_w(bf[c][t], a, acc[t]) : P::mma_a(a, bf[c][t], acc[t]);
@@ -862,7 +919,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
 // batched LayerNorm-GEMM: compiled for 3 waves per SIMD (<= 168 VGPRs; at 128 it spills to scratch; requesting the weights
 // only after the LayerNorm fits 5 waves per SIMD but measured slower: 370 vs 360 us/step at batch 16), see ln_rows LEAN
 template <class P, int EPI, int CH = 8>
-__global__ __launch_bounds__(256, CH > 8 ? 2 : 3) void k_gemm_lean(const GemmArgs g) { DSG_TL_SCOPE(); gemm_body<P, PRO_LN, EPI, 4, 1, 1, true, false, CH>(g); }
+__global__ __launch_bounds__(256, (CH > 8 || P::W2) ? 2 : 3) void k_gemm_lean(const GemmArgs g) { DSG_TL_SCOPE(); gemm_body<P, PRO_LN, EPI, 4, 1, 1, true, false, CH>(g); }
 
 // pose head with classifier-free guidance: conditional + unconditional rows per workgroup (GemmArgs::cfgB)
 template <class P, int CH = 8>
@@ -1157,8 +1214,8 @@ __global__ __launch_bounds__(64) void k_attn(const AttnArgs a) {
             f32x4 y;
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = o[e] * inv;
-            elem* dst = (elem*)a.out + qk_off<P>(b * a.ntok + q, h * HD + dt * 16 + 4 * lg, a.D / P::KB);      // fragment-major rows (the next GEMM's A operand)
-            P::store4(dst, y);
+            // fragment-major rows (the next GEMM's A operand; PBF16W2: hi + lo)
+            P::store4_afrag((elem*)a.out, (size_t)qk_off<P>(b * a.ntok + q, h * HD + dt * 16 + 4 * lg, a.D / P::KB), y);
         }
     }
 }

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "csrc", "libdsg_hip.so")
 
 E_INVALID, E_RUNTIME, E_UNEXPECTED_KEY, E_MISSING_KEY, E_NOT_IMPLEMENTED, E_STATE = -1, -2, -3, -4, -5, -6
-PREC_FP32, PREC_BF16 = 0, 1
+PREC_FP32, PREC_BF16, PREC_BF16W2 = 0, 1, 2
 MODE_DDPM, MODE_DDIM = 0, 1
 KERNEL_SETS = {"auto": 0, "latency": 1, "tile": 2, "block": 3, "stream": 4}          # DSG_KSET_* of include/dsg.h
 KERNEL_SET_NAMES = {v: k for k, v in KERNEL_SETS.items()}

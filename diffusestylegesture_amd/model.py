@@ -41,7 +41,7 @@ class DSGDenoiser:
         c.style_dim_in, c.window, c.num_layers = cfg.style_dim_in, cfg.window, cfg.num_layers
         c.num_heads, c.ff_size, c.local_heads = cfg.num_heads, cfg.ff_size, cfg.local_heads
         c.pe_max_len, c.train_steps, c.max_batch = cfg.pe_max_len, 1000, max_batch
-        c.precision = {"fp32": L.PREC_FP32, "bf16": L.PREC_BF16}[precision]
+        c.precision = {"fp32": L.PREC_FP32, "bf16": L.PREC_BF16, "bf16w2": L.PREC_BF16W2}[precision]
         c.device, c.steps_per_graph = device, steps_per_graph
         c.latency_mode = {"auto": 0, "off": 1, "on": 2}[latency_mode]
         h = C.c_void_p()

@@ -369,7 +369,8 @@ def build_parser():
     p.add_argument('--audiowavlm_path', type=str, default='')
     p.add_argument('--max_len', type=int, default=0)
     # framework additions
-    p.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    p.add_argument('--precision', default='bf16', choices=['bf16', 'bf16w2', 'fp32'],
+                   help='bf16 (default); bf16w2 = bf16 activations, weights as hi + lo bf16 (3x closer to fp32); fp32 = the reference arithmetic')
     p.add_argument('--features_npy', default='', help='pre-extracted WavLM features [K, n_poses, 1024] (the per-clip cache)')
     p.add_argument('--wavlm_path', default='./WavLM/WavLM-Large.pt', help='WavLM checkpoint (sample.py:33)')
     p.add_argument('--save_dir', default='sample_dir')

@@ -64,7 +64,8 @@ def build_parser():
     p.add_argument('--seed_npy', required=True, help='[n_seed + 2, motion_dim] raw seed poses (sample.py:112-124)')
     p.add_argument('--seed_last_npy', default='', help='DiffuseStyleGesture++: raw poses of the closing snippet (sample.py:85-93)')
     p.add_argument('--speaker', type=int, default=0, help='index of the one-hot style / speaker entry')
-    p.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    p.add_argument('--precision', default='bf16', choices=['bf16', 'bf16w2', 'fp32'],
+                   help='bf16 (default); bf16w2 = bf16 activations, weights as hi + lo bf16 (3x closer to fp32); fp32 = the reference arithmetic')
     p.add_argument('--version', default='v0', choices=['v0', 'v2'],
                    help="`version` of the reference's yml (sample.py:309-315): v0 = poses + velocities + accelerations (njoints = 3 x motion_dim), "
                         "v2 (BEAT only) = njoints = motion_dim = 1141")

@@ -1,0 +1,50 @@
+"""CPU tests of the round-5 additions under the SIMT emulator (the product sources, unchanged, compiled for the host):
+the bf16w2 precision mode -- weights and the step's own GEMM operands as hi + lo bf16 pairs."""
+import numpy as np
+import pytest
+
+from diffusestylegesture_amd import config as C
+from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+from diffusestylegesture_amd.model import DSGDenoiser
+from diffusestylegesture_amd.synth import synth_state_dict, synth_window_inputs
+from tests.util import rel_l2
+
+
+@pytest.mark.parametrize("cfg", [C.TINY, C.TINY4], ids=lambda c: c.name)
+def test_bf16w2_forward_and_chain_vs_oracle(emu_lib, cfg):
+    """precision "bf16w2" (DSG_PREC_BF16W2, ABI 320): every kernel of the LATENCY and TILE sets with two-register weight fragments and
+    hi + lo LayerNorm / attention / hidden operands -- forward rows at batch 1 and 3 and a 30-step DDPM chain against the fp32 oracle,
+    at least 3x closer to it than plain bf16; `auto` = TILE; BLOCK / STREAM are refused."""
+    from oracle import sampler
+    from oracle.mdm import MDMOracle
+    from oracle.schedule import OracleDiffusion
+    sd = synth_state_dict(cfg, 20240)
+    ref = MDMOracle(sd, cfg)
+    for B in (1, 3):
+        y = synth_window_inputs(cfg, B, window=1, seed_pose_scale=0.3)
+        x = np.random.RandomState(B).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+        ts = [10, 500, 999][:B]
+        want = ref(x, ts, y)
+        plain = DSGDenoiser(cfg, precision="bf16", max_batch=B, library=emu_lib).set_kernel_set("tile")
+        plain.load_state_dict(sd)
+        e_bf16 = rel_l2(np.asarray(plain(x, ts, y)), want)
+        m = DSGDenoiser(cfg, precision="bf16w2", max_batch=B, library=emu_lib)
+        m.load_state_dict(sd)
+        for ks in ("auto", "latency", "tile"):
+            out = np.asarray(m.set_kernel_set(ks)(x, ts, y))
+            e = rel_l2(out, want)
+            assert m.last_kernel_set() == ("tile" if ks == "auto" else ks) and e < 2e-3 and e < e_bf16 / 3, (cfg.name, B, ks, e, e_bf16)
+        for ks in ("block", "stream"):
+            with pytest.raises(NotImplementedError):
+                m.set_kernel_set(ks)
+    shape = (1, cfg.njoints, 1, cfg.n_poses)
+    y = synth_window_inputs(cfg, 1, window=1, seed_pose_scale=0.3)
+    m = DSGDenoiser(cfg, precision="bf16w2", max_batch=1, library=emu_lib)
+    m.load_state_dict(sd)
+    d = create_gaussian_diffusion(library=emu_lib)
+    got = np.asarray(d.manual_seed(7, 2).p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=970))
+    want = sampler.p_sample_loop(OracleDiffusion(), ref, shape, sampler.philox_noise_fn(shape, 7, 2), {"y": y}, skip_timesteps=970)
+    assert rel_l2(got, want) < 2e-3, rel_l2(got, want)
+    lane = m.clone()                                      # a lane over the same (hi + lo) weights reproduces the handle bit for bit
+    again = np.asarray(d.manual_seed(7, 2).p_sample_loop(lane, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=970))
+    assert np.array_equal(got, again)

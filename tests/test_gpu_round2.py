@@ -45,9 +45,11 @@ def _model(cfg, prec, max_batch=1, wseed=20240, spg=0, latency_mode="auto"):
 #   stated tolerance, bf16 kernels: rel-L2 <= 2e-2 on NORMALISED poses (the per-window bound; windows are chained);
 #       BVH rotation channels max <= 1.5 deg, median <= 0.03 deg; root position <= 0.7 cm   (~2x the measured values)
 #       (measured: 9.3e-3; max 0.72 / p99 0.26 / median 0.011 deg; 0.32 cm)
+#   stated tolerance, bf16w2 kernels (round 5; hi + lo bf16 weights and GEMM operands): rel-L2 <= 1.3e-3 (normalised), rotation max <= 0.09 deg,
+#       median <= 1.5e-3 deg, root position <= 0.025 cm   (2x the measured 6.4e-4; 0.045 / 7.3e-4 deg; 0.012 cm)
 # (the measured values are printed by the test and recorded in DESIGN.md s2 / profiles/)
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "bf16w2"])
 def test_full_clip_1000_steps_bvh_parity(gpu, golden_dir, tmp_path, prec):
     import torch
     from diffusestylegesture_amd import bvh
@@ -79,6 +81,8 @@ def test_full_clip_1000_steps_bvh_parity(gpu, golden_dir, tmp_path, prec):
     print(f"N1 {prec}: " + " ".join(f"{k}={v:.3e}" for k, v in stats.items()))
     if prec == "fp32":
         assert e_den < 1e-5 and drot.max() < 2e-3 and dpos.max() < 1e-3, stats
+    elif prec == "bf16w2":       # round 5: weights + the step's own GEMM operands as hi + lo bf16 (measured: 6.4e-4; max 0.045 / median 7.3e-4 deg; 0.012 cm)
+        assert e_norm < 1.3e-3 and drot.max() < 0.09 and np.median(drot) < 1.5e-3 and dpos.max() < 0.025, stats
     else:
         assert e_norm < 2e-2 and drot.max() < 1.5 and np.median(drot) < 0.03 and dpos.max() < 0.7, stats
 

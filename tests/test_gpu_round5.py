@@ -92,3 +92,55 @@ def test_uncached_pool_reuse_trim_and_cap(gpu, monkeypatch):
     rel, held = L.trim(0)
     print(f"dsg_trim: {rel >> 20} MB released, {held >> 20} MB held")
     assert rel >= (32 << 20)                             # at least one arena of the 48-clip handle holds no live block any more
+
+
+def test_bf16w2_forward_chains_and_dsgplus_dims(gpu, golden_dir):
+    """precision "bf16w2" (round-4 verdict item 6; DSG_PREC_BF16W2): the ZEGGS forward against the reference goldens (G2), the 25-step
+    and 1000-step DDPM chains and DDIM-50 against the reference driven with the same noise (G3), every set it has (auto = TILE, LATENCY),
+    a lane == the handle, and the DSG+ widths (TILE at latent_dim 384 / 512: 12 / 16 k-blocks of two-register fragments) against the
+    oracle.  Bounds = 2x the values measured on MI355X (printed)."""
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    from oracle.mdm import MDMOracle
+    g2, g3 = np.load(os.path.join(golden_dir, "g2_forward_zeggs.npz")), np.load(os.path.join(golden_dir, "g3_chains_zeggs.npz"))
+    cfg = C.ZEGGS
+    m = _model(cfg, "bf16w2", max_batch=2)
+    worst = 0.0
+    for name, B, ts, sps in (("b1_t0", 1, [0], 0.0), ("b1_t999", 1, [999], 0.5), ("b2_t999_3", 2, [999, 3], 0.5)):
+        y = synth_window_inputs(cfg, B, window=1, seed_pose_scale=sps)
+        x = np.random.RandomState(4242 + B).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+        for ks in ("auto", "latency"):
+            e = rel_l2(np.asarray(m.set_kernel_set(ks)(x, np.array(ts), y)), g2[name + "_out"])
+            assert m.last_kernel_set() == ("tile" if ks == "auto" else "latency")
+            worst = max(worst, e)
+    print(f"bf16w2 forward vs G2: worst rel-L2 {worst:.2e}")
+    assert worst < 1.0e-3, worst
+    m.set_kernel_set("auto")
+    shape = (1, cfg.njoints, 1, cfg.n_poses)
+    y0 = {"y": synth_window_inputs(cfg, 1, window=0)}
+    errs = {}
+    for tag, skip in (("ddpm25", 975), ("ddpm1000", 0)):
+        d = create_gaussian_diffusion().manual_seed(int(g3["noise_seed"]), 0)
+        s = np.asarray(d.p_sample_loop(m, shape, clip_denoised=False, model_kwargs=y0, skip_timesteps=skip))
+        errs[tag] = rel_l2(s, g3[tag])
+        assert d.last_sample_path() == "aql" and m.last_kernel_set() == "tile" and m.last_sample_fence_free()
+    lane = m.clone()
+    d = create_gaussian_diffusion().manual_seed(int(g3["noise_seed"]), 0)
+    assert np.array_equal(np.asarray(d.p_sample_loop(lane, shape, clip_denoised=False, model_kwargs=y0)), s)
+    d50 = create_gaussian_diffusion("ddim50").manual_seed(int(g3["noise_seed"]), 7)          # (the DDIM goldens drew stream 7)
+    errs["ddim50"] = rel_l2(np.asarray(d50.ddim_sample_loop(m, shape, clip_denoised=False, model_kwargs=y0, eta=0.0)), g3["ddim50"])
+    print("bf16w2 chains vs G3: " + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
+    assert max(errs.values()) < 1.0e-3, errs
+    for c2 in (C.BEAT, C.TWH):
+        sd = synth_state_dict(c2, 20240)
+        ref = MDMOracle(sd, c2)
+        for B in (1, 8):
+            mm = _model(c2, "bf16w2", max_batch=B)
+            y = synth_window_inputs(c2, B, window=1, seed_pose_scale=0.2)
+            x = np.random.RandomState(B).randn(B, c2.njoints, 1, c2.n_poses).astype(np.float32)
+            ts = (np.arange(B) * 97 + 5) % 1000
+            out = np.asarray(mm(x, ts, y))
+            b = B - 1
+            yb = {k: (v[b:b + 1] if v.shape[0] == B else v) for k, v in y.items()}
+            e = rel_l2(out[b:b + 1], ref(x[b:b + 1], [int(ts[b])], yb))
+            print(f"bf16w2 {c2.name} batch {B}: rel-L2 {e:.2e} ({mm.last_kernel_set()})")
+            assert mm.last_kernel_set() == "tile" and e < 8e-4, (c2.name, B, e)
