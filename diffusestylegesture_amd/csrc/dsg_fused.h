@@ -1148,6 +1148,184 @@ __global__ __launch_bounds__(256) void k_attn_op_w(const AttnOpArgs g) {
 
 
 // ---------------------------------------------------------------------------------------------------------
+// k_clip_attn (round 5, BLOCK set): the attention of an encoder layer per (clip, head) -- the workgroup projects ITS head's Q / K / V
+// slices of the clip's rows (the LayerNorm2 rows of the previous layer, already in the GEMM type), keeps them in LDS and runs the
+// self-attention of all NKT query tiles on them: the QKV GEMM disappears as a dispatch, K / V are projected once per (clip, head) and
+// Q / K / V^T (2.2 MB of 8-byte uncached stores per launch at 16 clips) never cross the fabric.  Output: the attention rows in the
+// GEMM type, fragment-major -- what k_attn writes; out_proj + residual + LayerNorm1 run as the prologue of k_ffn_part (OP = true).
+// Every global byte is requested once per workgroup: 8 KB of rows per wave (staged through LDS: every wave needs all row tiles) and
+// the head's 96 KB of W_qkv, column split over the waves.
+// wave w: projection columns [w C/NW, (w+1) C/NW) of the head's C = 3 hd / 16 tiles for all row tiles (Q and K tiles as W . X^T: a lane holds
+// 4 consecutive dims of one token; V tiles as X . W^T: 4 consecutive tokens of one dim = a V^T row), then the attention of query tile w
+// (exactly k_attn on LDS operands: same rounding points -- Q / K / V and P in the GEMM type, softmax in fp32).  A row's result depends
+// on nothing but its clip.  (First version, profiles/r05_h_*: with the head's share of out_proj as an fp32 slab per head the kernel was
+// 10.7 us at 16 clips -- 1.9 us of it the 5.8 MB of slab stores, 3.8 the projection with a per-MFMA operand-order branch -- against
+// 5.2 + 5.0 for the QKV GEMM + k_attn_op.)
+// Reference arithmetic: nn.MultiheadAttention of torch's TransformerEncoderLayer (main/model/mdm.py:79-86), in_proj + softmax(QK^T/sqrt(hd))V.
+// ---------------------------------------------------------------------------------------------------------
+struct ClipAttnArgs {
+    const void* X;          // [rows][D] rows in the GEMM type, fragment-major over the flattened (clip, token) rows (qk_off)
+    const void* Wqkv; const float* bqkv;
+    void* out;              // attention rows [rows][D] in the GEMM type, fragment-major (qk_off): out_proj's A operand
+    int B, ntok;
+};
+
+// projection of one row tile's CW column tiles, operand order fixed at compile time (V tiles: un-swapped)
+template <class P, int CW, int KD, bool VT>
+__device__ __forceinline__ void clip_proj_tile(const f32x4 (&wf)[CW][KD], const f32x4 (&a)[KD], f32x4 (&acc)[CW]) {
+#pragma unroll
+    for (int kb = 0; kb < KD; ++kb)
+#pragma unroll
+        for (int j = 0; j < CW; ++j) acc[j] = VT ? P::mma(a[kb], wf[j][kb], acc[j]) : P::mma(wf[j][kb], a[kb], acc[j]);
+}
+
+template <class P, int DT, int NKT>      // D = 64 DT, H = 4, hd = 16 DT, Tp = 16 NKT, NKT waves
+__global__ __launch_bounds__(64 * NKT) void k_clip_attn(const ClipAttnArgs g) {
+    DSG_TL_SCOPE();
+    typedef typename P::elem elem;
+    constexpr int ES = (int)sizeof(elem);
+    constexpr int D = DT * 64, HD = DT * 16, NW = NKT;
+    constexpr int KD = D / P::KB, KDH = HD / P::KB;
+    constexpr int ND = HD / 16;                      // 16-dim tiles of a head
+    constexpr int NVF = P::E == 4 ? NKT : NKT / 2;   // PV k-blocks
+    constexpr int CT = 3 * ND, CW = CT / NW;         // projection column tiles of the head, per wave
+    static_assert(CT % NW == 0 && HD % P::KB == 0, "shape");
+    static_assert(P::E == 4 || (NKT % 2) == 0, "bf16 pairs key tiles");
+    // LDS: the clip's rows as A fragments [NKT][KD]; Q, K [NKT][KDH]; V^T [ND][NVF] (1 KB fragments)
+    __shared__ __attribute__((aligned(16))) f32x4 xs[NKT * KD][64];
+    __shared__ __attribute__((aligned(16))) f32x4 qs[NKT * KDH][64];
+    __shared__ __attribute__((aligned(16))) f32x4 ks[NKT * KDH][64];
+    __shared__ __attribute__((aligned(16))) f32x4 vs[ND * NVF][64];
+    preload_kernargs(g);
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
+    // ---- every global load of the wave up front: its row tile, its projection columns
+    const int tok_ld = min(wave * 16 + lr, g.ntok - 1);          // (tokens past the clip: a valid row, masked / dropped later)
+    const int m_ld = b * g.ntok + tok_ld;
+    f32x4 xf[KD];
+#pragma unroll
+    for (int kb = 0; kb < KD; ++kb) xf[kb] = lda16<P>(g.X, (size_t)qk_off<P>(m_ld, kb * P::KB + P::E * lg, KD) * ES);
+    const f32x4* wq = (const f32x4*)g.Wqkv + lane;
+    const int ct0 = wave * CW;                       // first of this wave's column tiles in the head's [Q | K | V] order (ND tiles each)
+    f32x4 wf[CW][KD], pb[CW];
+    float pbs[CW];
+    int which[CW], d0[CW];                           // per tile: 0 Q, 1 K, 2 V (wave-uniform) and its first dim inside the head
+#pragma unroll
+    for (int j = 0; j < CW; ++j) {
+        which[j] = (ct0 + j) / ND; d0[j] = ((ct0 + j) - which[j] * ND) * 16;
+        const int nt = which[j] * (D / 16) + h * ND + d0[j] / 16;                 // column tile of the packed [3D / 16] in_proj weight
+#pragma unroll
+        for (int kb = 0; kb < KD; ++kb) wf[j][kb] = wq[((size_t)nt * KD + kb) * 64];
+        pb[j] = *(const f32x4*)(g.bqkv + nt * 16 + 4 * lg);
+        pbs[j] = g.bqkv[nt * 16 + lr];
+    }
+    DSG_LOADS_ISSUED();
+#pragma unroll
+    for (int kb = 0; kb < KD; ++kb) xs[wave * KD + kb][lane] = xf[kb];
+    DSG_LDS_BARRIER();
+    // ---- (1) projection of the head's Q / K / V for all row tiles -> LDS in the attention kernels' fragment order.  The operand order
+    //      of a tile (V: un-swapped) is decided ONCE per wave, outside the MFMA loops: all of a wave's tiles are of one kind at the ZEGGS
+    //      widths (waves 0-3 Q / K, 4-5 V); a wave with both kinds (tiny dims) takes the tile-by-tile form
+    const bool all_qk = which[CW - 1] < 2, all_v = which[0] == 2;
+#pragma unroll
+    for (int rt = 0; rt < NKT; ++rt) {
+        f32x4 a[KD], acc[CW];
+#pragma unroll
+        for (int kb = 0; kb < KD; ++kb) a[kb] = xs[rt * KD + kb][lane];
+#pragma unroll
+        for (int j = 0; j < CW; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (all_qk) clip_proj_tile<P, CW, KD, false>(wf, a, acc);
+        else if (all_v) clip_proj_tile<P, CW, KD, true>(wf, a, acc);
+        else {
+#pragma unroll
+            for (int j = 0; j < CW; ++j) {
+                if (which[j] < 2) {
+#pragma unroll
+                    for (int kb = 0; kb < KD; ++kb) acc[j] = P::mma(wf[j][kb], a[kb], acc[j]);
+                } else {
+#pragma unroll
+                    for (int kb = 0; kb < KD; ++kb) acc[j] = P::mma(a[kb], wf[j][kb], acc[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CW; ++j) {
+            if (which[j] < 2) {                                   // D[dim = 4 lg + r][token = lr]: 4 consecutive dims of one token
+                elem* dst = (elem*)(which[j] == 0 ? &qs[0][0] : &ks[0][0]) + qk_off<P>(rt * 16 + lr, d0[j] + 4 * lg, KDH);
+                P::store4(dst, acc[j] + pb[j]);
+            } else {                                              // D[token = 4 lg + r][dim = lr]: 4 consecutive tokens of one dim
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = acc[j][e] + pbs[j];
+                P::store4((elem*)&vs[0][0] + vt_off<P>(d0[j] + lr, rt * 16 + 4 * lg, NVF), y);
+            }
+        }
+    }
+    DSG_LDS_BARRIER();
+    // ---- (2) attention of query tile `wave` (k_attn on LDS operands)
+    const int qt = wave;
+    f32x4 s[NKT];
+#pragma unroll
+    for (int nt = 0; nt < NKT; ++nt) {
+        s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KDH; ++kb) s[nt] = P::mma(ks[nt * KDH + kb][lane], qs[qt * KDH + kb][lane], s[nt]);   // D[key = 4 lg + r][query = lr]
+    }
+    const float scale = 1.0f / sqrtf((float)HD);
+    float mx = -DSG_FLT_MAX;
+#pragma unroll
+    for (int nt = 0; nt < NKT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = nt * 16 + 4 * lg + r;
+            const float v = key < g.ntok ? s[nt][r] * scale : -DSG_FLT_MAX;
+            s[nt][r] = v;
+            mx = fmaxf(mx, v);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NKT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = nt * 16 + 4 * lg + r;
+            const float pv = key < g.ntok ? P::exp_sm(s[nt][r] - mx) : 0.f;
+            s[nt][r] = pv;
+            sum += pv;
+        }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    f32x4 pfr[NVF];
+#pragma unroll
+    for (int kb = 0; kb < NVF; ++kb) {
+        if constexpr (P::E == 4) {
+            pfr[kb] = s[kb];
+        } else {
+            typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+            u16x8 pp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pp[e] = f2bf(s[2 * kb][e]); pp[4 + e] = f2bf(s[2 * kb + 1][e]); }
+            pfr[kb] = __builtin_bit_cast(f32x4, pp);
+        }
+    }
+    const int q = qt * 16 + lr;
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) {
+        f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < NVF; ++kb) o = P::mma(vs[dt * NVF + kb][lane], pfr[kb], o);     // D[dim = 4 lg + r][query = lr]
+        if (q < g.ntok) {
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = o[e] * inv;
+            P::store4((elem*)g.out + qk_off<P>(b * g.ntok + q, h * HD + dt * 16 + 4 * lg, KD), y);      // the rounding point of the attention rows
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // k_ffn (round 4, BLOCK set): the whole feed-forward half of an encoder layer for a block of RT x 16 rows in ONE kernel --
 //   hidden = gelu(x1 . W1^T + b1)   (hidden stays in LDS, in the GEMM type: the rounding point of the `hidden` buffer)
 //   pre2   = x1 + hidden . W2^T + b2
@@ -1358,15 +1536,21 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {
 // Reference arithmetic: linear1 / activation / linear2 / norm2 of torch's TransformerEncoderLayer (main/model/mdm.py:79-86).
 // ---------------------------------------------------------------------------------------------------------
 struct FfnPartArgs {
-    const void* A;          // LayerNorm1 rows in the GEMM type, fragment-major (k_attn_op's X1a)
+    const void* A;          // LayerNorm1 rows in the GEMM type, fragment-major (k_attn_op's X1a); OP: the ATTENTION rows (k_clip_attn's output)
     const void* W1; const float* b1;
     const void* W2;
     float* part;            // [S][slab] fp32, slab >= M * D
     size_t slab;            // floats per slab
     int M, MT;
+    // OP (round 5): out_proj + bias + residual + LayerNorm1 of the row block as the kernel's prologue (every split recomputes it: 128 KB of
+    // W_o and 2 x DW x KD MFMAs per wave against a dispatch + a round trip of the rows); split 0 writes the fp32 rows k_ffn_ln adds back
+    const float* R;         // residual rows fp32 [rows][D]
+    const void* Wo; const float* bo;
+    const float* ln_g; const float* ln_b;
+    float* X1;              // LayerNorm1 rows fp32 [rows][D]
 };
 
-template <class P, int DT, int FT, int RT, int NW, int S>
+template <class P, int DT, int FT, int RT, int NW, int S, bool OP = false>
 __global__ __launch_bounds__(64 * NW) void k_ffn_part(const FfnPartArgs g) {
     DSG_TL_SCOPE();
     typedef typename P::elem elem;
@@ -1376,11 +1560,14 @@ __global__ __launch_bounds__(64 * NW) void k_ffn_part(const FfnPartArgs g) {
     constexpr int HP = FS * ES + 16;                 // LDS pitch of a hidden row
     static_assert(FF % S == 0 && FS % (16 * NW) == 0 && FS % P::KB == 0 && (D / 16) % NW == 0 && FWS >= 1 && KFS >= 1, "shape");
     __shared__ __attribute__((aligned(16))) char hid[RT * 16 * HP];
+    constexpr int XP = D * ES + 16;                  // OP: LDS pitch of a LayerNorm1 row
+    __shared__ __attribute__((aligned(16))) char xa[OP ? RT * 16 * XP : 16];
+    __shared__ float red[OP ? 2 * RT * NW * 16 : 1];
     preload_kernargs(g);
     const int mb = blockIdx.x / S, s = blockIdx.x - mb * S;
     const int lane = threadIdx.x & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
     const int m0 = mb * 16 * RT, mt_last = g.MT - 1;
-    // ---- every global load of the workgroup in one batch
+    // ---- every global load of the workgroup in one batch (OP: the prologue's operands and W1 first, W2 once W_o is dead)
     f32x4 af[RT][KD];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -1391,19 +1578,112 @@ __global__ __launch_bounds__(64 * NW) void k_ffn_part(const FfnPartArgs g) {
     const f32x4* w1 = (const f32x4*)g.W1 + lane;
     const f32x4* w2 = (const f32x4*)g.W2 + lane;
     f32x4 wb1[FWS][KD], pb1[FWS];
-#pragma unroll
-    for (int j = 0; j < FWS; ++j) {
-        const int nt = s * (FS / 16) + wave * FWS + j;
-#pragma unroll
-        for (int kb = 0; kb < KD; ++kb) wb1[j][kb] = w1[((size_t)nt * KD + kb) * 64];
-        pb1[j] = *(const f32x4*)(g.b1 + nt * 16 + 4 * lg);
-    }
     f32x4 wb2[KFS][DW];
+    auto load_w1 = [&]() {
 #pragma unroll
-    for (int k = 0; k < KFS; ++k)
+        for (int j = 0; j < FWS; ++j) {
+            const int nt = s * (FS / 16) + wave * FWS + j;
 #pragma unroll
-        for (int t = 0; t < DW; ++t) wb2[k][t] = w2[((size_t)(wave * DW + t) * KF + s * KFS + k) * 64];
-    DSG_LOADS_ISSUED();
+            for (int kb = 0; kb < KD; ++kb) wb1[j][kb] = w1[((size_t)nt * KD + kb) * 64];
+            pb1[j] = *(const f32x4*)(g.b1 + nt * 16 + 4 * lg);
+        }
+    };
+    auto load_w2 = [&]() {
+#pragma unroll
+        for (int k = 0; k < KFS; ++k)
+#pragma unroll
+            for (int t = 0; t < DW; ++t) wb2[k][t] = w2[((size_t)(wave * DW + t) * KF + s * KFS + k) * 64];
+    };
+    if constexpr (OP) {
+        // ---- prologue: pre1 = attention rows . W_o^T + b_o + residual; x1 = LayerNorm1(pre1) -> LDS (GEMM type), fp32 rows by split 0.
+        //      wave w owns output columns [w D/NW, (w+1) D/NW) of both row tiles (D[n = 4 lg + r][row = lr])
+        const f32x4* wo = (const f32x4*)g.Wo + lane;
+        f32x4 wof[DW][KD], pr[RT][DW], pbo[DW], pg[DW], pbt[DW];
+#pragma unroll
+        for (int t = 0; t < DW; ++t) {
+#pragma unroll
+            for (int kb = 0; kb < KD; ++kb) wof[t][kb] = wo[((size_t)(wave * DW + t) * KD + kb) * 64];
+            const int n = (wave * DW + t) * 16 + 4 * lg;
+            pbo[t] = *(const f32x4*)(g.bo + n);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const int m = min(m0 + rt * 16 + lr, g.M - 1);
+                pr[rt][t] = lda16<P>(g.R, ((size_t)m * D + n) * sizeof(float));
+            }
+        }
+        load_w1();
+        DSG_LOADS_ISSUED();
+        f32x4 acc[RT][DW];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < DW; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KD; ++kb)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int t = 0; t < DW; ++t) acc[rt][t] = P::mma(wof[t][kb], af[rt][kb], acc[rt][t]);
+        load_w2();                                            // (W_o is dead: its registers take W2's k-range; LayerNorm scale / shift: needed two barriers from here)
+#pragma unroll
+        for (int t = 0; t < DW; ++t) {
+            const int n = (wave * DW + t) * 16 + 4 * lg;
+            pg[t] = *(const f32x4*)(g.ln_g + n); pbt[t] = *(const f32x4*)(g.ln_b + n);
+        }
+        DSG_LOADS_ISSUED();
+        float sm[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            sm[rt] = 0.f;
+#pragma unroll
+            for (int t = 0; t < DW; ++t) { acc[rt][t] = acc[rt][t] + pbo[t] + pr[rt][t]; sm[rt] += (acc[rt][t][0] + acc[rt][t][1]) + (acc[rt][t][2] + acc[rt][t][3]); }
+            sm[rt] += __shfl_xor(sm[rt], 16); sm[rt] += __shfl_xor(sm[rt], 32);
+            if (lg == 0) red[(rt * NW + wave) * 16 + lr] = sm[rt];
+        }
+        DSG_LDS_BARRIER();
+        float mean[RT], qv[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) a += red[(rt * NW + w) * 16 + lr];
+            mean[rt] = a / (float)D;
+            qv[rt] = 0.f;
+#pragma unroll
+            for (int t = 0; t < DW; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = acc[rt][t][e] - mean[rt]; qv[rt] = __builtin_fmaf(d, d, qv[rt]); }
+            qv[rt] += __shfl_xor(qv[rt], 16); qv[rt] += __shfl_xor(qv[rt], 32);
+            if (lg == 0) red[((RT + rt) * NW + wave) * 16 + lr] = qv[rt];
+        }
+        DSG_LDS_BARRIER();
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) a += red[((RT + rt) * NW + w) * 16 + lr];
+            const float rstd = 1.0f / sqrtf(a / (float)D + 1e-5f);
+            const int m = m0 + rt * 16 + lr;
+#pragma unroll
+            for (int t = 0; t < DW; ++t) {
+                const int n = (wave * DW + t) * 16 + 4 * lg;
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = __builtin_fmaf((acc[rt][t][e] - mean[rt]) * rstd, pg[t][e], pbt[t][e]);
+                P::store4((elem*)(xa + (rt * 16 + lr) * XP) + n, y);
+                if (s == 0 && m < g.M) *(f32x4*)(g.X1 + (size_t)m * D + n) = y;
+            }
+        }
+        DSG_LDS_BARRIER();
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int kb = 0; kb < KD; ++kb) af[rt][kb] = *(const f32x4*)(xa + (rt * 16 + lr) * XP + (kb * P::KB + P::E * lg) * ES);
+    } else {
+        load_w1();
+        load_w2();
+        DSG_LOADS_ISSUED();
+    }
     // ---- phase 1: this wave's hidden tiles of the split
 #pragma unroll
     for (int j = 0; j < FWS; ++j) {

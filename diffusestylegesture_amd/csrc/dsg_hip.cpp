@@ -183,6 +183,7 @@ struct dsg_handle {
     int env_ffn_rt4 = -1;                // DSG_FFN_RT4=<rows>: k_ffn on 64-row blocks from that many token rows at any lane count (0: never)
     int env_ffn_split = -1;              // DSG_FFN_SPLIT=0: linear1 + linear2 + LayerNorm-on-read instead of k_ffn_part + k_ffn_ln (BLOCK)
     int env_attn_op2 = -1;               // DSG_ATTN_OP2=0|1: never / always the two-query-tile attention kernel (STREAM)
+    int env_clip_attn = -1;              // DSG_CLIP_ATTN=0: QKV GEMM + k_attn_op instead of k_clip_attn + k_ffn_ln (BLOCK; differs in the last bits)
     int* st_tmodel = nullptr; float* st_c[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int st_cap = 0, n_run = 1;
     bool st_valid = false; int st_mode = -1, st_skip = -1; float st_eta = 0.f;      // what the device tables hold
@@ -505,6 +506,7 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     if (const char* e = getenv("DSG_FFN_RT4")) h->env_ffn_rt4 = std::max(atoi(e), 0);
     if (const char* e = getenv("DSG_FFN_SPLIT")) h->env_ffn_split = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("DSG_ATTN_OP2")) h->env_attn_op2 = atoi(e) != 0 ? 1 : 0;
+    if (const char* e = getenv("DSG_CLIP_ATTN")) h->env_clip_attn = atoi(e) != 0 ? 1 : 0;
     *out = h;
 
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -951,6 +953,8 @@ struct KernelSel {
     bool ffn_rt4 = false;       // ... on 64-row blocks: 4 lanes x >= 4000 token rows (4 x 64 clips: 981 -> 903 us per step of the 4 lanes; 1 x 64: 376 -> 432,
                                 // 4 x 16: 334 -> 392, 4 x 32 even -- profiles/r04_y2_sweep_ffn_rt4_*.log).  Bit-identical to the 32-row form.
     bool ffn_split = false;     // BLOCK (round 4, bf16 ZEGGS / tiny dims): k_ffn split over the hidden dimension (k_ffn_part + k_ffn_ln); direct QKV / pose head
+    bool clip_attn = false;     // BLOCK (round 5, with ffn_split): the attention half per (clip, head) -- k_clip_attn (QKV slices + attention + partial out_proj)
+                                // + k_ffn_ln (head slabs + residual + LayerNorm1) instead of the QKV GEMM + k_attn_op
     bool xs_frag = false;       // BLOCK / STREAM (bf16, Jp 128 / 1152): the state shadow is fragment-major and the pose embedding streams it (k_ws2<EPI_PARTIAL>:
                                 // 8.9 -> 4.3 us at 1424 rows, 29.9 -> 11.0 at 5632; 3.8 -> 4.1 at 356)
 };
@@ -987,10 +991,12 @@ static int auto_kernel_set(const dsg_handle* h, int B, int lanes) {
     // 1 x 16: 282 vs 230)
     if (rows >= (lanes > 1 ? 1000 : 2000) && stream_set_ok(h)) return DSG_KSET_STREAM;
     if (lanes <= 1) {
-        if (B <= 2 && latency_set_ok(h)) return DSG_KSET_LATENCY;
+        // (fp32, round 5: k_attn_mid recomputes out_proj per hidden slice, and an fp32 MFMA is 1/16 of a bf16 one -- the un-fused 16 x 16
+        // tiles win at batch 1: 208.2 vs 218.5 us per step, profiles/r05_g_bench_fp32_*.log)
+        if (B <= 2 && latency_set_ok(h) && h->prec != DSG_PREC_FP32) return DSG_KSET_LATENCY;
         return rows >= 1000 ? DSG_KSET_BLOCK : DSG_KSET_TILE;
     }
-    if (B <= 1 && latency_set_ok(h)) return DSG_KSET_LATENCY;
+    if (B <= 1 && latency_set_ok(h) && h->prec != DSG_PREC_FP32) return DSG_KSET_LATENCY;
     return rows >= 300 ? DSG_KSET_BLOCK : DSG_KSET_TILE;
 }
 // what DSG_KSET_AUTO resolves to for `lanes` lanes of batch B: the measured table + dsg_config.latency_mode (1 = never LATENCY, 2 = always
@@ -1031,6 +1037,7 @@ static int select_kernels(const dsg_handle* h, int B, KernelSel& k) {
     k.attn_op = !k.lat && (have_attn_op_narrow(h) || (k.blk && have_attn_op_wide(h)));
     k.xs_frag = k.blk && h->prec == DSG_PREC_BF16 && (h->Jp == 1152 || h->Jp == 128);
     if (set == DSG_KSET_BLOCK && ffn_split_ok(h)) k.ffn_split = h->env_ffn_split != 0;      // (A/B: DSG_FFN_SPLIT=0 = linear1 + linear2 + LayerNorm-on-read, round 3)
+    k.clip_attn = k.ffn_split && h->env_clip_attn != 0;      // (A/B: DSG_CLIP_ATTN=0 = QKV GEMM + k_attn_op, round 4)
 
     return 0;
 }
@@ -1354,7 +1361,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
     la.emb1 = h->emb1; la.ctl = c.use_ctr ? h->ctl : nullptr; la.t_arr = h->t_arr;
     la.rcos = h->rcos; la.rsin = h->rsin; la.mask = h->mask; la.mb = h->mb; la.inv_mask_div = fastdiv_inv((int)((long long)B * h->Hl / h->mb)); la.B = B; la.T = T; la.D = D; la.Hl = h->Hl;
     la.hd = h->hdl; la.W = h->W; la.X0 = h->X0; la.X0a = h->X0a; la.nomask = h->nomask;
-    la.x0a_frag = (ks.stream && sizeof(typename P::elem) == 2) ? 1 : 0;
+    la.x0a_frag = ((ks.stream || ks.clip_attn) && sizeof(typename P::elem) == 2) ? 1 : 0;
     h->fence_next = 1;         // the first packet of a step reads the state the previous step's last packet wrote (state_fences)
     if (ks.lat) {              // pose embedding + local attention in one launch
         InLocArgs a;
@@ -1382,7 +1389,9 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
     }
     for (int l = 0; l < h->L; ++l) {
         const Layer& ly = h->layers[l];
-        {   // QKV projection (LayerNorm2 of the previous layer applied on read)
+        // (guidance: the last layer leaves pre2 to the two-pass pose head, i.e. it runs the round-3 feed-forward kernels, which read k_attn_op's rows)
+        const bool clip_l = ks.clip_attn && (l < h->L - 1 || h->cfgB == 0);
+        if (!clip_l) {   // QKV projection (LayerNorm2 of the previous layer applied on read)
             GemmArgs g = z;
             g.M = M; g.MT = MT; g.NT = 3 * D / 16; g.KBtot = D / KB; g.Wp = ly.Wqkv; g.bias = ly.bqkv;
             g.q = h->q; g.k = h->k; g.vt = h->vt;
@@ -1420,7 +1429,16 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
           if constexpr (!P::W2) {        // (bf16w2 runs LATENCY / TILE without k_attn_op: select_kernels)
             // attention + out_proj + residual + LayerNorm1 in one kernel per (query tile, batch element); linear1 reads the
             // normalised rows in the GEMM type
-            {
+            if (clip_l) {
+                // round 5: per (clip, head) -- QKV slices + attention in one kernel (k_clip_attn); out_proj + residual + LayerNorm1 are the
+                // prologue of k_ffn_part below (OP): Q / K / V never leave the CU and the QKV GEMM is gone as a dispatch
+                if constexpr (sizeof(typename P::elem) == 2) {
+                    ClipAttnArgs a;
+                    a.X = h->X0a; a.Wqkv = ly.Wqkv; a.bqkv = ly.bqkv; a.out = h->attn; a.B = B; a.ntok = ntok;
+                    if (D == 256) CHK((step_launch<&k_clip_attn<P, 4, 6>>(h, dim3(4, B), dim3(384), a)));
+                    else CHK((step_launch<&k_clip_attn<P, 2, 2>>(h, dim3(4, B), dim3(128), a)));
+                }
+            } else {
                 AttnOpArgs a;
                 a.q = h->q; a.k = h->k; a.vt = h->vt; a.R = l == 0 ? h->X0 : h->Xn; a.Wo = ly.Wo; a.bo = ly.bo; a.ln_g = ly.g1; a.ln_b = ly.be1;
                 a.X1 = h->X1; a.X1a = h->X1a; a.B = B; a.ntok = ntok; a.Tp = h->Tp;
@@ -1462,14 +1480,20 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
             if (ks.ffn_split && (l < h->L - 1 || h->cfgB == 0)) {
                 if constexpr (sizeof(typename P::elem) == 2) {
                     FfnPartArgs a;
+                    memset(&a, 0, sizeof(a));
                     a.A = h->X1a; a.W1 = ly.W1; a.b1 = ly.b1; a.W2 = ly.W2; a.part = h->ffn_part; a.slab = h->ffn_slab; a.M = M; a.MT = MT;
+                    if (clip_l) {      // out_proj + residual + LayerNorm1 as the prologue (OP)
+                        a.A = h->attn; a.R = l == 0 ? h->X0 : h->Xn; a.Wo = ly.Wo; a.bo = ly.bo; a.ln_g = ly.g1; a.ln_b = ly.be1; a.X1 = h->X1;
+                    }
                     FfnLnArgs b;
                     b.part = h->ffn_part; b.slab = h->ffn_slab; b.R = h->X1; b.b2 = ly.b2; b.ln_g = ly.g2; b.ln_b = ly.be2; b.Xn = h->Xn; b.Xa = h->X0a; b.M = M;
                     if (D == 256) {
-                        CHK((step_launch<&k_ffn_part<P, 4, 16, 2, 4, 4>>(h, dim3(cdiv(MT, 2) * 4), dim3(256), a)));
+                        if (clip_l) CHK((step_launch<&k_ffn_part<P, 4, 16, 2, 4, 4, true>>(h, dim3(cdiv(MT, 2) * 4), dim3(256), a)));
+                        else CHK((step_launch<&k_ffn_part<P, 4, 16, 2, 4, 4>>(h, dim3(cdiv(MT, 2) * 4), dim3(256), a)));
                         CHK((step_launch<&k_ffn_ln<P, 4, 4, 8>>(h, dim3(cdiv(M, 8)), dim3(128), b)));
                     } else {
-                        CHK((step_launch<&k_ffn_part<P, 2, 2, 2, 4, 2>>(h, dim3(cdiv(MT, 2) * 2), dim3(256), a)));
+                        if (clip_l) CHK((step_launch<&k_ffn_part<P, 2, 2, 2, 4, 2, true>>(h, dim3(cdiv(MT, 2) * 2), dim3(256), a)));
+                        else CHK((step_launch<&k_ffn_part<P, 2, 2, 2, 4, 2>>(h, dim3(cdiv(MT, 2) * 2), dim3(256), a)));
                         CHK((step_launch<&k_ffn_ln<P, 2, 2, 8>>(h, dim3(cdiv(M, 8)), dim3(128), b)));
                     }
                 }

@@ -53,7 +53,7 @@ def test_bench_single_rank_modes(emu_lib):
     assert a["n_gpus"] == 1 and a["config"]["mode"] == "lockstep" and a["sample_path"] == "hip"
     b = _run(["--steps", "1", "--warmup", "0", "--precision", "fp32"], {})
     assert b["config"]["clips_per_gpu"] == 1 and b["roofline"]["bound"] == "hbm"
-    assert b["value_emitted_frames"] < b["value"] and b["kernel_set"] == "latency" and "config3" not in b
+    assert b["value_emitted_frames"] < b["value"] and b["kernel_set"] == "tile" and "config3" not in b          # (fp32 at batch 1: TILE since round 5)
     # the config[3] sub-record the multi-GPU runs carry (16 clips per GPU as 4 lanes x batch 4), forced on one emulated rank
     c = _run(["--steps", "1", "--warmup", "0", "--precision", "fp32", "--config3", "on", "--no-cpu-baseline"], {"DSG_EMU_THREADS": "8", "DSG_BENCH_SKIP": "998"})
     assert c["config3"]["clips"] == 16 and c["config3"]["value"] > 0 and c["config3"]["kernel_set"] == "tile"

@@ -48,3 +48,38 @@ def test_bf16w2_forward_and_chain_vs_oracle(emu_lib, cfg):
     lane = m.clone()                                      # a lane over the same (hi + lo) weights reproduces the handle bit for bit
     again = np.asarray(d.manual_seed(7, 2).p_sample_loop(lane, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=970))
     assert np.array_equal(got, again)
+
+
+def _read_rows(lib, m, name, n):
+    import ctypes as C_
+    lib.cdll.dsg_debug_read.argtypes = [C_.c_void_p, C_.c_char_p, C_.c_void_p, C_.c_longlong, C_.POINTER(C_.c_longlong)]
+    buf, nb = np.zeros(n, np.float32), C_.c_longlong(0)
+    lib.check(lib.cdll.dsg_debug_read(m.handle, name.encode(), buf.ctypes.data, buf.nbytes, C_.byref(nb)))
+    return buf[:nb.value // 4].copy()
+
+
+@pytest.mark.parametrize("cfg,B", [(C.TINY, 3), (C.ZEGGS, 2)], ids=["tiny", "zeggs"])
+def test_clip_attention_kernels_vs_the_round4_block_set_and_oracle(emu_lib, cfg, B, monkeypatch):
+    """Round 5, BLOCK set: k_clip_attn (per (clip, head): Q / K / V slices + attention, nothing of Q / K / V in global memory) + the
+    out_proj / residual / LayerNorm1 prologue of k_ffn_part against the QKV GEMM + k_attn_op they replace (DSG_CLIP_ATTN=0) -- the
+    LayerNorm1 / LayerNorm2 rows of the last layer agree to bf16 noise (the tiny dims exercise a wave with K and V tiles, the ZEGGS
+    dims the all-of-one-kind form), and both forms match the oracle."""
+    from oracle.mdm import MDMOracle
+    sd = synth_state_dict(cfg, 20240)
+    y = synth_window_inputs(cfg, B, window=1, seed_pose_scale=0.3)
+    x = np.random.RandomState(0).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+    ts = [10, 999, 500][:B]
+    want = MDMOracle(sd, cfg)(x, ts, y)
+    rows, outs = {}, {}
+    M, D = B * (cfg.n_poses + 1), cfg.latent_dim
+    for v in ("1", "0"):
+        monkeypatch.setenv("DSG_CLIP_ATTN", v)
+        m = DSGDenoiser(cfg, precision="bf16", max_batch=B, library=emu_lib).set_kernel_set("block")
+        m.load_state_dict(sd)
+        outs[v] = np.asarray(m(x, ts, y))
+        assert m.last_kernel_set() == "block" and rel_l2(outs[v], want) < 1.2e-2
+        rows[v] = {k: _read_rows(emu_lib, m, k, M * D)[:M * D] for k in ("X1", "Xn")}
+    monkeypatch.delenv("DSG_CLIP_ATTN")
+    for k in ("X1", "Xn"):
+        e = rel_l2(rows["1"][k], rows["0"][k])
+        assert 0 < e < 6e-3, (k, e)                      # two different sets of kernels, the same function

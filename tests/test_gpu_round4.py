@@ -301,6 +301,13 @@ def test_block_set_with_the_ffn_split_over_hidden_vs_oracle(gpu, monkeypatch):
             old = np.asarray(_model(cfg, "bf16", max_batch=B).set_kernel_set("block")(x, ts, y))
             monkeypatch.delenv("DSG_FFN_SPLIT")
             assert 0 < rel_l2(out, old) < TOL_FWD["bf16"]            # a different set of kernels ran, same function
+            monkeypatch.setenv("DSG_CLIP_ATTN", "0")         # round 5: QKV GEMM + k_attn_op instead of k_clip_attn + the out_proj / LayerNorm1 prologue
+            old5 = np.asarray(_model(cfg, "bf16", max_batch=B).set_kernel_set("block")(x, ts, y))
+            monkeypatch.delenv("DSG_CLIP_ATTN")
+            assert 0 < rel_l2(out, old5) < TOL_FWD["bf16"] and 0 < rel_l2(old, old5)
+            for b in (0, B - 1):
+                yb = {k: (v[b:b + 1] if v.shape[0] == B else v) for k, v in y.items()}
+                assert rel_l2(old5[b:b + 1], ref(x[b:b + 1], [int(ts[b])], yb)) < TOL_FWD["bf16"]
             small = _model(cfg, "bf16", max_batch=2).set_kernel_set("block")
             ys = {k: (v[5:7] if v.shape[0] == B else v) for k, v in y.items()}
             assert np.array_equal(out[5:7], np.asarray(small(x[5:7], ts[5:7], ys)))
