@@ -1351,9 +1351,14 @@ struct FfnArgs {
     float* Xn;              // LayerNorm2 rows fp32 [rows][D]
     void* Xa;               // ... in the GEMM type, fragment-major
     int M, MT;
+    // OP (round 5): A = the ATTENTION rows (k_clip_attn), R = the rows the attention block adds back; out_proj + bias + residual + LayerNorm1 run
+    // as the prologue, the LayerNorm1 rows go to LDS (linear1's operand) and stay in registers (linear2's residual): no X1 / X1a round trip
+    const void* Wo; const float* bo;
+    const float* ln1_g; const float* ln1_b;
+    float* X1;              // OP on 64-row blocks (no LDS left to park them): the fp32 LayerNorm1 rows, written by the prologue and read back after phase 1
 };
 
-template <class P, int DT, int FT, int RT, int NW, int LA = 2, bool LATE_R = false>      // D = 64 DT, ff = 64 FT, RT row tiles per workgroup, NW waves, LA tiles / 2 LA k-blocks of look-ahead
+template <class P, int DT, int FT, int RT, int NW, int LA = 2, bool LATE_R = false, bool OP = false>      // D = 64 DT, ff = 64 FT, RT row tiles per workgroup, NW waves, LA tiles / 2 LA k-blocks of look-ahead
 __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {
     DSG_TL_SCOPE();
     typedef typename P::elem elem;
@@ -1367,18 +1372,31 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {
     __shared__ __attribute__((aligned(16))) char hid[RT * 16 * HP];
     __shared__ float red[RT][2][NW][16];
     __shared__ __attribute__((aligned(16))) float vecs[3][D];      // b2, LayerNorm2 scale / shift
+    constexpr int XP = D * ES + 16;                  // OP: LDS pitch of a LayerNorm1 row
+    constexpr bool BIG = OP && RT >= 4;              // 64-row blocks: `hidden` fills the LDS -- the LayerNorm1 rows alias its head (dead before phase 1
+                                                     // writes: linear1's operand sits in registers by then) and the fp32 rows go through g.X1
+    static_assert(!BIG || RT * 16 * XP <= RT * 16 * HP, "alias");
+    __shared__ __attribute__((aligned(16))) char xa_own[(OP && !BIG) ? RT * 16 * XP : 16];
+    char* const xa = BIG ? hid : xa_own;
+    __shared__ __attribute__((aligned(16))) float vecs1[OP ? 3 : 1][OP ? D : 4];      // OP: b_o, LayerNorm1 scale / shift
+    constexpr int X1P = D + 4;                       // OP: pitch (floats) of the fp32 LayerNorm1 rows parked in LDS across phase 1 (register budget)
+    __shared__ __attribute__((aligned(16))) float x1f[(OP && !BIG) ? RT * 16 * X1P : 4];
     preload_kernargs(g);
     const int mb = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
     const int m0 = mb * 16 * RT, mt_last = g.MT - 1;
     // ---- loads that do not depend on phase 1: A fragments, first W1 tiles, residual rows, the per-column vectors
+    constexpr int RH = (OP && RT >= 4) ? 2 : RT;     // OP on 64-row blocks: the prologue takes the row tiles two at a time (register budget)
     f32x4 af[RT][KD];
+    auto load_a = [&](int rt0) {
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        const int mt = min(mb * RT + rt, mt_last);           // clamped (rows past the end are computed and dropped)
+        for (int rt = rt0; rt < rt0 + RH; ++rt) {
+            const int mt = min(mb * RT + rt, mt_last);       // clamped (rows past the end are computed and dropped)
 #pragma unroll
-        for (int kb = 0; kb < KD; ++kb) af[rt][kb] = lda16<P>(g.A, ((size_t)(mt * KD + kb) * 64 + lane) * P::E * ES);
-    }
+            for (int kb = 0; kb < KD; ++kb) af[rt][kb] = lda16<P>(g.A, ((size_t)(mt * KD + kb) * 64 + lane) * P::E * ES);
+        }
+    };
+    load_a(0);
     const f32x4* w1 = (const f32x4*)g.W1 + lane;
     const f32x4* w2 = (const f32x4*)g.W2 + lane;
     f32x4 wb1[2][LA][KD], pb1[2][LA];                // [buffer][tile of the group][k-block]
@@ -1391,28 +1409,125 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {
             pb1[buf][j] = *(const f32x4*)(g.b1 + nt * 16 + 4 * lg);
         }
     };
-    load1(0, 0);
+    if constexpr (!OP) load1(0, 0);
     f32x4 pr[RT][DW];
-    bool rowok[RT];
-    size_t mrow[RT];
+    // (row index of this lane in row tile rt, clamped to a valid row; recomputed where it is used: four 64-bit offsets kept live across
+    //  the kernel were what spilled in the 64-row form with the prologue)
+    auto rowok_of = [&](int rt) { return m0 + rt * 16 + lr < g.M; };
+    auto mrow_of = [&](int rt) { return (unsigned)min(m0 + rt * 16 + lr, g.M - 1); };      // (32-bit: < 2^22 rows; byte offsets below stay 32-bit too)
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-        const int m = m0 + rt * 16 + lr;
-        rowok[rt] = m < g.M;
-        mrow[rt] = (size_t)(rowok[rt] ? m : g.M - 1);
-        if constexpr (!LATE_R) {
+        if ((!LATE_R || OP) && rt < RH) {      // (OP: the rows the ATTENTION block adds back; linear2's residual is computed below)
 #pragma unroll
-            for (int t = 0; t < DW; ++t) pr[rt][t] = lda16<P>(g.R, (mrow[rt] * D + (wave * DW + t) * 16 + 4 * lg) * sizeof(float));
+            for (int t = 0; t < DW; ++t) pr[rt][t] = lda16<P>(g.R, (size_t)((mrow_of(rt) * D + (wave * DW + t) * 16 + 4 * lg) * 4u));
         }
     }
     constexpr int NV = (3 * D / 4 + NT - 1) / NT;
-    f32x4 vload[NV];
+    f32x4 vload[NV], vload1[OP ? NV : 1];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int e = min(tid + NT * i, 3 * D / 4 - 1), vsel = e / (D / 4), vidx = e % (D / 4);
         vload[i] = ((const f32x4*)(vsel == 0 ? g.b2 : (vsel == 1 ? g.ln_g : g.ln_b)))[vidx];
+        if constexpr (OP) vload1[i] = ((const f32x4*)(vsel == 0 ? g.bo : (vsel == 1 ? g.ln1_g : g.ln1_b)))[vidx];
     }
-    DSG_LOADS_ISSUED();
+    if constexpr (OP) {
+        // ---- prologue: pre1 = attention rows . W_o^T + b_o + residual; x1 = LayerNorm1(pre1) -> LDS in the GEMM type (linear1's operand)
+        //      and, in fp32, this lane's registers: phase 2 adds exactly these (row, column) values back (same wave -> column map)
+        const f32x4* wo = (const f32x4*)g.Wo + lane;
+        f32x4 wof[DW][KD];
+#pragma unroll
+        for (int t = 0; t < DW; ++t)
+#pragma unroll
+            for (int kb = 0; kb < KD; ++kb) wof[t][kb] = wo[((size_t)(wave * DW + t) * KD + kb) * 64];
+        DSG_LOADS_ISSUED();
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = tid + NT * i;
+            if (e < 3 * D / 4) { *(f32x4*)(&vecs1[0][0] + e * 4) = vload1[i]; *(f32x4*)(&vecs[0][0] + e * 4) = vload[i]; }      // (b2 / LayerNorm2 too: no registers across the phases)
+        }
+        f32x4 acc1[RT][DW];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < DW; ++t) acc1[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r0 = 0; r0 < RT; r0 += RH) {
+#pragma unroll
+            for (int kb = 0; kb < KD; ++kb)
+#pragma unroll
+                for (int rt = r0; rt < r0 + RH; ++rt)
+#pragma unroll
+                    for (int t = 0; t < DW; ++t) acc1[rt][t] = P::mma(wof[t][kb], af[rt][kb], acc1[rt][t]);      // D[n 4lg+r][row lr]
+            if (r0 + RH < RT) {                               // (64-row blocks: the next two row tiles' attention rows and residual)
+                load_a(r0 + RH);
+#pragma unroll
+                for (int rt = r0 + RH; rt < r0 + 2 * RH; ++rt)
+#pragma unroll
+                    for (int t = 0; t < DW; ++t) pr[rt][t] = lda16<P>(g.R, (size_t)((mrow_of(rt) * D + (wave * DW + t) * 16 + 4 * lg) * 4u));
+                DSG_LOADS_ISSUED();
+            }
+        }
+        load1(0, 0);                                          // (W_o and the attention rows are dead: the first W1 tiles arrive behind LayerNorm1)
+        DSG_LOADS_ISSUED();
+        DSG_LDS_BARRIER();                                    // vecs1 is in place
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            float sm = 0.f;
+#pragma unroll
+            for (int t = 0; t < DW; ++t) {
+                const f32x4 pb = *(const f32x4*)(&vecs1[0][(wave * DW + t) * 16 + 4 * lg]);
+                acc1[rt][t] = acc1[rt][t] + pb + pr[rt][t];
+                sm += (acc1[rt][t][0] + acc1[rt][t][1]) + (acc1[rt][t][2] + acc1[rt][t][3]);
+            }
+            sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
+            if (lg == 0) red[rt][0][wave][lr] = sm;
+        }
+        DSG_LDS_BARRIER();
+        float mean1[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w2_ = 0; w2_ < NW; ++w2_) tot += red[rt][0][w2_][lr];
+            mean1[rt] = tot / (float)D;
+            float qv = 0.f;
+#pragma unroll
+            for (int t = 0; t < DW; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = acc1[rt][t][e] - mean1[rt]; qv = __builtin_fmaf(d, d, qv); }
+            qv += __shfl_xor(qv, 16); qv += __shfl_xor(qv, 32);
+            if (lg == 0) red[rt][1][wave][lr] = qv;
+        }
+        DSG_LDS_BARRIER();
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w2_ = 0; w2_ < NW; ++w2_) tot += red[rt][1][w2_][lr];
+            const float rstd = 1.0f / sqrtf(tot / (float)D + 1e-5f);
+#pragma unroll
+            for (int t = 0; t < DW; ++t) {
+                const int n = (wave * DW + t) * 16 + 4 * lg;
+                const f32x4 pg = *(const f32x4*)(&vecs1[1][n]), pbt = *(const f32x4*)(&vecs1[2][n]);
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = __builtin_fmaf((acc1[rt][t][e] - mean1[rt]) * rstd, pg[e], pbt[e]);
+                P::store4((elem*)(xa + (rt * 16 + lr) * XP) + n, y);
+                // linear2's residual: read back by the same lane after phase 2
+                // (64-row blocks: through g.X1, un-clamped and unconditional -- the row buffers are padded past the last 64-row block)
+                if constexpr (BIG) *(f32x4*)((char*)g.X1 + (size_t)(((unsigned)(m0 + rt * 16 + lr) * D + n) * 4u)) = y;
+                else *(f32x4*)(x1f + (rt * 16 + lr) * X1P + n) = y;
+            }
+        }
+        DSG_LDS_BARRIER();                                    // (also: red is free for LayerNorm2)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int kb = 0; kb < KD; ++kb) af[rt][kb] = *(const f32x4*)(xa + (rt * 16 + lr) * XP + (kb * P::KB + P::E * lg) * ES);
+        if constexpr (BIG) DSG_LDS_BARRIER();                 // every wave holds its operand: phase 1 may overwrite the aliased rows
+    } else {
+        DSG_LOADS_ISSUED();
+    }
     // ---- phase 1: hidden tiles of this wave, LA at a time, the next group's fragments in flight
 #pragma unroll
     for (int tp = 0; tp < FW / LA; ++tp) {
@@ -1441,17 +1556,27 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {
             for (int t = 0; t < DW; ++t) wb2[buf][k][t] = w2[((size_t)(wave * DW + t) * KF + c * KC + k) * 64];
     };
     load2(0, 0);
-    if constexpr (LATE_R) {      // (8 waves: the residual rows are requested only now -- the register budget of phase 1)
+    if constexpr ((LATE_R && !OP) || BIG) {      // (8 waves: the residual rows are requested only now -- the register budget of phase 1)
+        int lr_late = lr;
+        if constexpr (BIG) {
+#ifndef DSG_EMU
+            asm volatile("" : "+v"(lr_late));      // opaque: the row offsets are RE-computed here -- kept live across phase 1 they were what spilled
+#endif
+        }
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
+        for (int rt = 0; rt < RT; ++rt) {
+            const unsigned mr = BIG ? (unsigned)(m0 + rt * 16 + lr_late) : (unsigned)min(m0 + rt * 16 + lr_late, g.M - 1);
 #pragma unroll
-            for (int t = 0; t < DW; ++t) pr[rt][t] = lda16<P>(g.R, (mrow[rt] * D + (wave * DW + t) * 16 + 4 * lg) * sizeof(float));
+            for (int t = 0; t < DW; ++t) pr[rt][t] = lda16<P>(BIG ? (const float*)g.X1 : g.R, (size_t)((mr * D + (wave * DW + t) * 16 + 4 * lg) * 4u));
+        }
     }
     DSG_LOADS_ISSUED();
+    if constexpr (!OP) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int e = tid + NT * i;
-        if (e < 3 * D / 4) *(f32x4*)(&vecs[0][0] + e * 4) = vload[i];
+        for (int i = 0; i < NV; ++i) {
+            const int e = tid + NT * i;
+            if (e < 3 * D / 4) *(f32x4*)(&vecs[0][0] + e * 4) = vload[i];
+        }
     }
     DSG_LDS_BARRIER();
     f32x4 acc[RT][DW];
@@ -1479,6 +1604,7 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {
 #pragma unroll
         for (int t = 0; t < DW; ++t) {
             const f32x4 pb = *(const f32x4*)(&vecs[0][(wave * DW + t) * 16 + 4 * lg]);
+            if constexpr (OP && !BIG) pr[rt][t] = *(const f32x4*)(x1f + (rt * 16 + lr) * X1P + (wave * DW + t) * 16 + 4 * lg);
             acc[rt][t] = acc[rt][t] + pb + pr[rt][t];
             sm += (acc[rt][t][0] + acc[rt][t][1]) + (acc[rt][t][2] + acc[rt][t][3]);
         }
@@ -1508,7 +1634,7 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {
 #pragma unroll
         for (int w2_ = 0; w2_ < NW; ++w2_) tot += red[rt][1][w2_][lr];
         const float rstd = 1.0f / sqrtf(tot / (float)D + 1e-5f);
-        if (rowok[rt]) {
+        if (rowok_of(rt)) {
 #pragma unroll
             for (int t = 0; t < DW; ++t) {
                 const int n = (wave * DW + t) * 16 + 4 * lg;
@@ -1516,8 +1642,8 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {
                 f32x4 y;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] = __builtin_fmaf((acc[rt][t][e] - mean[rt]) * rstd, pg[e], pbt[e]);
-                *(f32x4*)(g.Xn + mrow[rt] * D + n) = y;
-                P::store4((elem*)g.Xa + qk_off<P>((int)mrow[rt], n, KD), y);
+                *(f32x4*)((char*)g.Xn + (size_t)((mrow_of(rt) * D + n) * 4u)) = y;
+                P::store4((elem*)g.Xa + qk_off<P>((int)mrow_of(rt), n, KD), y);
             }
         }
     }
@@ -1561,7 +1687,11 @@ __global__ __launch_bounds__(64 * NW) void k_ffn_part(const FfnPartArgs g) {
     static_assert(FF % S == 0 && FS % (16 * NW) == 0 && FS % P::KB == 0 && (D / 16) % NW == 0 && FWS >= 1 && KFS >= 1, "shape");
     __shared__ __attribute__((aligned(16))) char hid[RT * 16 * HP];
     constexpr int XP = D * ES + 16;                  // OP: LDS pitch of a LayerNorm1 row
-    __shared__ __attribute__((aligned(16))) char xa[OP ? RT * 16 * XP : 16];
+    constexpr bool BIG = OP && RT >= 4;              // 64-row blocks: `hidden` fills the LDS -- the LayerNorm1 rows alias its head (dead before phase 1
+                                                     // writes: linear1's operand sits in registers by then) and the fp32 rows go through g.X1
+    static_assert(!BIG || RT * 16 * XP <= RT * 16 * HP, "alias");
+    __shared__ __attribute__((aligned(16))) char xa_own[(OP && !BIG) ? RT * 16 * XP : 16];
+    char* const xa = BIG ? hid : xa_own;
     __shared__ float red[OP ? 2 * RT * NW * 16 : 1];
     preload_kernargs(g);
     const int mb = blockIdx.x / S, s = blockIdx.x - mb * S;

@@ -989,7 +989,9 @@ static int auto_kernel_set(const dsg_handle* h, int B, int lanes) {
     const int rows = B * h->ntok;
     // (round 4, STREAM with k_ffn; profiles/r04_n_sweep_sets.log: 4 x 12 clips 319 vs 383 us BLOCK, 4 x 8: 299 vs 286; 1 x 24: 295 vs 301,
     // 1 x 16: 282 vs 230)
-    if (rows >= (lanes > 1 ? 1000 : 2000) && stream_set_ok(h)) return DSG_KSET_STREAM;
+    // (round 5, k_clip_attn + the out_proj / LayerNorm1 prologue of k_ffn: profiles/r05_j_sweep_sets.log -- 4 x 10 clips 260 vs 278 us BLOCK,
+    // 4 x 8: 256 vs 234; 1 x 24: 249 vs 321, 1 x 20: 245 vs 224)
+    if (rows >= (lanes > 1 ? 850 : 2000) && stream_set_ok(h)) return DSG_KSET_STREAM;
     if (lanes <= 1) {
         // (fp32, round 5: k_attn_mid recomputes out_proj per hidden slice, and an fp32 MFMA is 1/16 of a bf16 one -- the un-fused 16 x 16
         // tiles win at batch 1: 208.2 vs 218.5 us per step, profiles/r05_g_bench_fp32_*.log)
@@ -1037,7 +1039,7 @@ static int select_kernels(const dsg_handle* h, int B, KernelSel& k) {
     k.attn_op = !k.lat && (have_attn_op_narrow(h) || (k.blk && have_attn_op_wide(h)));
     k.xs_frag = k.blk && h->prec == DSG_PREC_BF16 && (h->Jp == 1152 || h->Jp == 128);
     if (set == DSG_KSET_BLOCK && ffn_split_ok(h)) k.ffn_split = h->env_ffn_split != 0;      // (A/B: DSG_FFN_SPLIT=0 = linear1 + linear2 + LayerNorm-on-read, round 3)
-    k.clip_attn = k.ffn_split && h->env_clip_attn != 0;      // (A/B: DSG_CLIP_ATTN=0 = QKV GEMM + k_attn_op, round 4)
+    k.clip_attn = (k.ffn_split || k.ffn) && h->env_clip_attn != 0;      // (A/B: DSG_CLIP_ATTN=0 = QKV GEMM + k_attn_op, round 4)
 
     return 0;
 }
@@ -1462,10 +1464,20 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
             // (guidance: the last layer leaves pre2 to the two-pass pose head k_gemm_cfg, which normalises on read)
             if (ks.ffn && !(h->cfgB > 0 && l == h->L - 1)) {      // linear1 + GELU + linear2 + residual + LayerNorm2 (k_ffn): Xn fp32 + X0a in the GEMM type
                 FfnArgs a;
+                memset(&a, 0, sizeof(a));
                 a.A = h->X1a; a.R = h->X1; a.W1 = ly.W1; a.b1 = ly.b1; a.W2 = ly.W2; a.b2 = ly.b2; a.ln_g = ly.g2; a.ln_b = ly.be2;
                 a.Xn = h->Xn; a.Xa = h->X0a; a.M = M; a.MT = MT;
+                if (clip_l) {      // out_proj + residual + LayerNorm1 as the prologue (OP): A = the attention rows
+                    a.A = h->attn; a.R = l == 0 ? h->X0 : h->Xn; a.Wo = ly.Wo; a.bo = ly.bo; a.ln1_g = ly.g1; a.ln1_b = ly.be1; a.X1 = h->X1;
+                }
                 if constexpr (sizeof(typename P::elem) == 2) {
                     const dim3 grid(cdiv(MT, 2));
+                    if (clip_l) {
+                        if (D == 256 && ks.ffn_rt4) CHK((step_launch<&k_ffn<P, 4, 16, 4, 8, 1, true, true>>(h, dim3(cdiv(MT, 4)), dim3(512), a)));
+                        else if (D == 256) CHK((step_launch<&k_ffn<P, 4, 16, 2, 8, 2, true, true>>(h, grid, dim3(512), a)));
+                        else CHK((step_launch<&k_ffn<P, 2, 2, 2, 4, 2, false, true>>(h, grid, dim3(256), a)));
+                        continue;
+                    }
                     // 64 rows per workgroup (bit-identical: same waves, same k order) when several lanes fill the GPU with large batches:
                     // half the weight bytes through the CUs' load paths per row, half the workgroups (ffn_rt4 in select_kernels)
                     if (D == 256 && ks.ffn_rt4) CHK((step_launch<&k_ffn<P, 4, 16, 4, 8, 1, true>>(h, dim3(cdiv(MT, 4)), dim3(512), a)));
