@@ -993,6 +993,10 @@ __device__ __forceinline__ void local_attn_tail(const LocArgs& a, float (&rot)[2
     }
     DSG_LDS_BARRIER();
     const int ntok = a.T + 1, col0 = h * HD;
+    // Round 5: the W x HD output tile is staged in LDS and leaves in 16-byte stores -- the rows used to go out as 4-byte (fp32) and
+    // 2-byte (bf16) element stores, and an uncached narrow store is a fabric write of its own (4096 workgroups x 704 of them at 64
+    // clips: k_loc 19.4 us of a 287 us step).  Same values, same rounding point.
+    __shared__ __attribute__((aligned(16))) float ot[W][HD + 4];
 #pragma unroll
     for (int i = 0; i < NPO; ++i) {
         const int p = tid + 256 * i;
@@ -1001,15 +1005,23 @@ __device__ __forceinline__ void local_attn_tail(const LocArgs& a, float (&rot)[2
             float lo = 0.f, hi = 0.f;
 #pragma unroll
             for (int j = 0; j < W2; ++j) { const float pj = sc[q][j]; lo += pj * rot[j][dd]; hi += pj * rot[j][dd + half]; }
-            const float vlo = lo * c2[i] - hi * s2[i], vhi = hi * c2[i] + lo * s2[i];
-            const size_t o = (size_t)(b * ntok + 1 + w * W + q) * a.D + col0 + dd;
-            a.X0[o] = vlo; a.X0[o + half] = vhi;
-            if (a.x0a_frag) {
-                const int row = b * ntok + 1 + w * W + q, kdh = a.D / P::KB;
-                ((elem*)a.X0a)[qk_off<P>(row, col0 + dd, kdh)] = P::cvt(vlo); ((elem*)a.X0a)[qk_off<P>(row, col0 + dd + half, kdh)] = P::cvt(vhi);
-            } else {
-                ((elem*)a.X0a)[o] = P::cvt(vlo); ((elem*)a.X0a)[o + half] = P::cvt(vhi);
-            }
+            ot[q][dd] = lo * c2[i] - hi * s2[i]; ot[q][dd + half] = hi * c2[i] + lo * s2[i];
+        }
+    }
+    DSG_LDS_BARRIER();
+    constexpr int C4 = HD / 4, CE = HD / P::E;       // 16-byte chunks per row: fp32 rows / rows in the GEMM type
+    for (int p = tid; p < W * C4; p += 256) {
+        const int q = p / C4, c = p - q * C4;
+        *(f32x4*)(a.X0 + (size_t)(b * ntok + 1 + w * W + q) * a.D + col0 + 4 * c) = *(const f32x4*)&ot[q][4 * c];
+    }
+    for (int p = tid; p < W * CE; p += 256) {
+        const int q = p / CE, c = p - q * CE, row = b * ntok + 1 + w * W + q;
+        elem* dst = (elem*)a.X0a + (a.x0a_frag ? (size_t)qk_off<P>(row, col0 + P::E * c, a.D / P::KB) : (size_t)row * a.D + col0 + P::E * c);
+        if constexpr (P::E == 4) {
+            *(f32x4*)dst = *(const f32x4*)&ot[q][4 * c];
+        } else {
+            P::store4(dst, *(const f32x4*)&ot[q][8 * c]);
+            P::store4(dst + 4, *(const f32x4*)&ot[q][8 * c + 4]);
         }
     }
 }
@@ -1036,11 +1048,17 @@ __device__ __forceinline__ void loc_body(const LocArgs& a, int h, int w, int b) 
         lo[i] = a.Cf[base];
         hi[i] = a.Cf[base + half];
         c1[i] = a.rcos[f * half + dd]; s1[i] = a.rsin[f * half + dd];
+        if (a.KS == 1) {             // (uniform; the streamed pose embedding of the batched sets leaves ONE slab: without this, eight clamped
+                                     //  re-reads of it per element -- uncached memory, every one a trip to the memory side)
+            const size_t pb = ((size_t)b * a.T + f) * a.D + col0 + dd;
+            lo[i] += a.partial[pb]; hi[i] += a.partial[pb + half];
+        } else {
 #pragma unroll
-        for (int s = 0; s < MAXKS; ++s) {
-            const float wgt = s < a.KS ? 1.f : 0.f;
-            const size_t pb = ((size_t)min(s, a.KS - 1) * a.Min_pad + (size_t)b * a.T + f) * a.D + col0 + dd;
-            lo[i] += wgt * a.partial[pb]; hi[i] += wgt * a.partial[pb + half];
+            for (int s = 0; s < MAXKS; ++s) {
+                const float wgt = s < a.KS ? 1.f : 0.f;
+                const size_t pb = ((size_t)min(s, a.KS - 1) * a.Min_pad + (size_t)b * a.T + f) * a.D + col0 + dd;
+                lo[i] += wgt * a.partial[pb]; hi[i] += wgt * a.partial[pb + half];
+            }
         }
     }
     float c2[NPO], s2[NPO];
