@@ -20,18 +20,20 @@ $B --clips-per-gpu 64 --steps 1 --warmup 1 > $O/${TAG}_bench_64clips_l4_b16.log 
 $B --clips-per-gpu 128 --steps 1 --warmup 1 > $O/${TAG}_bench_128clips_l4_b32.log 2>&1
 $B --clips-per-gpu 192 --steps 1 --warmup 1 > $O/${TAG}_bench_192clips.log 2>&1
 $B --clips-per-gpu 256 --steps 1 --warmup 1 > $O/${TAG}_bench_256clips.log 2>&1
-$B --gpus 1 --config3 on --steps 1 --warmup 1 > $O/${TAG}_bench_with_config3_record.log 2>&1
+$B --clips-per-gpu 64 --lanes 1 --steps 1 --warmup 1 > $O/${TAG}_bench_64clips_lockstep.log 2>&1
 $B --config beat --steps 1 > $O/${TAG}_bench_beat.log 2>&1
 $B --config twh --steps 1 > $O/${TAG}_bench_twh.log 2>&1
+$B --config beat --precision bf16w2 --steps 1 --warmup 0 > $O/${TAG}_bench_beat_bf16w2.log 2>&1
 $B --config beat --clips-per-gpu 16 --steps 1 --warmup 1 > $O/${TAG}_bench_beat_16clips_l4_b4.log 2>&1
 $B --config twh --clips-per-gpu 16 --steps 1 --warmup 1 > $O/${TAG}_bench_twh_16clips_l4_b4.log 2>&1
-$B --precision fp32 --steps 1 --warmup 1 > $O/${TAG}_bench_fp32.log 2>&1
+$B --sub-records off --precision bf16w2 --steps 2 --warmup 1 > $O/${TAG}_bench_bf16w2.log 2>&1
+$B --sub-records off --precision fp32 --steps 1 --warmup 1 > $O/${TAG}_bench_fp32.log 2>&1
 $B --precision fp32 --clips-per-gpu 16 --steps 1 --warmup 1 > $O/${TAG}_bench_fp32_16clips_l4_b4.log 2>&1
 timeout 600 python tools/e2e.py --reps 3 > $O/${TAG}_e2e_wav_to_bvh.log 2>&1
 python tools/aql_timeline.py --config beat --steps 300 --first 100 --n 16 --out $O/${TAG}_aql_step_timeline_beat.json > /dev/null 2>&1
 python tools/aql_timeline.py --config twh --steps 300 --first 100 --n 16 --out $O/${TAG}_aql_step_timeline_twh.json > /dev/null 2>&1
 # kernel sets side by side (one process, same inputs)
-timeout 900 python tools/sweep.py --steps 150 --reps 3 --spec latency:1x1,tile:1x1,latency:4x1,latency:1x2,tile:1x2,tile:4x2,latency:4x2,tile:1x4,block:1x4,block:4x4,tile:4x4,block:1x16,tile:1x16,stream:1x16,block:4x8,stream:4x8,block:4x12,stream:4x12,block:4x16,stream:4x16,block:1x32,stream:1x32,block:4x32,stream:4x32,block:1x64,stream:1x64 2>&1 | grep -v amdgpu.ids > $O/${TAG}_sweep_kernel_sets.log
+timeout 900 python tools/sweep.py --steps 150 --reps 3 --spec latency:1x1,tile:1x1,latency:4x1,latency:1x2,tile:1x2,tile:4x2,latency:4x2,tile:1x4,block:1x4,block:4x4,tile:4x4,block:1x16,tile:1x16,stream:1x16,block:4x8,stream:4x8,block:4x10,stream:4x10,block:4x12,stream:4x12,block:1x20,stream:1x20,block:1x24,stream:1x24,block:4x16,stream:4x16,block:1x32,stream:1x32,block:4x32,stream:4x32,block:1x64,stream:1x64 2>&1 | grep -v amdgpu.ids > $O/${TAG}_sweep_kernel_sets.log
 # the timed path's own timeline (in-kernel stamps; command-processor timestamps)
 python tools/aql_timeline.py --out $O/${TAG}_aql_step_timeline.json > $O/${TAG}_aql_step_timeline.log 2>&1
 python tools/aql_timeline.py --batch 16 --n 16 --out $O/${TAG}_aql_step_timeline_b16.json > /dev/null 2>&1

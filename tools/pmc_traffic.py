@@ -18,7 +18,7 @@ def load(d, name):
 
 fd, wd, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
 F, W = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
-step_kernels = [k for k in F if any(t in k for t in ("k_gemm", "k_attn", "k_mid", "k_inloc", "k_loc", "k_ws", "k_ln_frag", "k_ffn"))]
+step_kernels = [k for k in F if any(t in k for t in ("k_gemm", "k_attn", "k_clip_attn", "k_mid", "k_inloc", "k_loc", "k_ws", "k_ln_frag", "k_ffn"))]
 fetch = sum(F[k] for k in step_kernels) * 1024 / steps
 write = sum(W.get(k, 0.0) for k in step_kernels) * 1024 / steps
 out = {"steps": steps, "fetch_bytes_per_step_raw": fetch, "write_bytes_per_step": write,
