@@ -1388,13 +1388,39 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {
     // ---- loads that do not depend on phase 1: A fragments, first W1 tiles, residual rows, the per-column vectors
     constexpr int RH = (OP && RT >= 4) ? 2 : RT;     // OP on 64-row blocks: the prologue takes the row tiles two at a time (register budget)
     f32x4 af[RT][KD];
+    // OP: the RH x KD attention-row fragments of a half are fetched ONCE per workgroup -- NFW of them per wave -- and handed round through LDS (the tail of
+    // `hid`, free until phase 1): every wave needs all of them, and eight waves loading the same 16 KB from uncached memory were 23 MB of memory-side reads
+    // per launch at 64 clips for 2.9 MB of rows
+    constexpr int NFH = RH * KD, NFW = (NFH + NW - 1) / NW;
+    f32x4* const stg = (f32x4*)(hid + RT * 16 * HP - NFH * 1024);
+    static_assert(!OP || NFH * 1024 + (RT >= 4 ? RT * 16 * (D * ES + 16) : 0) <= RT * 16 * HP, "the staged fragments sit behind the (aliased) LayerNorm1 rows");
+    f32x4 afw[OP ? NFW : 1];
     auto load_a = [&](int rt0) {
+        if constexpr (OP) {
 #pragma unroll
-        for (int rt = rt0; rt < rt0 + RH; ++rt) {
-            const int mt = min(mb * RT + rt, mt_last);       // clamped (rows past the end are computed and dropped)
+            for (int i = 0; i < NFW; ++i) {
+                const int f = min(wave * NFW + i, NFH - 1), rt = rt0 + f / KD, kb = f % KD;
+                const int mt = min(mb * RT + rt, mt_last);   // clamped (rows past the end are computed and dropped)
+                afw[i] = lda16<P>(g.A, ((size_t)(mt * KD + kb) * 64 + lane) * P::E * ES);
+            }
+        } else {
 #pragma unroll
-            for (int kb = 0; kb < KD; ++kb) af[rt][kb] = lda16<P>(g.A, ((size_t)(mt * KD + kb) * 64 + lane) * P::E * ES);
+            for (int rt = rt0; rt < rt0 + RH; ++rt) {
+                const int mt = min(mb * RT + rt, mt_last);   // clamped (rows past the end are computed and dropped)
+#pragma unroll
+                for (int kb = 0; kb < KD; ++kb) af[rt][kb] = lda16<P>(g.A, ((size_t)(mt * KD + kb) * 64 + lane) * P::E * ES);
+            }
         }
+    };
+    // (OP) afw -> LDS -> every wave's af[rt0 .. rt0 + RH)
+    auto share_a = [&](int rt0) {
+#pragma unroll
+        for (int i = 0; i < NFW; ++i) if (wave * NFW + i < NFH) stg[(wave * NFW + i) * 64 + lane] = afw[i];
+        DSG_LDS_BARRIER();
+#pragma unroll
+        for (int rt = rt0; rt < rt0 + RH; ++rt)
+#pragma unroll
+            for (int kb = 0; kb < KD; ++kb) af[rt][kb] = stg[((rt - rt0) * KD + kb) * 64 + lane];
     };
     load_a(0);
     const f32x4* w1 = (const f32x4*)g.W1 + lane;
@@ -1452,6 +1478,8 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {
             for (int t = 0; t < DW; ++t) acc1[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r0 = 0; r0 < RT; r0 += RH) {
+            if (r0 > 0) DSG_LDS_BARRIER();                    // every wave has read the previous half out of the stage
+            share_a(r0);
 #pragma unroll
             for (int kb = 0; kb < KD; ++kb)
 #pragma unroll
@@ -1693,12 +1721,14 @@ __global__ __launch_bounds__(64 * NW) void k_ffn_part(const FfnPartArgs g) {
     __shared__ __attribute__((aligned(16))) char xa_own[(OP && !BIG) ? RT * 16 * XP : 16];
     char* const xa = BIG ? hid : xa_own;
     __shared__ float red[OP ? 2 * RT * NW * 16 : 1];
+    __shared__ __attribute__((aligned(16))) float vecs1[OP ? 2 : 1][OP ? D : 4];      // OP: LayerNorm1 scale / shift
     preload_kernargs(g);
     const int mb = blockIdx.x / S, s = blockIdx.x - mb * S;
     const int lane = threadIdx.x & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
     const int m0 = mb * 16 * RT, mt_last = g.MT - 1;
     // ---- every global load of the workgroup in one batch (OP: the prologue's operands and W1 first, W2 once W_o is dead)
     f32x4 af[RT][KD];
+    // (every wave loads all RT x KD fragments itself: handing them round through LDS, as k_ffn<OP> does, measured 1.5 % SLOWER here -- 16 clips 202.3 vs 199.4 us)
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         const int mt = min(mb * RT + rt, mt_last);           // clamped (rows past the end are computed and dropped)
@@ -1729,6 +1759,15 @@ __global__ __launch_bounds__(64 * NW) void k_ffn_part(const FfnPartArgs g) {
         //      wave w owns output columns [w D/NW, (w+1) D/NW) of both row tiles (D[n = 4 lg + r][row = lr])
         const f32x4* wo = (const f32x4*)g.Wo + lane;
         f32x4 wof[DW][KD], pr[RT][DW], pbo[DW], pg[DW], pbt[DW];
+        // LayerNorm1 scale / shift: ONE 16-byte load per lane for the workgroup, requested up front and parked in LDS until the rows are normalised
+        // (per-wave copies requested up front cost 32 registers the stamps build did not have; requested after the MFMAs their latency showed)
+        constexpr int NV1 = (2 * D / 4 + 64 * NW - 1) / (64 * NW);
+        f32x4 vl1[NV1];
+#pragma unroll
+        for (int i = 0; i < NV1; ++i) {
+            const int e = min((int)threadIdx.x + 64 * NW * i, 2 * D / 4 - 1);
+            vl1[i] = ((const f32x4*)(e < D / 4 ? g.ln_g : g.ln_b))[e < D / 4 ? e : e - D / 4];
+        }
 #pragma unroll
         for (int t = 0; t < DW; ++t) {
 #pragma unroll
@@ -1754,13 +1793,13 @@ __global__ __launch_bounds__(64 * NW) void k_ffn_part(const FfnPartArgs g) {
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int t = 0; t < DW; ++t) acc[rt][t] = P::mma(wof[t][kb], af[rt][kb], acc[rt][t]);
-        load_w2();                                            // (W_o is dead: its registers take W2's k-range; LayerNorm scale / shift: needed two barriers from here)
-#pragma unroll
-        for (int t = 0; t < DW; ++t) {
-            const int n = (wave * DW + t) * 16 + 4 * lg;
-            pg[t] = *(const f32x4*)(g.ln_g + n); pbt[t] = *(const f32x4*)(g.ln_b + n);
-        }
+        load_w2();                                            // (W_o is dead: its registers take W2's k-range)
         DSG_LOADS_ISSUED();
+#pragma unroll
+        for (int i = 0; i < NV1; ++i) {
+            const int e = (int)threadIdx.x + 64 * NW * i;
+            if (e < 2 * D / 4) *(f32x4*)(&vecs1[0][0] + e * 4) = vl1[i];      // visible after the two LayerNorm barriers below
+        }
         float sm[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -1797,6 +1836,7 @@ __global__ __launch_bounds__(64 * NW) void k_ffn_part(const FfnPartArgs g) {
 #pragma unroll
             for (int t = 0; t < DW; ++t) {
                 const int n = (wave * DW + t) * 16 + 4 * lg;
+                pg[t] = *(const f32x4*)(&vecs1[0][n]); pbt[t] = *(const f32x4*)(&vecs1[1][n]);
                 f32x4 y;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] = __builtin_fmaf((acc[rt][t][e] - mean[rt]) * rstd, pg[t][e], pbt[t][e]);
