@@ -1715,11 +1715,7 @@ __global__ __launch_bounds__(64 * NW) void k_ffn_part(const FfnPartArgs g) {
     static_assert(FF % S == 0 && FS % (16 * NW) == 0 && FS % P::KB == 0 && (D / 16) % NW == 0 && FWS >= 1 && KFS >= 1, "shape");
     __shared__ __attribute__((aligned(16))) char hid[RT * 16 * HP];
     constexpr int XP = D * ES + 16;                  // OP: LDS pitch of a LayerNorm1 row
-    constexpr bool BIG = OP && RT >= 4;              // 64-row blocks: `hidden` fills the LDS -- the LayerNorm1 rows alias its head (dead before phase 1
-                                                     // writes: linear1's operand sits in registers by then) and the fp32 rows go through g.X1
-    static_assert(!BIG || RT * 16 * XP <= RT * 16 * HP, "alias");
-    __shared__ __attribute__((aligned(16))) char xa_own[(OP && !BIG) ? RT * 16 * XP : 16];
-    char* const xa = BIG ? hid : xa_own;
+    __shared__ __attribute__((aligned(16))) char xa[OP ? RT * 16 * XP : 16];
     __shared__ float red[OP ? 2 * RT * NW * 16 : 1];
     __shared__ __attribute__((aligned(16))) float vecs1[OP ? 2 : 1][OP ? D : 4];      // OP: LayerNorm1 scale / shift
     preload_kernargs(g);
