@@ -985,6 +985,12 @@ static bool stream_set_ok(const dsg_handle* h) {
     // linear1 reads the fragment-major LayerNorm1 rows k_attn_op writes
     return have_attn_op_narrow(h) && (h->D == 256 || h->D == 128) && (h->ff == 1024 || h->ff == 128) && (h->Jp == 1152 || h->Jp == 128);
 }
+// k_ffn_part + k_ffn_ln exist for the shapes the STREAM set exists for and (round 5) for the DSG+ widths in bf16 (latent_dim 384 / 512, ff 1024:
+// 8 ff-splits -- the two-batch weight fragments of these widths do not fit 4), behind k_attn_op_w
+static bool ffn_split_wide(const dsg_handle* h) {
+    return h->prec == DSG_PREC_BF16 && have_attn_op_wide(h) && h->ff == 1024 && (h->D == 384 || h->D == 512);
+}
+static bool ffn_split_ok(const dsg_handle* h) { return stream_set_ok(h) || ffn_split_wide(h); }
 static int auto_kernel_set(const dsg_handle* h, int B, int lanes) {
     const int rows = B * h->ntok;
     // (round 4, STREAM with k_ffn; profiles/r04_n_sweep_sets.log: 4 x 12 clips 319 vs 383 us BLOCK, 4 x 8: 299 vs 286; 1 x 24: 295 vs 301,
@@ -996,6 +1002,8 @@ static int auto_kernel_set(const dsg_handle* h, int B, int lanes) {
         // (fp32, round 5: k_attn_mid recomputes out_proj per hidden slice, and an fp32 MFMA is 1/16 of a bf16 one -- the un-fused 16 x 16
         // tiles win at batch 1: 208.2 vs 218.5 us per step, profiles/r05_g_bench_fp32_*.log)
         if (B <= 2 && latency_set_ok(h) && h->prec != DSG_PREC_FP32) return DSG_KSET_LATENCY;
+        // (DSG+ widths, round 5: with k_ffn_part + k_ffn_ln behind k_attn_op_w BLOCK wins from 4 clips -- BEAT 283 vs 303 us, TWH 310 vs 365; 2 clips: 259 vs 198)
+        if (ffn_split_wide(h) && h->env_ffn_split != 0 && rows >= 600) return DSG_KSET_BLOCK;
         return rows >= 1000 ? DSG_KSET_BLOCK : DSG_KSET_TILE;
     }
     if (B <= 1 && latency_set_ok(h) && h->prec != DSG_PREC_FP32) return DSG_KSET_LATENCY;
@@ -1013,8 +1021,6 @@ static int resolve_auto_set(const dsg_handle* h, int B, int lanes) {
     if (h->latency_mode == 1 && latency_set_ok(h)) set = DSG_KSET_LATENCY;
     return set;
 }
-// k_ffn_part + k_ffn_ln exist for the shapes the STREAM set exists for
-static bool ffn_split_ok(const dsg_handle* h) { return stream_set_ok(h); }
 static int select_kernels(const dsg_handle* h, int B, KernelSel& k) {
     int set = h->kset_req;
     if (set == DSG_KSET_AUTO) set = resolve_auto_set(h, B, 1);
@@ -1039,7 +1045,7 @@ static int select_kernels(const dsg_handle* h, int B, KernelSel& k) {
     k.attn_op = !k.lat && (have_attn_op_narrow(h) || (k.blk && have_attn_op_wide(h)));
     k.xs_frag = k.blk && h->prec == DSG_PREC_BF16 && (h->Jp == 1152 || h->Jp == 128);
     if (set == DSG_KSET_BLOCK && ffn_split_ok(h)) k.ffn_split = h->env_ffn_split != 0;      // (A/B: DSG_FFN_SPLIT=0 = linear1 + linear2 + LayerNorm-on-read, round 3)
-    k.clip_attn = (k.ffn_split || k.ffn) && h->env_clip_attn != 0;      // (A/B: DSG_CLIP_ATTN=0 = QKV GEMM + k_attn_op, round 4)
+    k.clip_attn = (k.ffn_split || k.ffn) && have_attn_op_narrow(h) && h->env_clip_attn != 0;      // (A/B: DSG_CLIP_ATTN=0 = QKV GEMM + k_attn_op, round 4)
 
     return 0;
 }
@@ -1050,7 +1056,7 @@ static int ensure_set_buffers(dsg_handle* h, const KernelSel& k) {
     if (k.ffn_split && !h->ffn_part) {
         const bool was = h->alloc_uc;
         h->alloc_uc = true;
-        const int rc = dalloc(h, &h->ffn_part, 4 * h->ffn_slab);      // [4][M_pad][D] fp32, loop-written: uncached like the other activations
+        const int rc = dalloc(h, &h->ffn_part, (size_t)(ffn_split_wide(h) ? 8 : 4) * h->ffn_slab);      // [S][M_pad][D] fp32, loop-written: uncached like the other activations
         h->alloc_uc = was;
         if (rc) return rc;
     }
@@ -1503,6 +1509,12 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                         if (clip_l) CHK((step_launch<&k_ffn_part<P, 4, 16, 2, 4, 4, true>>(h, dim3(cdiv(MT, 2) * 4), dim3(256), a)));
                         else CHK((step_launch<&k_ffn_part<P, 4, 16, 2, 4, 4>>(h, dim3(cdiv(MT, 2) * 4), dim3(256), a)));
                         CHK((step_launch<&k_ffn_ln<P, 4, 4, 8>>(h, dim3(cdiv(M, 8)), dim3(128), b)));
+                    } else if (D == 384) {      // DSG+ widths (round 5): 8 ff-splits, one row tile per workgroup-pair batch of fragments
+                        CHK((step_launch<&k_ffn_part<P, 6, 16, 2, 4, 8>>(h, dim3(cdiv(MT, 2) * 8), dim3(256), a)));
+                        CHK((step_launch<&k_ffn_ln<P, 6, 8, 8>>(h, dim3(cdiv(M, 8)), dim3(128), b)));
+                    } else if (D == 512) {
+                        CHK((step_launch<&k_ffn_part<P, 8, 16, 2, 4, 8>>(h, dim3(cdiv(MT, 2) * 8), dim3(256), a)));
+                        CHK((step_launch<&k_ffn_ln<P, 8, 8, 8>>(h, dim3(cdiv(M, 8)), dim3(128), b)));
                     } else {
                         if (clip_l) CHK((step_launch<&k_ffn_part<P, 2, 2, 2, 4, 2, true>>(h, dim3(cdiv(MT, 2) * 2), dim3(256), a)));
                         else CHK((step_launch<&k_ffn_part<P, 2, 2, 2, 4, 2>>(h, dim3(cdiv(MT, 2) * 2), dim3(256), a)));
