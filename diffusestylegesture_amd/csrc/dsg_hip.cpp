@@ -988,6 +988,7 @@ static bool stream_set_ok(const dsg_handle* h) {
 // k_ffn_part + k_ffn_ln exist for the shapes the STREAM set exists for and (round 5) for the DSG+ widths in bf16 (latent_dim 384 / 512, ff 1024:
 // 8 ff-splits -- the two-batch weight fragments of these widths do not fit 4), behind k_attn_op_w
 static bool ffn_split_wide(const dsg_handle* h) {
+    if (h->prec == DSG_PREC_FP32) return have_attn_op_wide(h) && h->ff == 1024 && h->D == 256;      // (fp32, ZEGGS widths: K = 256 is 16 k-blocks of 16)
     return h->prec == DSG_PREC_BF16 && have_attn_op_wide(h) && h->ff == 1024 && (h->D == 384 || h->D == 512);
 }
 static bool ffn_split_ok(const dsg_handle* h) { return stream_set_ok(h) || ffn_split_wide(h); }
@@ -1520,6 +1521,15 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                         else CHK((step_launch<&k_ffn_part<P, 2, 2, 2, 4, 2>>(h, dim3(cdiv(MT, 2) * 2), dim3(256), a)));
                         CHK((step_launch<&k_ffn_ln<P, 2, 2, 8>>(h, dim3(cdiv(M, 8)), dim3(128), b)));
                     }
+                } else {
+                    // fp32 at the ZEGGS widths (round 5, round-4 verdict item 7): the same split, 8 ways (16 k-blocks of 16 per K = 256 operand)
+                    FfnPartArgs a;
+                    memset(&a, 0, sizeof(a));
+                    a.A = h->X1a; a.W1 = ly.W1; a.b1 = ly.b1; a.W2 = ly.W2; a.part = h->ffn_part; a.slab = h->ffn_slab; a.M = M; a.MT = MT;
+                    FfnLnArgs b;
+                    b.part = h->ffn_part; b.slab = h->ffn_slab; b.R = h->X1; b.b2 = ly.b2; b.ln_g = ly.g2; b.ln_b = ly.be2; b.Xn = h->Xn; b.Xa = h->X0a; b.M = M;
+                    CHK((step_launch<&k_ffn_part<P, 4, 16, 2, 4, 8>>(h, dim3(cdiv(MT, 2) * 8), dim3(256), a)));
+                    CHK((step_launch<&k_ffn_ln<P, 4, 8, 8>>(h, dim3(cdiv(M, 8)), dim3(128), b)));
                 }
                 continue;
             }
