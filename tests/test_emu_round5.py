@@ -83,3 +83,27 @@ def test_clip_attention_kernels_vs_the_round4_block_set_and_oracle(emu_lib, cfg,
     for k in ("X1", "Xn"):
         e = rel_l2(rows["1"][k], rows["0"][k])
         assert 0 < e < 6e-3, (k, e)                      # two different sets of kernels, the same function
+
+
+@pytest.mark.parametrize("cfg,prec", [(C.BEAT, "bf16"), (C.ZEGGS, "fp32")], ids=["beat-bf16", "zeggs-fp32"])
+def test_ffn_split_at_dsgplus_widths_and_in_fp32(emu_lib, cfg, prec, monkeypatch):
+    """Round 5: k_ffn_part + k_ffn_ln with 8 ff-splits -- at the DSG+ widths in bf16 (latent_dim 384) and at the ZEGGS widths in fp32 -- behind
+    k_attn_op_w in the BLOCK set, the next QKV projection and the pose head direct: rows against the oracle, and against the round-4 composition
+    (DSG_FFN_SPLIT=0: linear1, linear2, LayerNorm-on-read)."""
+    from oracle.mdm import MDMOracle
+    sd = synth_state_dict(cfg, 20240)
+    B = 2
+    y = synth_window_inputs(cfg, B, window=1, seed_pose_scale=0.3)
+    x = np.random.RandomState(0).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+    ts = [10, 999]
+    want = MDMOracle(sd, cfg)(x, ts, y)
+    tol = 2e-5 if prec == "fp32" else 1.2e-2
+    outs = {}
+    for v in ("1", "0"):
+        monkeypatch.setenv("DSG_FFN_SPLIT", v)
+        m = DSGDenoiser(cfg, precision=prec, max_batch=B, library=emu_lib).set_kernel_set("block")
+        m.load_state_dict(sd)
+        outs[v] = np.asarray(m(x, ts, y))
+        assert m.last_kernel_set() == "block" and rel_l2(outs[v], want) < tol, (v, rel_l2(outs[v], want))
+    monkeypatch.delenv("DSG_FFN_SPLIT")
+    assert 0 < rel_l2(outs["1"], outs["0"]) < tol
