@@ -174,3 +174,46 @@ def test_dsgplus_widths_ffn_split_in_block(gpu, cfg, monkeypatch):
     old = np.asarray(_model(cfg, "bf16", max_batch=B).set_kernel_set("block")(x, ts, y))
     monkeypatch.delenv("DSG_FFN_SPLIT")
     assert 0 < rel_l2(out, old) < TOL_FWD["bf16"]
+
+
+def test_bf16w2_guidance_masks_and_lanes(gpu, golden_dir):
+    """bf16w2 beyond the plain loop: fused classifier-free guidance (k_gemm_cfg with two-register weight fragments and hi + lo LayerNorm rows,
+    two passes over them) vs the oracle with two evaluations per step; key masks / unconditional rows at the tiny dims vs the reference
+    goldens; four lanes x batch 2 (`generate_clips_streams`, TILE on four queues) == the lane alone."""
+    import torch
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    from diffusestylegesture_amd.model import ClassifierFreeSampleModel
+    from diffusestylegesture_amd.sample import generate_clip, generate_clips_streams
+    from oracle import sampler
+    from oracle.mdm import MDMOracle
+    from oracle.schedule import OracleDiffusion
+    gt = np.load(os.path.join(golden_dir, "gt_tiny_zeggs.npz"))
+    m = _model(C.TINY, "bf16w2", max_batch=4, wseed=int(gt["wseed"]))
+    y = synth_window_inputs(C.TINY, 2, window=2, seed_pose_scale=0.3)
+    x = np.random.RandomState(99).randn(2, C.TINY.njoints, 1, C.TINY.n_poses).astype(np.float32)
+    sc = np.array([2.5, 0.5], np.float32)
+    want = gt["fwd_uncond"] + sc.reshape(-1, 1, 1, 1) * (gt["fwd_allones"] - gt["fwd_uncond"])
+    e = rel_l2(ClassifierFreeSampleModel(m)(x, np.array([998, 17]), dict(y, scale=sc)), want)
+    print(f"bf16w2 guidance forward (tiny) vs the goldens: {e:.2e}")
+    assert e < 3e-3, e
+    cfg = C.ZEGGS
+    mz = _model(cfg, "bf16w2", max_batch=2)
+    ref = MDMOracle(synth_state_dict(cfg, 20240), cfg)
+    yz = synth_window_inputs(cfg, 1, window=1, seed_pose_scale=0.3)
+    shape = (1, cfg.njoints, 1, cfg.n_poses)
+    yy = dict(yz, scale=np.array([2.5], np.float32))
+    d = create_gaussian_diffusion().manual_seed(3, 9)
+    s = d.p_sample_loop(ClassifierFreeSampleModel(mz), shape, clip_denoised=False, model_kwargs={"y": yy}, skip_timesteps=990)
+    r = sampler.p_sample_loop(OracleDiffusion(), sampler.CFGModel(ref), shape, sampler.philox_noise_fn(shape, 3, 9), {"y": yy}, skip_timesteps=990)
+    e = rel_l2(s, r)
+    print(f"bf16w2 guided 10-step chain (ZEGGS, scale 2.5) vs the oracle: {e:.2e}")
+    assert e < 3e-3, e
+    NL, B = 4, 2
+    ml = _model(cfg, "bf16w2", max_batch=B)
+    lanes = [ml] + [ml.clone() for _ in range(NL - 1)]
+    feats = [[torch.from_numpy(synth_window_inputs(cfg, B, window=w, clips=[2 * ln, 2 * ln + 1])["audio"]).cuda() for w in range(2)] for ln in range(NL)]
+    dd = create_gaussian_diffusion()
+    got = generate_clips_streams(lanes, dd, feats, [1, 0, 0, 0, 0, 0], seed=11, skip_timesteps=980, stream_ids=[5, 6, 7, 8])
+    assert all(ln.last_kernel_set() == "tile" and ln.last_sample_path() == "aql" for ln in lanes) and np.isfinite(got).all()
+    alone = generate_clip(lanes[2], dd, feats[2], [1, 0, 0, 0, 0, 0], seed=11, smoothing=True, stream_id=7, skip_timesteps=980)
+    assert np.array_equal(got[2 * B:3 * B], alone)
