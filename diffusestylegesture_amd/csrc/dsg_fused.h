@@ -42,7 +42,7 @@ __device__ __forceinline__ void inloc_body(const InLocArgs& g) {
     constexpr int NSI = (W * 32 + 255) / 256, NP2 = W * half, NPO = (NP2 + 255) / 256;
     constexpr int NL = HD >= 16 ? HD / 16 : 1;                 // 16-col tiles covering the head
     __shared__ __attribute__((aligned(16))) float red[4][2][NL][64][4];      // per-wave partial accumulators
-    __shared__ float rot[W2][HD + 1];
+    __shared__ __attribute__((aligned(16))) float rot[W2][HD + 4];
     __shared__ float sc[W][W2 + 2];
     const int h = (int)blockIdx.x, w = blockIdx.y, b = blockIdx.z;            // grid (local heads, windows, batch [+1 bookkeeping])
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;

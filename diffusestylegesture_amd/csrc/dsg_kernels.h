@@ -958,7 +958,7 @@ struct LocArgs {
 // per (query, key) pair forms the masked score, the 32 lanes of a query row reduce max / sum with shuffles; phase B:
 // one thread per (query, dim pair) forms the attention output and applies the second rotary (position + 1).
 template <class P, int HD, int W>
-__device__ __forceinline__ void local_attn_tail(const LocArgs& a, float (&rot)[2 * W][HD + 1], float (&sc)[W][2 * W + 2],
+__device__ __forceinline__ void local_attn_tail(const LocArgs& a, float (&rot)[2 * W][HD + 4], float (&sc)[W][2 * W + 2],
                                                 int b, int w, int h, const bool (&keep)[(W * 32 + 255) / 256],
                                                 const float (&c2)[(W * (HD / 2) + 255) / 256],
                                                 const float (&s2)[(W * (HD / 2) + 255) / 256]) {
@@ -975,9 +975,17 @@ __device__ __forceinline__ void local_attn_tail(const LocArgs& a, float (&rot)[2
         const bool inq = q < W, valid = inq && j < W2;
         float sv = -DSG_FLT_MAX;
         if (valid) {
+            // (round 5: 16-byte LDS reads -- the rows are 16-byte aligned now, pitch HD + 4 -- a quarter of the LDS instructions of the 4-byte loop;
+            //  the products are added in the same order e = 0 .. HD - 1.  The same treatment of the P V loop -- 4 dims per thread, a quarter of the
+            //  threads -- was SLOWER: k_loc 13.3 -> 15.6 us at 64 clips)
             float d = 0.f;
-#pragma unroll 8
-            for (int e = 0; e < HD; ++e) d += rot[W + q][e] * rot[j][e];
+            const f32x4* qa = (const f32x4*)&rot[W + q][0];
+            const f32x4* kb = (const f32x4*)&rot[j][0];
+#pragma unroll
+            for (int c = 0; c < HD / 4; ++c) {
+                const f32x4 va = qa[c], vb = kb[c];
+                d += va[0] * vb[0]; d += va[1] * vb[1]; d += va[2] * vb[2]; d += va[3] * vb[3];
+            }
             const int fq = w * W + q, fk = f0 + j;
             const bool masked = ((fk >= 0) && (fq < fk)) || !keep[i];   // causal | key mask (pads are masked keys)
             sv = masked ? -DSG_FLT_MAX : d * scale;
@@ -1031,7 +1039,7 @@ __device__ __forceinline__ void loc_body(const LocArgs& a, int h, int w, int b) 
     typedef typename P::elem elem;
     constexpr int W2 = 2 * W, half = HD / 2, NP1 = W2 * half, NPI = (NP1 + 255) / 256;
     constexpr int NSI = (W * 32 + 255) / 256, NP2 = W * half, NPO = (NP2 + 255) / 256, MAXKS = 9;
-    __shared__ float rot[W2][HD + 1];
+    __shared__ __attribute__((aligned(16))) float rot[W2][HD + 4];
     __shared__ float sc[W][W2 + 2];
     const int tid = threadIdx.x;
     const int* tp = a.ctl ? &a.ctl->tA : a.t_arr + b;      // select the ADDRESS, then one unconditional load
