@@ -73,11 +73,14 @@ enum {
                                token rows, BLOCK from there, STREAM from 2000 */
     DSG_KSET_LATENCY = 1,   /* fused redundant-compute kernels, 2 + 3L dispatches: one clip in flight */
     DSG_KSET_TILE = 2,      /* one 16 x 16 MFMA tile per wave: small batches */
-    DSG_KSET_BLOCK = 3,     /* 32-row block GEMMs + fused attention/out_proj/LayerNorm: large batches, several lanes */
+    DSG_KSET_BLOCK = 3,     /* 32-row block GEMMs + fused attention/out_proj/LayerNorm: large batches, several lanes.  ABI 320 (bf16, ZEGGS / tiny
+                               widths): per layer k_clip_attn (per (clip, head): Q / K / V slices in LDS + attention) + the feed-forward half split
+                               over ff with out_proj + LayerNorm1 as its prologue + the slab sum / LayerNorm2 pass: 3 + 3L dispatches; the DSG+
+                               widths and fp32 get the ff-split behind k_attn_op_w */
     DSG_KSET_STREAM = 4     /* weight-stationary persistent GEMMs (32x32x16 MFMA, global->LDS staging, 64-row blocks) for the pose
-                               embedding, QKV and the pose head; linear1 + GELU + linear2 + residual + LayerNorm2 of a layer as one
-                               kernel (3 + 3L dispatches per step): >= 2000 token rows (23 ZEGGS clips) in one lane, >= 1000 rows
-                               (12 clips) per lane with several lanes.  bf16, latent_dim 128 / 256, 4 heads -- the ZEGGS model;
+                               embedding and the pose head; per layer k_clip_attn + ONE feed-forward kernel (out_proj + LayerNorm1 as its
+                               prologue, linear1 + GELU + linear2 + residual + LayerNorm2; ABI 320: 3 + 2L dispatches per step): >= 2000
+                               token rows (23 ZEGGS clips) in one lane, >= 850 rows (10 clips) per lane with several lanes.  bf16, latent_dim 128 / 256, 4 heads -- the ZEGGS model;
                                DSG_E_NOT_IMPLEMENTED elsewhere */
 };
 enum { DSG_MODE_DDPM = 0, DSG_MODE_DDIM = 1 };
