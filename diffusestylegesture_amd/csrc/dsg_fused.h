@@ -1180,7 +1180,7 @@ __device__ __forceinline__ void clip_proj_tile(const f32x4 (&wf)[CW][KD], const 
 }
 
 template <class P, int DT, int NKT>      // D = 64 DT, H = 4, hd = 16 DT, Tp = 16 NKT, NKT waves
-__global__ __launch_bounds__(64 * NKT) void k_clip_attn(const ClipAttnArgs g) {
+__global__ __launch_bounds__(64 * NKT, 2) void k_clip_attn(const ClipAttnArgs g) {
     DSG_TL_SCOPE();
     typedef typename P::elem elem;
     constexpr int ES = (int)sizeof(elem);
@@ -1191,11 +1191,18 @@ __global__ __launch_bounds__(64 * NKT) void k_clip_attn(const ClipAttnArgs g) {
     constexpr int CT = 3 * ND, CW = CT / NW;         // projection column tiles of the head, per wave
     static_assert(CT % NW == 0 && HD % P::KB == 0, "shape");
     static_assert(P::E == 4 || (NKT % 2) == 0, "bf16 pairs key tiles");
-    // LDS: the clip's rows as A fragments [NKT][KD]; Q, K [NKT][KDH]; V^T [ND][NVF] (1 KB fragments)
+    // LDS: the clip's rows as A fragments [NKT][KD]; Q, K [NKT][KDH]; V^T [ND][NVF] (1 KB fragments).  V^T takes the place of the rows once
+    // every wave is done projecting (the V tiles wait in registers, already rounded: 2 VGPRs each): 72 KB instead of 84 at the ZEGGS
+    // widths, i.e. TWO workgroups per CU -- with several lanes in flight (1024 workgroups at 4 x 64 clips) the load -> project -> attend
+    // chain of one workgroup runs under the other's
     __shared__ __attribute__((aligned(16))) f32x4 xs[NKT * KD][64];
     __shared__ __attribute__((aligned(16))) f32x4 qs[NKT * KDH][64];
     __shared__ __attribute__((aligned(16))) f32x4 ks[NKT * KDH][64];
-    __shared__ __attribute__((aligned(16))) f32x4 vs[ND * NVF][64];
+    f32x4 (* const vs)[64] = xs;
+    static_assert(ND * NVF <= NKT * KD, "V^T fits in the retired rows");
+    static_assert(ES == 2, "the parked V tiles are bf16 quads");
+    typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+    bf16x4v vkeep[NKT][CW];
     preload_kernargs(g);
     const int h = blockIdx.x, b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
@@ -1257,10 +1264,16 @@ __global__ __launch_bounds__(64 * NKT) void k_clip_attn(const ClipAttnArgs g) {
                 f32x4 y;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] = acc[j][e] + pbs[j];
-                P::store4((elem*)&vs[0][0] + vt_off<P>(d0[j] + lr, rt * 16 + 4 * lg, NVF), y);
+                vkeep[rt][j] = __builtin_convertvector(y, bf16x4v);      // (P::store4's rounding)
             }
         }
     }
+    DSG_LDS_BARRIER();                                            // every wave is done with the rows: V^T moves in
+#pragma unroll
+    for (int rt = 0; rt < NKT; ++rt)
+#pragma unroll
+        for (int j = 0; j < CW; ++j)
+            if (which[j] == 2) *(bf16x4v*)((elem*)&vs[0][0] + vt_off<P>(d0[j] + lr, rt * 16 + 4 * lg, NVF)) = vkeep[rt][j];
     DSG_LDS_BARRIER();
     // ---- (2) attention of query tile `wave` (k_attn on LDS operands)
     const int qt = wave;
