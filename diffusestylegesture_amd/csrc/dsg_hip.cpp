@@ -183,6 +183,7 @@ struct dsg_handle {
     int env_ffn_rt4 = -1;                // DSG_FFN_RT4=<rows>: k_ffn on 64-row blocks from that many token rows at any lane count (0: never)
     int env_ffn_split = -1;              // DSG_FFN_SPLIT=0: linear1 + linear2 + LayerNorm-on-read instead of k_ffn_part + k_ffn_ln (BLOCK)
     int env_attn_op2 = -1;               // DSG_ATTN_OP2=0|1: never / always the two-query-tile attention kernel (STREAM)
+    int env_ws_out_one = -1;             // DSG_WS_OUT_ONE=0: the STREAM pose head as persistent row-block groups (2 workgroups per CU) instead of one workgroup per row block (3 per CU)
     int env_clip_attn = -1;              // DSG_CLIP_ATTN=0: QKV GEMM + k_attn_op instead of k_clip_attn + k_ffn_ln (BLOCK; differs in the last bits)
     int* st_tmodel = nullptr; float* st_c[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int st_cap = 0, n_run = 1;
@@ -507,6 +508,7 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     if (const char* e = getenv("DSG_FFN_SPLIT")) h->env_ffn_split = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("DSG_ATTN_OP2")) h->env_attn_op2 = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("DSG_CLIP_ATTN")) h->env_clip_attn = atoi(e) != 0 ? 1 : 0;
+    if (const char* e = getenv("DSG_WS_OUT_ONE")) h->env_ws_out_one = atoi(e) != 0 ? 1 : 0;
     *out = h;
 
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -1199,8 +1201,16 @@ static int launch_ws(dsg_handle* h, GemmArgs g) {
     if (g.NT % 8) return fail(DSG_E_INVALID, "k_ws: N must be a multiple of 128");
     const int P = g.NT / 8, MB = cdiv(g.M, 64);
     g.ws_G = ws_groups(P, MB, 2);
-    const dim3 grid(ws_grid_x(P, g.ws_G) + (EPI == EPI_OUT ? 8 : 0));      // EPI_OUT: + the bookkeeping workgroup (one XCD round)
     const int K = g.KBtot * 32;
+    if constexpr (EPI == EPI_OUT) {
+        if (h->env_ws_out_one != 0) {      // (round 5; DSG_WS_OUT_ONE=0: the persistent row-block groups of rounds 3-4, bit-identical)
+            g.ws_G = rup(MB, 8);
+            const dim3 grid1(ws_grid_x(P, g.ws_G) + 8);
+            if (K == 256) return step_launch<&k_ws<EPI, 16, true>>(h, grid1, dim3(256), g);
+            if (K == 128) return step_launch<&k_ws<EPI, 8, true>>(h, grid1, dim3(256), g);
+        }
+    }
+    const dim3 grid(ws_grid_x(P, g.ws_G) + (EPI == EPI_OUT ? 8 : 0));      // EPI_OUT: + the bookkeeping workgroup (one XCD round)
     if (K == 256) return step_launch<&k_ws<EPI, 16>>(h, grid, dim3(256), g);
     if (K == 128) return step_launch<&k_ws<EPI, 8>>(h, grid, dim3(256), g);
     return fail(DSG_E_NOT_IMPLEMENTED, "k_ws: K must be 128 or 256");

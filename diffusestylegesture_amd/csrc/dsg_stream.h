@@ -117,13 +117,17 @@ __global__ __launch_bounds__(256) void k_ln_frag(const GemmArgs g) {
 //             for V^T -- is a per-workgroup scalar branch OUTSIDE the MFMA loop; v_mfma ignores EXEC, a per-MFMA select compiles into a
 //             branch around every MFMA)
 //   EPI_OUT   the pose head + sampler update (8 extra workgroups: the first one does the step bookkeeping, see StepCtl)
+//             Round 5 (ONE): a workgroup per (panel, row block) with ONE activation buffer -- 32 KB of LDS and 141 VGPRs, three workgroups per
+//             CU instead of two.  Alone the kernel does not move (30.5 vs 30.6 us at 64 clips: neither the x_t round trip, nor the noise
+//             chain's place, nor the 2-vs-1 block imbalance of the persistent groups is its bound -- experiments/README.md); with four
+//             lanes in flight the extra residency is worth 2 % of the step (4 x 64 clips 25.7 k -> 26.3 k frames/s, profiles/r05_x_*)
 // ---------------------------------------------------------------------------------------------------------
 // bytes of LDS staging the epilogue of k_ws<EPI> needs per row block of BM rows
 __host__ __device__ constexpr int ws_stage_bytes(int epi, int bm) {
     return epi == EPI_QKV ? 128 * (bm + 4) * 2 : (epi == EPI_OUT ? 4 * 32 * 36 * 4 : 0);
 }
-template <int EPI, int KD16, bool SW>       // SW: D[feature][token] (Q / K, linear1, pose head); !SW: D[token][feature] (V^T)
-__device__ __forceinline__ void ws_body(const GemmArgs& g, const WsId id, char* lds) {
+template <int EPI, int KD16, bool SW, bool ONE = false>       // SW: D[feature][token] (Q / K, linear1, pose head); !SW: D[token][feature] (V^T)
+__device__ __forceinline__ void ws_body(const GemmArgs& g, const WsId id, char* lds) {     // ONE: one row block per workgroup (G >= MB), one buffer
     typedef PBF16 P;
     constexpr int K = 16 * KD16, KB = K / 32, BM = 64;
     constexpr int ABYTES = BM * K * 2;
@@ -132,6 +136,7 @@ __device__ __forceinline__ void ws_body(const GemmArgs& g, const WsId id, char* 
     // round-3 advisor: at tiny dims with more than one block per workgroup the stage ran into the buffer being prefetched)
     constexpr int STAGE = ws_stage_bytes(EPI, BM);
     constexpr bool STAGE_IN_A = STAGE <= ABYTES;
+    constexpr int NBUF = ONE ? 1 : 2;
     const int G = g.ws_G, MB = (g.M + BM - 1) / BM;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -182,7 +187,7 @@ __device__ __forceinline__ void ws_body(const GemmArgs& g, const WsId id, char* 
         const int m0 = mb * BM;
         glds_wait();
         DSG_LDS_BARRIER();             // the block has landed for every wave; every wave is done with the other buffer
-        if (mb + G < MB) issue_a(mb + G, cur ^ 1);
+        if constexpr (!ONE) { if (mb + G < MB) issue_a(mb + G, cur ^ 1); }
         if constexpr (W_PER_BLOCK) {
             int zero = 0;
 #ifndef DSG_EMU
@@ -210,7 +215,7 @@ __device__ __forceinline__ void ws_body(const GemmArgs& g, const WsId id, char* 
             // ---- V^T: the block goes through the retired activation buffer and out in aligned token groups (vt_store_block)
             constexpr int SP = BM + 4;                             // 136-byte feature pitch: 8-byte aligned quads
             typedef typename P::elem elem;
-            elem* stage = (elem*)(STAGE_IN_A ? lds + cur * ABYTES : lds + 2 * ABYTES);
+            elem* stage = (elem*)(STAGE_IN_A ? lds + cur * ABYTES : lds + NBUF * ABYTES);
             static_assert(128 * SP * 2 <= (STAGE_IN_A ? ABYTES : STAGE), "V^T stage");
             DSG_LDS_BARRIER();                                     // every wave is done reading the activation block
 #pragma unroll
@@ -234,7 +239,7 @@ __device__ __forceinline__ void ws_body(const GemmArgs& g, const WsId id, char* 
             //      the retired activation buffer (LDS operations of a wave execute in order: no barrier between its write and read) so
             //      that 8 lanes cover 128 contiguous bytes of one token; the epilogue arithmetic is position-based (gemm_epilogue_tile).
             constexpr int TP = 36;                                 // floats per token: 144-byte pitch, conflict-free both ways
-            float* st = (float*)(STAGE_IN_A ? lds + cur * ABYTES : lds + 2 * ABYTES) + wave * (32 * TP);
+            float* st = (float*)(STAGE_IN_A ? lds + cur * ABYTES : lds + NBUF * ABYTES) + wave * (32 * TP);
             static_assert(4 * 32 * TP * 4 <= (STAGE_IN_A ? ABYTES : STAGE), "pose-head stage");
             DSG_LDS_BARRIER();                                     // every wave is done reading the activation block
             const int tok = lane >> 3, quad = lane & 7;
@@ -288,15 +293,16 @@ __device__ __forceinline__ void ws_body(const GemmArgs& g, const WsId id, char* 
     }
 }
 
-template <int EPI, int KD16>
-__global__ __launch_bounds__(256, 2) void k_ws(const GemmArgs g) {
+template <int EPI, int KD16, bool ONE = false>      // ONE (pose head): a workgroup per (panel, row block), one activation buffer, three workgroups per CU
+__global__ __launch_bounds__(256, ONE ? 3 : 2) void k_ws(const GemmArgs g) {
     DSG_TL_SCOPE();
     typedef PBF16 P;
     constexpr int K = 16 * KD16, BM = 64;
     static_assert(KD16 % 4 == 0 && KD16 <= 16, "K = 64, 128, 192 or 256");
     static_assert(EPI == EPI_GELU || EPI == EPI_QKV || EPI == EPI_OUT, "GEMMs of the step with K = D");
     constexpr int ABYTES = BM * K * 2, STAGE = ws_stage_bytes(EPI, BM);
-    __shared__ __attribute__((aligned(16))) char lds[2 * ABYTES + (STAGE <= ABYTES ? 0 : STAGE)];
+    static_assert(!ONE || EPI == EPI_OUT, "ONE belongs to the pose head");
+    __shared__ __attribute__((aligned(16))) char lds[(ONE ? 1 : 2) * ABYTES + (STAGE <= ABYTES ? 0 : STAGE)];
     preload_kernargs(g);
     const int n_panels = g.NT >> 3;
     const WsId id = ws_id(n_panels, g.ws_G);
@@ -313,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void k_ws(const GemmArgs g) {
         if (id.panel * 128 >= 2 * (g.H * g.hd)) ws_body<EPI, KD16, false>(g, id, lds);
         else ws_body<EPI, KD16, true>(g, id, lds);
     } else {
-        ws_body<EPI, KD16, true>(g, id, lds);
+        ws_body<EPI, KD16, true, ONE>(g, id, lds);
     }
 }
 
