@@ -1371,8 +1371,8 @@ struct FfnArgs {
     float* X1;              // OP on 64-row blocks (no LDS left to park them): the fp32 LayerNorm1 rows, written by the prologue and read back after phase 1
 };
 
-template <class P, int DT, int FT, int RT, int NW, int LA = 2, bool LATE_R = false, bool OP = false>      // D = 64 DT, ff = 64 FT, RT row tiles per workgroup, NW waves, LA tiles / 2 LA k-blocks of look-ahead
-__global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {
+template <class P, int DT, int FT, int RT, int NW, int LA = 2, bool LATE_R = false, bool OP = false, int RING = 0>      // D = 64 DT, ff = 64 FT, RT row tiles per workgroup, NW waves, LA tiles / 2 LA k-blocks of look-ahead
+__global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING > 0: the weights of both phases as ONE stream through a rolling ring of RING fragments (see below)
     DSG_TL_SCOPE();
     typedef typename P::elem elem;
     constexpr int ES = (int)sizeof(elem);
@@ -1448,6 +1448,23 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {
             pb1[buf][j] = *(const f32x4*)(g.b1 + nt * 16 + 4 * lg);
         }
     };
+    // RING (round 5): a wave's weight fragments of phase 1 (FW tiles x KD) and phase 2 (KF k-blocks x DW tiles) are ONE sequence; fragment i lives in
+    // slot i % RING and slot s is refilled with fragment i + RING right after the MFMAs that read fragment i are issued.  The double-buffered groups of
+    // the plain form ask for a group, compute the previous one, then WAIT for the group with nothing else in flight: a launch is (groups) x (latency +
+    // transfer); the ring has RING - 1 .. RING fragments of every wave in flight at every moment, across tiles, chunks and the phase switch, in the same
+    // registers.  Same MFMAs on the same operands, every accumulation chain in the same k order: bit-identical.
+    // Measured (profiles/r05_s_*, one box each): 32-row form, 32 slots: 19.25 -> 18.25 us per launch at 64 clips, 1 x 64 clips 282.7 -> 276.0 us per step, 4 x 16 clips
+    // 17.96 k -> 18.98 k frames/s, 4 x 32: 23.86 k -> 24.30 k; 64-row form, 12 slots (16: 32 B of scratch): 4 x 64 clips 26.2-26.3 k -> 26.6-26.9 k.  A whole chunk of
+    // look-ahead instead (hidden in 128-column chunks, the A operand in LDS: 33.0 vs 30.5 us per 64-row launch) and 4 waves of 512 registers (36.4) were slower:
+    // the kernel is not waiting for bytes in flight alone -- what the ring removes is the drain at every group boundary.
+    constexpr int N1 = FW * KD, N2 = KF * DW, NRING = RING > 0 ? RING : 1;
+    static_assert(RING == 0 || (OP && RING <= N1), "ring");
+    f32x4 ring[NRING];
+    auto ring_ptr = [&](int i) -> const f32x4* {
+        if (i < N1) return w1 + ((size_t)(wave * FW + i / KD) * KD + i % KD) * 64;
+        const int k = (i - N1) / DW, t = (i - N1) % DW;
+        return w2 + ((size_t)(wave * DW + t) * KF + k) * 64;
+    };
     if constexpr (!OP) load1(0, 0);
     f32x4 pr[RT][DW];
     // (row index of this lane in row tile rt, clamped to a valid row; recomputed where it is used: four 64-bit offsets kept live across
@@ -1508,7 +1525,12 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {
                 DSG_LOADS_ISSUED();
             }
         }
-        load1(0, 0);                                          // (W_o and the attention rows are dead: the first W1 tiles arrive behind LayerNorm1)
+        if constexpr (RING > 0) {
+#pragma unroll
+            for (int i = 0; i < RING; ++i) ring[i] = *ring_ptr(i);      // the ring's first fill arrives behind LayerNorm1
+        } else {
+            load1(0, 0);                                      // (W_o and the attention rows are dead: the first W1 tiles arrive behind LayerNorm1)
+        }
         DSG_LOADS_ISSUED();
         DSG_LDS_BARRIER();                                    // vecs1 is in place
 #pragma unroll
@@ -1569,72 +1591,136 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {
     } else {
         DSG_LOADS_ISSUED();
     }
-    // ---- phase 1: hidden tiles of this wave, LA at a time, the next group's fragments in flight
-#pragma unroll
-    for (int tp = 0; tp < FW / LA; ++tp) {
-        if (tp + 1 < FW / LA) { load1((tp + 1) & 1, tp + 1); DSG_LOADS_ISSUED(); }
-#pragma unroll
-        for (int j = 0; j < LA; ++j) {
-            const int nt = wave * FW + LA * tp + j;
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kb = 0; kb < KD; ++kb) c = P::mma(wb1[tp & 1][j][kb], af[rt][kb], c);      // D[n 4lg+r][row lr]
-                f32x4 y;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = gelu_erf<P>(c[e] + pb1[tp & 1][j][e]);
-                P::store4((elem*)(hid + (rt * 16 + lr) * HP) + nt * 16 + 4 * lg, y);
-            }
-        }
-    }
-    // ---- phase 2: first W2 chunk requested before the barrier
-    f32x4 wb2[2][KC][DW];
-    auto load2 = [&](int buf, int c) {
-#pragma unroll
-        for (int k = 0; k < KC; ++k)
-#pragma unroll
-            for (int t = 0; t < DW; ++t) wb2[buf][k][t] = w2[((size_t)(wave * DW + t) * KF + c * KC + k) * 64];
-    };
-    load2(0, 0);
-    if constexpr ((LATE_R && !OP) || BIG) {      // (8 waves: the residual rows are requested only now -- the register budget of phase 1)
-        int lr_late = lr;
-        if constexpr (BIG) {
-#ifndef DSG_EMU
-            asm volatile("" : "+v"(lr_late));      // opaque: the row offsets are RE-computed here -- kept live across phase 1 they were what spilled
-#endif
-        }
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const unsigned mr = BIG ? (unsigned)(m0 + rt * 16 + lr_late) : (unsigned)min(m0 + rt * 16 + lr_late, g.M - 1);
-#pragma unroll
-            for (int t = 0; t < DW; ++t) pr[rt][t] = lda16<P>(BIG ? (const float*)g.X1 : g.R, (size_t)((mr * D + (wave * DW + t) * 16 + 4 * lg) * 4u));
-        }
-    }
-    DSG_LOADS_ISSUED();
-    if constexpr (!OP) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int e = tid + NT * i;
-            if (e < 3 * D / 4) *(f32x4*)(&vecs[0][0] + e * 4) = vload[i];
-        }
-    }
-    DSG_LDS_BARRIER();
     f32x4 acc[RT][DW];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int t = 0; t < DW; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (RING > 0) {
+        static_assert(OP, "ring: the forms with the prologue");
+        // ---- phase 1 on the ring: tile j = fragments j KD .. j KD + KD - 1; the row tiles' chains advance side by side (independent MFMAs back to back)
+        f32x4 pbr[2];
+        pbr[0] = *(const f32x4*)(g.b1 + (wave * FW) * 16 + 4 * lg);
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        if (c + 1 < NC) { load2((c + 1) & 1, c + 1); DSG_LOADS_ISSUED(); }
+        for (int j = 0; j < FW; ++j) {
+            const int nt = wave * FW + j;
+            if (j + 1 < FW) pbr[(j + 1) & 1] = *(const f32x4*)(g.b1 + (nt + 1) * 16 + 4 * lg);
+            f32x4 c[RT];
 #pragma unroll
-        for (int k = 0; k < KC; ++k) {
+            for (int rt = 0; rt < RT; ++rt) c[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < KD; ++kb) {
+                const int i = j * KD + kb;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) c[rt] = P::mma(ring[i % NRING], af[rt][kb], c[rt]);      // D[n 4lg+r][row lr]
+                if (i + RING < N1 + N2) ring[i % NRING] = *ring_ptr(i + RING);
+                DSG_LOADS_ISSUED();
+            }
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                const f32x4 a = *(const f32x4*)(hid + (rt * 16 + lr) * HP + ((c * KC + k) * P::KB + P::E * lg) * ES);
+                f32x4 y;
 #pragma unroll
-                for (int t = 0; t < DW; ++t) acc[rt][t] = P::mma(wb2[c & 1][k][t], a, acc[rt][t]);
+                for (int e = 0; e < 4; ++e) y[e] = gelu_erf<P>(c[rt][e] + pbr[j & 1][e]);
+                P::store4((elem*)(hid + (rt * 16 + lr) * HP) + nt * 16 + 4 * lg, y);
+            }
+        }
+        if constexpr (BIG) {               // (64-row blocks: the fp32 LayerNorm1 rows come back from the padded X1 rows, as in the plain form)
+            int lr_late = lr;
+#ifndef DSG_EMU
+            asm volatile("" : "+v"(lr_late));
+#endif
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int t = 0; t < DW; ++t) pr[rt][t] = lda16<P>((const float*)g.X1, (size_t)(((unsigned)(m0 + rt * 16 + lr_late) * D + (wave * DW + t) * 16 + 4 * lg) * 4u));
+        }
+        DSG_LDS_BARRIER();                 // `hidden` is complete (the ring keeps streaming: the barrier does not wait for vector memory)
+        // ---- phase 2 on the ring: k-block k = fragments N1 + k DW .. + DW - 1
+        constexpr int AB = RT <= 2 ? 2 : 1;      // (32-row blocks: the next k-block's `hidden` fragments are read from LDS one step ahead)
+        f32x4 a[AB][RT];
+        if constexpr (AB == 2) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) a[0][rt] = *(const f32x4*)(hid + (rt * 16 + lr) * HP + (P::E * lg) * ES);
+        }
+#pragma unroll
+        for (int k = 0; k < KF; ++k) {
+            if (AB == 1 || k + 1 < KF) {
+                const int kn = AB == 2 ? k + 1 : k;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) a[kn % AB][rt] = *(const f32x4*)(hid + (rt * 16 + lr) * HP + (kn * P::KB + P::E * lg) * ES);
+            }
+#pragma unroll
+            for (int t = 0; t < DW; ++t) {
+                const int i = N1 + k * DW + t;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt][t] = P::mma(ring[i % NRING], a[k % AB][rt], acc[rt][t]);
+                if (i + RING < N1 + N2) ring[i % NRING] = *ring_ptr(i + RING);
+            }
+            DSG_LOADS_ISSUED();
+        }
+    } else {
+        // ---- phase 1: hidden tiles of this wave, LA at a time, the next group's fragments in flight
+    #pragma unroll
+        for (int tp = 0; tp < FW / LA; ++tp) {
+            if (tp + 1 < FW / LA) { load1((tp + 1) & 1, tp + 1); DSG_LOADS_ISSUED(); }
+    #pragma unroll
+            for (int j = 0; j < LA; ++j) {
+                const int nt = wave * FW + LA * tp + j;
+    #pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+                    for (int kb = 0; kb < KD; ++kb) c = P::mma(wb1[tp & 1][j][kb], af[rt][kb], c);      // D[n 4lg+r][row lr]
+                    f32x4 y;
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = gelu_erf<P>(c[e] + pb1[tp & 1][j][e]);
+                    P::store4((elem*)(hid + (rt * 16 + lr) * HP) + nt * 16 + 4 * lg, y);
+                }
+            }
+        }
+        // ---- phase 2: first W2 chunk requested before the barrier
+        f32x4 wb2[2][KC][DW];
+        auto load2 = [&](int buf, int c) {
+    #pragma unroll
+            for (int k = 0; k < KC; ++k)
+    #pragma unroll
+                for (int t = 0; t < DW; ++t) wb2[buf][k][t] = w2[((size_t)(wave * DW + t) * KF + c * KC + k) * 64];
+        };
+        load2(0, 0);
+        if constexpr ((LATE_R && !OP) || BIG) {      // (8 waves: the residual rows are requested only now -- the register budget of phase 1)
+            int lr_late = lr;
+            if constexpr (BIG) {
+    #ifndef DSG_EMU
+                asm volatile("" : "+v"(lr_late));      // opaque: the row offsets are RE-computed here -- kept live across phase 1 they were what spilled
+    #endif
+            }
+    #pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const unsigned mr = BIG ? (unsigned)(m0 + rt * 16 + lr_late) : (unsigned)min(m0 + rt * 16 + lr_late, g.M - 1);
+    #pragma unroll
+                for (int t = 0; t < DW; ++t) pr[rt][t] = lda16<P>(BIG ? (const float*)g.X1 : g.R, (size_t)((mr * D + (wave * DW + t) * 16 + 4 * lg) * 4u));
+            }
+        }
+        DSG_LOADS_ISSUED();
+        if constexpr (!OP) {
+    #pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int e = tid + NT * i;
+                if (e < 3 * D / 4) *(f32x4*)(&vecs[0][0] + e * 4) = vload[i];
+            }
+        }
+        DSG_LDS_BARRIER();
+    #pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (c + 1 < NC) { load2((c + 1) & 1, c + 1); DSG_LOADS_ISSUED(); }
+    #pragma unroll
+            for (int k = 0; k < KC; ++k) {
+    #pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const f32x4 a = *(const f32x4*)(hid + (rt * 16 + lr) * HP + ((c * KC + k) * P::KB + P::E * lg) * ES);
+    #pragma unroll
+                    for (int t = 0; t < DW; ++t) acc[rt][t] = P::mma(wb2[c & 1][k][t], a, acc[rt][t]);
+                }
             }
         }
     }

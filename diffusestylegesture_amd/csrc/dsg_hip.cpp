@@ -184,6 +184,7 @@ struct dsg_handle {
     int env_ffn_split = -1;              // DSG_FFN_SPLIT=0: linear1 + linear2 + LayerNorm-on-read instead of k_ffn_part + k_ffn_ln (BLOCK)
     int env_attn_op2 = -1;               // DSG_ATTN_OP2=0|1: never / always the two-query-tile attention kernel (STREAM)
     int env_ws_out_one = -1;             // DSG_WS_OUT_ONE=0: the STREAM pose head as persistent row-block groups (2 workgroups per CU) instead of one workgroup per row block (3 per CU)
+    int env_ffn_ring = -1;               // DSG_FFN_RING=0: k_ffn<OP> with double-buffered weight groups (rounds 4-5) instead of one rolling ring of weight fragments (bit-identical; A/B and tests)
     int env_clip_attn = -1;              // DSG_CLIP_ATTN=0: QKV GEMM + k_attn_op instead of k_clip_attn + k_ffn_ln (BLOCK; differs in the last bits)
     int* st_tmodel = nullptr; float* st_c[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int st_cap = 0, n_run = 1;
@@ -508,6 +509,7 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     if (const char* e = getenv("DSG_FFN_SPLIT")) h->env_ffn_split = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("DSG_ATTN_OP2")) h->env_attn_op2 = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("DSG_CLIP_ATTN")) h->env_clip_attn = atoi(e) != 0 ? 1 : 0;
+    if (const char* e = getenv("DSG_FFN_RING")) h->env_ffn_ring = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("DSG_WS_OUT_ONE")) h->env_ws_out_one = atoi(e) != 0 ? 1 : 0;
     *out = h;
 
@@ -1490,7 +1492,9 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                 if constexpr (sizeof(typename P::elem) == 2) {
                     const dim3 grid(cdiv(MT, 2));
                     if (clip_l) {
-                        if (D == 256 && ks.ffn_rt4) CHK((step_launch<&k_ffn<P, 4, 16, 4, 8, 1, true, true>>(h, dim3(cdiv(MT, 4)), dim3(512), a)));
+                        if (D == 256 && ks.ffn_rt4 && h->env_ffn_ring != 0) CHK((step_launch<&k_ffn<P, 4, 16, 4, 8, 1, true, true, 12>>(h, dim3(cdiv(MT, 4)), dim3(512), a)));
+                        else if (D == 256 && ks.ffn_rt4) CHK((step_launch<&k_ffn<P, 4, 16, 4, 8, 1, true, true>>(h, dim3(cdiv(MT, 4)), dim3(512), a)));
+                        else if (D == 256 && h->env_ffn_ring != 0) CHK((step_launch<&k_ffn<P, 4, 16, 2, 8, 2, true, true, 32>>(h, grid, dim3(512), a)));
                         else if (D == 256) CHK((step_launch<&k_ffn<P, 4, 16, 2, 8, 2, true, true>>(h, grid, dim3(512), a)));
                         else CHK((step_launch<&k_ffn<P, 2, 2, 2, 4, 2, false, true>>(h, grid, dim3(256), a)));
                         continue;

@@ -338,8 +338,17 @@ def test_ffn_64_row_blocks_with_four_large_lanes_bit_identical(gpu, monkeypatch)
     a = np.asarray(_model(cfg, "bf16", max_batch=B).set_kernel_set("stream")(x, ts, y))
     monkeypatch.setenv("DSG_FFN_RT4", "1")
     b = np.asarray(_model(cfg, "bf16", max_batch=B).set_kernel_set("stream")(x, ts, y))
+    monkeypatch.setenv("DSG_FFN_RT4", "0")
+    monkeypatch.setenv("DSG_FFN_RING", "1")             # round 5: the 32-row kernel with its weights on one rolling ring of fragments ...
+    r1 = np.asarray(_model(cfg, "bf16", max_batch=B).set_kernel_set("stream")(x, ts, y))
+    monkeypatch.setenv("DSG_FFN_RING", "0")             # ... and on double-buffered groups (rounds 4-5)
+    r0 = np.asarray(_model(cfg, "bf16", max_batch=B).set_kernel_set("stream")(x, ts, y))
+    monkeypatch.setenv("DSG_FFN_RT4", "1")
+    monkeypatch.setenv("DSG_FFN_RING", "1")             # (64-row blocks on a 12-fragment ring)
+    r4 = np.asarray(_model(cfg, "bf16", max_batch=B).set_kernel_set("stream")(x, ts, y))
+    monkeypatch.delenv("DSG_FFN_RING")
     monkeypatch.delenv("DSG_FFN_RT4")
-    assert np.array_equal(a, b) and np.isfinite(a).all()
+    assert np.array_equal(a, b) and np.array_equal(a, r1) and np.array_equal(a, r0) and np.array_equal(a, r4) and np.isfinite(a).all()
     m.set_kernel_set("auto")
     lanes = [m] + [m.clone() for _ in range(NL - 1)]
     d = create_gaussian_diffusion()
