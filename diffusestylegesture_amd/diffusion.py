@@ -118,8 +118,14 @@ class DSGDiffusion:
 
     # ---- fused loops -----------------------------------------------------------------------------------------
     def _check_unsupported(self, denoised_fn, cond_fn, randomize_class, cond_fn_with_grad):
-        if denoised_fn is not None or cond_fn is not None or randomize_class or cond_fn_with_grad:
-            raise NotImplementedError("denoised_fn / cond_fn / randomize_class / cond_fn_with_grad are not supported")
+        """Sampler hooks (gaussian_diffusion.py:364-370, :428-441, :458-480).  `denoised_fn` and `cond_fn` are Python callables evaluated once
+        per step: a loop that carries one runs step by step in the generic loop (the denoiser through the library, the hook in torch, the update
+        kernels of the library) instead of as one fence-free chain inside the library -- returns True then.  `cond_fn_with_grad` needs autograd
+        through the denoiser and `randomize_class` a class-conditional model (`model.num_classes`: the MDM denoisers of this path have none,
+        the reference raises AttributeError there): both stay NotImplementedError."""
+        if randomize_class or cond_fn_with_grad:
+            raise NotImplementedError("randomize_class / cond_fn_with_grad are not supported")
+        return denoised_fn is not None or cond_fn is not None
 
     @staticmethod
     def _library_model(model, batch=None):
@@ -200,13 +206,13 @@ class DSGDiffusion:
                       model_kwargs=None, device=None, progress=False, skip_timesteps=0, init_image=None,
                       randomize_class=False, cond_fn_with_grad=False, dump_steps=None, const_noise=False,
                       *, step_noise=None, seed=None, draw_base=None):
-        self._check_unsupported(denoised_fn, cond_fn, randomize_class, cond_fn_with_grad)
-        inner, guided = self._library_model(model, shape[0])
+        hooks = self._check_unsupported(denoised_fn, cond_fn, randomize_class, cond_fn_with_grad)
+        inner, guided = (None, False) if hooks else self._library_model(model, shape[0])
         if inner is not None:
             return self._fused(L.MODE_DDPM, inner, guided, shape, noise, model_kwargs, skip_timesteps, init_image,
                                dump_steps, const_noise, 0.0, step_noise, seed, draw_base, clip_denoised)
         return self._generic_loop(False, model, shape, noise, model_kwargs, skip_timesteps, init_image, dump_steps,
-                                  const_noise, 0.0, device, clip_denoised)
+                                  const_noise, 0.0, device, clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn)
 
     PROGRESSIVE_CHUNK = 50      # steps per library call of the generator forms
 
@@ -219,21 +225,21 @@ class DSGDiffusion:
         stops the work.  Same samples, bit for bit, as the one-call loops: draw indices are those of the whole chain, reserved HERE,
         when the generator is created (round-4 advisor: a generator body runs at the first next(), so reserving them inside it let a
         loop started between creation and first use draw the same noise)."""
-        self._check_unsupported(denoised_fn, cond_fn, randomize_class, cond_fn_with_grad)
-        inner, guided = self._library_model(model, shape[0])
+        hooks = self._check_unsupported(denoised_fn, cond_fn, randomize_class, cond_fn_with_grad)
+        inner, guided = (None, False) if hooks else self._library_model(model, shape[0])
         n_run = self.num_timesteps - skip_timesteps
         draw0 = None
         if inner is not None:
             draw0 = self._draw
             self._draw += 1 + n_run                  # the generator owns these draw indices from the moment it is created
         return self._progressive_gen(ddim, model, inner, guided, shape, noise, clip_denoised, model_kwargs, device, skip_timesteps,
-                                     init_image, const_noise, eta, n_run, draw0)
+                                     init_image, const_noise, eta, n_run, draw0, denoised_fn, cond_fn)
 
     def _progressive_gen(self, ddim, model, inner, guided, shape, noise, clip_denoised, model_kwargs, device, skip_timesteps,
-                         init_image, const_noise, eta, n_run, draw0):
+                         init_image, const_noise, eta, n_run, draw0, denoised_fn=None, cond_fn=None):
         if inner is None:
             outs = self._generic_loop(ddim, model, shape, noise, model_kwargs, skip_timesteps, init_image, list(range(n_run)),
-                                      const_noise, eta, device, clip_denoised)
+                                      const_noise, eta, device, clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn)
             for o in outs:
                 yield {"sample": o}
             return
@@ -312,13 +318,13 @@ class DSGDiffusion:
             raise NotImplementedError()
         if const_noise:
             raise NotImplementedError()
-        self._check_unsupported(denoised_fn, cond_fn, randomize_class, cond_fn_with_grad)
-        inner, guided = self._library_model(model, shape[0])
+        hooks = self._check_unsupported(denoised_fn, cond_fn, randomize_class, cond_fn_with_grad)
+        inner, guided = (None, False) if hooks else self._library_model(model, shape[0])
         if inner is not None:
             return self._fused(L.MODE_DDIM, inner, guided, shape, noise, model_kwargs, skip_timesteps, init_image, None,
                                False, eta, step_noise, seed, draw_base, clip_denoised)
         return self._generic_loop(True, model, shape, noise, model_kwargs, skip_timesteps, init_image, None, False,
-                                  eta, device, clip_denoised)
+                                  eta, device, clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn)
 
     def last_step_time_us(self):
         """GPU time per denoising step of the last fused call (HIP events inside the library)."""
@@ -339,9 +345,12 @@ class DSGDiffusion:
         return np.full((B,), np.float32(getattr(self, name)[idx]), dtype=np.float32)
 
     def _generic_loop(self, ddim, model, shape, noise, model_kwargs, skip_timesteps, init_image, dump_steps,
-                      const_noise, eta, device, clip_denoised=False):
+                      const_noise, eta, device, clip_denoised=False, denoised_fn=None, cond_fn=None):
         """Any callable as the denoiser.  The noise is the framework's Philox stream (dsg_noise), draw for draw the one the
-        fused loop consumes -- a wrapped model keeps seed parity with the fused path and the oracle."""
+        fused loop consumes -- a wrapped model keeps seed parity with the fused path and the oracle.  `denoised_fn(x0)` is applied to the
+        prediction before the clamp (gaussian_diffusion.py:364-370); `cond_fn(x_t, t, **model_kwargs)` -- t the MODEL timesteps, as the wrapped
+        cond_fn of SpacedDiffusion sees them (respace.py:117-129) -- shifts the DDPM mean by posterior_variance * grad (condition_mean, :428-441)
+        and the DDIM eps by -sqrt(1 - alpha_bar) * grad (condition_score, :458-480)."""
         import torch
         lib = self._lib or L.default_library()
         if device is None:
@@ -377,8 +386,11 @@ class DSGDiffusion:
             t = torch.full((B,), i, device=device, dtype=torch.long)
             with torch.no_grad():
                 x0 = model(img, tmap[t], **(model_kwargs or {})).contiguous().float()
-            if clip_denoised:
-                x0 = x0.clamp(-1, 1)
+                if denoised_fn is not None:
+                    x0 = denoised_fn(x0).contiguous().float()
+                if clip_denoised:
+                    x0 = x0.clamp(-1, 1)
+                grad = None if cond_fn is None else cond_fn(img, tmap[t], **(model_kwargs or {})).float()
             eps = z()
             if const_noise:
                 eps = eps[[0]].repeat(B, 1, 1, 1)
@@ -391,9 +403,15 @@ class DSGDiffusion:
                 c3 = np.full((B,), sig, np.float32)
                 lib.check(lib.cdll.dsg_posterior_step(out.data_ptr(), x0.data_ptr(), img.data_ptr(), eps.data_ptr(),
                                                       c1.ctypes.data, c2.ctypes.data, c3.ctypes.data, B, per, stream))
+                if grad is not None:
+                    out = out + float(np.float32(self.posterior_variance[i])) * grad
             else:
                 ab, abp = np.float32(self.alphas_cumprod[i]), np.float32(self.alphas_cumprod_prev[i])
                 one = np.float32(1)
+                if grad is not None:
+                    rc, rm = float(np.float32(self.sqrt_recip_alphas_cumprod[i])), float(np.float32(self.sqrt_recipm1_alphas_cumprod[i]))
+                    e = (rc * img - x0) / rm - float(np.sqrt(one - ab)) * grad
+                    x0 = (rc * img - rm * e).contiguous()
                 sigma = np.float32(eta) * np.sqrt((one - abp) / (one - ab)) * np.sqrt(one - ab / abp)
                 coef = np.tile(np.array([np.float32(self.sqrt_recip_alphas_cumprod[i]),
                                          np.float32(self.sqrt_recipm1_alphas_cumprod[i]), np.sqrt(abp),

@@ -3,6 +3,8 @@
   * p_sample_loop / p_sample / p_mean_variance (START_X, FIXED_SMALL, clip_denoised=False)
         `main/diffusion/gaussian_diffusion.py:608-740`, `:506-558`, `:280-398`, `:256-278`
   * ddim_sample_loop / ddim_sample                  `:889-1003`, `:742-792`, `:417-421`
+  * the sampler hooks: denoised_fn (`:364-370`, before the clamp), cond_fn through condition_mean (`:428-441`, DDPM: mean + variance * grad)
+    and condition_score (`:458-480`, DDIM: eps - sqrt(1 - alpha_bar) * grad -> pred_xstart); pinned by tests/golden/g17_sampler_hooks_tiny.npz
   * q_sample (skip_timesteps / init_image start)    `:236-254`, `:706-713`
   * _extract_into_tensor: float64 table -> `.float()` (fp32) at use   `:1607-1620`
   * _WrappedModel timestep mapping                  `main/diffusion/respace.py:117-129`
@@ -25,7 +27,7 @@ def _f(a, i):
 
 
 def p_sample_loop(diff: OracleDiffusion, model, shape, noise_fn, model_kwargs, skip_timesteps=0,
-                  init_image=None, noise=None, const_noise=False, dump_steps=None, clip_denoised=False):
+                  init_image=None, noise=None, const_noise=False, dump_steps=None, clip_denoised=False, denoised_fn=None, cond_fn=None):
     t = diff.t
     img = noise_fn(0).astype(np.float32) if noise is None else np.asarray(noise, np.float32)
     if skip_timesteps and init_image is None:
@@ -39,9 +41,13 @@ def p_sample_loop(diff: OracleDiffusion, model, shape, noise_fn, model_kwargs, s
     for n, i in enumerate(indices):
         ts = np.full((shape[0],), diff.timestep_map[i], dtype=np.int64)
         x0 = model(img, ts, **model_kwargs).astype(np.float32)
+        if denoised_fn is not None:                     # gaussian_diffusion.py:364-366
+            x0 = np.asarray(denoised_fn(x0), np.float32)
         if clip_denoised:                               # gaussian_diffusion.py:377-379
             x0 = np.clip(x0, np.float32(-1), np.float32(1))
         mean = _f(t["posterior_mean_coef1"], i) * x0 + _f(t["posterior_mean_coef2"], i) * img
+        if cond_fn is not None:                         # condition_mean, gaussian_diffusion.py:428-441 (variance = posterior_variance: FIXED_SMALL)
+            mean = mean + _f(t["posterior_variance"], i) * np.asarray(cond_fn(img, ts, **model_kwargs), np.float32)
         eps = noise_fn(1 + n).astype(np.float32)
         if const_noise:
             eps = np.repeat(eps[[0]], shape[0], 0)
@@ -54,7 +60,7 @@ def p_sample_loop(diff: OracleDiffusion, model, shape, noise_fn, model_kwargs, s
 
 
 def ddim_sample_loop(diff: OracleDiffusion, model, shape, noise_fn, model_kwargs, eta=0.0,
-                     skip_timesteps=0, init_image=None, noise=None, clip_denoised=False):
+                     skip_timesteps=0, init_image=None, noise=None, clip_denoised=False, denoised_fn=None, cond_fn=None):
     t = diff.t
     img = noise_fn(0).astype(np.float32) if noise is None else np.asarray(noise, np.float32)
     if skip_timesteps and init_image is None:
@@ -69,9 +75,15 @@ def ddim_sample_loop(diff: OracleDiffusion, model, shape, noise_fn, model_kwargs
     for n, i in enumerate(indices):
         ts = np.full((shape[0],), diff.timestep_map[i], dtype=np.int64)
         x0 = model(img, ts, **model_kwargs).astype(np.float32)
+        if denoised_fn is not None:
+            x0 = np.asarray(denoised_fn(x0), np.float32)
         if clip_denoised:
             x0 = np.clip(x0, np.float32(-1), np.float32(1))
         eps = (_f(t["sqrt_recip_alphas_cumprod"], i) * img - x0) / _f(t["sqrt_recipm1_alphas_cumprod"], i)
+        if cond_fn is not None:                         # condition_score, gaussian_diffusion.py:458-480
+            eps = eps - np.sqrt(one - _f(t["alphas_cumprod"], i)) * np.asarray(cond_fn(img, ts, **model_kwargs), np.float32)
+            x0 = _f(t["sqrt_recip_alphas_cumprod"], i) * img - _f(t["sqrt_recipm1_alphas_cumprod"], i) * eps
+            eps = (_f(t["sqrt_recip_alphas_cumprod"], i) * img - x0) / _f(t["sqrt_recipm1_alphas_cumprod"], i)
         ab, abp = _f(t["alphas_cumprod"], i), _f(t["alphas_cumprod_prev"], i)
         sigma = eta * np.sqrt((one - abp) / (one - ab)) * np.sqrt(one - ab / abp)
         z = noise_fn(1 + n).astype(np.float32)

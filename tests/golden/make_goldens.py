@@ -11,6 +11,7 @@
     python tests/golden/make_goldens.py clip1000   # G12: inference() at the full 1000 steps per window (config[1] workload)
     python tests/golden/make_goldens.py bvh1000    # G13: the reference .bvh channels of G12
     python tests/golden/make_goldens.py attn3beat  # G14: BEAT-TWH-main cross_local_attention3 (name "DiffuseStyleGesture")
+    python tests/golden/make_goldens.py hooks      # G17: p_sample_loop / ddim_sample_loop with denoised_fn and cond_fn (tiny dims)
 
 The two reference trees use the same module names, hence one process per tree.  Nothing from
 /root/reference is copied: the script imports it, feeds it seeded synthetic weights / inputs
@@ -216,6 +217,54 @@ def gen_zeggs():
                                                 progress=False).numpy()
     np.savez_compressed(os.path.join(HERE, "gt_tiny_zeggs.npz"), **gt)
     print("tiny ok", {k: float(np.abs(v).mean()) for k, v in gt.items() if k.startswith(("fwd", "dd"))})
+
+
+def hook_denoised(x):
+    """denoised_fn of G17 (works on torch tensors and numpy arrays): applied to pred_xstart before the clamp (gaussian_diffusion.py:364-370)"""
+    return 0.9 * x + 0.01
+
+
+def hook_cond_scale(t):
+    """per-sample factor of G17's cond_fn from the MODEL timestep the wrapped cond_fn receives (respace.py:117-129): t / 1000 + 0.1"""
+    return t / 1000.0 + 0.1
+
+
+def gen_fn_hooks():
+    """G17: the sampler hooks of `p_sample` / `ddim_sample` -- denoised_fn (gaussian_diffusion.py:364-370) and cond_fn through condition_mean
+    (:428-441, DDPM) / condition_score (:458-480, DDIM) -- at the tiny dims, batch 2.  cond_fn(x, t, y=...) = -5 x (t / 1000 + 0.1)."""
+    sys.path[:0] = [REF + "/main", REF + "/main/model"]
+    np.float = float
+    from utils.model_util import create_gaussian_diffusion
+    from diffusion import gaussian_diffusion as gd
+    from diffusion.respace import SpacedDiffusion, space_timesteps
+    diff = create_gaussian_diffusion()
+    d50 = SpacedDiffusion(use_timesteps=space_timesteps(1000, "ddim50"), betas=gd.get_named_beta_schedule('cosine', 1000, 1.),
+                          model_mean_type=gd.ModelMeanType.START_X, model_var_type=gd.ModelVarType.FIXED_SMALL,
+                          loss_type=gd.LossType.MSE, rescale_timesteps=False)
+    cfg = C.TINY
+    model, _ = _build_ref_zeggs(cfg)
+    B = 2
+    y = synth_window_inputs(cfg, B, window=2, seed_pose_scale=0.3)
+    shape = (B, cfg.njoints, 1, cfg.n_poses)
+
+    def cond_fn(x, t, y=None):
+        assert y is not None and "style" in y
+        return -5.0 * x * hook_cond_scale(t.float()).view(-1, 1, 1, 1)
+    g = {"wseed": WSEED}
+    with NoiseInjector(77, stream=11):
+        g["ddpm_both_clip_skip800"] = diff.p_sample_loop(model, shape, clip_denoised=True, denoised_fn=hook_denoised, cond_fn=cond_fn,
+                                                         model_kwargs={"y": _y_torch(y)}, skip_timesteps=800, progress=False).numpy()
+    with NoiseInjector(77, stream=12):
+        g["ddpm_denoised_skip992"] = diff.p_sample_loop(model, shape, clip_denoised=False, denoised_fn=hook_denoised,
+                                                        model_kwargs={"y": _y_torch(y)}, skip_timesteps=992, progress=False).numpy()
+    with NoiseInjector(77, stream=13):
+        g["ddpm_cond_skip800"] = diff.p_sample_loop(model, shape, clip_denoised=False, cond_fn=cond_fn,
+                                                    model_kwargs={"y": _y_torch(y)}, skip_timesteps=800, progress=False).numpy()    # (200 steps: posterior_variance * grad is ~1e-4 per step up there, nothing at t < 10)
+    with NoiseInjector(77, stream=14):
+        g["ddim50_both_eta05_skip40"] = d50.ddim_sample_loop(model, shape, clip_denoised=False, denoised_fn=hook_denoised, cond_fn=cond_fn,
+                                                             model_kwargs={"y": _y_torch(y)}, progress=False, eta=0.5, skip_timesteps=40).numpy()
+    np.savez_compressed(os.path.join(HERE, "g17_sampler_hooks_tiny.npz"), **g)
+    print("G17 ok", {k: float(np.abs(v).mean()) for k, v in g.items() if k.startswith("dd")})
 
 
 def gen_dsgplus():
@@ -545,4 +594,4 @@ if __name__ == "__main__":
     {"zeggs": gen_zeggs, "dsgplus": gen_dsgplus, "clip": gen_clip, "bvh": gen_bvh, "wavlm": gen_wavlm, "wavlm_large": gen_wavlm_large, "dsgpp": gen_dsgpp,
      "clip1000": lambda: gen_clip(0, "g12_clip1000_zeggs.npz", f32=True),
      "bvh1000": lambda: gen_bvh("g12_clip1000_zeggs.npz", "g13_bvh1000_zeggs.npz", full=False),
-     "attn3beat": gen_attn3_beat, "dsgplus_caller": gen_dsgplus_caller, "remaining_dims": gen_remaining_dims}[which]()
+     "hooks": gen_fn_hooks, "attn3beat": gen_attn3_beat, "dsgplus_caller": gen_dsgplus_caller, "remaining_dims": gen_remaining_dims}[which]()

@@ -215,7 +215,9 @@ def test_error_behaviour(tiny, emu_lib):
     with pytest.raises(NotImplementedError):
         d.ddim_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, const_noise=True)
     with pytest.raises(NotImplementedError):
-        d.p_sample_loop(m, shape, model_kwargs={"y": y}, cond_fn=lambda *a: None)       # guidance hooks are not on the path
+        d.p_sample_loop(m, shape, model_kwargs={"y": y}, cond_fn=lambda *a: None, cond_fn_with_grad=True)       # autograd through the denoiser: not on the path
+    with pytest.raises(NotImplementedError):
+        d.p_sample_loop(m, shape, model_kwargs={"y": y}, randomize_class=True)          # (denoised_fn / cond_fn run step by step on the device: test_gpu_round5.py)
     with pytest.raises(ValueError):
         d.p_sample_loop(m, (2, 5, 1, 22), clip_denoised=False, model_kwargs={"y": y})
     with pytest.raises(ValueError):

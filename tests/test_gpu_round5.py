@@ -239,3 +239,45 @@ def test_stream_pose_head_one_block_per_workgroup_is_bit_identical(gpu, monkeypa
         gc.collect()
     monkeypatch.delenv("DSG_WS_OUT_ONE")
     assert np.array_equal(outs["0"], outs["1"])
+
+
+def test_sampler_hooks_denoised_fn_and_cond_fn_vs_reference(gpu, golden_dir):
+    """`denoised_fn` and `cond_fn` of p_sample_loop / ddim_sample_loop (+ the progressive form): a loop that carries a hook runs step by step
+    -- the denoiser through the library, the hook in torch, the library's update kernels -- against the reference's own loops with the same
+    hooks (G17: gaussian_diffusion.py:364-370, condition_mean :428-441, condition_score :458-480; tiny dims, fp32).  `cond_fn_with_grad` /
+    `randomize_class` stay NotImplementedError."""
+    import torch
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    g = np.load(os.path.join(golden_dir, "g17_sampler_hooks_tiny.npz"))
+    cfg, B = C.TINY, 2
+    m = _model(cfg, "fp32", max_batch=B, wseed=int(g["wseed"]))
+    shape = (B, cfg.njoints, 1, cfg.n_poses)
+    y = {k: torch.from_numpy(v).cuda() for k, v in synth_window_inputs(cfg, B, window=2, seed_pose_scale=0.3).items()}
+    calls = []
+
+    def den(x):
+        return 0.9 * x + 0.01
+
+    def cond(x, t, y=None):
+        assert y is not None and "style" in y
+        calls.append(int(t[0]))
+        return -5.0 * x * (t.float() / 1000.0 + 0.1).view(-1, 1, 1, 1)
+    d, d50 = create_gaussian_diffusion(), create_gaussian_diffusion("ddim50")
+    npy = lambda s: s.cpu().numpy()
+    s = d.manual_seed(77, 11).p_sample_loop(m, shape, clip_denoised=True, denoised_fn=den, cond_fn=cond, model_kwargs={"y": y}, skip_timesteps=800)
+    assert rel_l2(npy(s), g["ddpm_both_clip_skip800"]) < TOL_CHAIN["fp32"] and calls == list(range(199, -1, -1))
+    s = d.manual_seed(77, 12).p_sample_loop(m, shape, clip_denoised=False, denoised_fn=den, model_kwargs={"y": y}, skip_timesteps=992)
+    assert rel_l2(npy(s), g["ddpm_denoised_skip992"]) < TOL_CHAIN["fp32"]
+    s = d.manual_seed(77, 13).p_sample_loop(m, shape, clip_denoised=False, cond_fn=cond, model_kwargs={"y": y}, skip_timesteps=800)
+    assert rel_l2(npy(s), g["ddpm_cond_skip800"]) < TOL_CHAIN["fp32"]
+    plain = d.manual_seed(77, 13).p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=800)
+    assert rel_l2(npy(plain), g["ddpm_cond_skip800"]) > 1e-3 and d.last_sample_path() in ("aql", "graph", "hip")      # (the hook-free loop stays inside the library)
+    del calls[:]
+    s = d50.manual_seed(77, 14).ddim_sample_loop(m, shape, clip_denoised=False, denoised_fn=den, cond_fn=cond, model_kwargs={"y": y}, eta=0.5, skip_timesteps=40)
+    assert rel_l2(npy(s), g["ddim50_both_eta05_skip40"]) < TOL_CHAIN["fp32"] and calls[0] == 9 * 20 and len(calls) == 10      # model timesteps (respace.py:117-129)
+    outs = [o["sample"] for o in d.manual_seed(77, 12).p_sample_loop_progressive(m, shape, clip_denoised=False, denoised_fn=den, model_kwargs={"y": y}, skip_timesteps=992)]
+    assert len(outs) == 8 and rel_l2(npy(outs[-1]), g["ddpm_denoised_skip992"]) < TOL_CHAIN["fp32"]
+    with pytest.raises(NotImplementedError):
+        d.p_sample_loop(m, shape, model_kwargs={"y": y}, cond_fn=cond, cond_fn_with_grad=True)
+    with pytest.raises(NotImplementedError):
+        d.p_sample_loop(m, shape, model_kwargs={"y": y}, randomize_class=True)
