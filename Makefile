@@ -29,8 +29,28 @@ $(CSRC)/libdsg_hip_stamps.so: $(STAMPS_SRC) $(CSRC)/dsg_bvh.cpp
 $(CSRC)/dsg_kernels_stamps.hsaco: $(STAMPS_SRC)
 	$(HIPCC) --offload-arch=gfx950 --cuda-device-only --no-gpu-bundle-output -O3 -std=c++17 -Wno-pass-failed -DDSG_STAMPS=1 -DDSG_BUILD_TAG=$(TAG)u $(CSRC)/dsg_hip.cpp -o $@
 
+# marks build: the stamps build + DSG_TL_MARK phase marks inside the kernels (tools/aql_timeline.py --lib marks)
+marks: $(CSRC)/libdsg_hip_marks.so $(CSRC)/dsg_kernels_marks.hsaco
+$(CSRC)/libdsg_hip_marks.so: $(STAMPS_SRC) $(CSRC)/dsg_bvh.cpp
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed -DDSG_STAMPS=2 -DDSG_BUILD_TAG=$(TAG)u $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_bvh.cpp -L/opt/rocm/lib -lhsa-runtime64 -lpthread -o $@
+$(CSRC)/dsg_kernels_marks.hsaco: $(STAMPS_SRC)
+	$(HIPCC) --offload-arch=gfx950 --cuda-device-only --no-gpu-bundle-output -O3 -std=c++17 -Wno-pass-failed -DDSG_STAMPS=2 -DDSG_BUILD_TAG=$(TAG)u $(CSRC)/dsg_hip.cpp -o $@
+
+# development build: bf16 only (a third of the instantiations, a third of the compile time), under its OWN file names so that it can never be
+# mistaken for the product library:   make dev [DEVNAME=devA] [DEVFLAGS="-DDSG_STAMPS=2 -DDSG_X_..."]   ->   libdsg_hip_$(DEVNAME).so + dsg_kernels_$(DEVNAME).hsaco
+# (DSG_LIB=.../libdsg_hip_devA.so python tools/...; two variants built under two names are A/B-ed on ONE box in one gpurun call: tools/ab_dev.sh)
+DEVFLAGS ?=
+DEVNAME ?= dev
+DEVDEF := -DDSG_DEV_BF16_ONLY=1 $(DEVFLAGS) '-DDSG_HSACO_NAME="dsg_kernels_$(DEVNAME).hsaco"' -DDSG_BUILD_TAG=$(TAG)u
+dev: $(CSRC)/libdsg_hip_$(DEVNAME).so $(CSRC)/dsg_kernels_$(DEVNAME).hsaco
+$(CSRC)/libdsg_hip_$(DEVNAME).so: $(STAMPS_SRC) $(CSRC)/dsg_bvh.cpp
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed $(DEVDEF) $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_bvh.cpp -L/opt/rocm/lib -lhsa-runtime64 -lpthread -o $@
+$(CSRC)/dsg_kernels_$(DEVNAME).hsaco: $(STAMPS_SRC)
+	$(HIPCC) --offload-arch=gfx950 --cuda-device-only --no-gpu-bundle-output -O3 -std=c++17 -Wno-pass-failed $(DEVDEF) \
+	    -Rpass-analysis=kernel-resource-usage $(CSRC)/dsg_hip.cpp -o $@ 2> $(CSRC)/dsg_kernels_$(DEVNAME).resources.txt || (cat $(CSRC)/dsg_kernels_$(DEVNAME).resources.txt >&2; exit 1)
+
 # the kernels that were measured slower and removed from the library: compile check only (experiments/, outside the package)
-experiments: experiments/experiments.hip experiments/dsg_rejected_kernels.h experiments/dsg_stream_ln.h $(CSRC)/dsg_kernels.h $(CSRC)/dsg_batched.h $(CSRC)/dsg_stream.h
+experiments: experiments/experiments.hip experiments/dsg_rejected_kernels.h experiments/dsg_stream_ln.h $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h $(CSRC)/dsg_batched.h $(CSRC)/dsg_stream.h
 	$(HIPCC) --offload-arch=gfx950 --cuda-device-only -O3 -std=c++17 -Wno-pass-failed -I$(CSRC) -c experiments/experiments.hip -o /dev/null
 
 emu: $(EMU)
@@ -54,4 +74,4 @@ tools/_build/aql_probe: tools/aql_probe.cpp
 
 clean:
 	rm -f $(LIB) $(EMU) $(CSRC)/dsg_kernels.hsaco $(CSRC)/dsg_kernels.resources.txt
-.PHONY: all emu stamps experiments tools clean
+.PHONY: all emu stamps marks dev experiments tools clean

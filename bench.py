@@ -25,7 +25,9 @@ The default line (`python bench.py`, 1 GPU, config[1]) also carries time-bounded
     config3   16 clips as 4 lanes x batch 4 = config[3]'s per-GPU share (with --gpus N: N x 16 clips gathered over RCCL)
     config4   DiffuseStyleGesture+ BEAT and TWH denoisers, batch 1, 2 of the 16 windows of an 1830-frame clip (config[4])
     stream    256 clips per GPU as 4 lanes x batch 64 (the STREAM kernel set), 1 pass
-Top-level `value` / `config` stay config[1].
+    precision config[1] in the two other arithmetic modes: fp32 (the reference's own arithmetic) and bf16w2 (hi + lo bf16), 1 pass each
+Top-level `value` / `config` stay config[1].  Sub-records with a committed PMC pass of their per-lane arrangement
+(profiles/r*_traffic_zeggs_b<B>_<set>_bf16.json, tools/measure_traffic.sh) carry it as `roofline.traffic`.
 """
 import argparse
 import json
@@ -175,29 +177,46 @@ def cpu_baseline(n_steps, one_core_steps=None):
 ALGO = {"zeggs": (7.183e6, 1.205e6, 1.3152), "beat": (13.25e6, 3.694e6, 4.183), "twh": (20.23e6, 4.018e6, 6.311)}
 
 
-def roofline_record(config, precision, NC, NL, B, us, with_traffic=False):
+def pmc_traffic(config, precision, B, kset):
+    """HBM-side bytes per denoising step of ONE lane of batch B under kernel set `kset`, from the newest committed rocprofv3 PMC passes
+    (tools/measure_traffic.sh -> tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in separate runs, FETCH doubled as the MI355X guide
+    prescribes for wide coalesced reads; HIP-launch path, the profiler cannot see AQL packets).  (corrected, raw, file) or None."""
+    import glob
+    if config != "zeggs" or precision != "bf16":
+        return None
+    name = f"r*_traffic_zeggs_b{B}_bf16.json" if B == 1 else f"r*_traffic_zeggs_b{B}_{kset}_bf16.json"
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", name)))       # newest round last
+    if not cands:
+        return None
+    d = json.load(open(cands[-1]))
+    return d["traffic_bytes_per_step_fetch_x2"], d["traffic_bytes_per_step_raw"], os.path.basename(cands[-1])
+
+
+def roofline_record(config, precision, NC, NL, B, us, with_traffic=False, kset=None):
     """The roofline object of one workload: `us` = time in which all NC clips in flight advance one denoising step."""
     wparams, sbytes, gflop = ALGO[config]
     wbytes = wparams * {"bf16": 2, "bf16w2": 4, "fp32": 4}[precision]      # (bf16w2: hi + lo bf16 per weight)
     abytes = wbytes + sbytes * NC           # the NC clips in flight share one pass over the weights
     if NC >= 8:
+        t = pmc_traffic(config, precision, B, kset) if (with_traffic and kset) else None
         # SURVEY s8d: from 8 clips in flight (>= 712 token rows) the path is a dense contraction -> MFMA roofline
         ach = gflop * NC / (us * 1e-6) / 1e3
         peak = 157.3 if precision == "fp32" else 2500.0
         return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 5),
-                "traffic": None, "algorithmic_gflop_per_denoise_step": gflop * NC,
+                # HBM-side bytes per denoising step of all NC clips: the PMC passes of ONE lane of batch B (HIP-launch path) x NL lanes
+                "traffic": None if t is None else t[0] * NL, "traffic_raw": None if t is None else t[1] * NL,
+                "traffic_source": None if t is None else t[2] + (f" (one lane of batch {B}; x {NL} lanes)" if NL > 1 else ""),
+                "algorithmic_bytes_per_denoise_step": abytes, "algorithmic_gflop_per_denoise_step": gflop * NC,
                 "note": f"{NC} clips in flight ({NL} lane(s) x batch {B}): achieved = {gflop} GFLOP x {NC} clips / time in which all of them "
                         "advance one denoising step; peak = dense MFMA " + ("fp32" if precision == "fp32" else "bf16")}
     achieved = abytes / (us * 1e-6) / 1e9
     # HBM-side traffic per step from the rocprofv3 PMC passes (tools/pmc_traffic.py; FETCH_SIZE doubled as the MI355X guide
     # prescribes for wide coalesced reads), measured for the headline configuration only
     traffic, tsrc = None, None
-    if with_traffic:
-        import glob
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_zeggs_b1_bf16.json")))   # newest round last
-        if config == "zeggs" and precision == "bf16" and NC == 1 and cands:
-            traffic = json.load(open(cands[-1]))["traffic_bytes_per_step_fetch_x2"]
-            tsrc = os.path.basename(cands[-1])
+    if with_traffic and NC == 1:
+        t = pmc_traffic(config, precision, 1, None)
+        if t is not None:
+            traffic, tsrc = t[0], t[2]
     return {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
             "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": tsrc,
             "algorithmic_bytes_per_denoise_step": abytes,
@@ -248,6 +267,8 @@ class Workload:
                       for ln in range(NL)]
         self.seed0s = [to_dev(synth_window_inputs(cfg, B, window=0, clips=lane_clips[ln], seed_pose_scale=0.1)["seed"]) for ln in range(NL)]
         self.style = [1] + [0] * (cfg.style_dim_in - 1)
+        if not emu:         # resident in HBM like the other inputs (a per-pass host -> device copy of it costs 1.8 ms per lane)
+            self.style = torch.tensor([self.style] * B, dtype=torch.float32).cuda(local)
         self.lane_streams = [lc[0] for lc in lane_clips]
         self.n_denoise = self.diffusion.num_timesteps - self.skip
 
@@ -333,15 +354,17 @@ def main():
             dt = float(tt.item())
         return dt, float(np.mean(us))
 
-    def sub_record(label, config, NC_, NL_, sampler, passes, n_windows=None, warm_skip=None, gather=False):
+    def sub_record(label, config, NC_, NL_, sampler, passes, n_windows=None, warm_skip=None, gather=False, precision=None):
         """One BASELINE configuration other than the headline's, timed like the main region on a bounded sample."""
-        w = Workload(a, config, NC_, NL_, sampler, local, rank, world, library, emu, n_windows=n_windows)
+        w = Workload(a, config, NC_, NL_, sampler, local, rank, world, library, emu, n_windows=n_windows, precision=precision)
         dt, us = timed(w, passes, gather_total=world * NC_ if gather else 0, warm_skip=warm_skip)
         rec = {"baseline_config": label, "workload": f"{world} GPU(s) x " + w.describe(), "clips": world * NC_,
                "value": round(world * NC_ * passes * w.frames_per_clip / dt, 2), "unit": "frames/s", "passes": passes,
                "ms_per_pass": round(1000.0 * dt / passes, 3), "us_per_denoise_step": round(us, 2),
                "kernel_set": w.lanes[0].last_kernel_set(), "sample_path": w.lanes[0].last_sample_path(),
-               "roofline": roofline_record(config, w.precision, NC_, NL_, w.B, us) if us > 0 else None}
+               "roofline": roofline_record(config, w.precision, NC_, NL_, w.B, us, with_traffic=True, kset=w.lanes[0].last_kernel_set()) if us > 0 else None}
+        if precision:
+            rec["dtype"] = w.precision
         if NC_ > 1:
             rec["us_per_denoise_step_all_clips"] = rec["us_per_denoise_step"]
         del w
@@ -384,6 +407,11 @@ def main():
                              name, 1, 1, "ddpm", 1, n_windows=2, warm_skip=900)
             for name in ("beat", "twh")}
         subs["stream"] = sub_record("256 clips per GPU (4 lanes x batch 64, STREAM kernel set)", "zeggs", 256, 4, "ddpm", 1, warm_skip=960)
+        # config[1] in the other two arithmetic modes (tolerances against the reference .bvh: README "which precision"): fp32 is the
+        # reference's own arithmetic (main/train/training_loop.py:39), bf16w2 keeps weights and the step's own GEMM operands as hi + lo bf16
+        if a.precision == "bf16":
+            subs["precision"] = {prec: sub_record(f"config[1] in {prec}: 1 clip, batch 1, 320-frame ZEGGS clip, 4 x 1000 DDPM steps", "zeggs", 1, 1, "ddpm", 1,
+                                                  warm_skip=900, precision=prec) for prec in ("fp32", "bf16w2")}
     if rank == 0 and os.environ.get("DSG_BENCH_DUMP"):      # TEST INFRASTRUCTURE (tests/test_bench_launch.py): the gathered poses, by clip id
         np.save(os.environ["DSG_BENCH_DUMP"], np.asarray(gathered, np.float32))
     if rank == 0:
@@ -394,7 +422,7 @@ def main():
         us = float(np.mean(step_us))
         if not us > 0:      # no device timer (emulated test run): wall clock per denoising step
             us = 1e6 * dt / (a.steps * n_windows * n_denoise)
-        roof = roofline_record(a.config, a.precision, NC, NL, B, us, with_traffic=True)
+        roof = roofline_record(a.config, a.precision, NC, NL, B, us, with_traffic=True, kset=model.last_kernel_set())
         out = {
             "metric": (f"gesture frames/sec, {'1000-step DDPM' if a.sampler == 'ddpm' else '50-step DDIM'}, "
                        + ("320-frame ZEGGS clip" if a.config == "zeggs" else f"1830-frame {a.config.upper()} clip (DSG+)")

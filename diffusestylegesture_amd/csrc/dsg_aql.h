@@ -57,6 +57,7 @@ struct Trace {
     char* ka_trace = nullptr; size_t ka_trace_cap = 0;      // timeline build: n copies of the argument blocks with slot indices
     char* ring = nullptr; size_t ring_cap = 0;              // ... and the per-wave stamp ring
     std::vector<double> us;                  // result: [n][packets][2] = start, end in us relative to the first traced start
+    std::vector<double> marks;               // marks build: [n][packets][12][3] = waves that passed mark k, mean, last wave (us after the packet's first wave start)
     std::vector<std::string> names;          // kernel of each packet of a step
     double traced_span_us = 0.0;             // first traced start -> last traced end
 };
@@ -129,8 +130,10 @@ inline bool init(Ctx& c, int hip_device, const void* addr_in_library) {
     Dl_info info;
     if (!dladdr(addr_in_library, &info) || !info.dli_fname) { c.err = "dladdr failed"; return false; }
     std::string path(info.dli_fname);
-#ifdef DSG_STAMPS
-    path = path.substr(0, path.find_last_of('/') + 1) + "dsg_kernels_stamps.hsaco";
+#if defined(DSG_HSACO_NAME)         // (development builds, Makefile: `make dev` -- bf16 only, own file names)
+    path = path.substr(0, path.find_last_of('/') + 1) + DSG_HSACO_NAME;
+#elif defined(DSG_STAMPS)
+    path = path.substr(0, path.find_last_of('/') + 1) + (DSG_STAMPS >= 2 ? "dsg_kernels_marks.hsaco" : "dsg_kernels_stamps.hsaco");
 #else
     path = path.substr(0, path.find_last_of('/') + 1) + "dsg_kernels.hsaco";
 #endif
@@ -283,8 +286,8 @@ inline bool run(Ctx& c, int n_steps, double timeout_s) {
     Trace& tr = c.trace;
     const size_t L = c.plan.size();
 #ifdef DSG_STAMPS
-    struct Entry { unsigned long long t0, t1; };
-    constexpr size_t TLW = 2048;             // = dsg::DSG_TL_WAVES
+    typedef dsg::TlEntry Entry;
+    constexpr size_t TLW = dsg::DSG_TL_WAVES;
 #endif
     if (tr.armed) {
         tr.n = std::max(0, std::min(tr.n, n_steps - 1 - tr.first));      // never the last step (its last packet carries the completion signal)
@@ -358,6 +361,21 @@ inline bool run(Ctx& c, int n_steps, double timeout_s) {
             last_end = std::max(last_end, t1[i]);
         }
         tr.traced_span_us = (double)(last_end - base) * 1000.0 / khz;
+#if DSG_STAMPS >= 2
+        constexpr int NM = dsg::DSG_TL_NMARK;
+        tr.marks.assign(NS * NM * 3, 0.0);
+        for (size_t sl = 0; sl < NS; ++sl)
+            for (int k = 0; k < NM; ++k) {
+                double cnt = 0.0, sum = 0.0, mx = 0.0;
+                for (size_t w = 0; w < TLW; ++w) {
+                    const Entry& en = got[sl * TLW + w];
+                    if (en.t0 == 0 || en.m[k] == 0) continue;
+                    const double d = (double)(long long)(en.m[k] - t0[sl]) * 1000.0 / khz;
+                    cnt += 1.0; sum += d; mx = std::max(mx, d);
+                }
+                tr.marks[(sl * NM + k) * 3] = cnt; tr.marks[(sl * NM + k) * 3 + 1] = cnt > 0 ? sum / cnt : 0.0; tr.marks[(sl * NM + k) * 3 + 2] = mx;
+            }
+#endif
         tr.armed = false;
     }
 #else

@@ -217,6 +217,7 @@ __device__ __forceinline__ void mid_tail(const MidArgs& g, f32x4 (&acc)[DT], con
     DSG_LDS_BARRIER();
     const float var = ((red[1][0][lr] + red[1][1][lr]) + (red[1][2][lr] + red[1][3][lr])) / (float)D;
     const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    DSG_TL_MARK(7);      // mid_tail: residual + LayerNorm1 statistics (two barriers)
     const bool wr = ng == 0 && (m0 + lr) < g.M;
 #pragma unroll
     for (int t = 0; t < DT; ++t) {
@@ -228,6 +229,7 @@ __device__ __forceinline__ void mid_tail(const MidArgs& g, f32x4 (&acc)[DT], con
         acc[t] = y;                                   // written to X1 at the very end (keeps stores out of the vmcnt queue)
     }
     DSG_LDS_BARRIER();
+    DSG_TL_MARK(8);      // LayerNorm1 rows in LDS
     // ---- linear1 slice + GELU
     f32x4 c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
     if constexpr (KD <= CH) {
@@ -246,12 +248,14 @@ __device__ __forceinline__ void mid_tail(const MidArgs& g, f32x4 (&acc)[DT], con
                     c1 = P::mma_w(bf[c], P::aload(a1 + lr * XP + ((kb0 + c) * P::KB + P::E * lg) * ES, 16 * XP), c1);
         }
     }
+    DSG_TL_MARK(9);      // linear1 slice issued (W1 has landed)
     if (m0 + lr < g.M) {
         f32x4 y;
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[e] = gelu_erf<P>(c1[e] + pb1[e]);
         P::store4_afrag((elem*)g.hidden, (size_t)qk_off<P>(m0 + lr, n1t * 16 + 4 * lg, g.ff / P::KB), y);       // fragment-major: linear2's A operand
     }
+    DSG_TL_MARK(10);     // GELU + `hidden` stores issued
     if (wr) {
 #pragma unroll
         for (int t = 0; t < DT; ++t) *(f32x4*)(g.X1 + (size_t)(m0 + lr) * D + (wave * DT + t) * 16 + 4 * lg) = acc[t];
@@ -412,6 +416,7 @@ __device__ __forceinline__ void attn_mid_body(const AttnMidArgs& ga) {
         for (int kb = 0; kb < NVF; ++kb) vfr[dt][kb] = lda16<P>(ga.vt, (VT + (size_t)((dt * NVF + kb) * 64 + lane) * P::E) * ES);       // fragment-major (vt_off)
     }
     DSG_LOADS_ISSUED();
+    DSG_TL_MARK(0);      // Q / K / V^T requested
     // ---- (2) everything the later phases need is requested WHILE the attention math runs, a few loads per slot: a wave
     //      issues in order, and a burst of ~70 loads stalls it in the issue stage for as long as the texture path needs
     //      to drain them (~100 cycles each with 4 waves loading) -- time in which no softmax instruction can run.
@@ -463,6 +468,7 @@ __device__ __forceinline__ void attn_mid_body(const AttnMidArgs& ga) {
 #pragma unroll
         for (int kb = 0; kb < KDH; ++kb) s[nt] = P::mma(kf[nt][kb], qf[kb], s[nt]);
     }
+    DSG_TL_MARK(1);      // Q K^T issued (Q / K have landed)
     const float scale = 1.0f / sqrtf((float)HD);
     float mx = -DSG_FLT_MAX;
 #pragma unroll
@@ -478,6 +484,7 @@ __device__ __forceinline__ void attn_mid_body(const AttnMidArgs& ga) {
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
+    DSG_TL_MARK(2);      // scores scaled, row max
     float sum = 0.f;
 #pragma unroll
     for (int nt = 0; nt < NKT; ++nt) {
@@ -493,6 +500,7 @@ __device__ __forceinline__ void attn_mid_body(const AttnMidArgs& ga) {
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
     const float inv = 1.0f / sum;
+    DSG_TL_MARK(3);      // exp + row sum
     f32x4 pfr[NVF];                                  // P^T fragments: exactly the values this lane already holds
 #pragma unroll
     for (int kb = 0; kb < NVF; ++kb) {
@@ -518,6 +526,7 @@ __device__ __forceinline__ void attn_mid_body(const AttnMidArgs& ga) {
         P::store4_a((elem*)(aT + lr * XP) + h * HD + dt * 16 + 4 * lg, 16 * XP, y);
         DSG_ISSUE_SLOT(2 * NKT + dt);
     }
+    DSG_TL_MARK(4);      // P V issued, attention rows on their way to LDS
 #undef DSG_ISSUE_SLOT
     // fp32 (KD = 16 at D = 256): K / V^T are dead now -- ALL remaining W_o k-blocks in one batch instead of a PD-deep pipeline of
     // exposed L2 round trips inside the out_proj loop (round 4: k_attn_mid<PF32, 4, 6> 20.4 us, 62 % of the fp32 step)
@@ -530,6 +539,7 @@ __device__ __forceinline__ void attn_mid_body(const AttnMidArgs& ga) {
         DSG_LOADS_ISSUED();
     }
     DSG_LDS_BARRIER();
+    DSG_TL_MARK(5);      // all four heads' rows are in LDS
 
     // ---- (5) out_proj from the LDS rows, remaining weight k-blocks PD ahead
     f32x4 acc[DT];
@@ -545,6 +555,7 @@ __device__ __forceinline__ void attn_mid_body(const AttnMidArgs& ga) {
 #pragma unroll
         for (int t = 0; t < DT; ++t) acc[t] = P::mma_w(bf[kb][t], af, acc[t]);      // D[n 4lg+r][row lr]
     }
+    DSG_TL_MARK(6);      // out_proj issued (W_o has landed)
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int e = tid + 256 * i;
@@ -751,210 +762,9 @@ __global__ __launch_bounds__(256) void k_attn_op(const AttnOpArgs g) {
     }
 }
 
-// (Round 4: "bit-identical" was only true under the emulator -- on the device the compiler contracted the LayerNorm's mul + add into
-// fma in k_attn_op and not in k_attn_op2, one ulp apart in ~10 % of the rows, enough to flip bf16 roundings downstream
-// (tools/debug_op2.py).  Both kernels now spell the two fma sites out; tests/test_gpu_round4.py compares them on the device.)
-// k_attn_op2: k_attn_op for TWO query tiles (32 queries) of a batch element per workgroup -- K, V^T (96 KB) and W_o (128 KB) are
-// pulled through the CU's load path once per 32 rows instead of once per 16 (136 instead of 248 KB per tile), which is what bounds
-// the kernel when the batch fills the GPU (>= 1400 token rows: STREAM set).  Row by row the arithmetic and its order are those of
-// k_attn_op: bit-identical.
-template <class P, int DT, int NKT>
-__global__ __launch_bounds__(256) void k_attn_op2(const AttnOpArgs g) {
-    DSG_TL_SCOPE();
-    typedef typename P::elem elem;
-    constexpr int ES = (int)sizeof(elem);
-    constexpr int D = DT * 64, HD = DT * 16;
-    constexpr int KD = D / P::KB, KDH = HD / P::KB;
-    constexpr int XP = D * ES + 16;
-    constexpr int ND = HD / 16;
-    constexpr int NVF = P::E == 4 ? NKT : NKT / 2;
-    static_assert(KDH >= 1 && KD <= 8, "shape");
-    static_assert(P::E == 4 || (NKT % 2) == 0, "bf16 pairs key tiles");
-    __shared__ __attribute__((aligned(16))) char aT[2][16 * XP];
-    __shared__ float red[2][2][4][16];
-    __shared__ __attribute__((aligned(16))) float vecs[3][D];
-    preload_kernargs(g);
-    const int qt0 = 2 * (int)blockIdx.x, b = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
-    const int h = wave;
-    const size_t bh = (size_t)b * 4 + h;
-    const elem* Q = (const elem*)g.q + bh * g.Tp * HD;
-    const elem* K = (const elem*)g.k + bh * g.Tp * HD;
-    const elem* VT = (const elem*)g.vt + bh * HD * g.Tp;
-    const f32x4* wo = (const f32x4*)g.Wo + lane;
-    const int nqt = g.Tp / 16;
-    f32x4 qf[2][KDH], kf[NKT][KDH], vfr[ND][NVF];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int kb = 0; kb < KDH; ++kb) qf[j][kb] = *(const f32x4*)(Q + (size_t)((min(qt0 + j, nqt - 1) * KDH + kb) * 64 + lane) * P::E);
-#pragma unroll
-    for (int nt = 0; nt < NKT; ++nt)
-#pragma unroll
-        for (int kb = 0; kb < KDH; ++kb) kf[nt][kb] = *(const f32x4*)(K + (size_t)((nt * KDH + kb) * 64 + lane) * P::E);
-#pragma unroll
-    for (int dt = 0; dt < ND; ++dt)
-#pragma unroll
-        for (int kb = 0; kb < NVF; ++kb) vfr[dt][kb] = *(const f32x4*)(VT + (size_t)((dt * NVF + kb) * 64 + lane) * P::E);
-    bool rowok[2];
-    size_t m[2];
-    f32x4 pr[2][DT];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int tq = (qt0 + j) * 16 + lr;
-        rowok[j] = tq < g.ntok;
-        m[j] = (size_t)b * g.ntok + (rowok[j] ? tq : g.ntok - 1);      // clamped: unconditional loads, predicated stores
-#pragma unroll
-        for (int t = 0; t < DT; ++t) pr[j][t] = *(const f32x4*)(g.R + m[j] * D + (wave * DT + t) * 16 + 4 * lg);
-    }
-    constexpr int NV = (3 * D / 4 + 255) / 256;
-    f32x4 vload[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int e = min(tid + 256 * i, 3 * D / 4 - 1), vsel = e / (D / 4), vidx = e % (D / 4);
-        vload[i] = ((const f32x4*)(vsel == 0 ? g.bo : (vsel == 1 ? g.ln_g : g.ln_b)))[vidx];
-    }
-    DSG_LOADS_ISSUED();
-    constexpr int KH = (KD + 1) / 2;
-    f32x4 bf[KD][DT];
-    const float scale = 1.0f / sqrtf((float)HD);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        // ---- S^T = K Q^T, softmax over the keys (D[key = 4*lg + r][query = lr])
-        f32x4 s[NKT];
-#pragma unroll
-        for (int nt = 0; nt < NKT; ++nt) {
-            s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kb = 0; kb < KDH; ++kb) s[nt] = P::mma(kf[nt][kb], qf[j][kb], s[nt]);
-        }
-        if (j == 0) {       // W_o: the first half of the k-blocks now (in flight during the softmax), the rest once V^T is dead
-#pragma unroll
-            for (int kb = 0; kb < KH; ++kb)
-#pragma unroll
-                for (int t = 0; t < DT; ++t) bf[kb][t] = wo[((size_t)(wave * DT + t) * KD + kb) * 64];
-        }
-        float mx = -DSG_FLT_MAX;
-#pragma unroll
-        for (int nt = 0; nt < NKT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = nt * 16 + 4 * lg + r;
-                const float v = key < g.ntok ? s[nt][r] * scale : -DSG_FLT_MAX;
-                s[nt][r] = v;
-                mx = fmaxf(mx, v);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float sum = 0.f;
-#pragma unroll
-        for (int nt = 0; nt < NKT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = nt * 16 + 4 * lg + r;
-                const float pv = key < g.ntok ? P::exp_sm(s[nt][r] - mx) : 0.f;
-                s[nt][r] = pv;
-                sum += pv;
-            }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
-        const float inv = 1.0f / sum;
-        f32x4 pfr[NVF];
-#pragma unroll
-        for (int kb = 0; kb < NVF; ++kb) {
-            if constexpr (P::E == 4) {
-                pfr[kb] = s[kb];
-            } else {
-                typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
-                u16x8 pp;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { pp[e] = f2bf(s[2 * kb][e]); pp[4 + e] = f2bf(s[2 * kb + 1][e]); }
-                pfr[kb] = __builtin_bit_cast(f32x4, pp);
-            }
-        }
-        // ---- O^T = V^T P^T -> LDS rows
-#pragma unroll
-        for (int dt = 0; dt < ND; ++dt) {
-            f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kb = 0; kb < NVF; ++kb) o = P::mma(vfr[dt][kb], pfr[kb], o);
-            f32x4 y;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = o[e] * inv;
-            P::store4((elem*)(aT[j] + lr * XP) + h * HD + dt * 16 + 4 * lg, y);
-        }
-    }
-#pragma unroll
-    for (int kb = KH; kb < KD; ++kb)
-#pragma unroll
-        for (int t = 0; t < DT; ++t) bf[kb][t] = wo[((size_t)(wave * DT + t) * KD + kb) * 64];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int e = tid + 256 * i;
-        if (e < 3 * D / 4) *(f32x4*)(&vecs[0][0] + e * 4) = vload[i];
-    }
-    DSG_LDS_BARRIER();
-    // ---- out_proj from the LDS rows: one W_o fragment feeds both tiles
-    f32x4 acc[2][DT];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int t = 0; t < DT; ++t) acc[j][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kb = 0; kb < KD; ++kb) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const f32x4 af = *(const f32x4*)(aT[j] + lr * XP + (kb * P::KB + P::E * lg) * ES);
-#pragma unroll
-            for (int t = 0; t < DT; ++t) acc[j][t] = P::mma(bf[kb][t], af, acc[j][t]);      // D[n 4lg+r][row lr]
-        }
-    }
-    // ---- residual + LayerNorm1 over whole rows
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        float sm = 0.f;
-#pragma unroll
-        for (int t = 0; t < DT; ++t) {
-            const f32x4 pbo = *(const f32x4*)(&vecs[0][(wave * DT + t) * 16 + 4 * lg]);
-            acc[j][t] = acc[j][t] + pbo + pr[j][t];
-            sm += (acc[j][t][0] + acc[j][t][1]) + (acc[j][t][2] + acc[j][t][3]);
-        }
-        sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
-        if (lg == 0) red[j][0][wave][lr] = sm;
-    }
-    DSG_LDS_BARRIER();
-    float mean[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        mean[j] = ((red[j][0][0][lr] + red[j][0][1][lr]) + (red[j][0][2][lr] + red[j][0][3][lr])) / (float)D;
-        float qv = 0.f;
-#pragma unroll
-        for (int t = 0; t < DT; ++t)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = acc[j][t][e] - mean[j]; qv = __builtin_fmaf(d, d, qv); }
-        qv += __shfl_xor(qv, 16); qv += __shfl_xor(qv, 32);
-        if (lg == 0) red[j][1][wave][lr] = qv;
-    }
-    DSG_LDS_BARRIER();
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const float var = ((red[j][1][0][lr] + red[j][1][1][lr]) + (red[j][1][2][lr] + red[j][1][3][lr])) / (float)D;
-        const float rstd = 1.0f / sqrtf(var + 1e-5f);
-        if (rowok[j]) {
-#pragma unroll
-            for (int t = 0; t < DT; ++t) {
-                const int n = (wave * DT + t) * 16 + 4 * lg;
-                const f32x4 pg = *(const f32x4*)(&vecs[1][n]), pbt = *(const f32x4*)(&vecs[2][n]);
-                f32x4 y;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = __builtin_fmaf((acc[j][t][e] - mean[j]) * rstd, pg[e], pbt[e]);
-                *(f32x4*)(g.X1 + m[j] * D + n) = y;
-                P::store4((elem*)g.X1a + qk_off<P>((int)m[j], n, D / P::KB), y);
-            }
-        }
-    }
-}
-
+// (Round 4: "bit-identical" with k_attn_op2 was only true under the emulator -- on the device the compiler contracted the LayerNorm's mul + add into
+// fma in k_attn_op and not in k_attn_op2, one ulp apart in ~10 % of the rows (tools/debug_op2.py): the two fma sites above are spelled out since.
+// k_attn_op2 itself -- two query tiles per workgroup -- is retired (round 6): experiments/dsg_rejected_kernels.h.)
 
 // ---------------------------------------------------------------------------------------------------------
 // k_attn_op_w (round 4): k_attn_op for the shapes whose W_o does not fit the register file next to the attention -- the DSG+ widths
@@ -1227,9 +1037,11 @@ __global__ __launch_bounds__(64 * NKT, 2) void k_clip_attn(const ClipAttnArgs g)
         pbs[j] = g.bqkv[nt * 16 + lr];
     }
     DSG_LOADS_ISSUED();
+    DSG_TL_MARK(0);      // rows + projection columns requested
 #pragma unroll
     for (int kb = 0; kb < KD; ++kb) xs[wave * KD + kb][lane] = xf[kb];
     DSG_LDS_BARRIER();
+    DSG_TL_MARK(1);      // the clip's rows are in LDS (they have landed for every wave)
     // ---- (1) projection of the head's Q / K / V for all row tiles -> LDS in the attention kernels' fragment order.  The operand order
     //      of a tile (V: un-swapped) is decided ONCE per wave, outside the MFMA loops: all of a wave's tiles are of one kind at the ZEGGS
     //      widths (waves 0-3 Q / K, 4-5 V); a wave with both kinds (tiny dims) takes the tile-by-tile form
@@ -1268,13 +1080,16 @@ __global__ __launch_bounds__(64 * NKT, 2) void k_clip_attn(const ClipAttnArgs g)
             }
         }
     }
+    DSG_TL_MARK(2);      // this wave's projection columns done for all row tiles (W_qkv has landed)
     DSG_LDS_BARRIER();                                            // every wave is done with the rows: V^T moves in
+    DSG_TL_MARK(3);
 #pragma unroll
     for (int rt = 0; rt < NKT; ++rt)
 #pragma unroll
         for (int j = 0; j < CW; ++j)
             if (which[j] == 2) *(bf16x4v*)((elem*)&vs[0][0] + vt_off<P>(d0[j] + lr, rt * 16 + 4 * lg, NVF)) = vkeep[rt][j];
     DSG_LDS_BARRIER();
+    DSG_TL_MARK(4);      // Q / K / V^T of the head in LDS
     // ---- (2) attention of query tile `wave` (k_attn on LDS operands)
     const int qt = wave;
     f32x4 s[NKT];
@@ -1284,6 +1099,7 @@ __global__ __launch_bounds__(64 * NKT, 2) void k_clip_attn(const ClipAttnArgs g)
 #pragma unroll
         for (int kb = 0; kb < KDH; ++kb) s[nt] = P::mma(ks[nt * KDH + kb][lane], qs[qt * KDH + kb][lane], s[nt]);   // D[key = 4 lg + r][query = lr]
     }
+    DSG_TL_MARK(5);      // Q K^T issued
     const float scale = 1.0f / sqrtf((float)HD);
     float mx = -DSG_FLT_MAX;
 #pragma unroll
@@ -1310,6 +1126,7 @@ __global__ __launch_bounds__(64 * NKT, 2) void k_clip_attn(const ClipAttnArgs g)
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
     const float inv = 1.0f / sum;
+    DSG_TL_MARK(6);      // softmax
     f32x4 pfr[NVF];
 #pragma unroll
     for (int kb = 0; kb < NVF; ++kb) {
@@ -1336,6 +1153,7 @@ __global__ __launch_bounds__(64 * NKT, 2) void k_clip_attn(const ClipAttnArgs g)
             P::store4((elem*)g.out + qk_off<P>(b * g.ntok + q, h * HD + dt * 16 + 4 * lg, KD), y);      // the rounding point of the attention rows
         }
     }
+    DSG_TL_MARK(7);      // P V + stores issued
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1496,6 +1314,7 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
 #pragma unroll
             for (int kb = 0; kb < KD; ++kb) wof[t][kb] = wo[((size_t)(wave * DW + t) * KD + kb) * 64];
         DSG_LOADS_ISSUED();
+        DSG_TL_MARK(0);      // attention rows (this wave's share), residual rows, W_o requested
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int e = tid + NT * i;
@@ -1525,6 +1344,7 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
                 DSG_LOADS_ISSUED();
             }
         }
+        DSG_TL_MARK(1);      // out_proj issued (attention rows shared through LDS, W_o landed)
         if constexpr (RING > 0) {
 #pragma unroll
             for (int i = 0; i < RING; ++i) ring[i] = *ring_ptr(i);      // the ring's first fill arrives behind LayerNorm1
@@ -1588,6 +1408,7 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
 #pragma unroll
             for (int kb = 0; kb < KD; ++kb) af[rt][kb] = *(const f32x4*)(xa + (rt * 16 + lr) * XP + (kb * P::KB + P::E * lg) * ES);
         if constexpr (BIG) DSG_LDS_BARRIER();                 // every wave holds its operand: phase 1 may overwrite the aliased rows
+        DSG_TL_MARK(2);      // LayerNorm1 (three barriers) -> linear1's operand registers
     } else {
         DSG_LOADS_ISSUED();
     }
@@ -1634,7 +1455,9 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
 #pragma unroll
                 for (int t = 0; t < DW; ++t) pr[rt][t] = lda16<P>((const float*)g.X1, (size_t)(((unsigned)(m0 + rt * 16 + lr_late) * D + (wave * DW + t) * 16 + 4 * lg) * 4u));
         }
+        DSG_TL_MARK(3);      // phase 1 on the ring: linear1 + GELU -> LDS
         DSG_LDS_BARRIER();                 // `hidden` is complete (the ring keeps streaming: the barrier does not wait for vector memory)
+        DSG_TL_MARK(4);
         // ---- phase 2 on the ring: k-block k = fragments N1 + k DW .. + DW - 1
         constexpr int AB = RT <= 2 ? 2 : 1;      // (32-row blocks: the next k-block's `hidden` fragments are read from LDS one step ahead)
         f32x4 a[AB][RT];
@@ -1724,6 +1547,7 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
             }
         }
     }
+    DSG_TL_MARK(5);          // phase 2: linear2 issued
     // ---- + bias + residual, LayerNorm2 over whole rows (row lr: 4 lane groups x NW waves hold its D values)
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -1774,6 +1598,7 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
             }
         }
     }
+    DSG_TL_MARK(6);          // LayerNorm2 (two barriers) + row stores issued
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1875,8 +1700,11 @@ __global__ __launch_bounds__(64 * NW) void k_ffn_part(const FfnPartArgs g) {
                 pr[rt][t] = lda16<P>(g.R, ((size_t)m * D + n) * sizeof(float));
             }
         }
+#ifndef DSG_X_FFNP_LATE_W1
         load_w1();
+#endif
         DSG_LOADS_ISSUED();
+        DSG_TL_MARK(0);      // attention rows, W_o, residual rows, W1 columns requested
         f32x4 acc[RT][DW];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -1888,8 +1716,14 @@ __global__ __launch_bounds__(64 * NW) void k_ffn_part(const FfnPartArgs g) {
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int t = 0; t < DW; ++t) acc[rt][t] = P::mma(wof[t][kb], af[rt][kb], acc[rt][t]);
+        DSG_TL_MARK(1);      // out_proj issued (attention rows + W_o have landed)
+#ifdef DSG_X_FFNP_LATE_W1
+        load_w1();                                            // (a wave stuck in the issue of 98 loads cannot start out_proj: W1 goes out behind it, under LayerNorm1)
+        DSG_LOADS_ISSUED();
+#else
         load_w2();                                            // (W_o is dead: its registers take W2's k-range)
         DSG_LOADS_ISSUED();
+#endif
 #pragma unroll
         for (int i = 0; i < NV1; ++i) {
             const int e = (int)threadIdx.x + 64 * NW * i;
@@ -1904,7 +1738,12 @@ __global__ __launch_bounds__(64 * NW) void k_ffn_part(const FfnPartArgs g) {
             sm[rt] += __shfl_xor(sm[rt], 16); sm[rt] += __shfl_xor(sm[rt], 32);
             if (lg == 0) red[(rt * NW + wave) * 16 + lr] = sm[rt];
         }
+        DSG_TL_MARK(2);      // bias + residual added (the residual rows have landed)
         DSG_LDS_BARRIER();
+#ifdef DSG_X_FFNP_LATE_W1
+        load_w2();
+        DSG_LOADS_ISSUED();
+#endif
         float mean[RT], qv[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -1921,6 +1760,7 @@ __global__ __launch_bounds__(64 * NW) void k_ffn_part(const FfnPartArgs g) {
             if (lg == 0) red[((RT + rt) * NW + wave) * 16 + lr] = qv[rt];
         }
         DSG_LDS_BARRIER();
+        DSG_TL_MARK(3);      // LayerNorm1 statistics (two barriers)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             float a = 0.f;
@@ -1944,10 +1784,12 @@ __global__ __launch_bounds__(64 * NW) void k_ffn_part(const FfnPartArgs g) {
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int kb = 0; kb < KD; ++kb) af[rt][kb] = *(const f32x4*)(xa + (rt * 16 + lr) * XP + (kb * P::KB + P::E * lg) * ES);
+        DSG_TL_MARK(4);      // LayerNorm1 rows through LDS into linear1's operand registers
     } else {
         load_w1();
         load_w2();
         DSG_LOADS_ISSUED();
+        DSG_TL_MARK(0);
     }
     // ---- phase 1: this wave's hidden tiles of the split
 #pragma unroll
@@ -1963,7 +1805,9 @@ __global__ __launch_bounds__(64 * NW) void k_ffn_part(const FfnPartArgs g) {
             P::store4((elem*)(hid + (rt * 16 + lr) * HP) + (wave * FWS + j) * 16 + 4 * lg, y);
         }
     }
+    DSG_TL_MARK(5);      // phase 1: linear1 slice + GELU -> LDS (W1 has landed)
     DSG_LDS_BARRIER();
+    DSG_TL_MARK(6);
     // ---- phase 2: partial linear2 over the split's k-range, all D columns (wave w: columns [w D/NW, (w+1) D/NW))
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -1983,6 +1827,7 @@ __global__ __launch_bounds__(64 * NW) void k_ffn_part(const FfnPartArgs g) {
             for (int t = 0; t < DW; ++t) *(f32x4*)(o + t * 16) = acc[t];
         }
     }
+    DSG_TL_MARK(7);      // phase 2 + slab stores issued (W2 has landed)
 }
 
 struct FfnLnArgs {
@@ -2015,6 +1860,7 @@ __global__ __launch_bounds__(16 * RW) void k_ffn_ln(const FfnLnArgs g) {
         pb[q] = *(const f32x4*)(g.b2 + n); pg[q] = *(const f32x4*)(g.ln_g + n); pt[q] = *(const f32x4*)(g.ln_b + n);
     }
     DSG_LOADS_ISSUED();
+    DSG_TL_MARK(0);
     f32x4 v[DT];
     float sm = 0.f;
 #pragma unroll
@@ -2036,6 +1882,7 @@ __global__ __launch_bounds__(16 * RW) void k_ffn_ln(const FfnLnArgs g) {
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) qv += __shfl_xor(qv, o);
     const float rstd = 1.0f / sqrtf(qv / (float)D + 1e-5f);
+    DSG_TL_MARK(1);      // slabs summed, statistics (every load has landed)
     if (ok) {
 #pragma unroll
         for (int q = 0; q < DT; ++q) {

@@ -177,14 +177,10 @@ struct dsg_handle {
     bool aql_warned = false;
     bool aql_timing = false;             // the last dsg_sample was timed by the host clock around the AQL run
     double aql_ms = 0.0;
-    bool fuse_attn_mid = true;           // k_attn_mid (attention inside the out_proj/LN/linear1 kernel) at batch 1; DSG_FUSE_ATTN_MID=0 to A/B
     // A/B switches of the batched sets, read ONCE at dsg_create (round-4 advisor: they used to be getenv calls in select_kernels /
     // run_step, i.e. in the hot path and outside the hipGraph key): -1 = not set
     int env_ffn_rt4 = -1;                // DSG_FFN_RT4=<rows>: k_ffn on 64-row blocks from that many token rows at any lane count (0: never)
     int env_ffn_split = -1;              // DSG_FFN_SPLIT=0: linear1 + linear2 + LayerNorm-on-read instead of k_ffn_part + k_ffn_ln (BLOCK)
-    int env_attn_op2 = -1;               // DSG_ATTN_OP2=0|1: never / always the two-query-tile attention kernel (STREAM)
-    int env_ws_out_one = -1;             // DSG_WS_OUT_ONE=0: the STREAM pose head as persistent row-block groups (2 workgroups per CU) instead of one workgroup per row block (3 per CU)
-    int env_ffn_ring = -1;               // DSG_FFN_RING=0: k_ffn<OP> with double-buffered weight groups (rounds 4-5) instead of one rolling ring of weight fragments (bit-identical; A/B and tests)
     int env_clip_attn = -1;              // DSG_CLIP_ATTN=0: QKV GEMM + k_attn_op instead of k_clip_attn + k_ffn_ln (BLOCK; differs in the last bits)
     int* st_tmodel = nullptr; float* st_c[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int st_cap = 0, n_run = 1;
@@ -263,9 +259,9 @@ static bool uc_arena_ok(char* base, size_t size) {
 }
 #endif
 // a block of `bytes` of uncached memory on device `dev`, or nullptr (no uncached memory here / pool cap reached)
-static void* uc_pool_take(int dev, size_t bytes) {
+static void* uc_pool_take(int dev, size_t bytes, bool ignore_cap = false) {
 #ifdef DSG_EMU
-    (void)dev; (void)bytes;
+    (void)dev; (void)bytes; (void)ignore_cap;
     return nullptr;
 #else
     UcPool& P = uc_pool();
@@ -289,9 +285,11 @@ static void* uc_pool_take(int dev, size_t bytes) {
         size_t total = 0;
         for (const UcArena& A : av) total += A.size;
         const size_t want = std::max(UC_ARENA_MIN, (bytes + UC_ARENA_GRAN - 1) / UC_ARENA_GRAN * UC_ARENA_GRAN);
-        if (total + want > UcPool::cap_bytes()) return nullptr;
+        if (!ignore_cap && total + want > UcPool::cap_bytes()) return nullptr;
         void* d = nullptr;
-        if (hipExtMallocWithFlags(&d, want, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        // (experiment, round 6: DSG_UC_KIND=1 asks for fine-grained instead of uncached device memory)
+        static const unsigned kind = (getenv("DSG_UC_KIND") && atoi(getenv("DSG_UC_KIND")) == 1) ? hipDeviceMallocFinegrained : hipDeviceMallocUncached;
+        if (hipExtMallocWithFlags(&d, want, kind) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         UcArena A;
         A.base = (char*)d; A.size = want;
         A.quarantined = !uc_arena_ok(A.base, want);
@@ -328,6 +326,9 @@ static void uc_pool_give(int dev, void* d) {
 // still held.  Meant for a long-lived service between bursts of work; arenas allocated afterwards are checked like any fresh one.
 extern "C" int dsg_trim(int device, long long* bytes_released, long long* bytes_held) {
     UcPool& P = uc_pool();
+    int dev_before = -1;
+    if (hipGetDevice(&dev_before) != hipSuccess) { (void)hipGetLastError(); dev_before = -1; }
+    struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{dev_before};      // the caller's current device is left as it was
     std::lock_guard<std::mutex> lock(P.mu);
     long long rel = 0, held = 0;
     for (int dev = 0; dev < 64; ++dev) {
@@ -454,9 +455,18 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     if (c->max_batch <= 0 || c->njoints <= 0 || c->n_seed < 0 || c->n_seed >= c->n_poses)
         return fail(DSG_E_INVALID, "bad dims");
     if (c->precision != DSG_PREC_FP32 && c->precision != DSG_PREC_BF16 && c->precision != DSG_PREC_BF16W2) return fail(DSG_E_INVALID, "precision");
+#ifdef DSG_DEV_BF16_ONLY
+    if (c->precision != DSG_PREC_BF16) return fail(DSG_E_NOT_IMPLEMENTED, "development build (make dev): bf16 only");
+#endif
     const int ntok = c->n_poses + 1, Tp = rup(ntok, 32);
     if (!(Tp == 32 || Tp == 96 || Tp == 160))
         return fail(DSG_E_NOT_IMPLEMENTED, "attention kernel is instantiated for n_poses+1 padded to 32, 96 or 160 tokens");
+    // (the kernels index rows and features in 32 bits on the 24-bit multiplier -- dsg_kernels.h: imul24)
+    {
+        const size_t widest = (size_t)std::max(std::max(c->ff_size, c->latent_dim), (c->njoints + 127) / 128 * 128);
+        if ((size_t)c->max_batch * (size_t)ntok >= ((size_t)1 << 23) || (size_t)c->max_batch * (size_t)ntok * widest >= ((size_t)1 << 30))
+            return fail(DSG_E_INVALID, "max_batch too large: token rows x widest row must stay below 2^30 elements (use several lanes / handles)");
+    }
     HIPCHK(hipSetDevice(c->device));
 
     dsg_handle* h = new dsg_handle();
@@ -479,7 +489,6 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     //   DSG_KSET  kernel set for every handle (1 latency, 2 tile, 3 block, 4 stream; overrides dsg_set_kernel_set)   [A/B runs]
     //   DSG_UC    0: cached loop buffers + fenced packets, 1: uncached + fence-free, 2: uncached + fenced
     //   DSG_AQL   0: HIP launches instead of hand-written AQL packets
-    //   DSG_FUSE_ATTN_MID  0: k_attn + k_mid instead of k_attn_mid at batch 1 (bit-identical; A/B)
     if (const char* e = getenv("DSG_KSET")) {
         char* end = nullptr;
         const long v = strtol(e, &end, 10);
@@ -504,13 +513,9 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
             if (val && (strstr(val, "rocprof") || strstr(v, "ROCPROF"))) h->aql_mode = 0;
         }
     }
-    if (const char* e = getenv("DSG_FUSE_ATTN_MID")) h->fuse_attn_mid = atoi(e) != 0;
     if (const char* e = getenv("DSG_FFN_RT4")) h->env_ffn_rt4 = std::max(atoi(e), 0);
     if (const char* e = getenv("DSG_FFN_SPLIT")) h->env_ffn_split = atoi(e) != 0 ? 1 : 0;
-    if (const char* e = getenv("DSG_ATTN_OP2")) h->env_attn_op2 = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("DSG_CLIP_ATTN")) h->env_clip_attn = atoi(e) != 0 ? 1 : 0;
-    if (const char* e = getenv("DSG_FFN_RING")) h->env_ffn_ring = atoi(e) != 0 ? 1 : 0;
-    if (const char* e = getenv("DSG_WS_OUT_ONE")) h->env_ws_out_one = atoi(e) != 0 ? 1 : 0;
     *out = h;
 
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -657,8 +662,9 @@ static int launch_mm(dsg_handle* h, float* C, int ldc, const float* A, long long
     a.add = add; a.sadd = sadd; a.add_div = add_div < 1 ? 1 : add_div; a.M = M; a.N = N; a.K = K; a.act = act;
     const size_t n = (size_t)M * N;
     if (n == 0) return 0;
-    if (K >= 512 && n <= (1u << 20)) {  // long reductions: a workgroup per output (k_mm_longk); the big set-up tables stay on k_mm_naive
-        hipLaunchKernelGGL(k_mm_longk, dim3((int)std::min<size_t>(n, 16384)), dim3(256), 0, h->stream, a);
+    if (K >= 512 && n <= (1u << 20)) {  // long reductions: a wave per (row, 4 columns) (k_mm_wave); the big set-up tables stay on k_mm_naive
+        const size_t nw = (size_t)M * ((N + 3) / 4);
+        hipLaunchKernelGGL(k_mm_wave, dim3((int)std::min<size_t>((nw + 3) / 4, 16384)), dim3(256), 0, h->stream, a);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -1008,7 +1014,8 @@ static int auto_kernel_set(const dsg_handle* h, int B, int lanes) {
         // tiles win at batch 1: 208.2 vs 218.5 us per step, profiles/r05_g_bench_fp32_*.log)
         if (B <= 2 && latency_set_ok(h) && h->prec != DSG_PREC_FP32) return DSG_KSET_LATENCY;
         // (DSG+ widths, round 5: with k_ffn_part + k_ffn_ln behind k_attn_op_w BLOCK wins from 4 clips -- BEAT 283 vs 303 us, TWH 310 vs 365; 2 clips: 259 vs 198)
-        if (ffn_split_wide(h) && h->env_ffn_split != 0 && rows >= 600) return DSG_KSET_BLOCK;
+        // (only there: ffn_split_wide() is also true for fp32 at the ZEGGS widths, which has no such measurement -- round-5 advisor)
+        if (ffn_split_wide(h) && h->prec == DSG_PREC_BF16 && (h->D == 384 || h->D == 512) && h->env_ffn_split != 0 && rows >= 600) return DSG_KSET_BLOCK;
         return rows >= 1000 ? DSG_KSET_BLOCK : DSG_KSET_TILE;
     }
     if (B <= 1 && latency_set_ok(h) && h->prec != DSG_PREC_FP32) return DSG_KSET_LATENCY;
@@ -1037,7 +1044,7 @@ static int select_kernels(const dsg_handle* h, int B, KernelSel& k) {
     k = KernelSel();
     k.set = set;
     k.lat = set == DSG_KSET_LATENCY;
-    k.attn_in_mid = k.lat && h->fuse_attn_mid && have_attn_mid(h, B);
+    k.attn_in_mid = k.lat && have_attn_mid(h, B);
     k.stream = set == DSG_KSET_STREAM;
     k.ffn = k.stream;           // (round 4: k_ffn instead of k_ws<GELU> + k_ws2<RESID> + k_ln_frag)
     {
@@ -1073,7 +1080,9 @@ extern "C" int dsg_set_kernel_set(dsg_handle* h, int set) {
     if (set < DSG_KSET_AUTO || set > DSG_KSET_STREAM) return fail(DSG_E_INVALID, "dsg_set_kernel_set: unknown kernel set");
     if (set == DSG_KSET_LATENCY && h->D > 512) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set LATENCY: latent_dim > 512");
     if (set == DSG_KSET_STREAM && !stream_set_ok(h)) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set STREAM: bf16, latent_dim 128 / 256, 4 heads, ff 128 / 1024 only");
-    if (h->prec == DSG_PREC_BF16W2 && set > DSG_KSET_TILE) return fail(DSG_E_NOT_IMPLEMENTED, "precision bf16w2: kernel sets LATENCY and TILE only");
+    // (the same rule as select_kernels: round-5 advisor -- this entry point used to accept LATENCY at latent_dim 384 / 512, and every later call failed)
+    if (h->prec == DSG_PREC_BF16W2 && (set > DSG_KSET_TILE || (set == DSG_KSET_LATENCY && h->D > 256)))
+        return fail(DSG_E_NOT_IMPLEMENTED, "precision bf16w2: kernel sets LATENCY (latent_dim <= 256) and TILE only");
     if (getenv("DSG_KSET")) {                  // an A/B run pinned the set for the whole process: say so once, keep the pinned set
         static std::atomic<bool> said{false};
         if (set != h->kset_req && !said.exchange(true))
@@ -1205,16 +1214,17 @@ static int launch_ws(dsg_handle* h, GemmArgs g) {
     g.ws_G = ws_groups(P, MB, 2);
     const int K = g.KBtot * 32;
     if constexpr (EPI == EPI_OUT) {
-        if (h->env_ws_out_one != 0) {      // (round 5; DSG_WS_OUT_ONE=0: the persistent row-block groups of rounds 3-4, bit-identical)
-            g.ws_G = rup(MB, 8);
-            const dim3 grid1(ws_grid_x(P, g.ws_G) + 8);
-            if (K == 256) return step_launch<&k_ws<EPI, 16, true>>(h, grid1, dim3(256), g);
-            if (K == 128) return step_launch<&k_ws<EPI, 8, true>>(h, grid1, dim3(256), g);
-        }
+        // the pose head: one workgroup per (panel, row block), three per CU (round 5; the persistent row-block groups of rounds 3-4 lost on two
+        // boxes and are retired -- experiments/README.md) + the bookkeeping workgroup (one XCD round)
+        g.ws_G = rup(MB, 8);
+        const dim3 grid1(ws_grid_x(P, g.ws_G) + 8);
+        if (K == 256) return step_launch<&k_ws<EPI, 16, true>>(h, grid1, dim3(256), g);
+        if (K == 128) return step_launch<&k_ws<EPI, 8, true>>(h, grid1, dim3(256), g);
+    } else {
+        const dim3 grid(ws_grid_x(P, g.ws_G));
+        if (K == 256) return step_launch<&k_ws<EPI, 16>>(h, grid, dim3(256), g);
+        if (K == 128) return step_launch<&k_ws<EPI, 8>>(h, grid, dim3(256), g);
     }
-    const dim3 grid(ws_grid_x(P, g.ws_G) + (EPI == EPI_OUT ? 8 : 0));      // EPI_OUT: + the bookkeeping workgroup (one XCD round)
-    if (K == 256) return step_launch<&k_ws<EPI, 16>>(h, grid, dim3(256), g);
-    if (K == 128) return step_launch<&k_ws<EPI, 8>>(h, grid, dim3(256), g);
     return fail(DSG_E_NOT_IMPLEMENTED, "k_ws: K must be 128 or 256");
 }
 // STREAM: LayerNorm once per row (k_ln_frag) -> fragment-major bf16 rows in X1a (free between linear1 and the next attention
@@ -1259,6 +1269,9 @@ static int launch_gemm_w(dsg_handle* h, const GemmArgs& g, const KernelSel& ks) 
     constexpr bool blk_wins = EPI == EPI_QKV || EPI == EPI_GELU;
     if constexpr (sizeof(typename P::elem) == 2 && !P::W2 && PRO == PRO_DIRECT && (EPI == EPI_GELU || EPI == EPI_QKV || EPI == EPI_OUT)) {
         if (ks.stream && g.a_frag) return launch_ws<EPI>(h, g);      // STREAM: linear1 on the fragment-major LayerNorm1 rows of k_attn_op
+#ifdef DSG_X_BLOCK_WS_HEAD
+        if constexpr (EPI == EPI_OUT) { if (ks.blk && g.a_frag && g.xs_frag && g.M >= DSG_X_BLOCK_WS_HEAD) return launch_ws<EPI>(h, g); }
+#endif
     }
     if constexpr (sizeof(typename P::elem) == 2 && !P::W2 && PRO == PRO_LN && (EPI == EPI_QKV || EPI == EPI_OUT)) {
         if (ks.stream) return launch_ln_ws<EPI>(h, g);                    // STREAM: LayerNorm once per row, then the same streaming GEMM
@@ -1345,7 +1358,7 @@ static int launch_mid(dsg_handle* h, const MidArgs& a) {
 // one dispatch less per layer.  With HIP launches it does not pay (152.4 vs 151.3 us/step): the four heads' strided
 // K / V^T fragment loads queue on ONE CU's load path (38 loads in ~6100 cycles) instead of running on 24 otherwise idle
 // CUs, which costs what the saved launch gains.  With the AQL submission the balance tips (136.0 vs 140.8 us/step,
-// measured twice on the same box), so it is on by default; DSG_FUSE_ATTN_MID=0 selects the separate kernels.
+// measured twice on the same box), so it is what batch 1 runs (batch 2 of the same set runs k_attn + k_mid: tests compare the two).
 template <class P>
 static int launch_attn_mid(dsg_handle* h, const AttnMidArgs& a) {
     const dim3 grid(xcd_grid_x(a.mid.ff / 64), a.mid.MT);
@@ -1465,13 +1478,9 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                 a.X1 = h->X1; a.X1a = h->X1a; a.B = B; a.ntok = ntok; a.Tp = h->Tp;
                 const dim3 grid(cdiv(ntok, 16), B);
                 if constexpr (sizeof(typename P::elem) == 2) {
-                    // two query tiles per workgroup (K / V^T / W_o once per 32 rows; bit-identical) once the batch fills the GPU:
-                    // (from 4000 token rows) 1 x 64: 478 -> 463 us; 4 x 32 within noise; 4 x 16: 436 -> 442 us, block 1 x 16: 235 -> 251 (slower)
-                    if (ks.stream && (h->env_attn_op2 >= 0 ? h->env_attn_op2 != 0 : M >= 4000)) {      // (A/B: DSG_ATTN_OP2 = 0 never, 1 always)
-                        const dim3 grid2(cdiv(cdiv(ntok, 16), 2), B);
-                        if (D == 256 && h->Tp == 96) CHK((step_launch<&k_attn_op2<P, 4, 6>>(h, grid2, dim3(256), a)));
-                        else CHK((step_launch<&k_attn_op2<P, 2, 2>>(h, grid2, dim3(256), a)));
-                    } else if (D == 256 && h->Tp == 96) CHK((step_launch<&k_attn_op<P, 4, 6>>(h, grid, dim3(256), a)));
+                    // (k_attn_op2 -- two query tiles per workgroup -- is retired: since round 5 this branch only serves the last layer under fused
+                    //  guidance and DSG_CLIP_ATTN=0; experiments/dsg_rejected_kernels.h)
+                    if (D == 256 && h->Tp == 96) CHK((step_launch<&k_attn_op<P, 4, 6>>(h, grid, dim3(256), a)));
                     else if (D == 128 && h->Tp == 32) CHK((step_launch<&k_attn_op<P, 2, 2>>(h, grid, dim3(256), a)));
                     else if (D == 384) CHK((step_launch<&k_attn_op_w<P, 6, 10>>(h, grid, dim3(256), a)));
                     else CHK((step_launch<&k_attn_op_w<P, 8, 10>>(h, grid, dim3(256), a)));
@@ -1492,10 +1501,10 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                 if constexpr (sizeof(typename P::elem) == 2) {
                     const dim3 grid(cdiv(MT, 2));
                     if (clip_l) {
-                        if (D == 256 && ks.ffn_rt4 && h->env_ffn_ring != 0) CHK((step_launch<&k_ffn<P, 4, 16, 4, 8, 1, true, true, 12>>(h, dim3(cdiv(MT, 4)), dim3(512), a)));
-                        else if (D == 256 && ks.ffn_rt4) CHK((step_launch<&k_ffn<P, 4, 16, 4, 8, 1, true, true>>(h, dim3(cdiv(MT, 4)), dim3(512), a)));
-                        else if (D == 256 && h->env_ffn_ring != 0) CHK((step_launch<&k_ffn<P, 4, 16, 2, 8, 2, true, true, 32>>(h, grid, dim3(512), a)));
-                        else if (D == 256) CHK((step_launch<&k_ffn<P, 4, 16, 2, 8, 2, true, true>>(h, grid, dim3(512), a)));
+                        // (the weights of both phases on one rolling ring of fragments: 12 slots on 64-row blocks, 32 on 32-row blocks; the double-buffered
+                        //  groups of rounds 4-5 are retired)
+                        if (D == 256 && ks.ffn_rt4) CHK((step_launch<&k_ffn<P, 4, 16, 4, 8, 1, true, true, 12>>(h, dim3(cdiv(MT, 4)), dim3(512), a)));
+                        else if (D == 256) CHK((step_launch<&k_ffn<P, 4, 16, 2, 8, 2, true, true, 32>>(h, grid, dim3(512), a)));
                         else CHK((step_launch<&k_ffn<P, 2, 2, 2, 4, 2, false, true>>(h, grid, dim3(256), a)));
                         continue;
                     }
@@ -1590,9 +1599,13 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
             g.KS = 1; g.kb_per_split = g.KBtot; g.inv_ntok = fastdiv_inv(g.ntok); g.inv_hd = fastdiv_inv(g.hd);
             if (g.NT % 4) return fail(DSG_E_INVALID, "gemm: NT not divisible by the workgroup tile");
             const dim3 grid(xcd_grid_x(g.NT / 4), g.MT + 1, 1);
-            if (pick_ch(g.KBtot) == 16) CHK((step_launch<&k_gemm_cfg<P, 16>>(h, grid, dim3(256), g)));
-            else if (pick_ch(g.KBtot) == 12) CHK((step_launch<&k_gemm_cfg<P, 12>>(h, grid, dim3(256), g)));
-            else CHK((step_launch<&k_gemm_cfg<P>>(h, grid, dim3(256), g)));
+            // (bf16w2: 16 k-blocks of two-register weight + activation fragments do not fit -- two batches of 8, as in launch_gemm_w; round-5 advisor)
+            bool done = false;
+            if constexpr (!P::W2) {
+                if (pick_ch(g.KBtot) == 16) { CHK((step_launch<&k_gemm_cfg<P, 16>>(h, grid, dim3(256), g))); done = true; }
+            }
+            if (!done && pick_ch(g.KBtot) == 12) { CHK((step_launch<&k_gemm_cfg<P, 12>>(h, grid, dim3(256), g))); done = true; }
+            if (!done) CHK((step_launch<&k_gemm_cfg<P>>(h, grid, dim3(256), g)));
         } else if (ks.ffn || ks.ffn_split) {      // the rows are normalised already (k_ffn / k_ffn_ln of the last layer; cfgB == 0 here)
             g.X = nullptr; g.ln_g = nullptr; g.ln_b = nullptr; g.A = h->X0a; g.lda = D; g.a_frag = 1;
             CHK((launch_gemm_w<P, PRO_DIRECT, EPI_OUT>(h, g, ks)));
@@ -1693,7 +1706,11 @@ extern "C" int dsg_debug_chain(dsg_handle* h, int which, int n, int use_graph, i
     if (!h || !h->finalized || !h->cond_set) return fail(DSG_E_STATE, "debug_chain needs a finalized, conditioned handle");
     HIPCHK(hipSetDevice(h->cfg.device));
     if (h->prec == DSG_PREC_BF16W2) return fail(DSG_E_NOT_IMPLEMENTED, "dsg_debug_chain: precision bf16w2");
+#ifdef DSG_DEV_BF16_ONLY
+    auto one = [&](int i) { return debug_launch<PBF16>(h, which, i, B); };
+#else
     auto one = [&](int i) { return h->prec == DSG_PREC_BF16 ? debug_launch<PBF16>(h, which, i, B) : debug_launch<PF32>(h, which, i, B); };
+#endif
     const int G = 64;
     hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
     if (use_graph) {
@@ -1749,9 +1766,29 @@ extern "C" int dsg_debug_trace_get(dsg_handle* h, double* us, int cap, int* n_st
 #endif
 }
 
+// marks build (-DDSG_STAMPS=2): per traced step, packet and mark k < 12: {waves that passed the mark, mean, last wave} in us after the packet's
+// first wave start (dsg_kernels.h: DSG_TL_MARK)
+extern "C" int dsg_debug_trace_marks(dsg_handle* h, double* out, int cap, int* n_marks) {
+    if (!h || !out || !n_marks) return fail(DSG_E_INVALID, "null argument");
+#if !defined(DSG_EMU) && defined(DSG_STAMPS) && DSG_STAMPS >= 2
+    const dsg_aql::Trace& t = h->aql.trace;
+    if (t.marks.empty()) return fail(DSG_E_STATE, "no marks: arm a trace, then sample through the AQL path");
+    if ((int)t.marks.size() > cap) return fail(DSG_E_INVALID, "marks buffer too small");
+    memcpy(out, t.marks.data(), t.marks.size() * sizeof(double));
+    *n_marks = DSG_TL_NMARK;
+    return 0;
+#else
+    (void)cap;
+    return fail(DSG_E_NOT_IMPLEMENTED, "phase marks exist in the marks build only (make marks)");
+#endif
+}
+
 static int run_step_p(dsg_handle* h, const StepCtx& c) {
+#ifndef DSG_DEV_BF16_ONLY
     if (h->prec == DSG_PREC_BF16W2) return run_step<PBF16W2>(h, c);
-    return h->prec == DSG_PREC_BF16 ? run_step<PBF16>(h, c) : run_step<PF32>(h, c);
+    if (h->prec == DSG_PREC_FP32) return run_step<PF32>(h, c);
+#endif
+    return run_step<PBF16>(h, c);
 }
 
 static int launch_x_in(dsg_handle* h, const float* x, const float* init, int do_q, float qa, float qb, int use_philox,
@@ -1918,7 +1955,10 @@ static bool uc_selfcheck(dsg_handle* h) {
     std::lock_guard<std::mutex> lock(g_uc_mutex);
     if (int v = g_uc_checked[dev].load(std::memory_order_acquire)) return v == 1;
     const int n_wg = 256, iters = 64;
-    unsigned* buf = (unsigned*)uc_pool_take(h->cfg.device, (size_t)(n_wg * 256 + 64) * sizeof(unsigned));
+    // The 257 KB probe buffer comes from outside the pool's cap (round-5 advisor: a pool that is full at this moment is a TRANSIENT condition,
+    // but the verdict stored here is permanent for the process); it goes back to the pool like every uncached block.  No uncached memory at
+    // all on this device: that IS permanent.
+    unsigned* buf = (unsigned*)uc_pool_take(h->cfg.device, (size_t)(n_wg * 256 + 64) * sizeof(unsigned), /*ignore_cap=*/true);
     if (!buf) {
         g_uc_checked[dev].store(2, std::memory_order_release);
         return false;
@@ -1950,6 +1990,21 @@ static bool uc_selfcheck(dsg_handle* h) {
 }
 #endif
 
+#ifdef DSG_X_HOSTPROF
+#include <chrono>
+struct HostProf {
+    double acc[16] = {0}; long n = 0; std::chrono::steady_clock::time_point t;
+    void start() { t = std::chrono::steady_clock::now(); ++n; }
+    void lap(int i) { auto u = std::chrono::steady_clock::now(); acc[i] += std::chrono::duration<double, std::micro>(u - t).count(); t = u; }
+    ~HostProf() { if (n) { fprintf(stderr, "hostprof (us per call, %ld calls):", n); for (int i = 0; i < 16; ++i) if (acc[i] > 0) fprintf(stderr, " [%d] %.1f", i, acc[i] / n); fprintf(stderr, "\n"); } }
+};
+static HostProf g_hp;
+#define HP_START() g_hp.start()
+#define HP_LAP(i) g_hp.lap(i)
+#else
+#define HP_START() ((void)0)
+#define HP_LAP(i) ((void)0)
+#endif
 static int sample_prepare(dsg_handle* h, const dsg_sample_args* a, int B, void* stream, SampleJob& job) {
     if (!h || !a) return fail(DSG_E_INVALID, "dsg_sample: null argument");
     if (!h->finalized || !h->cond_set) return fail(DSG_E_STATE, "dsg_sample before finalize / set_window_cond");
@@ -1961,9 +2016,11 @@ static int sample_prepare(dsg_handle* h, const dsg_sample_args* a, int B, void* 
     if (a->mode == DSG_MODE_DDIM && a->const_noise)
         return fail(DSG_E_NOT_IMPLEMENTED, "ddim_sample_loop: const_noise (gaussian_diffusion.py:915-916)");
     HIPCHK(hipSetDevice(h->cfg.device));
+    HP_START();
     CHK(order_after(h, stream));
     int n_run = 0;
     CHK(build_step_tables(h, a->mode, a->skip_timesteps, a->eta, &n_run));
+    HP_LAP(0);
     // a chain may be run in pieces (first_step / max_steps: the lazy generator forms of the loops): steps [first, first + n_iter)
     const int first = a->first_step, n_total = n_run;
     if (first < 0 || first >= n_total || a->max_steps < 0) return fail(DSG_E_INVALID, "first_step / max_steps out of range");
@@ -1998,11 +2055,13 @@ static int sample_prepare(dsg_handle* h, const dsg_sample_args* a, int B, void* 
     }
     hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(64), 0, h->stream, h->ctl, h->st_tmodel, first);
     HIPCHK(hipGetLastError());
+    HP_LAP(1);
     {
         const unsigned dyn[5] = {nk.k0, nk.k1, nk.s0, nk.s1, a->draw_base + 1u};
         HIPCHK(hipMemcpyAsync(h->dyn, dyn, sizeof(dyn), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
+    HP_LAP(2);
     StepCtx& c = job.c;
     c.B = rows; c.out_mode = a->mode == DSG_MODE_DDPM ? OUT_DDPM : OUT_DDIM; c.use_ctr = true; c.ext_noise = ext;
     c.const_noise = a->const_noise; c.clip_x0 = a->clip_denoised ? 1 : 0;
@@ -2028,10 +2087,13 @@ static int sample_prepare(dsg_handle* h, const dsg_sample_args* a, int B, void* 
         bool planned = dsg_aql::init(h->aql, h->cfg.device, (const void*)&dsg_version);
         bool nofence = false;
         if (planned && h->uc_mode == 1) nofence = uc_selfcheck(h);
+        HP_LAP(3);
         if (planned) {
             dsg_aql::begin(h->aql);
             const int rc = run_step_p(h, c);
+            HP_LAP(4);
             planned = dsg_aql::finish(h->aql) && rc == 0;
+            HP_LAP(5);
             h->aql.recording = false;
             h->aql.nofence = nofence;            // fence-free packets (see uc_mode; 2: uncached buffers behind the usual fences)
         }
@@ -2045,6 +2107,7 @@ static int sample_prepare(dsg_handle* h, const dsg_sample_args* a, int B, void* 
     }
 #endif
     HIPCHK(hipEventRecord(h->ev_t0, h->stream));
+    HP_LAP(6);
     return 0;
 }
 
@@ -2100,12 +2163,14 @@ static int sample_run_hip(dsg_handle* h, const dsg_sample_args* a, SampleJob& jo
 
 static int sample_finish(dsg_handle* h, float* out, void* stream, SampleJob& job) {
     const size_t n = (size_t)job.B * h->J * h->T;
+    HP_LAP(7);                               // (the step loop itself)
     HIPCHK(hipEventRecord(h->ev_t1, h->stream));
     h->last_steps = job.n_run; h->timing_valid = true;
     h->last_kset = job.c.ks.set;
     CHK(launch_x_out(h, h->fwd_out, job.B));
     CHK(from_dev(h, out, h->fwd_out, n));
     CHK(order_before(h, stream));
+    HP_LAP(8);
     return 0;
 }
 

@@ -47,6 +47,11 @@ typedef unsigned short bf16_t;
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __builtin_bit_cast(float, ((unsigned)h) << 16); }
 
+// Per-lane index arithmetic in 32 bits on the 24-bit multiplier (round 6).  A 64-bit product of lane-varying operands -- `(size_t)row * pitch` -- costs
+// the compiler a v_mad_u64_u32 + v_mul_lo_u32 group, all quarter rate (16 cycles per wave instruction): the STREAM pose head spent more cycles on
+// such products (27 v_mul_lo + 12 v_mad_u64 per Philox call) than on Philox itself, k_loc a third of its VALU time.  v_mul_u32_u24 is full rate; every
+// row / frame / feature count of the path is < 2^24 and every ELEMENT offset < 2^31 (dsg_create checks max_batch against that).
+__device__ __forceinline__ unsigned imul24(int a, int b) { return __umul24((unsigned)a, (unsigned)b); }
 // 16-lane ("DPP row") butterfly reductions: quad_perm xor-1, xor-2, row_half_mirror, row_mirror -- four DPP moves
 // (a few cycles each) instead of four ds_bpermute round trips through the LDS crossbar.
 __device__ __forceinline__ float dpp_f(float v, int ctrl_sel) {
@@ -60,6 +65,12 @@ __device__ __forceinline__ float dpp_f(float v, int ctrl_sel) {
     }
     return __builtin_bit_cast(float, r);
 }
+// 2^x as one v_exp_f32 (no denormal-range fix-up: callers' arguments stay far from it or do not care)
+#ifndef DSG_EMU
+__device__ __forceinline__ float dsg_exp2f(float x) { return __builtin_amdgcn_exp2f(x); }
+#else
+__device__ __forceinline__ float dsg_exp2f(float x) { return std::exp2(x); }
+#endif
 __device__ __forceinline__ float row16_sum(float v) {
     v += dpp_f(v, 0); v += dpp_f(v, 1); v += dpp_f(v, 2); v += dpp_f(v, 3);
     return v;
@@ -195,7 +206,7 @@ template <class P> __device__ __forceinline__ float ldwf(const float* p) { retur
 // The QKV epilogue scatters into this order (stores are off the critical path), the attention kernels read lane-linear.
 template <class P>
 __device__ __forceinline__ int qk_off(int tok, int d, int kdh) {
-    return ((((tok >> 4) * kdh + d / P::KB) * 64 + ((d % P::KB) / P::E) * 16 + (tok & 15)) * P::E) + (d % P::E);
+    return (((((int)imul24(tok >> 4, kdh)) + d / P::KB) * 64 + ((d % P::KB) / P::E) * 16 + (tok & 15)) * P::E) + (d % P::E);
 }
 template <class P>
 __device__ __forceinline__ int vt_off(int dim, int tok, int nvf) {
@@ -207,7 +218,7 @@ __device__ __forceinline__ int vt_off(int dim, int tok, int nvf) {
 // (the GEMM operand order, qk_off) when the kernel set streams it
 template <class P>
 __device__ __forceinline__ size_t xs_off(int row, int j, int Jp, int frag) {
-    return frag ? (size_t)qk_off<P>(row, j, Jp / P::KB) : (size_t)row * Jp + j;
+    return frag ? (size_t)qk_off<P>(row, j, Jp / P::KB) : (size_t)(imul24(row, Jp) + (unsigned)j);
 }
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // Load phases are written branch-free (clamped addresses, select afterwards): a load under a runtime predicate makes
@@ -226,29 +237,72 @@ extern "C" __device__ const unsigned dsg_device_build_tag = DSG_BUILD_TAG;
 // stamps the 100 MHz steady counter (s_memrealtime) when its first wave starts and when its last wave ends, into the slot the
 // AQL submission wrote BEHIND the kernel's arguments for this particular packet (dsg_aql.h: Trace; slot < 0: an untraced
 // packet, nothing happens).  One atomic min / max per wave; compiled out of the product library.
+// Phase marks (round 6; -DDSG_STAMPS=2, `make marks` -> libdsg_hip_marks.so + dsg_kernels_marks.hsaco): DSG_TL_MARK(k), k = 0 .. 11, placed between
+// the phases of a kernel, stores the same counter into slot k of the wave's entry when the wave PASSES that point (instruction issue: a mark
+// behind the first use of a batch of loads reads "the loads have landed").  The table per kernel -- mean and last wave per mark, relative to the
+// kernel's first wave -- is what tools/aql_timeline.py --lib marks prints.  Marks pin the instruction schedule around them (sched_barrier),
+// so the marks build is for reading phases, the plain stamps build for kernel totals.
 #ifdef DSG_STAMPS
+constexpr int DSG_TL_NMARK = 12;
+#if DSG_STAMPS >= 2
+struct TlEntry { unsigned long long t0, t1; unsigned long long m[DSG_TL_NMARK]; };
+#else
 struct TlEntry { unsigned long long t0, t1; };
+#endif
 constexpr int DSG_TL_WAVES = 2048, DSG_TL_ARG_OFF = 128;       // entries (waves) per traced packet; slot index + ring pointer: reserved
                                                                // dwords 128 / 136 of the implicit-argument block
+// the entry of this wave in the ring of its packet, or null (an untraced packet)
+__device__ __forceinline__ TlEntry* tl_entry() {
+    const char* ia = (const char*)__builtin_amdgcn_implicitarg_ptr();
+    const int slot = *(const int*)(ia + DSG_TL_ARG_OFF);
+    if (slot < 0) return nullptr;
+    TlEntry* ring = *(TlEntry* const*)(ia + DSG_TL_ARG_OFF + 8);
+    const unsigned w = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * ((blockDim.x + 63) >> 6) + (threadIdx.x >> 6);
+    // grids of more than 2048 waves: the first 1024 keep their own entries (-> first start), the later ones share the other
+    // 1024 round-robin; the last writers of those are the last waves of the grid (-> last end)
+    const unsigned ent = w < 1024u ? w : 1024u + (w & 1023u);
+    return ring + (size_t)slot * DSG_TL_WAVES + ent;
+}
+#if DSG_STAMPS >= 2
+// marks are parked in LDS while the kernel runs (one 8-byte LDS store by lane 0 per mark: no address arithmetic, no vector-memory traffic, no
+// live registers between marks) and copied to the wave's ring entry by its first 12 lanes when the wave ends
+__device__ __forceinline__ unsigned long long* tl_lds() { __shared__ unsigned long long m[16 * DSG_TL_NMARK]; return m; }
+#endif
 struct TlScope {           // every wave stores its own start / end stamp (plain 8-byte stores to its own entry: no contention)
-    TlEntry* e;
-    __device__ __forceinline__ TlScope() : e(nullptr) {
-        const char* ia = (const char*)__builtin_amdgcn_implicitarg_ptr();
-        const int slot = *(const int*)(ia + DSG_TL_ARG_OFF);
-        if (slot >= 0) {
-            TlEntry* ring = *(TlEntry* const*)(ia + DSG_TL_ARG_OFF + 8);
-            const unsigned w = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * ((blockDim.x + 63) >> 6) + (threadIdx.x >> 6);
-            // grids of more than 2048 waves: the first 1024 keep their own entries (-> first start), the later ones share the other
-            // 1024 round-robin; the last writers of those are the last waves of the grid (-> last end)
-            const unsigned ent = w < 1024u ? w : 1024u + (w & 1023u);
-            if ((threadIdx.x & 63) == 0) { e = ring + (size_t)slot * DSG_TL_WAVES + ent; e->t0 = __builtin_readsteadycounter(); }
+    bool on;
+    __device__ __forceinline__ TlScope() : on(false) {
+        TlEntry* p = tl_entry();
+        on = p != nullptr;
+        if (on) {
+#if DSG_STAMPS >= 2
+            if ((threadIdx.x & 63) < DSG_TL_NMARK) tl_lds()[(threadIdx.x >> 6) * DSG_TL_NMARK + (threadIdx.x & 63)] = 0ull;
+#endif
+            if ((threadIdx.x & 63) == 0) p->t0 = __builtin_readsteadycounter();
         }
     }
-    __device__ __forceinline__ ~TlScope() { if (e) e->t1 = __builtin_readsteadycounter(); }
+    __device__ __forceinline__ ~TlScope() {
+        if (on) {
+            TlEntry* p = tl_entry();       // (recomputed: nothing of the scope stays live in vector registers across the kernel)
+            const unsigned long long t = __builtin_readsteadycounter();
+#if DSG_STAMPS >= 2
+            if ((threadIdx.x & 63) < DSG_TL_NMARK) p->m[threadIdx.x & 63] = tl_lds()[(threadIdx.x >> 6) * DSG_TL_NMARK + (threadIdx.x & 63)];
+#endif
+            if ((threadIdx.x & 63) == 0) p->t1 = t;
+        }
+    }
 };
 #define DSG_TL_SCOPE() TlScope dsg_tl_scope_
+#if DSG_STAMPS >= 2
+__device__ __forceinline__ void tl_mark(int k) {
+    if ((threadIdx.x & 63) == 0) tl_lds()[(threadIdx.x >> 6) * DSG_TL_NMARK + k] = __builtin_readsteadycounter();
+}
+#define DSG_TL_MARK(k) do { __builtin_amdgcn_sched_barrier(0); dsg::tl_mark(k); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define DSG_TL_MARK(k) ((void)0)
+#endif
 #else
 #define DSG_TL_SCOPE() ((void)0)
+#define DSG_TL_MARK(k) ((void)0)
 #endif
 // Workgroup barrier for LDS hand-offs only.  __syncthreads() also drains every outstanding VECTOR memory operation
 // (s_waitcnt vmcnt(0)): in-flight weight loads and the acknowledgement of global stores issued before it.  Nothing in
@@ -309,6 +363,30 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
     }
     o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
+// Box-Muller pieces for the restricted arguments of the noise stream (round 6).  The libm routines (logf, sqrtf, sincospif: ~180 instructions per
+// Philox call with their general-argument handling) made the pose head of the STREAM set ALU-bound (2300 VALU instructions per wave, 13 us of
+// VALU issue per launch at 64 clips -- tools/pmc_valu.sh); here u1 is in [2^-24, 1] and t = 2 u2 a multiple of 2^-23 in [0, 2):
+//   r      = sqrt(-2 ln 2 . log2 u1)      v_log_f32 + v_sqrt_f32 (1 ulp each)
+//   sincos = quarter-turn reduction (exact: t - n / 2 with n = rint(2 t)) + degree-7 / degree-8 polynomials on [-1/4, 1/4]: 1.74 ulp max over all
+//            2^24 arguments (numpy float32 emulation); the oracle (oracle/philox.py) computes the transform in float64 and rounds.
+// tools/noise_probe.cpp measures both against double arithmetic on the device, and the old against the new normals.
+#ifndef DSG_EMU
+__device__ __forceinline__ float dsg_log2f(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float dsg_sqrtf(float x) { return __builtin_amdgcn_sqrtf(x); }
+#else
+__device__ __forceinline__ float dsg_log2f(float x) { return std::log2(x); }
+__device__ __forceinline__ float dsg_sqrtf(float x) { return std::sqrt(x); }
+#endif
+__device__ __forceinline__ void dsg_sincospi_02(float t, float& s, float& c) {          // sin(pi t), cos(pi t) for t in [0, 2)
+    const float n = __builtin_rintf(t + t);                                           // quarter turns 0 .. 4
+    const float f = __builtin_fmaf(n, -0.5f, t), f2 = f * f;                          // exact; |f| <= 1/4
+    const float sp = f * __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(-0.5890104174613953f, f2, 2.5497608184814453f), f2, -5.167707443237305f), f2, 3.1415927410125732f);
+    const float cp = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(__builtin_fmaf(0.231417715549469f, f2, -1.3350569009780884f), f2, 4.0587077140808105f), f2, -4.934802055358887f), f2, 1.0f);
+    const int q = (int)n;
+    const float a = (q & 1) ? cp : sp, b = (q & 1) ? sp : cp;
+    s = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) ^ ((unsigned)(q & 2) << 30));
+    c = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, b) ^ ((unsigned)((q + 1) & 2) << 30));
+}
 // four standard normals for element quad q (elements 4q..4q+3) of draw `draw`
 __device__ __forceinline__ f32x4 philox_normal4(unsigned q, unsigned draw, NoiseKey key) {
     unsigned x[4];
@@ -316,10 +394,16 @@ __device__ __forceinline__ f32x4 philox_normal4(unsigned q, unsigned draw, Noise
     const float sc = 5.9604644775390625e-08f;          // 2^-24
     float u1a = (float)((x[0] >> 8) + 1u) * sc, u2a = (float)(x[1] >> 8) * sc;
     float u1b = (float)((x[2] >> 8) + 1u) * sc, u2b = (float)(x[3] >> 8) * sc;
-    float ra = sqrtf(-2.0f * logf(u1a)), rb = sqrtf(-2.0f * logf(u1b));
     float sa, ca, sb, cb;
+#ifdef DSG_X_OLD_NOISE
+    float ra = sqrtf(-2.0f * logf(u1a)), rb = sqrtf(-2.0f * logf(u1b));
     sincospif(2.0f * u2a, &sa, &ca);
     sincospif(2.0f * u2b, &sb, &cb);
+#else
+    const float ra = dsg_sqrtf(-1.3862943611198906f * dsg_log2f(u1a)), rb = dsg_sqrtf(-1.3862943611198906f * dsg_log2f(u1b));
+    dsg_sincospi_02(2.0f * u2a, sa, ca);
+    dsg_sincospi_02(2.0f * u2b, sb, cb);
+#endif
     f32x4 z; z[0] = ra * ca; z[1] = ra * sa; z[2] = rb * cb; z[3] = rb * sb;
     return z;
 }
@@ -493,19 +577,31 @@ __device__ __forceinline__ void vt_store_block(const GemmArgs& g, const typename
     }
 }
 
-// Exact (erf) GELU.  fp32 kernels call erff; the bf16 kernels round the result to 8 mantissa bits anyway, so they use
-// Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7 in erf, ~15 instructions with v_rcp/v_exp) instead of the ~60-instruction
-// branchy libm routine -- at one wave per SIMD that is ~0.1 us per value on the critical path of every FFN kernel.
+// Exact (erf) GELU.  fp32 kernels call erff.  bf16w2 (its `hidden` keeps 16 mantissa bits) uses Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7 in erf,
+// ~17 instructions with v_rcp / v_exp) instead of the ~60-instruction branchy libm routine.  Plain bf16 rounds the result to 8 mantissa bits, and
+// from 16 clips on the feed-forward kernels are BOUND by this function (round 6, phase marks: 65 536 evaluations per 64-row block of k_ffn = 8.5 us
+// of VALU on a CU whose weight stream needs 7.8): there  gelu(x) = x Phi(x)  is evaluated as  x / (1 + 2^(x p(x^2)))  with the odd polynomial
+// -log2(e) logit(Phi(x)) ~ x (c0 + c1 x^2 + c2 x^4) fitted in fp32 arithmetic on [-8, 8] (x clamped there; beyond, Phi is 0 / 1 to 1e-12):
+// max |error| 2.6e-5 absolute, 1.2e-3 relative wherever |gelu| > 0.01 -- below half a bf16 ulp (2e-3) -- in 9 instructions (v_med3, 2 mul,
+// 2 fma, v_exp, add, v_rcp, mul).  The tanh form of the literature has 4.7e-4 / 4.7e-2 for the same cost less one fma.
 template <class P>
 __device__ __forceinline__ float gelu_erf(float x) {
     if constexpr (sizeof(typename P::elem) == 4) {
         return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
-    } else {
+#ifdef DSG_X_OLD_GELU
+    } else if constexpr (true) {
+#else
+    } else if constexpr (P::W2) {
+#endif
         const float ax = fabsf(x) * 0.70710678118654752440f;
         const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
         const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
         const float er = 1.0f - poly * __expf(-ax * ax);
         return 0.5f * x * (1.0f + copysignf(er, x));
+    } else {
+        const float xc = fminf(fmaxf(x, -8.0f), 8.0f), x2 = xc * xc;
+        const float t = xc * __builtin_fmaf(__builtin_fmaf(0.0010147836f, x2, -0.10677913f), x2, -2.301118f);
+        return x * __builtin_amdgcn_rcpf(1.0f + dsg_exp2f(t));
     }
 }
 
@@ -579,9 +675,11 @@ struct TileOps { f32x4 pb, pr, pz; float pbs; bool ovalid; };
 // x_t of (row m, features j0 .. j0 + 3) for the sampler epilogue: unconditional load from a clamped (always valid) row
 template <class P>
 __device__ __forceinline__ f32x4 out_xt_load(const GemmArgs& g, int m, int j0) {
-    const int b = fdiv(m, g.inv_ntok), sx = m - b * g.ntok;
-    const int bc = b < g.B ? b : g.B - 1, fc = sx > 0 ? sx - 1 : 0;
-    return lda16<P>(g.xs32, (((size_t)bc * g.T + fc) * g.Jp + j0) * sizeof(float));
+    // row of (batch element b, frame sx - 1) in the state = b T + sx - 1 = m - b - 1 (ntok = T + 1); token rows (sx = 0) and rows past the batch are
+    // clamped to a valid row, their value is never used
+    const int b = fdiv(m, g.inv_ntok);
+    const int row = min(max(m - b - 1, 0), g.B * g.T - 1);
+    return lda16<P>(g.xs32, (size_t)((imul24(row, g.Jp) + (unsigned)j0) * 4u));
 }
 template <class P, int EPI>
 __device__ __forceinline__ void gemm_prefetch_tile(const GemmArgs& g, int m0, int n0, int lr, int lg, int step, TileOps& o, const f32x4* xt_ready = nullptr) {
@@ -597,7 +695,7 @@ __device__ __forceinline__ void gemm_prefetch_tile(const GemmArgs& g, int m0, in
             o.pbs = g.bias[n0 + lr];
         } else if constexpr (EPI == EPI_OUT) {
             const int m = m0 + lr, j0 = n0 + 4 * lg;
-            const int b = fdiv(m, g.inv_ntok), sx = m - b * g.ntok;
+            const int b = fdiv(m, g.inv_ntok), sx = m - (int)imul24(b, g.ntok);
             o.ovalid = m < g.M && sx > 0 && j0 < g.J;
             o.pb = *(const f32x4*)(g.bias + j0);
             // x_t: unconditional load from a clamped (always valid) row; unused when the lane is not `ovalid`
@@ -612,8 +710,7 @@ __device__ __forceinline__ void gemm_prefetch_tile(const GemmArgs& g, int m0, in
                                        ? g.ext_noise[(((size_t)step * g.B + bn) * g.J + j0 + e) * g.T + f] : 0.f;
                 } else {
                     const NoiseKey nk = {g.dyn[0], g.dyn[1], g.dyn[2], g.dyn[3]};
-                    o.pz = philox_normal4((unsigned)((((size_t)bn * g.T + f) * g.Jq + j0) >> 2),
-                                           g.dyn[4] + (unsigned)step, nk);
+                    o.pz = philox_normal4((imul24((int)imul24(bn, g.T) + f, g.Jq) + (unsigned)j0) >> 2, g.dyn[4] + (unsigned)step, nk);
                 }
             }
         }
@@ -672,9 +769,10 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmArgs& g, int m0, in
             }
         } else if constexpr (EPI == EPI_OUT) {
             const int m = m0 + lr, j0 = n0 + 4 * lg;
-            const int b = fdiv(m, g.inv_ntok), sx = m - b * g.ntok;
+            const int b = fdiv(m, g.inv_ntok), sx = m - (int)imul24(b, g.ntok);
             if (o.ovalid) {
                 const int f = sx - 1;
+                const int srow = m - b - 1;                 // = b T + f: row of the state
                 f32x4 x0 = acc + o.pb;
                 if (g.cfgB > 0) {                       // cfg_sampler.py:31: out_uncond + scale * (out - out_uncond)
                     const f32x4 xu = acc_u + o.pb;
@@ -710,11 +808,12 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmArgs& g, int m0, in
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (j0 + e >= g.J) xn[e] = 0.f;
-                    *(f32x4*)(g.xs32 + ((size_t)b * g.T + f) * g.Jp + j0) = xn;
-                    if (g.xsA) P::store4((elem*)g.xsA + xs_off<P>(b * g.T + f, j0, g.Jp, g.xs_frag), xn);
+                    *(f32x4*)((char*)g.xs32 + (size_t)((imul24(srow, g.Jp) + (unsigned)j0) * 4u)) = xn;
+                    if (g.xsA) P::store4((elem*)g.xsA + xs_off<P>(srow, j0, g.Jp, g.xs_frag), xn);
                     if (g.cfgB > 0) {                   // the unconditional twin advances with the same x_{t-1}
-                        *(f32x4*)(g.xs32 + ((size_t)(b + g.cfgB) * g.T + f) * g.Jp + j0) = xn;
-                        if (g.xsA) P::store4((elem*)g.xsA + xs_off<P>((b + g.cfgB) * g.T + f, j0, g.Jp, g.xs_frag), xn);
+                        const int trow = srow + (int)imul24(g.cfgB, g.T);
+                        *(f32x4*)((char*)g.xs32 + (size_t)((imul24(trow, g.Jp) + (unsigned)j0) * 4u)) = xn;
+                        if (g.xsA) P::store4((elem*)g.xsA + xs_off<P>(trow, j0, g.Jp, g.xs_frag), xn);
                     }
                 }
             }
@@ -811,6 +910,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
     TileOps ops[TNW];
 #pragma unroll
     for (int t = 0; t < TNW; ++t) gemm_prefetch_tile<P, EPI>(g, m0, (nt0 + t) * 16, lr, lg, step, ops[t]);
+    DSG_TL_MARK(0);          // weight fragments + epilogue operands requested (EPI_OUT: the Philox draw is behind this mark)
 
     // ---- prologue: LayerNorm-on-read (rows are owned whole: K == D)
     int pitch = 0;
@@ -849,6 +949,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
             else ln_rows<P, 0>(g, mp, tid, lds_a, pitch, v, nullptr, LDS_A);
         }
         DSG_LDS_BARRIER();
+        DSG_TL_MARK(1);      // LayerNorm-on-read rows in LDS
     }
 
     for (int kb0 = kb_lo; kb0 < kb_hi; kb0 += CH) {
@@ -878,6 +979,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
         if (kb0 + CH < kb_hi) load_b(kb0 + CH);
     }
     }   // pass
+    DSG_TL_MARK(2);          // main loop issued (operands have landed)
 
     // The normalised rows go back to global memory only now: a global store issued before the MFMA phase would sit
     // in the same vmcnt queue as the weight loads (stores and loads retire out of order with each other, so the
@@ -914,6 +1016,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
     for (int t = 0; t < TNW; ++t)
         gemm_epilogue_tile<P, EPI>(g, m0, (nt0 + t) * 16, lr, lg, ks, swapped[t], acc[t], ops[t], k1, k2, k3, k4, k5, acc_u[CFG ? t : 0]);
     }
+    DSG_TL_MARK(3);          // epilogue stores issued
 }
 
 // batched LayerNorm-GEMM: compiled for 3 waves per SIMD (<= 168 VGPRs; at 128 it spills to scratch; requesting the weights
@@ -1000,6 +1103,7 @@ __device__ __forceinline__ void local_attn_tail(const LocArgs& a, float (&rot)[2
         if (valid) sc[q][j] = pv / sum;
     }
     DSG_LDS_BARRIER();
+    DSG_TL_MARK(2);          // local attention: scores + softmax
     const int ntok = a.T + 1, col0 = h * HD;
     // Round 5: the W x HD output tile is staged in LDS and leaves in 16-byte stores -- the rows used to go out as 4-byte (fp32) and
     // 2-byte (bf16) element stores, and an uncached narrow store is a fabric write of its own (4096 workgroups x 704 of them at 64
@@ -1017,14 +1121,15 @@ __device__ __forceinline__ void local_attn_tail(const LocArgs& a, float (&rot)[2
         }
     }
     DSG_LDS_BARRIER();
+    DSG_TL_MARK(3);          // P V + second rotary -> staged tile
     constexpr int C4 = HD / 4, CE = HD / P::E;       // 16-byte chunks per row: fp32 rows / rows in the GEMM type
     for (int p = tid; p < W * C4; p += 256) {
         const int q = p / C4, c = p - q * C4;
-        *(f32x4*)(a.X0 + (size_t)(b * ntok + 1 + w * W + q) * a.D + col0 + 4 * c) = *(const f32x4*)&ot[q][4 * c];
+        *(f32x4*)(a.X0 + (imul24(b * ntok + 1 + w * W + q, a.D) + (unsigned)(col0 + 4 * c))) = *(const f32x4*)&ot[q][4 * c];
     }
     for (int p = tid; p < W * CE; p += 256) {
         const int q = p / CE, c = p - q * CE, row = b * ntok + 1 + w * W + q;
-        elem* dst = (elem*)a.X0a + (a.x0a_frag ? (size_t)qk_off<P>(row, col0 + P::E * c, a.D / P::KB) : (size_t)row * a.D + col0 + P::E * c);
+        elem* dst = (elem*)a.X0a + (a.x0a_frag ? (unsigned)qk_off<P>(row, col0 + P::E * c, a.D / P::KB) : imul24(row, a.D) + (unsigned)(col0 + P::E * c));
         if constexpr (P::E == 4) {
             *(f32x4*)dst = *(const f32x4*)&ot[q][4 * c];
         } else {
@@ -1052,19 +1157,18 @@ __device__ __forceinline__ void loc_body(const LocArgs& a, int h, int w, int b) 
     for (int i = 0; i < NPI; ++i) {
         const int p = min(tid + 256 * i, NP1 - 1);
         const int r = p / half, dd = p % half, f = max(f0 + r, 0);
-        const size_t base = ((size_t)b * a.T + f) * a.D + col0 + dd;
+        const unsigned base = imul24(b * a.T + f, a.D) + (unsigned)(col0 + dd);      // (32-bit element offsets: imul24)
         lo[i] = a.Cf[base];
         hi[i] = a.Cf[base + half];
         c1[i] = a.rcos[f * half + dd]; s1[i] = a.rsin[f * half + dd];
         if (a.KS == 1) {             // (uniform; the streamed pose embedding of the batched sets leaves ONE slab: without this, eight clamped
                                      //  re-reads of it per element -- uncached memory, every one a trip to the memory side)
-            const size_t pb = ((size_t)b * a.T + f) * a.D + col0 + dd;
-            lo[i] += a.partial[pb]; hi[i] += a.partial[pb + half];
+            lo[i] += a.partial[base]; hi[i] += a.partial[base + half];
         } else {
 #pragma unroll
             for (int s = 0; s < MAXKS; ++s) {
                 const float wgt = s < a.KS ? 1.f : 0.f;
-                const size_t pb = ((size_t)min(s, a.KS - 1) * a.Min_pad + (size_t)b * a.T + f) * a.D + col0 + dd;
+                const unsigned pb = imul24(min(s, a.KS - 1) * a.Min_pad, a.D) + base;
                 lo[i] += wgt * a.partial[pb]; hi[i] += wgt * a.partial[pb + half];
             }
         }
@@ -1081,20 +1185,22 @@ __device__ __forceinline__ void loc_body(const LocArgs& a, int h, int w, int b) 
 #pragma unroll
     for (int i = 0; i < NSI; ++i) {
         const int idx = tid + 256 * i, q = idx >> 5, j = idx & 31, fk = f0 + j;
-        const unsigned char mk = a.mask[(size_t)mrow * a.T + min(max(fk, 0), a.T - 1)];
+        const unsigned char mk = a.mask[(unsigned)(mrow * a.T + min(max(fk, 0), a.T - 1))];
         keep[i] = ((int)(q < W) & (int)(j < W2) & ((int)(a.nomask != 0) | ((int)(fk >= 0) & (int)(mk != 0)))) != 0;   // bitwise: keeps the load unconditional
     }
     const int tc = min(tid, HD - 1);
-    float tokv = a.emb1[(size_t)b * a.D + col0 + tc];
+    float tokv = a.emb1[(unsigned)(b * a.D + col0 + tc)];
     // the loads that depend on the model timestep go out last (t itself was requested first)
+    const float* te2 = a.TE2 + (size_t)t * a.D + col0;        // (t is wave-uniform: scalar arithmetic)
 #pragma unroll
     for (int i = 0; i < NPI; ++i) {
         const int p = min(tid + 256 * i, NP1 - 1), dd = p % half;
-        lo[i] += a.TE2[(size_t)t * a.D + col0 + dd];
-        hi[i] += a.TE2[(size_t)t * a.D + col0 + dd + half];
+        lo[i] += te2[dd];
+        hi[i] += te2[dd + half];
     }
     tokv += a.TE[(size_t)t * a.D + col0 + tc];
     DSG_LOADS_ISSUED();
+    DSG_TL_MARK(0);          // k_loc: every load requested
     if (w == 0 && tid < HD) {                              // token row (position 0: rotary is the identity)
         a.X0[(size_t)(b * ntok) * a.D + col0 + tid] = tokv;
         ((elem*)a.X0a)[a.x0a_frag ? (size_t)qk_off<P>(b * ntok, col0 + tid, a.D / P::KB) : (size_t)(b * ntok) * a.D + col0 + tid] = P::cvt(tokv);
@@ -1110,6 +1216,7 @@ __device__ __forceinline__ void loc_body(const LocArgs& a, int h, int w, int b) 
         }
     }
     DSG_LDS_BARRIER();
+    DSG_TL_MARK(1);          // rotary rows in LDS (the loads have landed)
     local_attn_tail<P, HD, W>(a, rot, sc, b, w, h, keep, c2, s2);
 }
 
@@ -1389,33 +1496,43 @@ __global__ void k_mm_naive(const MMArgs a) {
         a.C[(size_t)m * a.ldc + nn] = v;
     }
 }
-// the same product for LONG reductions (the seed-pose embedding: K = J * n_seed = 9128): one workgroup per output element, the
-// 256 lanes stride over k, double accumulation, fixed-order tree reduction -- the one-thread-per-output kernel above needs
-// 1.4 ms for that GEMV, which was most of the per-window host-side gap (2 ms per 115 ms window)
-__global__ __launch_bounds__(256) void k_mm_longk(const MMArgs a) {
-    __shared__ double red[256];
-    const size_t n = (size_t)a.M * a.N;
-    for (size_t i = blockIdx.x; i < n; i += gridDim.x) {
-        const int nn = (int)(i % a.N), m = (int)(i / a.N);
+// the same product for LONG reductions (the seed-pose embedding: K = J * n_seed = 9128; the audio feature map: K = 1133 for every frame of the
+// window): one WAVE per (row, 4 output columns), the 64 lanes stride over k, double accumulation, a fixed-order butterfly over the lanes.
+// (Rounds 2-5 used one WORKGROUP per output with a __syncthreads tree: 130-200 us of conditioning per window at batch 16, which the host waits
+// for before the first packet of the step loop -- 2 % of a 50-step DDIM window; round 6, tools/prof_host.py.)
+__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)u, m), hi = (unsigned)__shfl_xor((int)(unsigned)(u >> 32), m);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__global__ __launch_bounds__(256) void k_mm_wave(const MMArgs a) {
+    const int lane = threadIdx.x & 63, n4s = (a.N + 3) / 4;
+    const size_t nw = (size_t)a.M * n4s;
+    for (size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < nw; w += (size_t)gridDim.x * 4) {
+        const int n4 = (int)(w % n4s), m = (int)(w / n4s);
         const float* pa = a.A + (long long)m * a.sam;
-        const float* pb = a.Bm + (long long)nn * a.sbn;
-        double acc = 0.0;
-        for (int k = threadIdx.x; k < a.K; k += 256) acc += (double)pa[(long long)k * a.sak] * (double)pb[(long long)k * a.sbk];
-        red[threadIdx.x] = acc;
-        __syncthreads();
-        for (int s2 = 128; s2 > 0; s2 >>= 1) {
-            if ((int)threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
-            __syncthreads();
+        const float* pb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pb[j] = a.Bm + (long long)min(4 * n4 + j, a.N - 1) * a.sbn;      // clamped: computed and dropped
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int k = lane; k < a.K; k += 64) {
+            const double av = (double)pa[(long long)k * a.sak];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += av * (double)pb[j][(long long)k * a.sbk];
         }
-        if (threadIdx.x == 0) {
-            double r = red[0];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc[j] += shfl_xor_f64(acc[j], o);
+        if (lane < 4 && 4 * n4 + lane < a.N) {
+            const int nn = 4 * n4 + lane;
+            double r = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : (lane == 2 ? acc[2] : acc[3]));
             if (a.bias) r += (double)a.bias[nn];
             if (a.add) r += (double)a.add[(long long)(m / a.add_div) * a.sadd + nn];
             float v = (float)r;
             if (a.act == 1) v = v / (1.0f + expf(-v));
             a.C[(size_t)m * a.ldc + nn] = v;
         }
-        __syncthreads();
     }
 }
 // pack W[N][K] fp32 (row pitch ldw, column offset folded into the pointer) into MFMA fragment order

@@ -187,6 +187,7 @@ __device__ __forceinline__ void ws_body(const GemmArgs& g, const WsId id, char* 
         const int m0 = mb * BM;
         glds_wait();
         DSG_LDS_BARRIER();             // the block has landed for every wave; every wave is done with the other buffer
+        if constexpr (ONE) DSG_TL_MARK(0);      // (pose head, one block per workgroup) the activation block is in LDS
         if constexpr (!ONE) { if (mb + G < MB) issue_a(mb + G, cur ^ 1); }
         if constexpr (W_PER_BLOCK) {
             int zero = 0;
@@ -241,7 +242,9 @@ __device__ __forceinline__ void ws_body(const GemmArgs& g, const WsId id, char* 
             constexpr int TP = 36;                                 // floats per token: 144-byte pitch, conflict-free both ways
             float* st = (float*)(STAGE_IN_A ? lds + cur * ABYTES : lds + NBUF * ABYTES) + wave * (32 * TP);
             static_assert(4 * 32 * TP * 4 <= (STAGE_IN_A ? ABYTES : STAGE), "pose-head stage");
+            if constexpr (ONE) DSG_TL_MARK(1);                     // MFMA loop issued (the W panel has landed)
             DSG_LDS_BARRIER();                                     // every wave is done reading the activation block
+            if constexpr (ONE) DSG_TL_MARK(2);
             const int tok = lane >> 3, quad = lane & 7;
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
@@ -263,6 +266,7 @@ __device__ __forceinline__ void ws_body(const GemmArgs& g, const WsId id, char* 
                     gemm_prefetch_tile<P, EPI>(g, mw + t, nb[ct] + 4 * quad, 0, 0, step, ops, &xt[i]);
                     gemm_epilogue_tile<P, EPI>(g, mw + t, nb[ct] + 4 * quad, 0, 0, 0, true, v, ops, k1, k2, k3, k4, k5);
                 }
+                if constexpr (ONE) { if (ct == 0) DSG_TL_MARK(3); else DSG_TL_MARK(4); }      // column tile ct: 4 x (Philox draw + update + stores)
                 DSG_WAVE_LDS_SYNC();
             }
             cur ^= 1;

@@ -228,19 +228,20 @@ class DSGDiffusion:
         hooks = self._check_unsupported(denoised_fn, cond_fn, randomize_class, cond_fn_with_grad)
         inner, guided = (None, False) if hooks else self._library_model(model, shape[0])
         n_run = self.num_timesteps - skip_timesteps
-        draw0 = None
-        if inner is not None:
-            draw0 = self._draw
-            self._draw += 1 + n_run                  # the generator owns these draw indices from the moment it is created
+        # the generator owns these draw indices from the moment it is created -- the fused path AND (round-5 advisor) the generic path
+        # (hooks / a wrapped model): noise indices are fixed here, not at the first next()
+        draw0 = self._draw
+        self._draw += 1 + n_run
         return self._progressive_gen(ddim, model, inner, guided, shape, noise, clip_denoised, model_kwargs, device, skip_timesteps,
                                      init_image, const_noise, eta, n_run, draw0, denoised_fn, cond_fn)
 
     def _progressive_gen(self, ddim, model, inner, guided, shape, noise, clip_denoised, model_kwargs, device, skip_timesteps,
                          init_image, const_noise, eta, n_run, draw0, denoised_fn=None, cond_fn=None):
         if inner is None:
-            outs = self._generic_loop(ddim, model, shape, noise, model_kwargs, skip_timesteps, init_image, list(range(n_run)),
-                                      const_noise, eta, device, clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn)
-            for o in outs:
+            # LAZY like the fused form: one step per next() (the whole chain used to run, and every step be cloned on the device -- 0.4 GB per
+            # clip at ZEGGS dims -- before the first yield; an abandoned generator now stops the work)
+            for o in self._generic_steps(ddim, model, shape, noise, model_kwargs, skip_timesteps, init_image, const_noise, eta, device,
+                                         clip_denoised, denoised_fn, cond_fn, draw0):
                 yield {"sample": o}
             return
         mode = L.MODE_DDIM if ddim else L.MODE_DDPM
@@ -346,7 +347,21 @@ class DSGDiffusion:
 
     def _generic_loop(self, ddim, model, shape, noise, model_kwargs, skip_timesteps, init_image, dump_steps,
                       const_noise, eta, device, clip_denoised=False, denoised_fn=None, cond_fn=None):
-        """Any callable as the denoiser.  The noise is the framework's Philox stream (dsg_noise), draw for draw the one the
+        """The generic loop run to its end: the last sample, or clones of the samples after the steps listed in `dump_steps`."""
+        n_run = self.num_timesteps - skip_timesteps
+        draw0 = self._draw
+        self._draw += 1 + n_run
+        img, dump = None, []
+        for n, img in enumerate(self._generic_steps(ddim, model, shape, noise, model_kwargs, skip_timesteps, init_image, const_noise, eta,
+                                                    device, clip_denoised, denoised_fn, cond_fn, draw0)):
+            if dump_steps is not None and n in dump_steps:
+                dump.append(img.clone())
+        return dump if dump_steps is not None else img
+
+    def _generic_steps(self, ddim, model, shape, noise, model_kwargs, skip_timesteps, init_image, const_noise, eta, device,
+                       clip_denoised, denoised_fn, cond_fn, draw0):
+        """Generator: x_{t-1} after every step of the loop, any callable as the denoiser; draw indices draw0 (x_T), draw0 + 1 + n (step n) --
+        reserved by the caller.  The noise is the framework's Philox stream (dsg_noise), draw for draw the one the
         fused loop consumes -- a wrapped model keeps seed parity with the fused path and the oracle.  `denoised_fn(x0)` is applied to the
         prediction before the clamp (gaussian_diffusion.py:364-370); `cond_fn(x_t, t, **model_kwargs)` -- t the MODEL timesteps, as the wrapped
         cond_fn of SpacedDiffusion sees them (respace.py:117-129) -- shifts the DDPM mean by posterior_variance * grad (condition_mean, :428-441)
@@ -358,17 +373,13 @@ class DSGDiffusion:
         B = int(shape[0])
         per = int(np.prod(shape[1:]))
         stream = L.current_stream_ptr()
-        draw0 = self._draw
+        seed, stream_id = self._seed & (2 ** 64 - 1), self.stream_id      # (as they are when the loop / generator is created)
 
-        def z():
+        def z(draw):
             t = torch.empty(*shape, device=device, dtype=torch.float32)
-            lib.check(lib.cdll.dsg_noise(t.data_ptr(), B, int(shape[1]) * int(shape[2]), int(shape[3]),
-                                         self._seed & (2 ** 64 - 1), self.stream_id, self._draw, stream))
-            self._draw += 1
+            lib.check(lib.cdll.dsg_noise(t.data_ptr(), B, int(shape[1]) * int(shape[2]), int(shape[3]), seed, stream_id, draw, stream))
             return t
-        if noise is not None:
-            self._draw += 1            # the fused loop reserves the x_T draw index as well
-        img = noise if noise is not None else z()
+        img = noise if noise is not None else z(draw0)      # (the x_T draw index is reserved either way, as in the fused loop)
         if skip_timesteps and init_image is None:
             init_image = torch.zeros_like(img)
         indices = list(range(self.num_timesteps - skip_timesteps))[::-1]
@@ -381,7 +392,6 @@ class DSGDiffusion:
                                             B, per, stream))
             img = out
         tmap = torch.tensor(self.timestep_map, device=device, dtype=torch.long)
-        dump = []
         for n, i in enumerate(indices):
             t = torch.full((B,), i, device=device, dtype=torch.long)
             with torch.no_grad():
@@ -391,7 +401,7 @@ class DSGDiffusion:
                 if clip_denoised:
                     x0 = x0.clamp(-1, 1)
                 grad = None if cond_fn is None else cond_fn(img, tmap[t], **(model_kwargs or {})).float()
-            eps = z()
+            eps = z(draw0 + 1 + n)
             if const_noise:
                 eps = eps[[0]].repeat(B, 1, 1, 1)
             nz = np.float32(0.0 if i == 0 else 1.0)
@@ -420,10 +430,7 @@ class DSGDiffusion:
                 lib.check(lib.cdll.dsg_ddim_step(out.data_ptr(), x0.data_ptr(), img.data_ptr(), eps.data_ptr(),
                                                  coef.ctypes.data, B, per, stream))
             img = out
-            if dump_steps is not None and n in dump_steps:
-                dump.append(img.clone())
-        assert self._draw == draw0 + 1 + len(indices)
-        return dump if dump_steps is not None else img
+            yield img
 
 
 def create_gaussian_diffusion(timestep_respacing="", steps=1000, noise_schedule="cosine", library=None):

@@ -15,6 +15,7 @@
 //   overlapped launches (DepWait, k_mid<OVL>, DSG_OVERLAP): 158 vs 144 us/step (round 1)
 //   dsg_stream_ln.h (this directory): the weight-stationary GEMM with LayerNorm-on-read, round 3
 #pragma once
+#include "dsg_fused.h"
 #include "dsg_batched.h"
 
 namespace dsg {
@@ -357,6 +358,214 @@ __global__ __launch_bounds__(256) void k_qkv_attn(const QkvAttnArgs g) {
         }
     }
 }
+
+
+// ---- round 6: retired with its switch (DSG_ATTN_OP2).  Two query tiles per workgroup; bit-identical to k_attn_op; won only in the round-4 STREAM set
+//      (1 x 64: 478 -> 463 us), which k_clip_attn replaced in round 5.
+// (Round 4: "bit-identical" was only true under the emulator -- on the device the compiler contracted the LayerNorm's mul + add into
+// fma in k_attn_op and not in k_attn_op2, one ulp apart in ~10 % of the rows, enough to flip bf16 roundings downstream
+// (tools/debug_op2.py).  Both kernels now spell the two fma sites out; tests/test_gpu_round4.py compares them on the device.)
+// k_attn_op2: k_attn_op for TWO query tiles (32 queries) of a batch element per workgroup -- K, V^T (96 KB) and W_o (128 KB) are
+// pulled through the CU's load path once per 32 rows instead of once per 16 (136 instead of 248 KB per tile), which is what bounds
+// the kernel when the batch fills the GPU (>= 1400 token rows: STREAM set).  Row by row the arithmetic and its order are those of
+// k_attn_op: bit-identical.
+template <class P, int DT, int NKT>
+__global__ __launch_bounds__(256) void k_attn_op2(const AttnOpArgs g) {
+    DSG_TL_SCOPE();
+    typedef typename P::elem elem;
+    constexpr int ES = (int)sizeof(elem);
+    constexpr int D = DT * 64, HD = DT * 16;
+    constexpr int KD = D / P::KB, KDH = HD / P::KB;
+    constexpr int XP = D * ES + 16;
+    constexpr int ND = HD / 16;
+    constexpr int NVF = P::E == 4 ? NKT : NKT / 2;
+    static_assert(KDH >= 1 && KD <= 8, "shape");
+    static_assert(P::E == 4 || (NKT % 2) == 0, "bf16 pairs key tiles");
+    __shared__ __attribute__((aligned(16))) char aT[2][16 * XP];
+    __shared__ float red[2][2][4][16];
+    __shared__ __attribute__((aligned(16))) float vecs[3][D];
+    preload_kernargs(g);
+    const int qt0 = 2 * (int)blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
+    const int h = wave;
+    const size_t bh = (size_t)b * 4 + h;
+    const elem* Q = (const elem*)g.q + bh * g.Tp * HD;
+    const elem* K = (const elem*)g.k + bh * g.Tp * HD;
+    const elem* VT = (const elem*)g.vt + bh * HD * g.Tp;
+    const f32x4* wo = (const f32x4*)g.Wo + lane;
+    const int nqt = g.Tp / 16;
+    f32x4 qf[2][KDH], kf[NKT][KDH], vfr[ND][NVF];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int kb = 0; kb < KDH; ++kb) qf[j][kb] = *(const f32x4*)(Q + (size_t)((min(qt0 + j, nqt - 1) * KDH + kb) * 64 + lane) * P::E);
+#pragma unroll
+    for (int nt = 0; nt < NKT; ++nt)
+#pragma unroll
+        for (int kb = 0; kb < KDH; ++kb) kf[nt][kb] = *(const f32x4*)(K + (size_t)((nt * KDH + kb) * 64 + lane) * P::E);
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+        for (int kb = 0; kb < NVF; ++kb) vfr[dt][kb] = *(const f32x4*)(VT + (size_t)((dt * NVF + kb) * 64 + lane) * P::E);
+    bool rowok[2];
+    size_t m[2];
+    f32x4 pr[2][DT];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int tq = (qt0 + j) * 16 + lr;
+        rowok[j] = tq < g.ntok;
+        m[j] = (size_t)b * g.ntok + (rowok[j] ? tq : g.ntok - 1);      // clamped: unconditional loads, predicated stores
+#pragma unroll
+        for (int t = 0; t < DT; ++t) pr[j][t] = *(const f32x4*)(g.R + m[j] * D + (wave * DT + t) * 16 + 4 * lg);
+    }
+    constexpr int NV = (3 * D / 4 + 255) / 256;
+    f32x4 vload[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int e = min(tid + 256 * i, 3 * D / 4 - 1), vsel = e / (D / 4), vidx = e % (D / 4);
+        vload[i] = ((const f32x4*)(vsel == 0 ? g.bo : (vsel == 1 ? g.ln_g : g.ln_b)))[vidx];
+    }
+    DSG_LOADS_ISSUED();
+    constexpr int KH = (KD + 1) / 2;
+    f32x4 bf[KD][DT];
+    const float scale = 1.0f / sqrtf((float)HD);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        // ---- S^T = K Q^T, softmax over the keys (D[key = 4*lg + r][query = lr])
+        f32x4 s[NKT];
+#pragma unroll
+        for (int nt = 0; nt < NKT; ++nt) {
+            s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < KDH; ++kb) s[nt] = P::mma(kf[nt][kb], qf[j][kb], s[nt]);
+        }
+        if (j == 0) {       // W_o: the first half of the k-blocks now (in flight during the softmax), the rest once V^T is dead
+#pragma unroll
+            for (int kb = 0; kb < KH; ++kb)
+#pragma unroll
+                for (int t = 0; t < DT; ++t) bf[kb][t] = wo[((size_t)(wave * DT + t) * KD + kb) * 64];
+        }
+        float mx = -DSG_FLT_MAX;
+#pragma unroll
+        for (int nt = 0; nt < NKT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = nt * 16 + 4 * lg + r;
+                const float v = key < g.ntok ? s[nt][r] * scale : -DSG_FLT_MAX;
+                s[nt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NKT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = nt * 16 + 4 * lg + r;
+                const float pv = key < g.ntok ? P::exp_sm(s[nt][r] - mx) : 0.f;
+                s[nt][r] = pv;
+                sum += pv;
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        f32x4 pfr[NVF];
+#pragma unroll
+        for (int kb = 0; kb < NVF; ++kb) {
+            if constexpr (P::E == 4) {
+                pfr[kb] = s[kb];
+            } else {
+                typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+                u16x8 pp;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { pp[e] = f2bf(s[2 * kb][e]); pp[4 + e] = f2bf(s[2 * kb + 1][e]); }
+                pfr[kb] = __builtin_bit_cast(f32x4, pp);
+            }
+        }
+        // ---- O^T = V^T P^T -> LDS rows
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) {
+            f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < NVF; ++kb) o = P::mma(vfr[dt][kb], pfr[kb], o);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = o[e] * inv;
+            P::store4((elem*)(aT[j] + lr * XP) + h * HD + dt * 16 + 4 * lg, y);
+        }
+    }
+#pragma unroll
+    for (int kb = KH; kb < KD; ++kb)
+#pragma unroll
+        for (int t = 0; t < DT; ++t) bf[kb][t] = wo[((size_t)(wave * DT + t) * KD + kb) * 64];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int e = tid + 256 * i;
+        if (e < 3 * D / 4) *(f32x4*)(&vecs[0][0] + e * 4) = vload[i];
+    }
+    DSG_LDS_BARRIER();
+    // ---- out_proj from the LDS rows: one W_o fragment feeds both tiles
+    f32x4 acc[2][DT];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int t = 0; t < DT; ++t) acc[j][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < KD; ++kb) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const f32x4 af = *(const f32x4*)(aT[j] + lr * XP + (kb * P::KB + P::E * lg) * ES);
+#pragma unroll
+            for (int t = 0; t < DT; ++t) acc[j][t] = P::mma(bf[kb][t], af, acc[j][t]);      // D[n 4lg+r][row lr]
+        }
+    }
+    // ---- residual + LayerNorm1 over whole rows
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float sm = 0.f;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            const f32x4 pbo = *(const f32x4*)(&vecs[0][(wave * DT + t) * 16 + 4 * lg]);
+            acc[j][t] = acc[j][t] + pbo + pr[j][t];
+            sm += (acc[j][t][0] + acc[j][t][1]) + (acc[j][t][2] + acc[j][t][3]);
+        }
+        sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
+        if (lg == 0) red[j][0][wave][lr] = sm;
+    }
+    DSG_LDS_BARRIER();
+    float mean[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        mean[j] = ((red[j][0][0][lr] + red[j][0][1][lr]) + (red[j][0][2][lr] + red[j][0][3][lr])) / (float)D;
+        float qv = 0.f;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = acc[j][t][e] - mean[j]; qv = __builtin_fmaf(d, d, qv); }
+        qv += __shfl_xor(qv, 16); qv += __shfl_xor(qv, 32);
+        if (lg == 0) red[j][1][wave][lr] = qv;
+    }
+    DSG_LDS_BARRIER();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float var = ((red[j][1][0][lr] + red[j][1][1][lr]) + (red[j][1][2][lr] + red[j][1][3][lr])) / (float)D;
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        if (rowok[j]) {
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                const int n = (wave * DT + t) * 16 + 4 * lg;
+                const f32x4 pg = *(const f32x4*)(&vecs[1][n]), pbt = *(const f32x4*)(&vecs[2][n]);
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = __builtin_fmaf((acc[j][t][e] - mean[j]) * rstd, pg[e], pbt[e]);
+                *(f32x4*)(g.X1 + m[j] * D + n) = y;
+                P::store4((elem*)g.X1a + qk_off<P>((int)m[j], n, D / P::KB), y);
+            }
+        }
+    }
+}
+
 
 
 }  // namespace dsg

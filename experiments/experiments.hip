@@ -8,4 +8,5 @@ template __global__ void k_gemm_tp<PBF16, PRO_DIRECT, EPI_RESID, 256, 128>(const
 template __global__ void k_qkv_attn<PBF16, 64, 6, 256>(const QkvAttnArgs);
 template __global__ void k_ws_ln<EPI_QKV, 16>(const GemmArgs);
 template __global__ void k_ws_ln<EPI_OUT, 16>(const GemmArgs);
+template __global__ void k_attn_op2<PBF16, 4, 6>(const AttnOpArgs);
 }  // namespace dsg

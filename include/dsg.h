@@ -208,7 +208,11 @@ int dsg_last_sample_fence_free(dsg_handle* h, int* fence_free);
  * without a live block back to the HIP allocator -- for a long-lived service between bursts of work -- and reports the bytes
  * released / still held (either pointer may be null).  DSG_UC_POOL_CAP_MB (default 16384) bounds the arenas of a device; a handle
  * created past the cap gets cached loop buffers + fenced packets (dsg_last_sample_fence_free reports 0).  No reference counterpart
- * (torch's caching allocator: torch.cuda.empty_cache()). */
+ * (torch's caching allocator: torch.cuda.empty_cache()).
+ * HAZARD (stated, not solved): a trimmed range returns to the HIP allocator, i.e. the very recycling the pool exists to avoid can happen to
+ * whoever allocates next -- a later uncached arena is fill / read-back checked before its first use, a CACHED allocation (the caller's tensors,
+ * this library's weights) that lands on the range is not.  Call it between bursts, when no handle of the device is live or about to be
+ * created, and prefer leaving the pool alone.  The caller's current HIP device is left as it was. */
 int dsg_trim(int device, long long* bytes_released, long long* bytes_held);
 /* the framework's noise stream as a tensor: out [B, J, 1, T] (device) = draw `draw` of (seed, stream_id), i.e. exactly the
  * noise the fused sampler uses for that draw index (x_T is draw_base, step i is draw_base + 1 + i).  Stands in for

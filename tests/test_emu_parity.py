@@ -103,22 +103,23 @@ def test_throughput_kernels_tiny(tiny, emu_lib, prec):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
-def test_batch1_attention_fused_into_mid(tiny, emu_lib, prec, monkeypatch):
+def test_batch1_attention_fused_into_mid(tiny, emu_lib, prec):
     """Batch 1 takes k_attn_mid (self-attention inside the out_proj/LayerNorm/linear1 kernel).  Same arithmetic and
     rounding points as k_attn + k_mid, so the two must agree bit for bit; and both match the reference goldens."""
     gt, _, y, x = tiny
     y1 = {k: (v[:1] if v.shape[0] == 2 else v) for k, v in y.items()}
     sd = synth_state_dict(C.TINY, int(gt["wseed"]))
     outs = {}
-    for fused in ("1", "0"):
-        monkeypatch.setenv("DSG_FUSE_ATTN_MID", fused)
-        m = DSGDenoiser(C.TINY, precision=prec, max_batch=1, library=emu_lib, latency_mode="on")
+    # fused: batch 1 (k_attn_mid); un-fused: the SAME set at batch 2 (k_attn + k_mid), both rows = the clip (round 6: the DSG_FUSE_ATTN_MID switch is gone)
+    for fused, B in (("1", 1), ("0", 2)):
+        m = DSGDenoiser(C.TINY, precision=prec, max_batch=B, library=emu_lib, latency_mode="on")
         m.load_state_dict(sd)
-        outs[fused] = np.asarray(m(x[:1], np.array([998]), y1)).copy()
+        yb = {k: (np.repeat(v[:1], B, 0) if v.shape[0] == 2 else v) for k, v in y.items()}
+        outs[fused] = np.asarray(m(np.repeat(x[:1], B, 0), np.array([998] * B), yb))[:1].copy()
         assert rel_l2(outs[fused], gt["fwd_allones"][:1]) < TOL[prec]
         d = create_gaussian_diffusion(library=emu_lib)
         outs["chain" + fused] = np.asarray(d.manual_seed(5, 1).p_sample_loop(
-            m, (1, C.TINY.njoints, 1, C.TINY.n_poses), clip_denoised=False, model_kwargs={"y": y1}, skip_timesteps=995)).copy()
+            m, (B, C.TINY.njoints, 1, C.TINY.n_poses), clip_denoised=False, model_kwargs={"y": yb}, skip_timesteps=995))[:1].copy()
     assert np.array_equal(outs["1"], outs["0"])
     assert np.array_equal(outs["chain1"], outs["chain0"])
 

@@ -264,13 +264,15 @@ def test_batch1_attention_fused_into_mid_is_bit_identical(gpu, prec, monkeypatch
     y = synth_window_inputs(cfg, 1, window=1, seed_pose_scale=0.5)
     x = np.random.RandomState(4243).randn(1, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
     outs = {}
-    for fused in ("1", "0"):
-        monkeypatch.setenv("DSG_FUSE_ATTN_MID", fused)
-        m = _model(cfg, prec, max_batch=1, latency_mode="on")
-        outs[fused] = np.asarray(m(x, np.array([999]), y)).copy()
+    # fused: batch 1 (k_attn_mid); un-fused: the SAME set at batch 2 (k_attn + k_mid), both rows = the clip (round 6: the DSG_FUSE_ATTN_MID switch is gone)
+    for fused, B in (("1", 1), ("0", 2)):
+        m = _model(cfg, prec, max_batch=B, latency_mode="on")
+        yb = {k: np.repeat(v, B, 0) if v.shape[0] == 1 and k != "mask_local" else v for k, v in y.items()}
+        xb = np.repeat(x, B, 0)
+        outs[fused] = np.asarray(m(xb, np.array([999] * B), yb))[:1].copy()
         d = create_gaussian_diffusion()
-        outs["c" + fused] = np.asarray(d.manual_seed(3, 2).p_sample_loop(m, x.shape, clip_denoised=False, model_kwargs={"y": y},
-                                                                         skip_timesteps=970)).copy()
+        outs["c" + fused] = np.asarray(d.manual_seed(3, 2).p_sample_loop(m, xb.shape, clip_denoised=False, model_kwargs={"y": yb},
+                                                                         skip_timesteps=970))[:1].copy()
     assert np.array_equal(outs["1"], outs["0"])
     assert np.array_equal(outs["c1"], outs["c0"])
 

@@ -194,31 +194,21 @@ def test_handle_created_after_a_destroyed_one_is_clean(gpu):
         gc.collect()
 
 
-def test_attn_op2_equals_attn_op_and_rows_do_not_depend_on_the_batch(gpu, monkeypatch):
-    """k_attn_op2 (two query tiles per workgroup, STREAM from 4000 token rows) against k_attn_op at the SAME batch (DSG_ATTN_OP2 = 0 / 1),
-    bit for bit on the device -- round 3 claimed it from the emulator; the device compiler contracted the LayerNorm differently in the
-    two kernels (one ulp in ~10 % of the rows).  And the contract it serves: within a kernel set a clip's rows are the same bits
-    whatever batch they ride in -- ZEGGS, every set, batch 8 (712 rows: the 3-waves-per-SIMD LayerNorm GEMMs of TILE) and batch 48
-    (4272 rows: k_attn_op2 in STREAM) against batch 2."""
+def test_rows_do_not_depend_on_the_batch(gpu):
+    """Within a kernel set a clip's rows are the same bits whatever batch they ride in -- ZEGGS, every set, batch 8 (712 rows: the
+    3-waves-per-SIMD LayerNorm GEMMs of TILE) and batch 48 (4272 rows) against batch 2.  (Round 4 found with this test that k_attn_op2 was one ulp
+    off k_attn_op on the device -- a differently contracted LayerNorm; k_attn_op2 is retired in round 6, experiments/dsg_rejected_kernels.h.)"""
     cfg = C.ZEGGS
     sd = synth_state_dict(cfg, 20240)
     B = 48
     y = synth_window_inputs(cfg, B, window=1, seed_pose_scale=0.3)
     x = np.random.RandomState(5).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
     ts = (np.arange(B) * 7 + 3) % 1000
-    outs = {}
-    for v in ("0", "1"):
-        monkeypatch.setenv("DSG_ATTN_OP2", v)
-        outs[v] = np.asarray(_model(cfg, "bf16", max_batch=B).set_kernel_set("stream")(x, ts, y)).copy()
-    monkeypatch.delenv("DSG_ATTN_OP2")
-    assert np.array_equal(outs["0"], outs["1"])
     for ks, Bs in (("tile", (8,)), ("block", (8, 48)), ("stream", (8, 48))):
         small = _model(cfg, "bf16", max_batch=2).set_kernel_set(ks)
         for Bb in Bs:
             big = _model(cfg, "bf16", max_batch=Bb).set_kernel_set(ks)
             out = np.asarray(big({8: x[:8], 48: x}[Bb], ts[:Bb], {k: (v[:Bb] if v.shape[0] == B else v) for k, v in y.items()}))
-            if ks == "stream" and Bb == 48:
-                assert np.array_equal(out, outs["1"])
             for lo in (0, Bb - 2):
                 ys = {k: (v[lo:lo + 2] if v.shape[0] == B else v) for k, v in y.items()}
                 assert np.array_equal(out[lo:lo + 2], np.asarray(small(x[lo:lo + 2], ts[lo:lo + 2], ys))), (ks, Bb, lo)
@@ -338,17 +328,8 @@ def test_ffn_64_row_blocks_with_four_large_lanes_bit_identical(gpu, monkeypatch)
     a = np.asarray(_model(cfg, "bf16", max_batch=B).set_kernel_set("stream")(x, ts, y))
     monkeypatch.setenv("DSG_FFN_RT4", "1")
     b = np.asarray(_model(cfg, "bf16", max_batch=B).set_kernel_set("stream")(x, ts, y))
-    monkeypatch.setenv("DSG_FFN_RT4", "0")
-    monkeypatch.setenv("DSG_FFN_RING", "1")             # round 5: the 32-row kernel with its weights on one rolling ring of fragments ...
-    r1 = np.asarray(_model(cfg, "bf16", max_batch=B).set_kernel_set("stream")(x, ts, y))
-    monkeypatch.setenv("DSG_FFN_RING", "0")             # ... and on double-buffered groups (rounds 4-5)
-    r0 = np.asarray(_model(cfg, "bf16", max_batch=B).set_kernel_set("stream")(x, ts, y))
-    monkeypatch.setenv("DSG_FFN_RT4", "1")
-    monkeypatch.setenv("DSG_FFN_RING", "1")             # (64-row blocks on a 12-fragment ring)
-    r4 = np.asarray(_model(cfg, "bf16", max_batch=B).set_kernel_set("stream")(x, ts, y))
-    monkeypatch.delenv("DSG_FFN_RING")
-    monkeypatch.delenv("DSG_FFN_RT4")
-    assert np.array_equal(a, b) and np.array_equal(a, r1) and np.array_equal(a, r0) and np.array_equal(a, r4) and np.isfinite(a).all()
+    monkeypatch.delenv("DSG_FFN_RT4")                   # (32-row blocks: a 32-fragment weight ring; 64-row blocks: 12 fragments)
+    assert np.array_equal(a, b) and np.isfinite(a).all()
     m.set_kernel_set("auto")
     lanes = [m] + [m.clone() for _ in range(NL - 1)]
     d = create_gaussian_diffusion()

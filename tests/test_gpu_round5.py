@@ -219,28 +219,6 @@ def test_bf16w2_guidance_masks_and_lanes(gpu, golden_dir):
     assert np.array_equal(got[2 * B:3 * B], alone)
 
 
-def test_stream_pose_head_one_block_per_workgroup_is_bit_identical(gpu, monkeypatch):
-    """STREAM pose head (k_ws<EPI_OUT>) at the ZEGGS widths, 24 clips (2136 token rows: 34 row blocks over 9 panels): one workgroup per
-    (panel, row block) with a single activation buffer, three per CU (DSG_WS_OUT_ONE=1) against the persistent row-block groups (=0) -- a
-    12-step DDPM chain, bit for bit, on the fence-free AQL path."""
-    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
-    cfg, B = C.ZEGGS, 24
-    shape = (B, cfg.njoints, 1, cfg.n_poses)
-    y = synth_window_inputs(cfg, B, window=1, seed_pose_scale=0.3)
-    outs = {}
-    for v in ("0", "1"):
-        monkeypatch.setenv("DSG_WS_OUT_ONE", v)
-        m = _model(cfg, "bf16", max_batch=B).set_kernel_set("stream")
-        d = create_gaussian_diffusion()
-        s = d.manual_seed(11, 3).p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=988)
-        outs[v] = s.cpu().numpy() if hasattr(s, "cpu") else np.asarray(s)
-        assert m.last_kernel_set() == "stream" and np.isfinite(outs[v]).all()
-        del m, d
-        gc.collect()
-    monkeypatch.delenv("DSG_WS_OUT_ONE")
-    assert np.array_equal(outs["0"], outs["1"])
-
-
 def test_sampler_hooks_denoised_fn_and_cond_fn_vs_reference(gpu, golden_dir):
     """`denoised_fn` and `cond_fn` of p_sample_loop / ddim_sample_loop (+ the progressive form): a loop that carries a hook runs step by step
     -- the denoiser through the library, the hook in torch, the library's update kernels -- against the reference's own loops with the same

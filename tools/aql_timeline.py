@@ -32,14 +32,15 @@ p.add_argument("--steps", type=int, default=600)
 p.add_argument("--first", type=int, default=200)
 p.add_argument("--n", type=int, default=32)
 p.add_argument("--config", default="zeggs")
-p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+p.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16w2"])
 p.add_argument("--out", default="")
-p.add_argument("--lib", default="stamps", choices=["stamps", "product"],
+p.add_argument("--lib", default="stamps",
                help="stamps: libdsg_hip_stamps.so (`make stamps`): in-kernel first-wave / last-wave stamps, ~1 %% overhead; "
                     "product: libdsg_hip.so with command-processor dispatch timestamps (queue profiling), ~20 %% overhead")
 a = p.parse_args()
-if a.lib == "stamps":
-    os.environ["DSG_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "diffusestylegesture_amd", "csrc", "libdsg_hip_stamps.so")
+if a.lib != "product":      # (dev: `make dev DEVFLAGS=-DDSG_STAMPS=2`, the bf16-only development build with marks)
+    # marks: `make marks` -- the stamps build + DSG_TL_MARK phase marks inside the kernels (dsg_kernels.h)
+    os.environ["DSG_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "diffusestylegesture_amd", "csrc", f"libdsg_hip_{a.lib}.so")
 cfg = CFG.CONFIGS[a.config]
 m = DSGDenoiser(cfg, precision=a.precision, max_batch=a.batch, device=0).set_kernel_set(a.kset)
 m.load_state_dict(synth_state_dict(cfg, 20240))
@@ -84,6 +85,13 @@ def short_name(m):          # _ZN3dsg6k_gemmINS_5PBF16ELi1ELi1ELi4ELi1ELi1EEEvNS
 
 
 short = [short_name(n) for n in mangled]
+marks = None
+if a.lib == "marks" or a.lib.startswith("dev"):
+    mb = np.zeros(S * L * 12 * 3, np.float64)
+    nm = C.c_int()
+    cdll.dsg_debug_trace_marks.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    m.lib.check(cdll.dsg_debug_trace_marks(m.handle, mb.ctypes.data, mb.size, C.byref(nm)))
+    marks = mb.reshape(S, L, 12, 3)
 busy = t[:, :, 1] - t[:, :, 0]
 flat = t.reshape(S * L, 2)
 gap = np.concatenate([[np.nan], flat[1:, 0] - flat[:-1, 1]]).reshape(S, L)      # gap BEFORE each packet (first traced packet: unknown)
@@ -99,7 +107,7 @@ for q in pk:
     e["launches_per_step"] += 1; e["busy_us"] = round(e["busy_us"] + q["busy_us"], 3); e["gap_before_us"] = round(e["gap_before_us"] + q["gap_before_us"], 3)
 res = {
     "what": "per-packet timeline of one denoising step on the fence-free AQL path: " +
-            ("in-kernel first-wave-start / last-wave-end stamps (timeline build)" if a.lib == "stamps" else "command-processor dispatch timestamps (queue profiling: start = packet taken up, so the gaps read 0 and busy includes the dispatch overhead)"),
+            ("in-kernel first-wave-start / last-wave-end stamps (timeline build)" if a.lib != "product" else "command-processor dispatch timestamps (queue profiling: start = packet taken up, so the gaps read 0 and busy includes the dispatch overhead)"),
     "library": a.lib,
     "config": a.config, "batch": a.batch, "kernel_set": m.last_kernel_set(), "fence_free": bool(m.last_sample_fence_free()),
     "traced_steps": S, "packets_per_step": L,
@@ -117,7 +125,31 @@ res = {
     "samples_identical_to_untraced": bool(np.array_equal(np.asarray(out.cpu()), np.asarray(ref.cpu()))),
     "by_kernel": by_kernel, "packets": pk,
 }
+if marks is not None:
+    # per kernel (all its packets of a step, all traced steps): mark k -> waves that passed it per launch, mean and last-wave time in us
+    # after the kernel's first wave start; `busy` of the same launches for scale.  What each mark means: the DSG_TL_MARK sites in csrc/.
+    ph = {}
+    for i in range(L):
+        e = ph.setdefault(short[i], {"launches": 0, "busy_us": 0.0, "marks": {}})
+        e["launches"] += 1; e["busy_us"] += float(busy[:, i].mean())
+        for k in range(12):
+            cnt = marks[:, i, k, 0]
+            if cnt.max() <= 0:
+                continue
+            q = e["marks"].setdefault(k, {"waves": 0.0, "mean_us": 0.0, "last_wave_us": 0.0, "n": 0})
+            q["waves"] += float(cnt.mean()); q["mean_us"] += float(marks[:, i, k, 1].mean()); q["last_wave_us"] += float(marks[:, i, k, 2].mean()); q["n"] += 1
+    for e in ph.values():
+        e["busy_us"] = round(e["busy_us"] / e["launches"], 3)
+        for q in e["marks"].values():
+            n = q.pop("n")
+            for kk in ("waves", "mean_us", "last_wave_us"):
+                q[kk] = round(q[kk] / n, 3)
+    res["phase_marks"] = ph
 print(json.dumps({k: v for k, v in res.items() if k != "packets"}, indent=1))
+if marks is not None:
+    for kn, e in res["phase_marks"].items():
+        print(f"{kn[:70]:70s} busy {e['busy_us']:7.2f} us/launch  marks (mean / last wave, us after first wave start): " +
+              "  ".join(f"[{k}] {q['mean_us']:.2f}/{q['last_wave_us']:.2f}" for k, q in sorted(e["marks"].items())))
 for q in pk:
     print(f"{q['packet']:3d} {q['kernel'][:60]:60s} busy {q['busy_us']:7.2f} (min {q['busy_us_min']:6.2f})  gap before {q['gap_before_us']:6.2f}")
 if a.out:

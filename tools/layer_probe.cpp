@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("ERR %s @%d: %s\n", #x, __LINE__, hipGetErrorString(e)); exit(1); } } while (0)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -70,6 +71,28 @@ __global__ __launch_bounds__(256) void k_reduce(float* slab, unsigned long long*
     }
 }
 
+// DSG+ at batch 1 (round-5 verdict item 4): `out_proj + LayerNorm1 + linear1` with W_o split by COLUMNS over the NS hidden-slice workgroups of a
+// row tile needs the row statistics of all NS column slices before any of them can normalise: a barrier among the NS workgroups of a row tile
+// INSIDE the kernel.  Deterministic form: every workgroup stores its partial (sum, sum of squares) of its 16 rows into its own slot of uncached
+// memory, bumps the row tile's arrival counter (agent scope), spins until all NS have arrived, then reads the NS slots in slot order.  `epoch`
+// makes the counters reusable across launches without a reset.
+__global__ __launch_bounds__(256) void k_exchange(float* slots, unsigned* counters, unsigned epoch, int NS, float* out) {
+    const int s = blockIdx.x, mt = blockIdx.y, lane = threadIdx.x;
+    float part = 1.0f + s + lane;                               // (sum, sumsq) of 16 rows: 32 floats per workgroup
+    if (lane < 32) slots[((size_t)mt * NS + s) * 32 + lane] = part;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (lane == 0) {
+        __hip_atomic_fetch_add(&counters[mt * 32], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(&counters[mt * 32], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < epoch * (unsigned)NS) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+    float tot = 0.f;
+    if (lane < 32)
+        for (int k = 0; k < NS; ++k) tot += __hip_atomic_load(&slots[((size_t)mt * NS + k) * 32 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tot == 123.456f) out[lane] = tot;
+}
+
 template <class F>
 static float time_chain(hipStream_t st, int N, F launch) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -93,7 +116,8 @@ static void run_stream(const char* what, const f32x4* w, float* out, int n_wg, b
            NW * RD, KBYTES, n_wg, cycle ? "8 layers cycling" : "one layer      ", shared ? "shared " : "private", us, us - floor_us, KBYTES * 1024.0 / ((us - floor_us) * 1e3));
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const bool dsgplus_only = argc > 1 && std::string(argv[1]) == "dsgplus";
     CK(hipSetDevice(0));
     hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     const size_t bytes = (size_t)8 * 6 * 1536 * 1024;   // 8 layers x 6 private regions x 1.5 MB = 72 MB
@@ -103,6 +127,30 @@ int main() {
     const float floor6 = time_chain(st, 400, [&](int) { hipLaunchKernelGGL(k_null, dim3(6), dim3(512), 0, st, out); });
     const float floor96 = time_chain(st, 400, [&](int) { hipLaunchKernelGGL(k_null, dim3(96, 6), dim3(256), 0, st, out); });
     printf("# launch floor of this harness (HIP launches back to back): 6 x 512 threads %.2f us, 96 x 6 x 256 threads %.2f us\n", floor6, floor96);
+    {   // ---- DSG+ widths at batch 1 (BEAT: latent 384, 96-dim heads; TWH: latent 512, 128-dim heads; 151 tokens = 10 row tiles; round 6)
+        const float floor20 = time_chain(st, 400, [&](int) { hipLaunchKernelGGL(k_null, dim3(20), dim3(512), 0, st, out); });
+        const float floor160 = time_chain(st, 400, [&](int) { hipLaunchKernelGGL(k_null, dim3(16, 10), dim3(256), 0, st, out); });
+        printf("# DSG+ batch 1: launch floor 20 x 512 threads %.2f us, 16 x 10 x 256 threads %.2f us\n", floor20, floor160);
+        // (A) LayerNorm + QKV + attention per (head, query-tile pair): 4 heads x 5 pairs = 20 workgroups, each pulling the clip's rows (151 x D bf16)
+        //     and its head's W_q / W_k / W_v slices (3 x hd x D bf16): 116 + 221 = 337 KB (BEAT), 155 + 393 = 548 KB (TWH)
+        for (int cyc = 0; cyc < 2; ++cyc) {
+            run_stream<8, 14, 336>("(A) BEAT rows + head's W_qkv", w, out, 20, cyc, true, st, floor20);
+            run_stream<8, 17, 544>("(A) TWH  rows + head's W_qkv", w, out, 20, cyc, true, st, floor20);
+        }
+        // (B) out_proj + LayerNorm1 + linear1, W_o split by columns over 16 hidden-slice workgroups per row tile: W_o / 16 + W1 slice + the rows
+        //     (18 + 48 + 12 = 78 KB BEAT, 32 + 64 + 16 = 112 KB TWH) -- and the exchange of the row statistics among the 16 workgroups
+        run_stream<4, 20, 80>("(B) BEAT W_o/16 + W1 slice + rows", w, out, 160, true, true, st, floor160);
+        run_stream<4, 28, 112>("(B) TWH  W_o/16 + W1 slice + rows", w, out, 160, true, true, st, floor160);
+        float* slots; unsigned* counters;
+        CK(hipExtMallocWithFlags((void**)&slots, (size_t)10 * 16 * 32 * 4, hipDeviceMallocUncached));
+        CK(hipExtMallocWithFlags((void**)&counters, (size_t)10 * 32 * 4, hipDeviceMallocUncached));
+        CK(hipMemset(counters, 0, (size_t)10 * 32 * 4)); CK(hipStreamSynchronize(st)); CK(hipDeviceSynchronize());
+        unsigned epoch = 0;
+        const float ex = time_chain(st, 400, [&](int) { ++epoch; hipLaunchKernelGGL(k_exchange, dim3(16, 10), dim3(256), 0, st, slots, counters, epoch, 16, out); });
+        printf("(B) exchange of the LayerNorm statistics among the 16 column-slice workgroups of a row tile (slots + arrival counter, uncached memory, "
+               "160 workgroups): %6.2f us per launch, %6.2f above the floor\n", ex, ex - floor160);
+    }
+    if (dsgplus_only) return 0;
     for (int cyc = 0; cyc < 2; ++cyc) {
         run_stream<8, 16>("layer stream", w, out, 6, cyc, true, st, floor6);
         run_stream<8, 32>("layer stream", w, out, 6, cyc, true, st, floor6);

@@ -12,6 +12,7 @@ frames/s that corresponds to for 320-frame clips of 4 x 1000 steps, which path /
 distance of the samples to those of the FIRST spec with the same lanes x batch (a cross-check of the kernel sets against
 each other; parity against the oracle lives in tests/)."""
 import argparse
+import hashlib
 import os
 import sys
 
@@ -74,5 +75,5 @@ for spec in a.spec.split(","):
     best, med = min(us), float(np.median(us))
     fps = nl * b * 320 / (4000 * best * 1e-6)
     print(f"{spec:28s} {nl}x{b:<3d} {best:8.2f} us/step (median {med:8.2f})  {fps:9.0f} frames/s-equivalent  set={m.last_kernel_set()} "
-          f"path={m.last_sample_path()} fence_free={int(m.last_sample_fence_free())} finite={bool(np.isfinite(res).all())} dist_to_first={dist:.2e}", flush=True)
+          f"path={m.last_sample_path()} fence_free={int(m.last_sample_fence_free())} finite={bool(np.isfinite(res).all())} dist_to_first={dist:.2e} sha1={hashlib.sha1(res.tobytes()).hexdigest()[:12]}", flush=True)
     del lanes, m
