@@ -1890,8 +1890,13 @@ __global__ __launch_bounds__(16 * RW) void k_ffn_ln(const FfnLnArgs g) {
             f32x4 y;
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = __builtin_fmaf((v[q][e] - mean) * rstd, pg[q][e], pt[q][e]);
+#ifdef DSG_X_FFNLN_NOSTORE          // (timing experiment: does the boundary behind this kernel wait for its stores?)
+            if (y[0] == 123.456f)
+#endif
+            {
             *(f32x4*)(g.Xn + mr * D + n) = y;
             P::store4((elem*)g.Xa + qk_off<P>((int)mr, n, KD), y);
+            }
         }
     }
 }

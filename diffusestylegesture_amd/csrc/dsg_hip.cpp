@@ -492,9 +492,9 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     if (const char* e = getenv("DSG_KSET")) {
         char* end = nullptr;
         const long v = strtol(e, &end, 10);
-        if (end == e || *end != 0 || v < DSG_KSET_AUTO || v > DSG_KSET_STREAM) {
+        if (end == e || *end != 0 || v < DSG_KSET_AUTO || v > DSG_KSET_ROWS) {
             delete h;
-            return fail(DSG_E_INVALID, std::string("DSG_KSET must be 0 (auto) .. 4 (stream), got '") + e + "'");
+            return fail(DSG_E_INVALID, std::string("DSG_KSET must be 0 (auto) .. 5 (rows), got '") + e + "'");
         }
         h->kset_req = (int)v;
     }
@@ -960,6 +960,7 @@ struct KernelSel {
     bool stream = false;        // STREAM: BLOCK with the weight-stationary persistent GEMMs of dsg_stream.h (LayerNorm + QKV, linear1, linear2, pose head)
     bool ffn = false;           // STREAM (round 4): linear1 + GELU + linear2 + residual + LayerNorm2 in one kernel (k_ffn); QKV of the next layer
                                 // and the pose head then read normalised rows: direct streaming GEMMs, no k_ln_frag
+    bool ffn16 = false;         // ROWS (round 6): k_ffn on 16-row tiles (one workgroup per row tile), behind k_clip_attn; everything else as BLOCK
     bool ffn_rt4 = false;       // ... on 64-row blocks: 4 lanes x >= 4000 token rows (4 x 64 clips: 981 -> 903 us per step of the 4 lanes; 1 x 64: 376 -> 432,
                                 // 4 x 16: 334 -> 392, 4 x 32 even -- profiles/r04_y2_sweep_ffn_rt4_*.log).  Bit-identical to the 32-row form.
     bool ffn_split = false;     // BLOCK (round 4, bf16 ZEGGS / tiny dims): k_ffn split over the hidden dimension (k_ffn_part + k_ffn_ln); direct QKV / pose head
@@ -1003,23 +1004,31 @@ static bool ffn_split_wide(const dsg_handle* h) {
 }
 static bool ffn_split_ok(const dsg_handle* h) { return stream_set_ok(h) || ffn_split_wide(h); }
 static int auto_kernel_set(const dsg_handle* h, int B, int lanes) {
-    const int rows = B * h->ntok;
-    // (round 4, STREAM with k_ffn; profiles/r04_n_sweep_sets.log: 4 x 12 clips 319 vs 383 us BLOCK, 4 x 8: 299 vs 286; 1 x 24: 295 vs 301,
-    // 1 x 16: 282 vs 230)
-    // (round 5, k_clip_attn + the out_proj / LayerNorm1 prologue of k_ffn: profiles/r05_j_sweep_sets.log -- 4 x 10 clips 260 vs 278 us BLOCK,
-    // 4 x 8: 256 vs 234; 1 x 24: 249 vs 321, 1 x 20: 245 vs 224)
-    if (rows >= (lanes > 1 ? 850 : 2000) && stream_set_ok(h)) return DSG_KSET_STREAM;
+    const int rows = B * h->ntok, MT = cdiv(rows, 16);
+    const bool s_ok = stream_set_ok(h);       // (bf16, the ZEGGS / tiny widths: STREAM and ROWS exist)
+    // Round 6 (profiles/r06_u_*, r06_v_*, r06_w_*: one-box sweeps of every set, us per step): ROWS -- k_ffn on one 16-row tile per workgroup -- wins
+    // wherever the row tiles of ALL lanes fit the 256 CUs in one round: 1 x 12 clips 188.9 vs 190.4 (BLOCK), 1 x 16: 192.2 vs 204.3, 1 x 24: 202.7 vs
+    // 298 (BLOCK) / 249 (STREAM), 1 x 40: 221 vs 235 (STREAM), 1 x 46 (256 row tiles): 231 vs 242; 1 x 48 (267 tiles: two rounds): 328 vs 244 -> STREAM;
+    // 4 x 5: 194.9 vs 198.1 (BLOCK), 4 x 8: 205.8 vs 222.2, 4 x 12 (268 tiles): 230 vs 240 (STREAM), 4 x 14 (312): 250 = 249, 4 x 16: 271 vs 255 -> STREAM;
+    // 3 x 16: 222 vs 245, 2 x 16: 209 vs 231, 2 x 32: 279 vs 253 -> STREAM.  Below ~1500 token rows over all lanes BLOCK's ff-split is even or ahead
+    // (4 x 4: 191.8 = 191.3, 2 x 8: 190.2 vs 191.4, 2 x 6: 182.9 vs 188.6, 1 x 10: 186.2 vs 188.6, 1 x 8: 181.4 vs 187.2).
+    // (rounds 4-5, STREAM against BLOCK: profiles/r04_n_sweep_sets.log, r05_j_sweep_sets.log)
     if (lanes <= 1) {
+        if (s_ok && rows >= 1000) return MT <= 256 ? DSG_KSET_ROWS : DSG_KSET_STREAM;
         // (fp32, round 5: k_attn_mid recomputes out_proj per hidden slice, and an fp32 MFMA is 1/16 of a bf16 one -- the un-fused 16 x 16
         // tiles win at batch 1: 208.2 vs 218.5 us per step, profiles/r05_g_bench_fp32_*.log)
         if (B <= 2 && latency_set_ok(h) && h->prec != DSG_PREC_FP32) return DSG_KSET_LATENCY;
         // (DSG+ widths, round 5: with k_ffn_part + k_ffn_ln behind k_attn_op_w BLOCK wins from 4 clips -- BEAT 283 vs 303 us, TWH 310 vs 365; 2 clips: 259 vs 198)
         // (only there: ffn_split_wide() is also true for fp32 at the ZEGGS widths, which has no such measurement -- round-5 advisor)
         if (ffn_split_wide(h) && h->prec == DSG_PREC_BF16 && (h->D == 384 || h->D == 512) && h->env_ffn_split != 0 && rows >= 600) return DSG_KSET_BLOCK;
-        return rows >= 1000 ? DSG_KSET_BLOCK : DSG_KSET_TILE;
+        // (round 6, bf16 ZEGGS widths: BLOCK from 5 clips -- 1 x 6: 178.0 vs 190.1 TILE, 1 x 4: 173.9 vs 157.4, 1 x 10: 186.2 vs 233.1)
+        return rows >= (s_ok ? 500 : 1000) ? DSG_KSET_BLOCK : DSG_KSET_TILE;
     }
+    if (s_ok && rows >= 850 && lanes * MT > 300) return DSG_KSET_STREAM;
+    if (s_ok && rows >= 300 && lanes * rows >= 1500 && lanes * MT <= 300) return DSG_KSET_ROWS;
     if (B <= 1 && latency_set_ok(h) && h->prec != DSG_PREC_FP32) return DSG_KSET_LATENCY;
-    return rows >= 300 ? DSG_KSET_BLOCK : DSG_KSET_TILE;
+    // (4 x 3: BLOCK 187.1 vs TILE 203.2; 4 x 2: 183.4 vs 180.1; 2 x 3: 175.1 = 173.8)
+    return rows >= (s_ok ? 250 : 300) ? DSG_KSET_BLOCK : DSG_KSET_TILE;
 }
 // what DSG_KSET_AUTO resolves to for `lanes` lanes of batch B: the measured table + dsg_config.latency_mode (1 = never LATENCY, 2 = always
 // where LATENCY is a sensible choice at all: latent_dim <= 256, see latency_set_ok).  ONE function for select_kernels and
@@ -1037,8 +1046,8 @@ static int select_kernels(const dsg_handle* h, int B, KernelSel& k) {
     int set = h->kset_req;
     if (set == DSG_KSET_AUTO) set = resolve_auto_set(h, B, 1);
     if (set == DSG_KSET_LATENCY && h->D > 512) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set LATENCY: latent_dim > 512");
-    if (set == DSG_KSET_STREAM && !stream_set_ok(h)) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set STREAM: bf16, latent_dim 128 / 256, 4 heads, ff 128 / 1024 only");
-    if (set < DSG_KSET_LATENCY || set > DSG_KSET_STREAM) return fail(DSG_E_INVALID, "unknown kernel set");
+    if ((set == DSG_KSET_STREAM || set == DSG_KSET_ROWS) && !stream_set_ok(h)) return fail(DSG_E_NOT_IMPLEMENTED, "kernel sets STREAM / ROWS: bf16, latent_dim 128 / 256, 4 heads, ff 128 / 1024 only");
+    if (set < DSG_KSET_LATENCY || set > DSG_KSET_ROWS) return fail(DSG_E_INVALID, "unknown kernel set");
     if (h->prec == DSG_PREC_BF16W2 && (set > DSG_KSET_TILE || (set == DSG_KSET_LATENCY && h->D > 256)))
         return fail(DSG_E_NOT_IMPLEMENTED, "precision bf16w2: kernel sets LATENCY (latent_dim <= 256) and TILE only");
     k = KernelSel();
@@ -1047,11 +1056,16 @@ static int select_kernels(const dsg_handle* h, int B, KernelSel& k) {
     k.attn_in_mid = k.lat && have_attn_mid(h, B);
     k.stream = set == DSG_KSET_STREAM;
     k.ffn = k.stream;           // (round 4: k_ffn instead of k_ws<GELU> + k_ws2<RESID> + k_ln_frag)
+    // ROWS (round 6): BLOCK's first and last kernels around STREAM's per-layer pair, with k_ffn on ONE 16-row tile per workgroup -- no ff-split,
+    // no partial slabs, no k_ffn_ln: 3 + 2L dispatches.  Every workgroup streams W_o + W1 + W2 (1.15 MB) for 16 rows, so it pays while the row
+    // tiles of all lanes fit the 256 CUs in one round
+    k.ffn16 = set == DSG_KSET_ROWS;
+    if (k.ffn16) k.ffn = true;
     {
         const int rows = B * h->ntok, e = h->env_ffn_rt4;      // (test hook / A/B: 64-row blocks from this many token rows at any lane count; 0: never)
         k.ffn_rt4 = k.ffn && (e >= 0 ? (e > 0 && rows >= e) : (h->lanes_now >= 4 && rows >= 4000));
     }
-    k.blk = set == DSG_KSET_BLOCK || k.stream;      // (STREAM: pose embedding and layer-0 QKV as in BLOCK)
+    k.blk = set == DSG_KSET_BLOCK || set == DSG_KSET_ROWS || k.stream;      // (STREAM / ROWS: pose embedding and layer-0 QKV as in BLOCK)
     // the wide form (W_o streamed: DSG+ widths, fp32) belongs to BLOCK / STREAM only -- a set's arithmetic never depends on the batch,
     // and at batch 1 its 10 workgroups per layer lose to k_attn + out_proj (BEAT: 200 vs 163 us/step; 16 clips: 3371 vs 2904 frames/s)
     k.attn_op = !k.lat && (have_attn_op_narrow(h) || (k.blk && have_attn_op_wide(h)));
@@ -1077,9 +1091,9 @@ static int ensure_set_buffers(dsg_handle* h, const KernelSel& k) {
 
 extern "C" int dsg_set_kernel_set(dsg_handle* h, int set) {
     if (!h) return fail(DSG_E_INVALID, "null handle");
-    if (set < DSG_KSET_AUTO || set > DSG_KSET_STREAM) return fail(DSG_E_INVALID, "dsg_set_kernel_set: unknown kernel set");
+    if (set < DSG_KSET_AUTO || set > DSG_KSET_ROWS) return fail(DSG_E_INVALID, "dsg_set_kernel_set: unknown kernel set");
     if (set == DSG_KSET_LATENCY && h->D > 512) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set LATENCY: latent_dim > 512");
-    if (set == DSG_KSET_STREAM && !stream_set_ok(h)) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set STREAM: bf16, latent_dim 128 / 256, 4 heads, ff 128 / 1024 only");
+    if ((set == DSG_KSET_STREAM || set == DSG_KSET_ROWS) && !stream_set_ok(h)) return fail(DSG_E_NOT_IMPLEMENTED, "kernel sets STREAM / ROWS: bf16, latent_dim 128 / 256, 4 heads, ff 128 / 1024 only");
     // (the same rule as select_kernels: round-5 advisor -- this entry point used to accept LATENCY at latent_dim 384 / 512, and every later call failed)
     if (h->prec == DSG_PREC_BF16W2 && (set > DSG_KSET_TILE || (set == DSG_KSET_LATENCY && h->D > 256)))
         return fail(DSG_E_NOT_IMPLEMENTED, "precision bf16w2: kernel sets LATENCY (latent_dim <= 256) and TILE only");
@@ -1503,6 +1517,11 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                     if (clip_l) {
                         // (the weights of both phases on one rolling ring of fragments: 12 slots on 64-row blocks, 32 on 32-row blocks; the double-buffered
                         //  groups of rounds 4-5 are retired)
+                        if (ks.ffn16) {         // ROWS: one 16-row tile per workgroup
+                            if (D == 256) CHK((step_launch<&k_ffn<P, 4, 16, 1, 8, 2, true, true, 32>>(h, dim3(MT), dim3(512), a)));
+                            else CHK((step_launch<&k_ffn<P, 2, 2, 1, 4, 2, false, true>>(h, dim3(MT), dim3(256), a)));
+                            continue;
+                        }
                         if (D == 256 && ks.ffn_rt4) CHK((step_launch<&k_ffn<P, 4, 16, 4, 8, 1, true, true, 12>>(h, dim3(cdiv(MT, 4)), dim3(512), a)));
                         else if (D == 256) CHK((step_launch<&k_ffn<P, 4, 16, 2, 8, 2, true, true, 32>>(h, grid, dim3(512), a)));
                         else CHK((step_launch<&k_ffn<P, 2, 2, 2, 4, 2, false, true>>(h, grid, dim3(256), a)));

@@ -282,8 +282,9 @@ struct TlScope {           // every wave stores its own start / end stamp (plain
     }
     __device__ __forceinline__ ~TlScope() {
         if (on) {
+            const unsigned long long t = __builtin_readsteadycounter();       // (the stamp FIRST: the entry's address costs a scalar-cache miss)
+            __builtin_amdgcn_sched_barrier(0);
             TlEntry* p = tl_entry();       // (recomputed: nothing of the scope stays live in vector registers across the kernel)
-            const unsigned long long t = __builtin_readsteadycounter();
 #if DSG_STAMPS >= 2
             if ((threadIdx.x & 63) < DSG_TL_NMARK) p->m[threadIdx.x & 63] = tl_lds()[(threadIdx.x >> 6) * DSG_TL_NMARK + (threadIdx.x & 63)];
 #endif

@@ -16,7 +16,7 @@ DEFAULT_LIB = os.path.join(_HERE, "csrc", "libdsg_hip.so")
 E_INVALID, E_RUNTIME, E_UNEXPECTED_KEY, E_MISSING_KEY, E_NOT_IMPLEMENTED, E_STATE = -1, -2, -3, -4, -5, -6
 PREC_FP32, PREC_BF16, PREC_BF16W2 = 0, 1, 2
 MODE_DDPM, MODE_DDIM = 0, 1
-KERNEL_SETS = {"auto": 0, "latency": 1, "tile": 2, "block": 3, "stream": 4}          # DSG_KSET_* of include/dsg.h
+KERNEL_SETS = {"auto": 0, "latency": 1, "tile": 2, "block": 3, "stream": 4, "rows": 5}          # DSG_KSET_* of include/dsg.h
 KERNEL_SET_NAMES = {v: k for k, v in KERNEL_SETS.items()}
 
 
@@ -95,7 +95,7 @@ class DSGLibrary:
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(self.cdll, name)          # AttributeError if the library does not export it
             fn.restype, fn.argtypes = res, args
-        if self.cdll.dsg_version() < 320:
+        if self.cdll.dsg_version() < 330:
             raise DSGError("libdsg_hip.so is older than this package")
 
     def check(self, rc: int):

@@ -284,18 +284,15 @@ def generate_clip_dsgplus(model, diffusion, feats, style, seed0, real_n_frames, 
     S, T, J = cfg.n_seed, cfg.n_poses, cfg.njoints
     use_torch = L.is_torch(feats[0])
     B = int(feats[0].shape[0])
-    sty = np.asarray(style, np.float32)
-    if sty.ndim == 1:
-        sty = np.repeat(sty[None], B, 0)
     sample_fn = sample_fn or diffusion.p_sample_loop
     diffusion.manual_seed(seed, stream_id)
     shape = (B, J, 1, T)
     out = []
+    sty = _style_batch(style, B, use_torch, feats[0].device if use_torch else None)
     if use_torch:
         import torch
         dev = feats[0].device
         mask = torch.ones(1, T, dtype=torch.bool, device=dev)
-        sty = torch.from_numpy(sty).to(dev)
     else:
         mask = np.ones((1, T), bool)
     for c in range(len(feats)):

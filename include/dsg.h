@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define DSG_VERSION 320
+#define DSG_VERSION 330
 
 enum {
     DSG_OK = 0,
@@ -77,11 +77,16 @@ enum {
                                widths): per layer k_clip_attn (per (clip, head): Q / K / V slices in LDS + attention) + the feed-forward half split
                                over ff with out_proj + LayerNorm1 as its prologue + the slab sum / LayerNorm2 pass: 3 + 3L dispatches; the DSG+
                                widths and fp32 get the ff-split behind k_attn_op_w */
-    DSG_KSET_STREAM = 4     /* weight-stationary persistent GEMMs (32x32x16 MFMA, global->LDS staging, 64-row blocks) for the pose
+    DSG_KSET_STREAM = 4,    /* weight-stationary persistent GEMMs (32x32x16 MFMA, global->LDS staging, 64-row blocks) for the pose
                                embedding and the pose head; per layer k_clip_attn + ONE feed-forward kernel (out_proj + LayerNorm1 as its
                                prologue, linear1 + GELU + linear2 + residual + LayerNorm2; ABI 320: 3 + 2L dispatches per step): >= 2000
                                token rows (23 ZEGGS clips) in one lane, >= 850 rows (10 clips) per lane with several lanes.  bf16, latent_dim 128 / 256, 4 heads -- the ZEGGS model;
                                DSG_E_NOT_IMPLEMENTED elsewhere */
+    DSG_KSET_ROWS = 5       /* ABI 330: BLOCK's pose embedding / local attention / pose head around STREAM's per-layer pair, the feed-forward kernel on
+                               ONE 16-row tile per workgroup (no ff-split, no partial slabs, no slab-sum pass: 3 + 2L dispatches).  Every workgroup
+                               streams a layer's W_o + W1 + W2 for its 16 rows: it pays while the row tiles of all lanes fit the 256 CUs in one
+                               round -- 1000 .. 4000 token rows in one lane (12 .. 45 ZEGGS clips), fewer per lane with several lanes.  Same shapes
+                               as STREAM; DSG_E_NOT_IMPLEMENTED elsewhere */
 };
 enum { DSG_MODE_DDPM = 0, DSG_MODE_DDIM = 1 };
 

@@ -25,7 +25,7 @@ def test_header_symbols_exported(hip_lib_path):
         assert hasattr(cdll, n), f"libdsg_hip.so does not export {n}"
     assert set(names) == set(L.SYMBOLS), "ctypes binding and header disagree"
     lib = L.DSGLibrary(hip_lib_path)
-    assert lib.cdll.dsg_version() == 320
+    assert lib.cdll.dsg_version() == 330
 
 
 def test_missing_library_fails_loudly(tmp_path):

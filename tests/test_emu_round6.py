@@ -1,0 +1,76 @@
+"""CPU tests of the round-6 additions under the SIMT emulator (the product sources, unchanged, compiled for the host): the ROWS kernel set
+(k_ffn on one 16-row tile per workgroup behind k_clip_attn), the noise transform, the automatic choice of the set."""
+import numpy as np
+import pytest
+
+from diffusestylegesture_amd import config as C
+from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+from diffusestylegesture_amd.model import DSGDenoiser
+from diffusestylegesture_amd.synth import synth_state_dict, synth_window_inputs
+from tests.util import rel_l2
+
+
+def test_rows_kernel_set_vs_oracle_and_batch_independence(emu_lib):
+    """DSG_KSET_ROWS (ABI 330) at the tiny dims: forward rows at batch 3 and 5 (an odd number of row tiles) and a 6-step DDPM chain against the
+    fp32 oracle; a row's bits do not depend on the batch it rides in; a lane over the same weights reproduces the handle; fp32 / bf16w2 handles
+    refuse the set like STREAM."""
+    from oracle import sampler
+    from oracle.mdm import MDMOracle
+    from oracle.schedule import OracleDiffusion
+    cfg = C.TINY
+    sd = synth_state_dict(cfg, 20240)
+    ref = MDMOracle(sd, cfg)
+    small = DSGDenoiser(cfg, precision="bf16", max_batch=2, library=emu_lib).set_kernel_set("rows")
+    small.load_state_dict(sd)
+    for B in (3, 5):
+        y = synth_window_inputs(cfg, B, window=1, seed_pose_scale=0.3)
+        x = np.random.RandomState(B).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+        ts = [10, 500, 999, 3, 77][:B]
+        m = DSGDenoiser(cfg, precision="bf16", max_batch=B, library=emu_lib).set_kernel_set("rows")
+        m.load_state_dict(sd)
+        out = np.asarray(m(x, ts, y))
+        assert m.last_kernel_set() == "rows" and rel_l2(out, ref(x, ts, y)) < 1.2e-2
+        ys = {k: (v[B - 2:B] if v.shape[0] == B else v) for k, v in y.items()}
+        assert np.array_equal(out[B - 2:B], np.asarray(small(x[B - 2:B], ts[B - 2:B], ys)))
+    shape = (3, cfg.njoints, 1, cfg.n_poses)
+    y = synth_window_inputs(cfg, 3, window=1, seed_pose_scale=0.3)
+    m = DSGDenoiser(cfg, precision="bf16", max_batch=3, library=emu_lib).set_kernel_set("rows")
+    m.load_state_dict(sd)
+    d = create_gaussian_diffusion(library=emu_lib)
+    got = np.asarray(d.manual_seed(11, 3).p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=994))
+    want = sampler.p_sample_loop(OracleDiffusion(), ref, shape, sampler.philox_noise_fn(shape, 11, 3), {"y": y}, skip_timesteps=994)
+    assert m.last_kernel_set() == "rows" and rel_l2(got, want) < 2e-2
+    lane = m.clone()
+    assert lane.kernel_set() == "rows"
+    again = np.asarray(d.manual_seed(11, 3).p_sample_loop(lane, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=994))
+    assert np.array_equal(got, again)
+    for prec in ("fp32", "bf16w2"):
+        with pytest.raises(NotImplementedError):
+            DSGDenoiser(cfg, precision=prec, max_batch=2, library=emu_lib).set_kernel_set("rows")
+
+
+def test_auto_kernel_set_table_round6(emu_lib):
+    """What DSG_KSET_AUTO resolves to (dsg_recommend_kernel_set; tiny dims: 23 token rows per clip): ROWS from 1000 token rows in one lane while the
+    row tiles fit the 256 CUs in one round, STREAM beyond; with several lanes ROWS from 1500 rows over all lanes and 300 per lane, STREAM once the
+    lanes' row tiles exceed 300; BLOCK from 500 rows in one lane / 250 per lane below that."""
+    m = DSGDenoiser(C.TINY, precision="bf16", max_batch=2, library=emu_lib)
+    m.load_state_dict(synth_state_dict(C.TINY, 20240))
+    r = m.recommend_kernel_set
+    assert [r(b, 1) for b in (1, 2, 3, 21, 22, 43, 44, 178, 179)] == ["latency", "latency", "tile", "tile", "block", "block", "rows", "rows", "stream"]
+    assert [r(b, 4) for b in (1, 2, 10, 11, 14, 17, 52, 53)] == ["latency", "tile", "tile", "block", "block", "rows", "rows", "stream"]
+    f = DSGDenoiser(C.TINY, precision="fp32", max_batch=2, library=emu_lib)
+    f.load_state_dict(synth_state_dict(C.TINY, 20240))
+    assert [f.recommend_kernel_set(b, 1) for b in (1, 3, 43, 44, 200)] == ["tile", "tile", "tile", "block", "block"]
+
+
+def test_noise_stream_vs_oracle(emu_lib):
+    """The round-6 Box-Muller (v_log / v_sqrt + polynomial sincospi on the device; libm stand-ins under the emulator) against the float64 transform
+    of the oracle: every element of a [2, J, 1, T] draw within 2e-6."""
+    import ctypes as C_
+    from oracle import philox
+    cfg = C.TINY
+    B, J, T = 2, cfg.njoints, cfg.n_poses
+    out = np.zeros((B, J, 1, T), np.float32)
+    emu_lib.check(emu_lib.cdll.dsg_noise(out.ctypes.data, B, J, T, C_.c_uint64(77), C_.c_uint64(5), 9, None))
+    want = philox.normal_bj1t((B, J, 1, T), 77, 9, 5)
+    assert np.max(np.abs(out - want)) < 2e-6

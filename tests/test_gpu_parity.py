@@ -296,8 +296,8 @@ def test_throughput_kernel_set_vs_reference(gpu, golden_dir, prec):
 
 def test_batch16_consistency(gpu, monkeypatch):
     """B = 16 identical clips with shared noise: all 16 results are bit-identical (rows are independent), and they agree
-    with the B = 1 run (a different kernel set: latency) to rounding-order level.  From 1000 rows up `auto` is the "block" set
-    (32-row block GEMMs of dsg_batched.h + k_attn_op); selected at batch 1 it must reproduce the batch-16 rows bit for bit."""
+    with the B = 1 run (a different kernel set: latency) to rounding-order level.  From 1000 rows up `auto` is the "rows" set
+    (round 6; "block" in rounds 2-5); selected at batch 1 it must reproduce the batch-16 rows bit for bit."""
     from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
     from oracle import philox
     cfg = C.ZEGGS
@@ -315,8 +315,8 @@ def test_batch16_consistency(gpu, monkeypatch):
     for b in range(1, B):
         assert np.array_equal(sB[b], sB[0]), f"batch element {b} differs"
     assert rel_l2(sB[0], s1[0]) < 1e-2
-    assert m.last_kernel_set() == "block"
-    for kset, exact in (("block", True), ("tile", False)):
+    assert m.last_kernel_set() == "rows"          # (round 6: from 1000 rows `auto` is ROWS -- k_clip_attn + k_ffn on 16-row tiles)
+    for kset, exact in (("rows", True), ("tile", False)):
         m1 = _model(cfg, "bf16", max_batch=1).set_kernel_set(kset)
         d.manual_seed(3, 0)
         s1_off = d.p_sample_loop(m1, (1, cfg.njoints, 1, cfg.n_poses), noise=x1, clip_denoised=False,

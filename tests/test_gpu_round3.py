@@ -231,7 +231,7 @@ def test_block_set_at_dsgplus_dims_batch_8(gpu, cfg_name):
     assert e < TOL_CHAIN["bf16"]
 
 
-@pytest.mark.parametrize("kset", ["block", "stream"])
+@pytest.mark.parametrize("kset", ["block", "stream", "rows"])
 def test_guidance_in_the_batched_kernel_sets(gpu, kset):
     """Classifier-free guidance fused into the step loop (cfg_sampler.py:8-31: conditional rows + their unconditional twins in one
     batch, combined in the pose-head epilogue) in the BLOCK and STREAM sets, whose state shadow is fragment-major and whose pose
@@ -275,7 +275,7 @@ def test_stream_and_block_sets_at_tiny_dims(gpu):
     x = np.random.RandomState(B).randn(*shape).astype(np.float32)
     ts = np.arange(B) * 40 + 3
     want = ref(x, list(ts), y)
-    for kset in ("stream", "block"):
+    for kset in ("stream", "block", "rows"):
         m = _model(cfg, "bf16", max_batch=B, wseed=77).set_kernel_set(kset)
         assert rel_l2(np.asarray(m(x, ts, y)), want) < TOL_FWD["bf16"] and m.last_kernel_set() == kset
         s = np.asarray(create_gaussian_diffusion().manual_seed(3, 1).p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=990))

@@ -204,7 +204,7 @@ def test_rows_do_not_depend_on_the_batch(gpu):
     y = synth_window_inputs(cfg, B, window=1, seed_pose_scale=0.3)
     x = np.random.RandomState(5).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
     ts = (np.arange(B) * 7 + 3) % 1000
-    for ks, Bs in (("tile", (8,)), ("block", (8, 48)), ("stream", (8, 48))):
+    for ks, Bs in (("tile", (8,)), ("block", (8, 48)), ("stream", (8, 48)), ("rows", (8, 48))):
         small = _model(cfg, "bf16", max_batch=2).set_kernel_set(ks)
         for Bb in Bs:
             big = _model(cfg, "bf16", max_batch=Bb).set_kernel_set(ks)
@@ -251,8 +251,8 @@ def test_stream_set_with_fused_ffn_vs_oracle_and_lanes(gpu):
     NL, B, K = 4, 16, 2
     m = _model(cfg, "bf16", max_batch=B)
     lanes = [m] + [m.clone() for _ in range(NL - 1)]
-    assert m.recommend_kernel_set(12, 4) == "stream" and m.recommend_kernel_set(8, 4) == "block"
-    assert m.recommend_kernel_set(16, 1) == "block" and m.recommend_kernel_set(24, 1) == "stream"
+    assert m.recommend_kernel_set(16, 4) == "stream" and m.recommend_kernel_set(12, 4) == "rows" and m.recommend_kernel_set(4, 4) == "block"      # (round 6: ROWS in between)
+    assert m.recommend_kernel_set(16, 1) == "rows" and m.recommend_kernel_set(48, 1) == "stream"
     d = create_gaussian_diffusion()
     feats = [[torch.from_numpy(synth_window_inputs(cfg, B, window=w, clip0=ln * B)["audio"]).cuda() for w in range(K)] for ln in range(NL)]
     got = generate_clips_streams(lanes, d, feats, [1, 0, 0, 0, 0, 0], seed=5, skip_timesteps=960, stream_ids=[0, 1, 2, 3])

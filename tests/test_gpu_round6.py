@@ -1,0 +1,137 @@
+"""GPU parity tests added in round 6 (all through the C ABI / ctypes shim): the ROWS kernel set, the automatic choice of the set, the noise
+transform, the lazy generic progressive loop."""
+import numpy as np
+import pytest
+
+from diffusestylegesture_amd import config as C
+from diffusestylegesture_amd.synth import synth_state_dict, synth_window_inputs
+from tests.util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL_FWD = {"fp32": 2e-5, "bf16": 1.2e-2}
+TOL_CHAIN = {"fp32": 1e-4, "bf16": 2e-2}
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from diffusestylegesture_amd import lib as L
+    return L.default_library()
+
+
+def _model(cfg, prec, max_batch=1, wseed=20240, **kw):
+    from diffusestylegesture_amd.model import DSGDenoiser
+    m = DSGDenoiser(cfg, precision=prec, max_batch=max_batch, device=0, **kw)
+    m.load_state_dict(synth_state_dict(cfg, wseed))
+    return m
+
+
+def test_rows_kernel_set_vs_oracle(gpu):
+    """DSG_KSET_ROWS (ABI 330) at the ZEGGS widths: k_clip_attn + k_ffn on ONE 16-row tile per workgroup (out_proj + LayerNorm1 as its prologue,
+    linear1 + GELU + linear2 + residual + LayerNorm2) between BLOCK's pose embedding / local attention and the 16 x 16 pose head -- forward rows
+    at batch 12 / 16 / 23 / 46 (256 row tiles: the largest single-lane batch `auto` gives it) and a 30-step DDPM chain at batch 16 against the
+    oracle; the rows of a clip are the same bits whatever batch they ride in; `auto` picks it from 1000 token rows."""
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    from oracle import sampler
+    from oracle.mdm import MDMOracle
+    from oracle.schedule import OracleDiffusion
+    cfg = C.ZEGGS
+    sd = synth_state_dict(cfg, 20240)
+    ref = MDMOracle(sd, cfg)
+    small = _model(cfg, "bf16", max_batch=2).set_kernel_set("rows")
+    for B in (12, 16, 23, 46):
+        y = synth_window_inputs(cfg, B, window=1, clip0=3, seed_pose_scale=0.2)
+        x = np.random.RandomState(100 + B).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+        ts = (np.arange(B) * 41 + 7) % 1000
+        m = _model(cfg, "bf16", max_batch=B)
+        assert m.recommend_kernel_set(B, 1) == "rows"
+        out = np.asarray(m(x, ts, y))
+        assert m.last_kernel_set() == "rows"                  # what `auto` ran
+        for b in sorted({0, B // 2, B - 1}):
+            yb = {k: (v[b:b + 1] if v.shape[0] == B else v) for k, v in y.items()}
+            e = rel_l2(out[b:b + 1], ref(x[b:b + 1], [int(ts[b])], yb))
+            assert e < TOL_FWD["bf16"], (B, b, e)
+        ys = {k: (v[5:7] if v.shape[0] == B else v) for k, v in y.items()}
+        assert np.array_equal(out[5:7], np.asarray(small(x[5:7], ts[5:7], ys))), B
+        if B == 16:
+            d = create_gaussian_diffusion()
+            shape = (B, cfg.njoints, 1, cfg.n_poses)
+            got = np.asarray(d.manual_seed(13, 1).p_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=970))
+            assert m.last_sample_path() == "aql" and m.last_kernel_set() == "rows" and m.last_sample_fence_free()
+            b = 9
+            yb = {k: (v[b:b + 1] if v.shape[0] == B else v) for k, v in y.items()}
+            w = sampler.p_sample_loop(OracleDiffusion(), ref, (1,) + shape[1:], lambda k: sampler.philox.normal_bj1t(shape, 13, k, 1)[b:b + 1], {"y": yb}, skip_timesteps=970)
+            assert rel_l2(got[b:b + 1], w) < TOL_CHAIN["bf16"]
+            d50 = create_gaussian_diffusion("ddim50")          # config[2]'s arrangement: 50-step DDIM, batch 16 in lock step
+            got = np.asarray(d50.manual_seed(14, 2).ddim_sample_loop(m, shape, clip_denoised=False, model_kwargs={"y": y}))
+            w = sampler.ddim_sample_loop(OracleDiffusion(timestep_respacing="ddim50"), ref, (1,) + shape[1:],
+                                         lambda k: sampler.philox.normal_bj1t(shape, 14, k, 2)[b:b + 1], {"y": yb})
+            assert m.last_kernel_set() == "rows" and rel_l2(got[b:b + 1], w) < TOL_CHAIN["bf16"]
+
+
+def test_rows_kernel_set_on_lanes(gpu):
+    """4 lanes x 8 clips (what `auto` gives ROWS with several lanes: 1500 token rows over all lanes, the lanes' row tiles within one round of the
+    CUs): fence-free AQL packets on 4 queues, a lane reproduces itself alone bit for bit."""
+    import torch
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    from diffusestylegesture_amd.sample import generate_clip, generate_clips_streams
+    cfg, NL, B, K = C.ZEGGS, 4, 8, 2
+    m = _model(cfg, "bf16", max_batch=B)
+    lanes = [m] + [m.clone() for _ in range(NL - 1)]
+    assert m.recommend_kernel_set(B, NL) == "rows" and m.recommend_kernel_set(4, 4) == "block" and m.recommend_kernel_set(16, 4) == "stream"
+    d = create_gaussian_diffusion()
+    feats = [[torch.from_numpy(synth_window_inputs(cfg, B, window=w, clip0=ln * B)["audio"]).cuda() for w in range(K)] for ln in range(NL)]
+    got = generate_clips_streams(lanes, d, feats, [1, 0, 0, 0, 0, 0], seed=5, skip_timesteps=960, stream_ids=[0, 1, 2, 3])
+    assert all(ln.last_kernel_set() == "rows" and ln.last_sample_path() == "aql" and ln.last_sample_fence_free() for ln in lanes) and np.isfinite(got).all()
+    lanes[1].set_kernel_set("rows")
+    alone = generate_clip(lanes[1], d, feats[1], [1, 0, 0, 0, 0, 0], seed=5, skip_timesteps=960, stream_id=1)
+    assert np.array_equal(alone, got[B:2 * B])
+
+
+def test_noise_stream_vs_oracle(gpu):
+    """The round-6 Box-Muller of the noise stream (v_log / v_sqrt + polynomial sincospi; tools/noise_probe.cpp measures the pieces over all 2^24
+    arguments) against the float64 transform of the oracle: every element of a [4, 1141, 1, 88] draw within 2e-6 -- as close as the libm form of
+    rounds 1-5 (8.3e-7 max over 2^26 calls against 7.5e-7 now, profiles/r06_l_noise_probe.log)."""
+    import ctypes as C_
+    from oracle import philox
+    cfg = C.ZEGGS
+    B, J, T = 4, cfg.njoints, cfg.n_poses
+    out = np.zeros((B, J, 1, T), np.float32)
+    gpu.check(gpu.cdll.dsg_noise(out.ctypes.data, B, J, T, C_.c_uint64(77), C_.c_uint64(5), 9, None))
+    want = philox.normal_bj1t((B, J, 1, T), 77, 9, 5)
+    assert np.max(np.abs(out - want)) < 2e-6 and abs(float(out.std()) - 1.0) < 5e-3
+
+
+def test_generic_progressive_loop_is_lazy_and_owns_its_draws(gpu):
+    """Round-5 advisor: the generator forms on the GENERIC path (a wrapped model / hooks) reserve their draw indices when they are CREATED and run
+    ONE step per next(): a second generator created before the first is consumed draws other noise, and each reproduces the one-call loop."""
+    import torch
+    from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
+    cfg = C.TINY
+    m = _model(cfg, "fp32", max_batch=1)
+    calls = []
+
+    class Wrapped:       # not a DSGDenoiser -> generic loop
+        def __call__(self, xx, tt, y=None):
+            calls.append(int(tt[0]))
+            return m(xx, tt, y)
+
+        def parameters(self):
+            return m.parameters()
+    shape = (1, cfg.njoints, 1, cfg.n_poses)
+    y = {k: torch.from_numpy(v).cuda() for k, v in synth_window_inputs(cfg, 1, window=0, seed_pose_scale=0.3).items()}
+    d = create_gaussian_diffusion().manual_seed(3, 1)
+    g1 = d.p_sample_loop_progressive(Wrapped(), shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=996)
+    g2 = d.p_sample_loop_progressive(Wrapped(), shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=996)
+    assert calls == []                                   # nothing has run yet
+    first = next(g1)["sample"].clone()
+    assert len(calls) == 1                               # ONE denoiser evaluation per next()
+    a = [first] + [s["sample"] for s in g1]
+    b = [s["sample"] for s in g2]
+    assert len(a) == len(b) == 4 and not torch.equal(a[-1], b[-1])
+    d.manual_seed(3, 1)
+    one = d.p_sample_loop(Wrapped(), shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=996)
+    two = d.p_sample_loop(Wrapped(), shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=996)
+    assert torch.equal(a[-1], one) and torch.equal(b[-1], two)

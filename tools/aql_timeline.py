@@ -90,8 +90,8 @@ if a.lib == "marks" or a.lib.startswith("dev"):
     mb = np.zeros(S * L * 12 * 3, np.float64)
     nm = C.c_int()
     cdll.dsg_debug_trace_marks.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
-    m.lib.check(cdll.dsg_debug_trace_marks(m.handle, mb.ctypes.data, mb.size, C.byref(nm)))
-    marks = mb.reshape(S, L, 12, 3)
+    if cdll.dsg_debug_trace_marks(m.handle, mb.ctypes.data, mb.size, C.byref(nm)) == 0:      # (a dev build without -DDSG_STAMPS=2 has none)
+        marks = mb.reshape(S, L, 12, 3)
 busy = t[:, :, 1] - t[:, :, 0]
 flat = t.reshape(S * L, 2)
 gap = np.concatenate([[np.nan], flat[1:, 0] - flat[:-1, 1]]).reshape(S, L)      # gap BEFORE each packet (first traced packet: unknown)
