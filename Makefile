@@ -60,7 +60,7 @@ $(EMU): $(CSRC)/dsg_hip.cpp $(CSRC)/dsg_kernels.h $(CSRC)/dsg_fused.h $(CSRC)/ds
 	    $(CSRC)/dsg_hip.cpp tests/emu/emu_rt.cpp $(CSRC)/dsg_bvh.cpp -o $@
 
 # micro-probes behind the numbers in DESIGN.md s5 (tools/*.cpp; run on the GPU box, logs under profiles/)
-PROBES := xcd_probe persist_probe dep_probe icache_probe loadpath_probe
+PROBES := xcd_probe persist_probe dep_probe icache_probe loadpath_probe layer_probe noise_probe
 tools: $(addprefix tools/_build/,$(PROBES)) tools/_build/aql_probe tools/_build/aql_kernels.hsaco
 tools/_build/%: tools/%.cpp
 	mkdir -p tools/_build

@@ -982,15 +982,18 @@ struct ClipAttnArgs {
 
 // projection of one row tile's CW column tiles, operand order fixed at compile time (V tiles: un-swapped)
 template <class P, int CW, int KD, bool VT>
-__device__ __forceinline__ void clip_proj_tile(const f32x4 (&wf)[CW][KD], const f32x4 (&a)[KD], f32x4 (&acc)[CW]) {
+__device__ __forceinline__ void clip_proj_tile(const typename P::wfrag (&wf)[CW][KD], const typename P::afrag (&a)[KD], f32x4 (&acc)[CW]) {
 #pragma unroll
     for (int kb = 0; kb < KD; ++kb)
 #pragma unroll
-        for (int j = 0; j < CW; ++j) acc[j] = VT ? P::mma(a[kb], wf[j][kb], acc[j]) : P::mma(wf[j][kb], a[kb], acc[j]);
+        for (int j = 0; j < CW; ++j) acc[j] = VT ? P::mma_a(a[kb], wf[j][kb], acc[j]) : P::mma_w(wf[j][kb], a[kb], acc[j]);
 }
 
+// bf16w2 (round 6, ROWS set): the rows (LayerNorm2 of the previous layer / the embedding output) arrive as hi + lo images and W_qkv as hi + lo
+// fragments -- three MFMAs per fragment pair, like every weight product of the mode; Q / K / V / P stay single bf16 (PBF16W2) and the attention rows
+// leave as a hi + lo pair (k_attn's rounding point in this mode).  The rows' LDS stage doubles (96 KB at the ZEGGS widths): one workgroup per CU.
 template <class P, int DT, int NKT>      // D = 64 DT, H = 4, hd = 16 DT, Tp = 16 NKT, NKT waves
-__global__ __launch_bounds__(64 * NKT, 2) void k_clip_attn(const ClipAttnArgs g) {
+__global__ __launch_bounds__(64 * NKT, P::W2 ? 1 : 2) void k_clip_attn(const ClipAttnArgs g) {
     DSG_TL_SCOPE();
     typedef typename P::elem elem;
     constexpr int ES = (int)sizeof(elem);
@@ -1005,7 +1008,8 @@ __global__ __launch_bounds__(64 * NKT, 2) void k_clip_attn(const ClipAttnArgs g)
     // every wave is done projecting (the V tiles wait in registers, already rounded: 2 VGPRs each): 72 KB instead of 84 at the ZEGGS
     // widths, i.e. TWO workgroups per CU -- with several lanes in flight (1024 workgroups at 4 x 64 clips) the load -> project -> attend
     // chain of one workgroup runs under the other's
-    __shared__ __attribute__((aligned(16))) f32x4 xs[NKT * KD][64];
+    __shared__ __attribute__((aligned(16))) f32x4 xs[P::AF * NKT * KD][64];      // (bf16w2: the lo images behind the hi images)
+    constexpr int XS_LO = NKT * KD * 1024;
     __shared__ __attribute__((aligned(16))) f32x4 qs[NKT * KDH][64];
     __shared__ __attribute__((aligned(16))) f32x4 ks[NKT * KDH][64];
     f32x4 (* const vs)[64] = xs;
@@ -1019,12 +1023,13 @@ __global__ __launch_bounds__(64 * NKT, 2) void k_clip_attn(const ClipAttnArgs g)
     // ---- every global load of the wave up front: its row tile, its projection columns
     const int tok_ld = min(wave * 16 + lr, g.ntok - 1);          // (tokens past the clip: a valid row, masked / dropped later)
     const int m_ld = b * g.ntok + tok_ld;
-    f32x4 xf[KD];
+    typename P::afrag xf[KD];
 #pragma unroll
-    for (int kb = 0; kb < KD; ++kb) xf[kb] = lda16<P>(g.X, (size_t)qk_off<P>(m_ld, kb * P::KB + P::E * lg, KD) * ES);
+    for (int kb = 0; kb < KD; ++kb) xf[kb] = P::aload_off(g.X, (size_t)qk_off<P>(m_ld, kb * P::KB + P::E * lg, KD));
     const f32x4* wq = (const f32x4*)g.Wqkv + lane;
     const int ct0 = wave * CW;                       // first of this wave's column tiles in the head's [Q | K | V] order (ND tiles each)
-    f32x4 wf[CW][KD], pb[CW];
+    typename P::wfrag wf[CW][KD];
+    f32x4 pb[CW];
     float pbs[CW];
     int which[CW], d0[CW];                           // per tile: 0 Q, 1 K, 2 V (wave-uniform) and its first dim inside the head
 #pragma unroll
@@ -1032,14 +1037,17 @@ __global__ __launch_bounds__(64 * NKT, 2) void k_clip_attn(const ClipAttnArgs g)
         which[j] = (ct0 + j) / ND; d0[j] = ((ct0 + j) - which[j] * ND) * 16;
         const int nt = which[j] * (D / 16) + h * ND + d0[j] / 16;                 // column tile of the packed [3D / 16] in_proj weight
 #pragma unroll
-        for (int kb = 0; kb < KD; ++kb) wf[j][kb] = wq[((size_t)nt * KD + kb) * 64];
+        for (int kb = 0; kb < KD; ++kb) wf[j][kb] = P::wload(wq, (size_t)nt * KD + kb);
         pb[j] = *(const f32x4*)(g.bqkv + nt * 16 + 4 * lg);
         pbs[j] = g.bqkv[nt * 16 + lr];
     }
     DSG_LOADS_ISSUED();
     DSG_TL_MARK(0);      // rows + projection columns requested
 #pragma unroll
-    for (int kb = 0; kb < KD; ++kb) xs[wave * KD + kb][lane] = xf[kb];
+    for (int kb = 0; kb < KD; ++kb) {
+        if constexpr (P::W2) { xs[wave * KD + kb][lane] = xf[kb].h; xs[NKT * KD + wave * KD + kb][lane] = xf[kb].l; }
+        else xs[wave * KD + kb][lane] = xf[kb];
+    }
     DSG_LDS_BARRIER();
     DSG_TL_MARK(1);      // the clip's rows are in LDS (they have landed for every wave)
     // ---- (1) projection of the head's Q / K / V for all row tiles -> LDS in the attention kernels' fragment order.  The operand order
@@ -1048,9 +1056,10 @@ __global__ __launch_bounds__(64 * NKT, 2) void k_clip_attn(const ClipAttnArgs g)
     const bool all_qk = which[CW - 1] < 2, all_v = which[0] == 2;
 #pragma unroll
     for (int rt = 0; rt < NKT; ++rt) {
-        f32x4 a[KD], acc[CW];
+        typename P::afrag a[KD];
+        f32x4 acc[CW];
 #pragma unroll
-        for (int kb = 0; kb < KD; ++kb) a[kb] = xs[rt * KD + kb][lane];
+        for (int kb = 0; kb < KD; ++kb) a[kb] = P::aload((const char*)&xs[rt * KD + kb][lane], XS_LO);
 #pragma unroll
         for (int j = 0; j < CW; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (all_qk) clip_proj_tile<P, CW, KD, false>(wf, a, acc);
@@ -1060,10 +1069,10 @@ __global__ __launch_bounds__(64 * NKT, 2) void k_clip_attn(const ClipAttnArgs g)
             for (int j = 0; j < CW; ++j) {
                 if (which[j] < 2) {
 #pragma unroll
-                    for (int kb = 0; kb < KD; ++kb) acc[j] = P::mma(wf[j][kb], a[kb], acc[j]);
+                    for (int kb = 0; kb < KD; ++kb) acc[j] = P::mma_w(wf[j][kb], a[kb], acc[j]);
                 } else {
 #pragma unroll
-                    for (int kb = 0; kb < KD; ++kb) acc[j] = P::mma(a[kb], wf[j][kb], acc[j]);
+                    for (int kb = 0; kb < KD; ++kb) acc[j] = P::mma_a(a[kb], wf[j][kb], acc[j]);
                 }
             }
         }
@@ -1150,7 +1159,7 @@ __global__ __launch_bounds__(64 * NKT, 2) void k_clip_attn(const ClipAttnArgs g)
             f32x4 y;
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = o[e] * inv;
-            P::store4((elem*)g.out + qk_off<P>(b * g.ntok + q, h * HD + dt * 16 + 4 * lg, KD), y);      // the rounding point of the attention rows
+            P::store4_afrag((elem*)g.out, (size_t)qk_off<P>(b * g.ntok + q, h * HD + dt * 16 + 4 * lg, KD), y);      // the rounding point of the attention rows (bf16w2: hi + lo)
         }
     }
     DSG_TL_MARK(7);      // P V + stores issued
@@ -1200,14 +1209,17 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
     constexpr int KC0 = (DW >= 4 ? 2 : 4) * LA, KC = KC0 < KF ? KC0 : KF, NC = KF / KC;   // phase 2: k-blocks per weight chunk (8 LA fragments in flight)
     constexpr int NT = 64 * NW;
     static_assert(FW >= LA && FW % LA == 0 && DW >= 1 && KF % KC == 0 && (FF / 16) % NW == 0 && (D / 16) % NW == 0, "shape");
-    __shared__ __attribute__((aligned(16))) char hid[RT * 16 * HP];
+    static_assert(!P::W2 || (OP && RING > 0 && RT < 4), "bf16w2: the ring forms with the prologue");
+    constexpr int HID_LO = RT * 16 * HP;             // bf16w2: `hidden` as a hi + lo pair of images (P::store4_a / P::aload)
+    __shared__ __attribute__((aligned(16))) char hid[P::AF * RT * 16 * HP];
     __shared__ float red[RT][2][NW][16];
     __shared__ __attribute__((aligned(16))) float vecs[3][D];      // b2, LayerNorm2 scale / shift
     constexpr int XP = D * ES + 16;                  // OP: LDS pitch of a LayerNorm1 row
     constexpr bool BIG = OP && RT >= 4;              // 64-row blocks: `hidden` fills the LDS -- the LayerNorm1 rows alias its head (dead before phase 1
                                                      // writes: linear1's operand sits in registers by then) and the fp32 rows go through g.X1
     static_assert(!BIG || RT * 16 * XP <= RT * 16 * HP, "alias");
-    __shared__ __attribute__((aligned(16))) char xa_own[(OP && !BIG) ? RT * 16 * XP : 16];
+    constexpr int XA_LO = RT * 16 * XP;              // (bf16w2: ... and the LayerNorm1 rows)
+    __shared__ __attribute__((aligned(16))) char xa_own[(OP && !BIG) ? P::AF * RT * 16 * XP : 16];
     char* const xa = BIG ? hid : xa_own;
     __shared__ __attribute__((aligned(16))) float vecs1[OP ? 3 : 1][OP ? D : 4];      // OP: b_o, LayerNorm1 scale / shift
     constexpr int X1P = D + 4;                       // OP: pitch (floats) of the fp32 LayerNorm1 rows parked in LDS across phase 1 (register budget)
@@ -1218,40 +1230,43 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
     const int m0 = mb * 16 * RT, mt_last = g.MT - 1;
     // ---- loads that do not depend on phase 1: A fragments, first W1 tiles, residual rows, the per-column vectors
     constexpr int RH = (OP && RT >= 4) ? 2 : RT;     // OP on 64-row blocks: the prologue takes the row tiles two at a time (register budget)
-    f32x4 af[RT][KD];
+    typename P::afrag af[RT][KD];
     // OP: the RH x KD attention-row fragments of a half are fetched ONCE per workgroup -- NFW of them per wave -- and handed round through LDS (the tail of
     // `hid`, free until phase 1): every wave needs all of them, and eight waves loading the same 16 KB from uncached memory were 23 MB of memory-side reads
     // per launch at 64 clips for 2.9 MB of rows
     constexpr int NFH = RH * KD, NFW = (NFH + NW - 1) / NW;
-    f32x4* const stg = (f32x4*)(hid + RT * 16 * HP - NFH * 1024);
+    f32x4* const stg = (f32x4*)(hid + P::AF * (RT * 16 * HP - NFH * 1024));      // [fragment][image][lane]
     static_assert(!OP || NFH * 1024 + (RT >= 4 ? RT * 16 * (D * ES + 16) : 0) <= RT * 16 * HP, "the staged fragments sit behind the (aliased) LayerNorm1 rows");
-    f32x4 afw[OP ? NFW : 1];
+    typename P::afrag afw[OP ? NFW : 1];
     auto load_a = [&](int rt0) {
         if constexpr (OP) {
 #pragma unroll
             for (int i = 0; i < NFW; ++i) {
                 const int f = min(wave * NFW + i, NFH - 1), rt = rt0 + f / KD, kb = f % KD;
                 const int mt = min(mb * RT + rt, mt_last);   // clamped (rows past the end are computed and dropped)
-                afw[i] = lda16<P>(g.A, ((size_t)(mt * KD + kb) * 64 + lane) * P::E * ES);
+                afw[i] = P::aload_frag(g.A, (size_t)(mt * KD + kb), lane);
             }
         } else {
 #pragma unroll
             for (int rt = rt0; rt < rt0 + RH; ++rt) {
                 const int mt = min(mb * RT + rt, mt_last);   // clamped (rows past the end are computed and dropped)
 #pragma unroll
-                for (int kb = 0; kb < KD; ++kb) af[rt][kb] = lda16<P>(g.A, ((size_t)(mt * KD + kb) * 64 + lane) * P::E * ES);
+                for (int kb = 0; kb < KD; ++kb) af[rt][kb] = P::aload_frag(g.A, (size_t)(mt * KD + kb), lane);
             }
         }
     };
     // (OP) afw -> LDS -> every wave's af[rt0 .. rt0 + RH)
     auto share_a = [&](int rt0) {
 #pragma unroll
-        for (int i = 0; i < NFW; ++i) if (wave * NFW + i < NFH) stg[(wave * NFW + i) * 64 + lane] = afw[i];
+        for (int i = 0; i < NFW; ++i) if (wave * NFW + i < NFH) {
+            if constexpr (P::W2) { stg[((wave * NFW + i) * 2) * 64 + lane] = afw[i].h; stg[((wave * NFW + i) * 2 + 1) * 64 + lane] = afw[i].l; }
+            else stg[(wave * NFW + i) * 64 + lane] = afw[i];
+        }
         DSG_LDS_BARRIER();
 #pragma unroll
         for (int rt = rt0; rt < rt0 + RH; ++rt)
 #pragma unroll
-            for (int kb = 0; kb < KD; ++kb) af[rt][kb] = stg[((rt - rt0) * KD + kb) * 64 + lane];
+            for (int kb = 0; kb < KD; ++kb) af[rt][kb] = P::aload((const char*)&stg[((rt - rt0) * KD + kb) * P::AF * 64 + lane], 1024);
     };
     load_a(0);
     const f32x4* w1 = (const f32x4*)g.W1 + lane;
@@ -1277,11 +1292,11 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
     // the kernel is not waiting for bytes in flight alone -- what the ring removes is the drain at every group boundary.
     constexpr int N1 = FW * KD, N2 = KF * DW, NRING = RING > 0 ? RING : 1;
     static_assert(RING == 0 || (OP && RING <= N1), "ring");
-    f32x4 ring[NRING];
-    auto ring_ptr = [&](int i) -> const f32x4* {
-        if (i < N1) return w1 + ((size_t)(wave * FW + i / KD) * KD + i % KD) * 64;
+    typename P::wfrag ring[NRING];
+    auto ring_load = [&](int i) -> typename P::wfrag {
+        if (i < N1) return P::wload(w1, (size_t)(wave * FW + i / KD) * KD + i % KD);
         const int k = (i - N1) / DW, t = (i - N1) % DW;
-        return w2 + ((size_t)(wave * DW + t) * KF + k) * 64;
+        return P::wload(w2, (size_t)(wave * DW + t) * KF + k);
     };
     if constexpr (!OP) load1(0, 0);
     f32x4 pr[RT][DW];
@@ -1308,11 +1323,14 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
         // ---- prologue: pre1 = attention rows . W_o^T + b_o + residual; x1 = LayerNorm1(pre1) -> LDS in the GEMM type (linear1's operand)
         //      and, in fp32, this lane's registers: phase 2 adds exactly these (row, column) values back (same wave -> column map)
         const f32x4* wo = (const f32x4*)g.Wo + lane;
-        f32x4 wof[DW][KD];
+        typename P::wfrag wof[DW][KD];
 #pragma unroll
         for (int t = 0; t < DW; ++t)
 #pragma unroll
-            for (int kb = 0; kb < KD; ++kb) wof[t][kb] = wo[((size_t)(wave * DW + t) * KD + kb) * 64];
+            for (int kb = 0; kb < KD; ++kb) wof[t][kb] = P::wload(wo, (size_t)(wave * DW + t) * KD + kb);
+        // (round 6, measured no: on 16-row tiles the register file has room for half of the weight ring next to W_o, but requesting it HERE puts
+        //  W1 ahead of the attention rows and W_o in the CU's load path and delays out_proj: 1 x 16 clips 192.6 -> 195.4 us per step with 16 slots
+        //  early, 198.2 with all 32 -- profiles/r06_z_*)
         DSG_LOADS_ISSUED();
         DSG_TL_MARK(0);      // attention rows (this wave's share), residual rows, W_o requested
 #pragma unroll
@@ -1334,7 +1352,7 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
 #pragma unroll
                 for (int rt = r0; rt < r0 + RH; ++rt)
 #pragma unroll
-                    for (int t = 0; t < DW; ++t) acc1[rt][t] = P::mma(wof[t][kb], af[rt][kb], acc1[rt][t]);      // D[n 4lg+r][row lr]
+                    for (int t = 0; t < DW; ++t) acc1[rt][t] = P::mma_w(wof[t][kb], af[rt][kb], acc1[rt][t]);      // D[n 4lg+r][row lr]
             if (r0 + RH < RT) {                               // (64-row blocks: the next two row tiles' attention rows and residual)
                 load_a(r0 + RH);
 #pragma unroll
@@ -1347,7 +1365,7 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
         DSG_TL_MARK(1);      // out_proj issued (attention rows shared through LDS, W_o landed)
         if constexpr (RING > 0) {
 #pragma unroll
-            for (int i = 0; i < RING; ++i) ring[i] = *ring_ptr(i);      // the ring's first fill arrives behind LayerNorm1
+            for (int i = 0; i < RING; ++i) ring[i] = ring_load(i);      // the ring's first fill arrives behind LayerNorm1
         } else {
             load1(0, 0);                                      // (W_o and the attention rows are dead: the first W1 tiles arrive behind LayerNorm1)
         }
@@ -1395,7 +1413,7 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
                 f32x4 y;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] = __builtin_fmaf((acc1[rt][t][e] - mean1[rt]) * rstd, pg[e], pbt[e]);
-                P::store4((elem*)(xa + (rt * 16 + lr) * XP) + n, y);
+                P::store4_a((elem*)(xa + (rt * 16 + lr) * XP) + n, XA_LO, y);
                 // linear2's residual: read back by the same lane after phase 2
                 // (64-row blocks: through g.X1, un-clamped and unconditional -- the row buffers are padded past the last 64-row block)
                 if constexpr (BIG) *(f32x4*)((char*)g.X1 + (size_t)(((unsigned)(m0 + rt * 16 + lr) * D + n) * 4u)) = y;
@@ -1406,7 +1424,7 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int kb = 0; kb < KD; ++kb) af[rt][kb] = *(const f32x4*)(xa + (rt * 16 + lr) * XP + (kb * P::KB + P::E * lg) * ES);
+            for (int kb = 0; kb < KD; ++kb) af[rt][kb] = P::aload(xa + (rt * 16 + lr) * XP + (kb * P::KB + P::E * lg) * ES, XA_LO);
         if constexpr (BIG) DSG_LDS_BARRIER();                 // every wave holds its operand: phase 1 may overwrite the aliased rows
         DSG_TL_MARK(2);      // LayerNorm1 (three barriers) -> linear1's operand registers
     } else {
@@ -1433,8 +1451,8 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
             for (int kb = 0; kb < KD; ++kb) {
                 const int i = j * KD + kb;
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) c[rt] = P::mma(ring[i % NRING], af[rt][kb], c[rt]);      // D[n 4lg+r][row lr]
-                if (i + RING < N1 + N2) ring[i % NRING] = *ring_ptr(i + RING);
+                for (int rt = 0; rt < RT; ++rt) c[rt] = P::mma_w(ring[i % NRING], af[rt][kb], c[rt]);      // D[n 4lg+r][row lr]
+                if (i + RING < N1 + N2) ring[i % NRING] = ring_load(i + RING);
                 DSG_LOADS_ISSUED();
             }
 #pragma unroll
@@ -1442,7 +1460,7 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
                 f32x4 y;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] = gelu_erf<P>(c[rt][e] + pbr[j & 1][e]);
-                P::store4((elem*)(hid + (rt * 16 + lr) * HP) + nt * 16 + 4 * lg, y);
+                P::store4_a((elem*)(hid + (rt * 16 + lr) * HP) + nt * 16 + 4 * lg, HID_LO, y);
             }
         }
         if constexpr (BIG) {               // (64-row blocks: the fp32 LayerNorm1 rows come back from the padded X1 rows, as in the plain form)
@@ -1460,24 +1478,24 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
         DSG_TL_MARK(4);
         // ---- phase 2 on the ring: k-block k = fragments N1 + k DW .. + DW - 1
         constexpr int AB = RT <= 2 ? 2 : 1;      // (32-row blocks: the next k-block's `hidden` fragments are read from LDS one step ahead)
-        f32x4 a[AB][RT];
+        typename P::afrag a[AB][RT];
         if constexpr (AB == 2) {
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) a[0][rt] = *(const f32x4*)(hid + (rt * 16 + lr) * HP + (P::E * lg) * ES);
+            for (int rt = 0; rt < RT; ++rt) a[0][rt] = P::aload(hid + (rt * 16 + lr) * HP + (P::E * lg) * ES, HID_LO);
         }
 #pragma unroll
         for (int k = 0; k < KF; ++k) {
             if (AB == 1 || k + 1 < KF) {
                 const int kn = AB == 2 ? k + 1 : k;
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) a[kn % AB][rt] = *(const f32x4*)(hid + (rt * 16 + lr) * HP + (kn * P::KB + P::E * lg) * ES);
+                for (int rt = 0; rt < RT; ++rt) a[kn % AB][rt] = P::aload(hid + (rt * 16 + lr) * HP + (kn * P::KB + P::E * lg) * ES, HID_LO);
             }
 #pragma unroll
             for (int t = 0; t < DW; ++t) {
                 const int i = N1 + k * DW + t;
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) acc[rt][t] = P::mma(ring[i % NRING], a[k % AB][rt], acc[rt][t]);
-                if (i + RING < N1 + N2) ring[i % NRING] = *ring_ptr(i + RING);
+                for (int rt = 0; rt < RT; ++rt) acc[rt][t] = P::mma_w(ring[i % NRING], a[k % AB][rt], acc[rt][t]);
+                if (i + RING < N1 + N2) ring[i % NRING] = ring_load(i + RING);
             }
             DSG_LOADS_ISSUED();
         }
@@ -1594,7 +1612,7 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] = __builtin_fmaf((acc[rt][t][e] - mean[rt]) * rstd, pg[e], pbt[e]);
                 *(f32x4*)((char*)g.Xn + (size_t)((mrow_of(rt) * D + n) * 4u)) = y;
-                P::store4((elem*)g.Xa + qk_off<P>((int)mrow_of(rt), n, KD), y);
+                P::store4_afrag((elem*)g.Xa, (size_t)qk_off<P>((int)mrow_of(rt), n, KD), y);
             }
         }
     }
@@ -1700,9 +1718,7 @@ __global__ __launch_bounds__(64 * NW) void k_ffn_part(const FfnPartArgs g) {
                 pr[rt][t] = lda16<P>(g.R, ((size_t)m * D + n) * sizeof(float));
             }
         }
-#ifndef DSG_X_FFNP_LATE_W1
         load_w1();
-#endif
         DSG_LOADS_ISSUED();
         DSG_TL_MARK(0);      // attention rows, W_o, residual rows, W1 columns requested
         f32x4 acc[RT][DW];
@@ -1717,13 +1733,11 @@ __global__ __launch_bounds__(64 * NW) void k_ffn_part(const FfnPartArgs g) {
 #pragma unroll
                 for (int t = 0; t < DW; ++t) acc[rt][t] = P::mma(wof[t][kb], af[rt][kb], acc[rt][t]);
         DSG_TL_MARK(1);      // out_proj issued (attention rows + W_o have landed)
-#ifdef DSG_X_FFNP_LATE_W1
-        load_w1();                                            // (a wave stuck in the issue of 98 loads cannot start out_proj: W1 goes out behind it, under LayerNorm1)
-        DSG_LOADS_ISSUED();
-#else
+        // (round 6, measured no: requesting W1 only HERE -- out_proj then starts after 56 instead of 98 loads per wave -- moves the phases (mark 0
+        //  at 2.2 instead of 3.8 us) and not the kernel: the workgroup's 480 KB through the CU's load path are what it waits for, in any order;
+        //  profiles/r06_c_*, r06_dA / r06_dB_*)
         load_w2();                                            // (W_o is dead: its registers take W2's k-range)
         DSG_LOADS_ISSUED();
-#endif
 #pragma unroll
         for (int i = 0; i < NV1; ++i) {
             const int e = (int)threadIdx.x + 64 * NW * i;
@@ -1740,10 +1754,6 @@ __global__ __launch_bounds__(64 * NW) void k_ffn_part(const FfnPartArgs g) {
         }
         DSG_TL_MARK(2);      // bias + residual added (the residual rows have landed)
         DSG_LDS_BARRIER();
-#ifdef DSG_X_FFNP_LATE_W1
-        load_w2();
-        DSG_LOADS_ISSUED();
-#endif
         float mean[RT], qv[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -1890,13 +1900,10 @@ __global__ __launch_bounds__(16 * RW) void k_ffn_ln(const FfnLnArgs g) {
             f32x4 y;
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = __builtin_fmaf((v[q][e] - mean) * rstd, pg[q][e], pt[q][e]);
-#ifdef DSG_X_FFNLN_NOSTORE          // (timing experiment: does the boundary behind this kernel wait for its stores?)
-            if (y[0] == 123.456f)
-#endif
-            {
+            // (round 6: the boundary behind this kernel WAITS for these stores -- with them compiled out the gap to the next kernel drops from 2.78 to
+            //  1.70 us and the 16-clip step from 208.6 to 195.6 us, profiles/r06_s_*: uncached stores drain at ~2 MB/us.  The ROWS set has no such pass.)
             *(f32x4*)(g.Xn + mr * D + n) = y;
             P::store4((elem*)g.Xa + qk_off<P>((int)mr, n, KD), y);
-            }
         }
     }
 }

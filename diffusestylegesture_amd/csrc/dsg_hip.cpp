@@ -287,9 +287,9 @@ static void* uc_pool_take(int dev, size_t bytes, bool ignore_cap = false) {
         const size_t want = std::max(UC_ARENA_MIN, (bytes + UC_ARENA_GRAN - 1) / UC_ARENA_GRAN * UC_ARENA_GRAN);
         if (!ignore_cap && total + want > UcPool::cap_bytes()) return nullptr;
         void* d = nullptr;
-        // (experiment, round 6: DSG_UC_KIND=1 asks for fine-grained instead of uncached device memory)
-        static const unsigned kind = (getenv("DSG_UC_KIND") && atoi(getenv("DSG_UC_KIND")) == 1) ? hipDeviceMallocFinegrained : hipDeviceMallocUncached;
-        if (hipExtMallocWithFlags(&d, want, kind) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        // (round 6, measured no: FINE-GRAINED device memory instead of uncached is cached non-coherently across the XCDs -- the hand-off self-check
+        //  fails with 4 M stale words, the fences come back: 16 clips 204 -> 221 us per step, profiles/r06_e_finegrained_vs_uncached.log)
+        if (hipExtMallocWithFlags(&d, want, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         UcArena A;
         A.base = (char*)d; A.size = want;
         A.quarantined = !uc_arena_ok(A.base, want);
@@ -435,6 +435,7 @@ static std::map<std::string, std::vector<int64_t>> expected_tensors(const dsg_ha
 }
 
 static bool stream_set_ok(const dsg_handle* h);
+static bool rows_w2_ok(const dsg_handle* h);
 extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     if (!c || !out) return fail(DSG_E_INVALID, "dsg_create: null argument");
     if (c->variant < 3 || c->variant > 5) return fail(DSG_E_NOT_IMPLEMENTED, "variant must be 3, 4 or 5");
@@ -502,7 +503,7 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     // fences save (4 x 16: 9667 vs 9680 frames/s, 4 x 32: 10 430 vs 10 695): cached + fenced from batch 17 -- unless the handle can run
     // the STREAM set, which large batches select and which reads an activation block once per 128-column panel: fence-free wins there
     // at every size (1 x 64: 505 -> 479 us, 1 x 32: 356 -> 338, 4 x 32: 13.3k -> 13.8k frames/s; profiles/r03_q_uc_stream.log)
-    if (c->max_batch > 16 && !stream_set_ok(h)) h->uc_mode = 0;
+    if (c->max_batch > 16 && !stream_set_ok(h) && !rows_w2_ok(h)) h->uc_mode = 0;      // (bf16w2: ROWS at these sizes, every activation read once per workgroup)
     if (const char* e = getenv("DSG_UC")) h->uc_mode = atoi(e);
     if (const char* e = getenv("DSG_AQL")) h->aql_mode = atoi(e);
     else {
@@ -541,7 +542,7 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
     h->alloc_uc = true;                  // ---- written AND read inside one step by the kernels of the loop
     CHK(dalloc(h, &h->partial, (size_t)h->KSin * Min_pad * D));
     CHK(dalloc(h, &h->X0, M_pad * D));
-    CHK(dalloc_bytes(h, &h->X0a, M_pad * D * h->es));
+    CHK(dalloc_bytes(h, &h->X0a, M_pad * D * h->es * (h->prec == DSG_PREC_BF16W2 ? 2 : 1)));      // (bf16w2, ROWS: hi + lo images)
     CHK(dalloc(h, &h->pre1, M_pad * D));
     CHK(dalloc(h, &h->pre2, M_pad * D));
     CHK(dalloc(h, &h->Xn, M_pad * D));
@@ -1003,6 +1004,11 @@ static bool ffn_split_wide(const dsg_handle* h) {
     return h->prec == DSG_PREC_BF16 && have_attn_op_wide(h) && h->ff == 1024 && (h->D == 384 || h->D == 512);
 }
 static bool ffn_split_ok(const dsg_handle* h) { return stream_set_ok(h) || ffn_split_wide(h); }
+// bf16w2 (round 6): the ROWS pair -- k_clip_attn + k_ffn on one 16-row tile -- exists with the two-register fragments at the ZEGGS / tiny widths
+// (not under fused guidance: its last layer runs the QKV GEMM + k_attn_op, which have no bf16w2 form)
+static bool rows_w2_ok(const dsg_handle* h) {
+    return h->prec == DSG_PREC_BF16W2 && h->H == 4 && ((h->D == 256 && h->Tp == 96 && h->ff == 1024) || (h->D == 128 && h->Tp == 32 && h->ff == 128));
+}
 static int auto_kernel_set(const dsg_handle* h, int B, int lanes) {
     const int rows = B * h->ntok, MT = cdiv(rows, 16);
     const bool s_ok = stream_set_ok(h);       // (bf16, the ZEGGS / tiny widths: STREAM and ROWS exist)
@@ -1038,7 +1044,14 @@ static int resolve_auto_set(const dsg_handle* h, int B, int lanes) {
     if (h->latency_mode == 0 && set == DSG_KSET_LATENCY) set = DSG_KSET_TILE;
     // bf16w2: 16 x 16 tiles at every batch size.  Its weight fragments are twice the bytes, so the redundant W_o of the fused LATENCY
     // kernels costs more than the dispatches it saves: 168 vs 155 us per batch-1 step (profiles/r05_e_*); LATENCY stays selectable
-    if (h->prec == DSG_PREC_BF16W2) set = DSG_KSET_TILE;
+    // (round 6: ... and ROWS -- k_clip_attn + k_ffn with the two-register fragments -- from 800 token rows in one lane / 1400 over several lanes of >= 300:
+    //  1 x 16 clips 331 vs 453 us per step, 4 x 4: 330 vs 348, 1 x 8: 315 vs 311, 1 x 4: 310 vs 208 -- profiles/r06_bb_w2_rows.log.  Every workgroup
+    //  streams W_o + W1 + W2 as hi + lo pairs, 2.3 MB through one CU's 64 B / clk load path: k_ffn is 23.7 us whatever the batch, r06_bc_marks_b16_rows_w2.log)
+    if (h->prec == DSG_PREC_BF16W2) {
+        const int rows = B * h->ntok;
+        const bool big = rows >= 800 || (lanes > 1 && rows >= 300 && lanes * rows >= 1400);
+        set = (rows_w2_ok(h) && h->cfgB == 0 && big) ? DSG_KSET_ROWS : DSG_KSET_TILE;
+    }
     if (h->latency_mode == 1 && latency_set_ok(h)) set = DSG_KSET_LATENCY;
     return set;
 }
@@ -1046,10 +1059,11 @@ static int select_kernels(const dsg_handle* h, int B, KernelSel& k) {
     int set = h->kset_req;
     if (set == DSG_KSET_AUTO) set = resolve_auto_set(h, B, 1);
     if (set == DSG_KSET_LATENCY && h->D > 512) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set LATENCY: latent_dim > 512");
-    if ((set == DSG_KSET_STREAM || set == DSG_KSET_ROWS) && !stream_set_ok(h)) return fail(DSG_E_NOT_IMPLEMENTED, "kernel sets STREAM / ROWS: bf16, latent_dim 128 / 256, 4 heads, ff 128 / 1024 only");
+    if ((set == DSG_KSET_STREAM || set == DSG_KSET_ROWS) && !stream_set_ok(h) && !(set == DSG_KSET_ROWS && rows_w2_ok(h)))
+        return fail(DSG_E_NOT_IMPLEMENTED, "kernel sets STREAM / ROWS: bf16 (ROWS: bf16w2 as well), latent_dim 128 / 256, 4 heads, ff 128 / 1024 only");
     if (set < DSG_KSET_LATENCY || set > DSG_KSET_ROWS) return fail(DSG_E_INVALID, "unknown kernel set");
-    if (h->prec == DSG_PREC_BF16W2 && (set > DSG_KSET_TILE || (set == DSG_KSET_LATENCY && h->D > 256)))
-        return fail(DSG_E_NOT_IMPLEMENTED, "precision bf16w2: kernel sets LATENCY (latent_dim <= 256) and TILE only");
+    if (h->prec == DSG_PREC_BF16W2 && ((set > DSG_KSET_TILE && !(set == DSG_KSET_ROWS && rows_w2_ok(h))) || (set == DSG_KSET_LATENCY && h->D > 256)))
+        return fail(DSG_E_NOT_IMPLEMENTED, "precision bf16w2: kernel sets LATENCY (latent_dim <= 256), TILE and ROWS (latent_dim 128 / 256) only");
     k = KernelSel();
     k.set = set;
     k.lat = set == DSG_KSET_LATENCY;
@@ -1068,10 +1082,12 @@ static int select_kernels(const dsg_handle* h, int B, KernelSel& k) {
     k.blk = set == DSG_KSET_BLOCK || set == DSG_KSET_ROWS || k.stream;      // (STREAM / ROWS: pose embedding and layer-0 QKV as in BLOCK)
     // the wide form (W_o streamed: DSG+ widths, fp32) belongs to BLOCK / STREAM only -- a set's arithmetic never depends on the batch,
     // and at batch 1 its 10 workgroups per layer lose to k_attn + out_proj (BEAT: 200 vs 163 us/step; 16 clips: 3371 vs 2904 frames/s)
-    k.attn_op = !k.lat && (have_attn_op_narrow(h) || (k.blk && have_attn_op_wide(h)));
+    if (k.ffn16 && h->prec == DSG_PREC_BF16W2 && h->cfgB > 0) return fail(DSG_E_NOT_IMPLEMENTED, "precision bf16w2, kernel set ROWS: no fused guidance (TILE has it)");
+    k.attn_op = !k.lat && (have_attn_op_narrow(h) || (k.blk && have_attn_op_wide(h)) || (k.ffn16 && rows_w2_ok(h)));
     k.xs_frag = k.blk && h->prec == DSG_PREC_BF16 && (h->Jp == 1152 || h->Jp == 128);
     if (set == DSG_KSET_BLOCK && ffn_split_ok(h)) k.ffn_split = h->env_ffn_split != 0;      // (A/B: DSG_FFN_SPLIT=0 = linear1 + linear2 + LayerNorm-on-read, round 3)
     k.clip_attn = (k.ffn_split || k.ffn) && have_attn_op_narrow(h) && h->env_clip_attn != 0;      // (A/B: DSG_CLIP_ATTN=0 = QKV GEMM + k_attn_op, round 4)
+    if (k.ffn16 && h->prec == DSG_PREC_BF16W2) k.clip_attn = true;
 
     return 0;
 }
@@ -1093,10 +1109,11 @@ extern "C" int dsg_set_kernel_set(dsg_handle* h, int set) {
     if (!h) return fail(DSG_E_INVALID, "null handle");
     if (set < DSG_KSET_AUTO || set > DSG_KSET_ROWS) return fail(DSG_E_INVALID, "dsg_set_kernel_set: unknown kernel set");
     if (set == DSG_KSET_LATENCY && h->D > 512) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set LATENCY: latent_dim > 512");
-    if ((set == DSG_KSET_STREAM || set == DSG_KSET_ROWS) && !stream_set_ok(h)) return fail(DSG_E_NOT_IMPLEMENTED, "kernel sets STREAM / ROWS: bf16, latent_dim 128 / 256, 4 heads, ff 128 / 1024 only");
+    if ((set == DSG_KSET_STREAM || set == DSG_KSET_ROWS) && !stream_set_ok(h) && !(set == DSG_KSET_ROWS && rows_w2_ok(h)))
+        return fail(DSG_E_NOT_IMPLEMENTED, "kernel sets STREAM / ROWS: bf16 (ROWS: bf16w2 as well), latent_dim 128 / 256, 4 heads, ff 128 / 1024 only");
     // (the same rule as select_kernels: round-5 advisor -- this entry point used to accept LATENCY at latent_dim 384 / 512, and every later call failed)
-    if (h->prec == DSG_PREC_BF16W2 && (set > DSG_KSET_TILE || (set == DSG_KSET_LATENCY && h->D > 256)))
-        return fail(DSG_E_NOT_IMPLEMENTED, "precision bf16w2: kernel sets LATENCY (latent_dim <= 256) and TILE only");
+    if (h->prec == DSG_PREC_BF16W2 && ((set > DSG_KSET_TILE && !(set == DSG_KSET_ROWS && rows_w2_ok(h))) || (set == DSG_KSET_LATENCY && h->D > 256)))
+        return fail(DSG_E_NOT_IMPLEMENTED, "precision bf16w2: kernel sets LATENCY (latent_dim <= 256), TILE and ROWS (latent_dim 128 / 256) only");
     if (getenv("DSG_KSET")) {                  // an A/B run pinned the set for the whole process: say so once, keep the pinned set
         static std::atomic<bool> said{false};
         if (set != h->kset_req && !said.exchange(true))
@@ -1283,9 +1300,7 @@ static int launch_gemm_w(dsg_handle* h, const GemmArgs& g, const KernelSel& ks) 
     constexpr bool blk_wins = EPI == EPI_QKV || EPI == EPI_GELU;
     if constexpr (sizeof(typename P::elem) == 2 && !P::W2 && PRO == PRO_DIRECT && (EPI == EPI_GELU || EPI == EPI_QKV || EPI == EPI_OUT)) {
         if (ks.stream && g.a_frag) return launch_ws<EPI>(h, g);      // STREAM: linear1 on the fragment-major LayerNorm1 rows of k_attn_op
-#ifdef DSG_X_BLOCK_WS_HEAD
-        if constexpr (EPI == EPI_OUT) { if (ks.blk && g.a_frag && g.xs_frag && g.M >= DSG_X_BLOCK_WS_HEAD) return launch_ws<EPI>(h, g); }
-#endif
+        // (the streaming pose head below the STREAM sizes loses: BLOCK 1 x 16 clips 207.5 -> 211.6 us per step, 4 x 4: 197.5 -> 205.4 -- profiles/r06_h_*, round 6)
     }
     if constexpr (sizeof(typename P::elem) == 2 && !P::W2 && PRO == PRO_LN && (EPI == EPI_QKV || EPI == EPI_OUT)) {
         if (ks.stream) return launch_ln_ws<EPI>(h, g);                    // STREAM: LayerNorm once per row, then the same streaming GEMM
@@ -1404,14 +1419,15 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
     // split-K of the pose-embedding GEMM across workgroups: one split per 256 pose features for the 16 x 16 tile kernel; the
     // block kernel splits K over its 4 waves already, so 2 workgroup splits keep a wave's share at <= 8 k-blocks (one batch of
     // loads) without fragmenting the work 5 ways
-    const int ks_in = ks.xs_frag ? 1 : (ks.blk ? std::min(h->KSin, 2) : h->KSin);      // (streamed embedding: K stays whole, see k_ws2)
+    const int ks_in = ks.xs_frag ? 1 : ((ks.blk && !P::W2) ? std::min(h->KSin, 2) : h->KSin);      // (streamed embedding: K stays whole, see k_ws2; bf16w2: the 16 x 16 tiles)
     la.partial = h->partial; la.KS = ks_in; la.Min_pad = MTin * 16; la.Cf = h->Cf; la.TE2 = h->TE2; la.TE = h->TE;
     la.emb1 = h->emb1; la.ctl = c.use_ctr ? h->ctl : nullptr; la.t_arr = h->t_arr;
     la.rcos = h->rcos; la.rsin = h->rsin; la.mask = h->mask; la.mb = h->mb; la.inv_mask_div = fastdiv_inv((int)((long long)B * h->Hl / h->mb)); la.B = B; la.T = T; la.D = D; la.Hl = h->Hl;
     la.hd = h->hdl; la.W = h->W; la.X0 = h->X0; la.X0a = h->X0a; la.nomask = h->nomask;
-    la.x0a_frag = ((ks.stream || ks.clip_attn) && sizeof(typename P::elem) == 2) ? 1 : 0;
+    la.x0a_frag = ((ks.stream || ks.clip_attn) && sizeof(typename P::elem) == 2) ? (P::W2 ? 2 : 1) : 0;      // (bf16w2: as a hi + lo pair)
     h->fence_next = 1;         // the first packet of a step reads the state the previous step's last packet wrote (state_fences)
-    if (ks.lat) {              // pose embedding + local attention in one launch
+    if (ks.lat) {              // pose embedding + local attention in one launch (in the batched sets it loses: 1 x 16 clips 192.1 -> 198.5 us per
+                               // step, 1 x 64: 258 -> 291, 4 x 4 even -- profiles/r06_ab_*, round 6)
         InLocArgs a;
         a.xs = is_bf16(h) ? h->xsA : (void*)h->xs32; a.Jp = h->Jp; a.Wp = h->Wp_in; a.KBtot = h->Jp / KB;
         a.loc = la; a.ctl_upd = c.use_ctr ? h->ctl : nullptr; a.st = step_tables(h); a.n_tab = h->n_run;
@@ -1474,7 +1490,20 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                 CHK(launch_mid<P>(h, a));
             }
         } else if (ks.attn_op) {
-          if constexpr (!P::W2) {        // (bf16w2 runs LATENCY / TILE without k_attn_op: select_kernels)
+          if constexpr (P::W2) {         // bf16w2 in the ROWS set (round 6): k_clip_attn + k_ffn on one 16-row tile, two-register fragments
+            if (!clip_l || !ks.ffn16) return fail(DSG_E_NOT_IMPLEMENTED, "precision bf16w2: k_clip_attn + k_ffn in the ROWS set only");
+            ClipAttnArgs a;
+            a.X = h->X0a; a.Wqkv = ly.Wqkv; a.bqkv = ly.bqkv; a.out = h->attn; a.B = B; a.ntok = ntok;
+            if (D == 256) CHK((step_launch<&k_clip_attn<P, 4, 6>>(h, dim3(4, B), dim3(384), a)));
+            else CHK((step_launch<&k_clip_attn<P, 2, 2>>(h, dim3(4, B), dim3(128), a)));
+            FfnArgs f;
+            memset(&f, 0, sizeof(f));
+            f.W1 = ly.W1; f.b1 = ly.b1; f.W2 = ly.W2; f.b2 = ly.b2; f.ln_g = ly.g2; f.ln_b = ly.be2; f.Xn = h->Xn; f.Xa = h->X0a; f.M = M; f.MT = MT;
+            f.A = h->attn; f.R = l == 0 ? h->X0 : h->Xn; f.Wo = ly.Wo; f.bo = ly.bo; f.ln1_g = ly.g1; f.ln1_b = ly.be1; f.X1 = h->X1;
+            if (D == 256) CHK((step_launch<&k_ffn<P, 4, 16, 1, 8, 2, true, true, 12>>(h, dim3(MT), dim3(512), f)));
+            else CHK((step_launch<&k_ffn<P, 2, 2, 1, 4, 2, false, true, 8>>(h, dim3(MT), dim3(256), f)));
+            continue;
+          } else {                       // (bf16w2 runs LATENCY / TILE without k_attn_op: select_kernels)
             // attention + out_proj + residual + LayerNorm1 in one kernel per (query tile, batch element); linear1 reads the
             // normalised rows in the GEMM type
             if (clip_l) {

@@ -108,6 +108,9 @@ struct PF32 {                       // fp32 storage, v_mfma_f32_16x16x4_f32
     // fragment-major global A operand written by one kernel and read by the next (`hidden`): element offset of the PBF16 order -> here
     static __device__ __forceinline__ void store4_afrag(elem* base, size_t off, f32x4 v) { store4(base + off, v); }
     static __device__ __forceinline__ afrag aload_frag(const void* base, size_t frag, int lane) { return *(const f32x4*)((const char*)base + (frag * 64 + lane) * 16); }
+    // ... at the element offset of a lane's 16 bytes (qk_off of a row that need not start a tile), and one element of it
+    static __device__ __forceinline__ afrag aload_off(const void* base, size_t off) { return *(const f32x4*)((const char*)base + off * sizeof(elem)); }
+    static __device__ __forceinline__ void store1_afrag(elem* base, size_t off, float v) { base[off] = cvt(v); }
 };
 struct PBF16 {                      // bf16 storage, v_mfma_f32_16x16x32_bf16, fp32 accumulate
     typedef bf16_t elem;
@@ -140,6 +143,9 @@ struct PBF16 {                      // bf16 storage, v_mfma_f32_16x16x32_bf16, f
     // fragment-major global A operand written by one kernel and read by the next (`hidden`): element offset of the PBF16 order -> here
     static __device__ __forceinline__ void store4_afrag(elem* base, size_t off, f32x4 v) { store4(base + off, v); }
     static __device__ __forceinline__ afrag aload_frag(const void* base, size_t frag, int lane) { return *(const f32x4*)((const char*)base + (frag * 64 + lane) * 16); }
+    // ... at the element offset of a lane's 16 bytes (qk_off of a row that need not start a tile), and one element of it
+    static __device__ __forceinline__ afrag aload_off(const void* base, size_t off) { return *(const f32x4*)((const char*)base + off * sizeof(elem)); }
+    static __device__ __forceinline__ void store1_afrag(elem* base, size_t off, float v) { base[off] = cvt(v); }
 };
 // "bf16w2" (round 5): bf16 activations, every WEIGHT as the sum of two bf16 numbers -- hi = bf16(w), lo = bf16(w - hi): 16 mantissa
 // bits instead of 8 -- two v_mfma_f32_16x16x32_bf16 per fragment, fp32 accumulate.  The bf16 drift of a 1000-step chain is the
@@ -178,6 +184,15 @@ struct PBF16W2 : PBF16 {
     }
     static __device__ __forceinline__ afrag aload_frag(const void* base, size_t frag, int lane) {
         afrag a; a.h = *(const f32x4*)((const char*)base + (frag * 128 + lane) * 16); a.l = *(const f32x4*)((const char*)base + (frag * 128 + 64 + lane) * 16); return a;
+    }
+    static __device__ __forceinline__ afrag aload_off(const void* base, size_t off) {
+        const size_t o2 = off + (off / (64 * E)) * (64 * E);
+        afrag a; a.h = *(const f32x4*)((const elem*)base + o2); a.l = *(const f32x4*)((const elem*)base + o2 + 64 * E); return a;
+    }
+    static __device__ __forceinline__ void store1_afrag(elem* base, size_t off, float v) {
+        const size_t o2 = off + (off / (64 * E)) * (64 * E);
+        const elem hi = f2bf(v);
+        base[o2] = hi; base[o2 + 64 * E] = f2bf(v - bf2f(hi));
     }
     static __device__ __forceinline__ f32x4 mma_w(const wfrag& w, const afrag& a, f32x4 c) { return PBF16::mma(w.h, a.l, PBF16::mma(w.l, a.h, PBF16::mma(w.h, a.h, c))); }
     static __device__ __forceinline__ f32x4 mma_a(const afrag& a, const wfrag& w, f32x4 c) { return PBF16::mma(a.l, w.h, PBF16::mma(a.h, w.l, PBF16::mma(a.h, w.h, c))); }
@@ -396,15 +411,9 @@ __device__ __forceinline__ f32x4 philox_normal4(unsigned q, unsigned draw, Noise
     float u1a = (float)((x[0] >> 8) + 1u) * sc, u2a = (float)(x[1] >> 8) * sc;
     float u1b = (float)((x[2] >> 8) + 1u) * sc, u2b = (float)(x[3] >> 8) * sc;
     float sa, ca, sb, cb;
-#ifdef DSG_X_OLD_NOISE
-    float ra = sqrtf(-2.0f * logf(u1a)), rb = sqrtf(-2.0f * logf(u1b));
-    sincospif(2.0f * u2a, &sa, &ca);
-    sincospif(2.0f * u2b, &sb, &cb);
-#else
     const float ra = dsg_sqrtf(-1.3862943611198906f * dsg_log2f(u1a)), rb = dsg_sqrtf(-1.3862943611198906f * dsg_log2f(u1b));
     dsg_sincospi_02(2.0f * u2a, sa, ca);
     dsg_sincospi_02(2.0f * u2b, sb, cb);
-#endif
     f32x4 z; z[0] = ra * ca; z[1] = ra * sa; z[2] = rb * cb; z[3] = rb * sb;
     return z;
 }
@@ -589,11 +598,7 @@ template <class P>
 __device__ __forceinline__ float gelu_erf(float x) {
     if constexpr (sizeof(typename P::elem) == 4) {
         return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
-#ifdef DSG_X_OLD_GELU
-    } else if constexpr (true) {
-#else
     } else if constexpr (P::W2) {
-#endif
         const float ax = fabsf(x) * 0.70710678118654752440f;
         const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
         const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
@@ -839,7 +844,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
     __shared__ __attribute__((aligned(16))) char lds_a[IS_LN ? LDS_A * P::AF : 16];
     // PBF16W2: the A operand is a hi + lo pair where a kernel of the step produced it for this GEMM -- the LayerNorm rows (LDS) and
     // the two direct GEMMs with the residual epilogue: out_proj (k_attn's rows) and linear2 (`hidden`), both fragment-major
-    constexpr bool A2 = P::W2 && (IS_LN || (PRO == PRO_DIRECT && EPI == EPI_RESID));
+    // (round 6: ... and the pose head of the ROWS set, which reads the LayerNorm2 rows k_ffn wrote as a hi + lo pair)
+    constexpr bool A2 = P::W2 && (IS_LN || (PRO == PRO_DIRECT && (EPI == EPI_RESID || EPI == EPI_OUT)));
     typedef typename std::conditional<A2, typename P::afrag, f32x4>::type AFrag;
     __shared__ __attribute__((aligned(16))) float lds_red[WK > 1 ? (WK - 1) * WN * TNW * 64 * 4 : 4];
 
@@ -1055,7 +1061,7 @@ struct LocArgs {
     int B, T, D, Hl, hd, W;   // hd / W must match the kernel's template arguments
     float* X0;              // [M_pad][D] fp32, row = b*(T+1) + 1 + f ; row b*(T+1) = token
     void* X0a;              // same in P::elem (GEMM operand copy)
-    int x0a_frag;           // ... stored fragment-major (qk_off over [rows][D]): the STREAM set streams it into the layer-0 QKV
+    int x0a_frag;           // ... stored fragment-major (qk_off over [rows][D]): the STREAM set streams it into the layer-0 QKV; 2 (bf16w2, ROWS): as a hi + lo pair
 };
 
 // Shared tail of k_loc / k_inloc.  `rot` holds the rotary-embedded [2W][HD] tile (pad rows = -1).  Phase A: one thread
@@ -1134,6 +1140,14 @@ __device__ __forceinline__ void local_attn_tail(const LocArgs& a, float (&rot)[2
         if constexpr (P::E == 4) {
             *(f32x4*)dst = *(const f32x4*)&ot[q][4 * c];
         } else {
+            if constexpr (P::W2) {
+                if (a.x0a_frag == 2) {       // bf16w2 in the ROWS set: hi + lo images, like every other A operand k_clip_attn reads
+                    const size_t off = (size_t)qk_off<P>(row, col0 + P::E * c, a.D / P::KB);
+                    P::store4_afrag((elem*)a.X0a, off, *(const f32x4*)&ot[q][8 * c]);
+                    P::store4_afrag((elem*)a.X0a, off + 4, *(const f32x4*)&ot[q][8 * c + 4]);
+                    continue;
+                }
+            }
             P::store4(dst, *(const f32x4*)&ot[q][8 * c]);
             P::store4(dst + 4, *(const f32x4*)&ot[q][8 * c + 4]);
         }
@@ -1204,7 +1218,8 @@ __device__ __forceinline__ void loc_body(const LocArgs& a, int h, int w, int b) 
     DSG_TL_MARK(0);          // k_loc: every load requested
     if (w == 0 && tid < HD) {                              // token row (position 0: rotary is the identity)
         a.X0[(size_t)(b * ntok) * a.D + col0 + tid] = tokv;
-        ((elem*)a.X0a)[a.x0a_frag ? (size_t)qk_off<P>(b * ntok, col0 + tid, a.D / P::KB) : (size_t)(b * ntok) * a.D + col0 + tid] = P::cvt(tokv);
+        if (P::W2 && a.x0a_frag == 2) P::store1_afrag((elem*)a.X0a, (size_t)qk_off<P>(b * ntok, col0 + tid, a.D / P::KB), tokv);
+        else ((elem*)a.X0a)[a.x0a_frag ? (size_t)qk_off<P>(b * ntok, col0 + tid, a.D / P::KB) : (size_t)(b * ntok) * a.D + col0 + tid] = P::cvt(tokv);
     }
 #pragma unroll
     for (int i = 0; i < NPI; ++i) {
