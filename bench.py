@@ -412,6 +412,9 @@ def main():
         if a.precision == "bf16":
             subs["precision"] = {prec: sub_record(f"config[1] in {prec}: 1 clip, batch 1, 320-frame ZEGGS clip, 4 x 1000 DDPM steps", "zeggs", 1, 1, "ddpm", 1,
                                                   warm_skip=900, precision=prec) for prec in ("fp32", "bf16w2")}
+            # ... and 16 clips in lock step in bf16w2 (round 6: the ROWS kernel set on two-register fragments), one window of 1000 steps
+            subs["precision"]["bf16w2_16clips"] = sub_record("16 clips in lock step in bf16w2 (1 of the 4 windows of a 320-frame ZEGGS clip, 1000 DDPM steps)",
+                                                             "zeggs", 16, 1, "ddpm", 1, n_windows=1, warm_skip=960, precision="bf16w2")
     if rank == 0 and os.environ.get("DSG_BENCH_DUMP"):      # TEST INFRASTRUCTURE (tests/test_bench_launch.py): the gathered poses, by clip id
         np.save(os.environ["DSG_BENCH_DUMP"], np.asarray(gathered, np.float32))
     if rank == 0:

@@ -62,7 +62,9 @@ enum {
 
 /* DSG_PREC_BF16W2 (ABI 320): bf16 activations, every weight as hi + lo bf16 (16 mantissa bits), two MFMAs per weight fragment --
  * the precision mode between bf16 and fp32 (the bf16 drift of a 1000-step chain is the weights' 8-bit mantissa).  Kernel sets
- * LATENCY and TILE (every batch size); BLOCK / STREAM are DSG_E_NOT_IMPLEMENTED.  The reference computes in fp32
+ * LATENCY and TILE (every batch size) and, at latent_dim 128 / 256 without fused guidance, ROWS (round 6: k_clip_attn + the feed-forward kernel on
+ * two-register fragments; DSG_KSET_AUTO picks it from 800 token rows -- 16 clips in lock step 453 -> 331 us per step); BLOCK / STREAM are
+ * DSG_E_NOT_IMPLEMENTED.  The reference computes in fp32
  * (main/train/training_loop.py:39: no autocast): DSG_PREC_FP32 is its arithmetic, the other two trade accuracy for speed. */
 enum { DSG_PREC_FP32 = 0, DSG_PREC_BF16 = 1, DSG_PREC_BF16W2 = 2 };
 /* kernel sets (dsg_set_kernel_set): which hand-written kernels one denoising step is made of.  Same arithmetic, different
@@ -86,7 +88,7 @@ enum {
                                ONE 16-row tile per workgroup (no ff-split, no partial slabs, no slab-sum pass: 3 + 2L dispatches).  Every workgroup
                                streams a layer's W_o + W1 + W2 for its 16 rows: it pays while the row tiles of all lanes fit the 256 CUs in one
                                round -- 1000 .. 4000 token rows in one lane (12 .. 45 ZEGGS clips), fewer per lane with several lanes.  Same shapes
-                               as STREAM; DSG_E_NOT_IMPLEMENTED elsewhere */
+                               as STREAM, in bf16 and (without fused guidance) bf16w2; DSG_E_NOT_IMPLEMENTED elsewhere */
 };
 enum { DSG_MODE_DDPM = 0, DSG_MODE_DDIM = 1 };
 
