@@ -1365,7 +1365,12 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
         DSG_TL_MARK(1);      // out_proj issued (attention rows shared through LDS, W_o landed)
         if constexpr (RING > 0) {
 #pragma unroll
-            for (int i = 0; i < RING; ++i) ring[i] = ring_load(i);      // the ring's first fill arrives behind LayerNorm1
+            // Round 6: the ring's first fill goes out in FOUR quarters, one here and one behind each of LayerNorm1's next three stages.  A wave issues in
+            // order: the 32 loads of a whole fill keep it in the issue stage while the CU's load path takes them (8 waves x 32 KB at 64 B / clk = 1.7 us) --
+            // LayerNorm1 then ran AFTER the fill was issued, with the load path idle behind it (marks: 2.9 us for a 1.2 us LayerNorm).  Spread, the same
+            // loads are issued while the other waves compute: 1 x 16 clips 192.6 -> 188.0 us per step (ROWS), 4 x 8: 207.3 -> 201.4, 1 x 64: 259.8 -> 255.2
+            // (STREAM), bit-identical -- profiles/r06_ca_ab_dev{A,B}.log.  (k_attn_mid spreads its W_o / W1 loads over the softmax the same way.)
+            for (int i = 0; i < RING / 4; ++i) ring[i] = ring_load(i);
         } else {
             load1(0, 0);                                      // (W_o and the attention rows are dead: the first W1 tiles arrive behind LayerNorm1)
         }
@@ -1383,6 +1388,11 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
             sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
             if (lg == 0) red[rt][0][wave][lr] = sm;
         }
+        if constexpr (RING > 0) {
+#pragma unroll
+            for (int i = RING / 4; i < RING / 2; ++i) ring[i] = ring_load(i);
+            DSG_LOADS_ISSUED();
+        }
         DSG_LDS_BARRIER();
         float mean1[RT];
 #pragma unroll
@@ -1398,6 +1408,11 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
                 for (int e = 0; e < 4; ++e) { const float d = acc1[rt][t][e] - mean1[rt]; qv = __builtin_fmaf(d, d, qv); }
             qv += __shfl_xor(qv, 16); qv += __shfl_xor(qv, 32);
             if (lg == 0) red[rt][1][wave][lr] = qv;
+        }
+        if constexpr (RING > 0) {
+#pragma unroll
+            for (int i = RING / 2; i < 3 * (RING / 4); ++i) ring[i] = ring_load(i);
+            DSG_LOADS_ISSUED();
         }
         DSG_LDS_BARRIER();
 #pragma unroll
@@ -1419,6 +1434,11 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
                 if constexpr (BIG) *(f32x4*)((char*)g.X1 + (size_t)(((unsigned)(m0 + rt * 16 + lr) * D + n) * 4u)) = y;
                 else *(f32x4*)(x1f + (rt * 16 + lr) * X1P + n) = y;
             }
+        }
+        if constexpr (RING > 0) {
+#pragma unroll
+            for (int i = 3 * (RING / 4); i < RING; ++i) ring[i] = ring_load(i);
+            DSG_LOADS_ISSUED();
         }
         DSG_LDS_BARRIER();                                    // (also: red is free for LayerNorm2)
 #pragma unroll

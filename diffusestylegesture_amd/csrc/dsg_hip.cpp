@@ -1012,28 +1012,29 @@ static bool rows_w2_ok(const dsg_handle* h) {
 static int auto_kernel_set(const dsg_handle* h, int B, int lanes) {
     const int rows = B * h->ntok, MT = cdiv(rows, 16);
     const bool s_ok = stream_set_ok(h);       // (bf16, the ZEGGS / tiny widths: STREAM and ROWS exist)
-    // Round 6 (profiles/r06_u_*, r06_v_*, r06_w_*: one-box sweeps of every set, us per step): ROWS -- k_ffn on one 16-row tile per workgroup -- wins
-    // wherever the row tiles of ALL lanes fit the 256 CUs in one round: 1 x 12 clips 188.9 vs 190.4 (BLOCK), 1 x 16: 192.2 vs 204.3, 1 x 24: 202.7 vs
-    // 298 (BLOCK) / 249 (STREAM), 1 x 40: 221 vs 235 (STREAM), 1 x 46 (256 row tiles): 231 vs 242; 1 x 48 (267 tiles: two rounds): 328 vs 244 -> STREAM;
-    // 4 x 5: 194.9 vs 198.1 (BLOCK), 4 x 8: 205.8 vs 222.2, 4 x 12 (268 tiles): 230 vs 240 (STREAM), 4 x 14 (312): 250 = 249, 4 x 16: 271 vs 255 -> STREAM;
-    // 3 x 16: 222 vs 245, 2 x 16: 209 vs 231, 2 x 32: 279 vs 253 -> STREAM.  Below ~1500 token rows over all lanes BLOCK's ff-split is even or ahead
-    // (4 x 4: 191.8 = 191.3, 2 x 8: 190.2 vs 191.4, 2 x 6: 182.9 vs 188.6, 1 x 10: 186.2 vs 188.6, 1 x 8: 181.4 vs 187.2).
+    // Round 6 (one-box sweeps of every set, us per step; profiles/r06_u_*, r06_v_*, r06_w_* before, r06_cb_sweep_rows_gradual.log after the ring's first fill
+    // was spread over LayerNorm1): ROWS -- k_ffn on one 16-row tile per workgroup -- wins wherever the row tiles of ALL lanes fit the 256 CUs in one round:
+    // 1 x 10 clips 183.0 vs 186.0 (BLOCK), 1 x 12: 184.3 vs 190.3, 1 x 16: 188.0 vs 204, 1 x 24: 203 vs 298 (BLOCK) / 249 (STREAM), 1 x 46 (256 row tiles):
+    // 228.7 vs 237.8 (STREAM); 1 x 48 (267 tiles: two rounds): 320 vs 240 -> STREAM; 4 x 3: 184.6 vs 187.1 (BLOCK), 4 x 4: 186.8 vs 194.2, 4 x 5: 189.9 vs
+    // 198.7, 2 x 8: 186.4 vs 189.9, 4 x 12 (268 tiles): 225.5 vs 230.4 (STREAM), 4 x 14 (312): 243.4 = 240.7, 4 x 16: 264 vs 250 -> STREAM; 2 x 24: 229 vs
+    // 238, 2 x 32: 274 vs 249 -> STREAM.  Below ~900 token rows over all lanes BLOCK's ff-split is even or ahead (1 x 8: 181.9 vs 180.8, 1 x 6: 180.6 vs
+    // 177.6, 1 x 5: 180.3 vs 176.4 -- TILE 161.6 --, 2 x 4: 180.5 vs 178.1, 2 x 6: 184.0 = 183.8; 4 x 2: 181.7 vs 183.3, TILE 179.4).
     // (rounds 4-5, STREAM against BLOCK: profiles/r04_n_sweep_sets.log, r05_j_sweep_sets.log)
     if (lanes <= 1) {
-        if (s_ok && rows >= 1000) return MT <= 256 ? DSG_KSET_ROWS : DSG_KSET_STREAM;
+        if (s_ok && rows >= 800) return MT <= 256 ? DSG_KSET_ROWS : DSG_KSET_STREAM;
         // (fp32, round 5: k_attn_mid recomputes out_proj per hidden slice, and an fp32 MFMA is 1/16 of a bf16 one -- the un-fused 16 x 16
         // tiles win at batch 1: 208.2 vs 218.5 us per step, profiles/r05_g_bench_fp32_*.log)
         if (B <= 2 && latency_set_ok(h) && h->prec != DSG_PREC_FP32) return DSG_KSET_LATENCY;
         // (DSG+ widths, round 5: with k_ffn_part + k_ffn_ln behind k_attn_op_w BLOCK wins from 4 clips -- BEAT 283 vs 303 us, TWH 310 vs 365; 2 clips: 259 vs 198)
         // (only there: ffn_split_wide() is also true for fp32 at the ZEGGS widths, which has no such measurement -- round-5 advisor)
         if (ffn_split_wide(h) && h->prec == DSG_PREC_BF16 && (h->D == 384 || h->D == 512) && h->env_ffn_split != 0 && rows >= 600) return DSG_KSET_BLOCK;
-        // (round 6, bf16 ZEGGS widths: BLOCK from 5 clips -- 1 x 6: 178.0 vs 190.1 TILE, 1 x 4: 173.9 vs 157.4, 1 x 10: 186.2 vs 233.1)
+        // (round 6, bf16 ZEGGS widths: BLOCK from 6 clips -- 1 x 6: 177.6 vs 190.1 TILE, 1 x 5: 176.4 vs 161.6, 1 x 4: 173.9 vs 157.4)
         return rows >= (s_ok ? 500 : 1000) ? DSG_KSET_BLOCK : DSG_KSET_TILE;
     }
     if (s_ok && rows >= 850 && lanes * MT > 300) return DSG_KSET_STREAM;
-    if (s_ok && rows >= 300 && lanes * rows >= 1500 && lanes * MT <= 300) return DSG_KSET_ROWS;
+    if (s_ok && rows >= 250 && lanes * rows >= 1000 && lanes * MT <= 300) return DSG_KSET_ROWS;
     if (B <= 1 && latency_set_ok(h) && h->prec != DSG_PREC_FP32) return DSG_KSET_LATENCY;
-    // (4 x 3: BLOCK 187.1 vs TILE 203.2; 4 x 2: 183.4 vs 180.1; 2 x 3: 175.1 = 173.8)
+    // (2 x 4: BLOCK 178.1 vs ROWS 180.5; 4 x 2: TILE 179.4 vs BLOCK 183.3; 2 x 3: 175.1 = 173.8)
     return rows >= (s_ok ? 250 : 300) ? DSG_KSET_BLOCK : DSG_KSET_TILE;
 }
 // what DSG_KSET_AUTO resolves to for `lanes` lanes of batch B: the measured table + dsg_config.latency_mode (1 = never LATENCY, 2 = always

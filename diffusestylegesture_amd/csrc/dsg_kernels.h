@@ -851,8 +851,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
 
     preload_kernargs(g);
     const int NG = g.NT / (WN * TNW);
-    const int ng = xcd_ngroup<P>(), ks = blockIdx.z;
-    const int mt_first = blockIdx.y;
+    int ng = xcd_ngroup<P>();
+    const int ks = blockIdx.z;
+    int mt_first = blockIdx.y;
     if constexpr (EPI == EPI_PARTIAL || EPI == EPI_OUT) {
         // step bookkeeping runs in ONE EXTRA workgroup (first block of an extra grid row), concurrently with the real
         // work and off every critical path; see StepCtl for why this is race free
@@ -862,6 +863,23 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
                 else if (g.out_mode != OUT_FORWARD) step_advance_A<P>(g.ctl, g.st, g.n_tab);
             }
             return;
+        }
+    }
+    // Round 6: column group ng runs on XCD ng % 8 (grid x is padded to a multiple of 8: a group's weight columns stay in ONE L2), which left the
+    // XCDs with NG / 8 or NG / 8 + 1 groups each -- the pose head at 16 clips: 18 groups, XCDs 0-1 three, the others two: 270 against 180
+    // workgroups, the kernel as long as its two fullest XCDs (marks: loads requested at 5.1 us on average, 10.7 for the last wave).  The NG % 8
+    // groups past the last full round of 8 are now dealt out by ROW TILE over the 8 padded columns of the grid (item j = y * 8 + xcd), so every
+    // XCD gets the same share of them; the dead slots are the last rows of the grid and exit at once.  Same tiles, same arithmetic.
+    // From 16 row tiles only: with few row tiles every XCD finishes in one round of its CUs anyway, and the fixed group -> XCD map keeps a group's
+    // weight columns resident in one L2 across the steps (batch 1 with the remap: 106.9 -> 108.7 us per step; 16 clips 187.7 -> 185.6, 4 x 8 clips
+    // 202.0 -> 199.4, TILE at 4 clips 157.4 -> 153.6 -- profiles/r06_cd_ab_dev{A,B}.log).
+    {
+        const int NG8 = NG & ~7, rem = NG - NG8;
+        if (rem && ng >= NG8 && g.MT >= 16) {
+            const int j = mt_first * 8 + (ng - NG8);
+            if (j >= rem * g.MT) return;
+            mt_first = (int)((unsigned)j / (unsigned)rem);
+            ng = NG8 + (j - mt_first * rem);
         }
     }
     if (ng >= NG || mt_first >= g.MT) return;

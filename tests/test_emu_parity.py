@@ -188,7 +188,7 @@ def test_kernel_set_is_a_property_of_the_lane_not_of_the_call(tiny, emu_lib):
     m.load_state_dict(synth_state_dict(cfg, int(gt["wseed"])))
     assert m.recommend_kernel_set(1, 1) == "latency" and m.recommend_kernel_set(2, 1) == "latency"
     assert m.recommend_kernel_set(1, 4) == "latency" and m.recommend_kernel_set(2, 4) == "tile"
-    assert m.recommend_kernel_set(14, 4) == "block" and m.recommend_kernel_set(14, 1) == "tile" and m.recommend_kernel_set(44, 1) == "rows"
+    assert m.recommend_kernel_set(14, 4) == "rows" and m.recommend_kernel_set(14, 2) == "block" and m.recommend_kernel_set(14, 1) == "tile" and m.recommend_kernel_set(44, 1) == "rows"
     assert m.recommend_kernel_set(130, 1) == "rows" and m.recommend_kernel_set(130, 4) == "stream"      # (round 6: ROWS while one lane's row tiles fit the CUs in one round)
     assert m.recommend_kernel_set(62, 4) == "stream" and m.recommend_kernel_set(62, 1) == "rows"          # ... STREAM once the lanes' row tiles exceed it (tests/test_emu_round6.py has the table)
     shape = (2, cfg.njoints, 1, cfg.n_poses)

@@ -87,14 +87,15 @@ def test_rows_kernel_set_bf16w2_vs_oracle(emu_lib):
 
 
 def test_auto_kernel_set_table_round6(emu_lib):
-    """What DSG_KSET_AUTO resolves to (dsg_recommend_kernel_set; tiny dims: 23 token rows per clip): ROWS from 1000 token rows in one lane while the
-    row tiles fit the 256 CUs in one round, STREAM beyond; with several lanes ROWS from 1500 rows over all lanes and 300 per lane, STREAM once the
+    """What DSG_KSET_AUTO resolves to (dsg_recommend_kernel_set; tiny dims: 23 token rows per clip): ROWS from 800 token rows in one lane while the
+    row tiles fit the 256 CUs in one round, STREAM beyond; with several lanes ROWS from 1000 rows over all lanes and 250 per lane, STREAM once the
     lanes' row tiles exceed 300; BLOCK from 500 rows in one lane / 250 per lane below that."""
     m = DSGDenoiser(C.TINY, precision="bf16", max_batch=2, library=emu_lib)
     m.load_state_dict(synth_state_dict(C.TINY, 20240))
     r = m.recommend_kernel_set
-    assert [r(b, 1) for b in (1, 2, 3, 21, 22, 43, 44, 178, 179)] == ["latency", "latency", "tile", "tile", "block", "block", "rows", "rows", "stream"]
-    assert [r(b, 4) for b in (1, 2, 10, 11, 14, 17, 52, 53)] == ["latency", "tile", "tile", "block", "block", "rows", "rows", "stream"]
+    assert [r(b, 1) for b in (1, 2, 3, 21, 22, 34, 35, 178, 179)] == ["latency", "latency", "tile", "tile", "block", "block", "rows", "rows", "stream"]
+    assert [r(b, 4) for b in (1, 2, 10, 11, 14, 17, 52, 53)] == ["latency", "tile", "tile", "rows", "rows", "rows", "rows", "stream"]
+    assert [r(b, 2) for b in (10, 11, 21, 22)] == ["tile", "block", "block", "rows"]
     f = DSGDenoiser(C.TINY, precision="fp32", max_batch=2, library=emu_lib)
     f.load_state_dict(synth_state_dict(C.TINY, 20240))
     assert [f.recommend_kernel_set(b, 1) for b in (1, 3, 43, 44, 200)] == ["tile", "tile", "tile", "block", "block"]
@@ -111,3 +112,26 @@ def test_noise_stream_vs_oracle(emu_lib):
     emu_lib.check(emu_lib.cdll.dsg_noise(out.ctypes.data, B, J, T, C_.c_uint64(77), C_.c_uint64(5), 9, None))
     want = philox.normal_bj1t((B, J, 1, T), 77, 9, 5)
     assert np.max(np.abs(out - want)) < 2e-6
+
+
+def test_tile_gemm_xcd_balanced_mapping_from_16_row_tiles(emu_lib):
+    """Round 6: from 16 row tiles the column groups past the last full round of 8 are dealt out by row tile over the padded grid columns (gemm_body).
+    Tiny dims: every K = D GEMM has such groups (QKV 6, pose head 2) -- batch 12 (18 row tiles) on the TILE and ROWS sets against the oracle, and a
+    clip's rows are the bits they are at batch 2 (5 row tiles: the fixed map)."""
+    from oracle.mdm import MDMOracle
+    cfg = C.TINY
+    sd = synth_state_dict(cfg, 20240)
+    ref = MDMOracle(sd, cfg)
+    B = 12
+    y = synth_window_inputs(cfg, B, window=1, seed_pose_scale=0.3)
+    x = np.random.RandomState(B).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+    ts = [(37 * b + 5) % 1000 for b in range(B)]
+    for prec, kset, tol in (("bf16", "tile", 1.2e-2), ("fp32", "tile", 2e-5), ("bf16", "rows", 1.2e-2), ("bf16w2", "rows", 1e-3)):
+        m = DSGDenoiser(cfg, precision=prec, max_batch=B, library=emu_lib).set_kernel_set(kset)
+        m.load_state_dict(sd)
+        out = np.asarray(m(x, ts, y))
+        assert m.last_kernel_set() == kset and rel_l2(out, ref(x, ts, y)) < tol, (prec, kset)
+        small = DSGDenoiser(cfg, precision=prec, max_batch=2, library=emu_lib).set_kernel_set(kset)
+        small.load_state_dict(sd)
+        ys = {k: (v[7:9] if v.shape[0] == B else v) for k, v in y.items()}
+        assert np.array_equal(out[7:9], np.asarray(small(x[7:9], ts[7:9], ys))), (prec, kset)

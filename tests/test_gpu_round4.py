@@ -251,7 +251,7 @@ def test_stream_set_with_fused_ffn_vs_oracle_and_lanes(gpu):
     NL, B, K = 4, 16, 2
     m = _model(cfg, "bf16", max_batch=B)
     lanes = [m] + [m.clone() for _ in range(NL - 1)]
-    assert m.recommend_kernel_set(16, 4) == "stream" and m.recommend_kernel_set(12, 4) == "rows" and m.recommend_kernel_set(4, 4) == "block"      # (round 6: ROWS in between)
+    assert m.recommend_kernel_set(16, 4) == "stream" and m.recommend_kernel_set(12, 4) == "rows" and m.recommend_kernel_set(4, 4) == "rows" and m.recommend_kernel_set(4, 2) == "block"      # (round 6: ROWS in between, from 1000 rows over all lanes)
     assert m.recommend_kernel_set(16, 1) == "rows" and m.recommend_kernel_set(48, 1) == "stream"
     d = create_gaussian_diffusion()
     feats = [[torch.from_numpy(synth_window_inputs(cfg, B, window=w, clip0=ln * B)["audio"]).cuda() for w in range(K)] for ln in range(NL)]

@@ -80,7 +80,7 @@ def test_rows_kernel_set_on_lanes(gpu):
     cfg, NL, B, K = C.ZEGGS, 4, 8, 2
     m = _model(cfg, "bf16", max_batch=B)
     lanes = [m] + [m.clone() for _ in range(NL - 1)]
-    assert m.recommend_kernel_set(B, NL) == "rows" and m.recommend_kernel_set(4, 4) == "block" and m.recommend_kernel_set(16, 4) == "stream"
+    assert m.recommend_kernel_set(B, NL) == "rows" and m.recommend_kernel_set(4, 4) == "rows" and m.recommend_kernel_set(4, 2) == "block" and m.recommend_kernel_set(16, 4) == "stream"
     d = create_gaussian_diffusion()
     feats = [[torch.from_numpy(synth_window_inputs(cfg, B, window=w, clip0=ln * B)["audio"]).cuda() for w in range(K)] for ln in range(NL)]
     got = generate_clips_streams(lanes, d, feats, [1, 0, 0, 0, 0, 0], seed=5, skip_timesteps=960, stream_ids=[0, 1, 2, 3])
