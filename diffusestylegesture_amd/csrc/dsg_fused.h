@@ -203,21 +203,13 @@ __device__ __forceinline__ void mid_tail(const MidArgs& g, f32x4 (&acc)[DT], con
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < DT; ++t) { acc[t] = acc[t] + pbo[t] + pr[t]; s += (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]); }
-    s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
-    if (lg == 0) red[0][wave][lr] = s;
+    // (round 6: the statistics in ONE exchange -- ln_wave_moments, dsg_kernels.h -- one barrier instead of two: batch 1 107.9 -> 107.1 us per step, r06_cg_*)
+    ln_wave_moments<DT>(acc, s, red[0][wave], red[1][wave], lr, lg);
     DSG_LDS_BARRIER();
-    const float mean = ((red[0][0][lr] + red[0][1][lr]) + (red[0][2][lr] + red[0][3][lr])) / (float)D;
-    float q = 0.f;
-#pragma unroll
-    for (int t = 0; t < DT; ++t)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const float d = acc[t][e] - mean; q += d * d; }
-    q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
-    if (lg == 0) red[1][wave][lr] = q;
-    DSG_LDS_BARRIER();
-    const float var = ((red[1][0][lr] + red[1][1][lr]) + (red[1][2][lr] + red[1][3][lr])) / (float)D;
+    float mean, var;
+    ln_combine_moments<4, D>(red[0], red[1], lr, mean, var);
     const float rstd = 1.0f / sqrtf(var + 1e-5f);
-    DSG_TL_MARK(7);      // mid_tail: residual + LayerNorm1 statistics (two barriers)
+    DSG_TL_MARK(7);      // mid_tail: residual + LayerNorm1 statistics (one barrier)
     const bool wr = ng == 0 && (m0 + lr) < g.M;
 #pragma unroll
     for (int t = 0; t < DT; ++t) {
@@ -1375,7 +1367,9 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
             load1(0, 0);                                      // (W_o and the attention rows are dead: the first W1 tiles arrive behind LayerNorm1)
         }
         DSG_LOADS_ISSUED();
-        DSG_LDS_BARRIER();                                    // vecs1 is in place
+        // (vecs1 was written before share_a's barrier: it is in place.  Round 6: LayerNorm1 / LayerNorm2 statistics in ONE exchange -- ln_wave_moments --
+        //  and no barrier of its own for vecs1: two barriers less per LayerNorm1, one per LayerNorm2: 1 x 16 clips 186.2 -> 184.4 us per step,
+        //  1 x 64: 252.9 -> 249.5, profiles/r06_cf_ab_dev{A,B}.log)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             float sm = 0.f;
@@ -1385,8 +1379,7 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
                 acc1[rt][t] = acc1[rt][t] + pb + pr[rt][t];
                 sm += (acc1[rt][t][0] + acc1[rt][t][1]) + (acc1[rt][t][2] + acc1[rt][t][3]);
             }
-            sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
-            if (lg == 0) red[rt][0][wave][lr] = sm;
+            ln_wave_moments<DW>(acc1[rt], sm, red[rt][0][wave], red[rt][1][wave], lr, lg);
         }
         if constexpr (RING > 0) {
 #pragma unroll
@@ -1395,32 +1388,17 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
         }
         DSG_LDS_BARRIER();
         float mean1[RT];
+        float var1[RT];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            float tot = 0.f;
-#pragma unroll
-            for (int w2_ = 0; w2_ < NW; ++w2_) tot += red[rt][0][w2_][lr];
-            mean1[rt] = tot / (float)D;
-            float qv = 0.f;
-#pragma unroll
-            for (int t = 0; t < DW; ++t)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { const float d = acc1[rt][t][e] - mean1[rt]; qv = __builtin_fmaf(d, d, qv); }
-            qv += __shfl_xor(qv, 16); qv += __shfl_xor(qv, 32);
-            if (lg == 0) red[rt][1][wave][lr] = qv;
-        }
+        for (int rt = 0; rt < RT; ++rt) ln_combine_moments<NW, D>(red[rt][0], red[rt][1], lr, mean1[rt], var1[rt]);
         if constexpr (RING > 0) {
 #pragma unroll
             for (int i = RING / 2; i < 3 * (RING / 4); ++i) ring[i] = ring_load(i);
             DSG_LOADS_ISSUED();
         }
-        DSG_LDS_BARRIER();
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-            float tot = 0.f;
-#pragma unroll
-            for (int w2_ = 0; w2_ < NW; ++w2_) tot += red[rt][1][w2_][lr];
-            const float rstd = 1.0f / sqrtf(tot / (float)D + 1e-5f);
+            const float rstd = 1.0f / sqrtf(var1[rt] + 1e-5f);
 #pragma unroll
             for (int t = 0; t < DW; ++t) {
                 const int n = (wave * DW + t) * 16 + 4 * lg;
@@ -1597,32 +1575,16 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
             acc[rt][t] = acc[rt][t] + pb + pr[rt][t];
             sm += (acc[rt][t][0] + acc[rt][t][1]) + (acc[rt][t][2] + acc[rt][t][3]);
         }
-        sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
-        if (lg == 0) red[rt][0][wave][lr] = sm;
+        ln_wave_moments<DW>(acc[rt], sm, red[rt][0][wave], red[rt][1][wave], lr, lg);
     }
     DSG_LDS_BARRIER();
     float mean[RT];
+    float var2[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) ln_combine_moments<NW, D>(red[rt][0], red[rt][1], lr, mean[rt], var2[rt]);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-        float tot = 0.f;
-#pragma unroll
-        for (int w2_ = 0; w2_ < NW; ++w2_) tot += red[rt][0][w2_][lr];
-        mean[rt] = tot / (float)D;
-        float qv = 0.f;
-#pragma unroll
-        for (int t = 0; t < DW; ++t)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = acc[rt][t][e] - mean[rt]; qv = __builtin_fmaf(d, d, qv); }
-        qv += __shfl_xor(qv, 16); qv += __shfl_xor(qv, 32);
-        if (lg == 0) red[rt][1][wave][lr] = qv;
-    }
-    DSG_LDS_BARRIER();
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        float tot = 0.f;
-#pragma unroll
-        for (int w2_ = 0; w2_ < NW; ++w2_) tot += red[rt][1][w2_][lr];
-        const float rstd = 1.0f / sqrtf(tot / (float)D + 1e-5f);
+        const float rstd = 1.0f / sqrtf(var2[rt] + 1e-5f);
         if (rowok_of(rt)) {
 #pragma unroll
             for (int t = 0; t < DW; ++t) {

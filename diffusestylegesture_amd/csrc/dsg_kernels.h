@@ -76,6 +76,44 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// LayerNorm statistics of rows spread over the 4 lane groups x NW waves of a workgroup in ONE exchange (round 6): every (wave, lane) forms the sum and
+// the centred second moment of its own 4 DW values, the lane groups of a wave merge theirs with two shuffle steps and the waves theirs through LDS --
+// M2(a + b) = M2(a) + M2(b) + (mean_a - mean_b)^2 n_a n_b / (n_a + n_b) (Chan et al.), which is as stable as the two-pass form it replaces and needs no
+// second round trip through LDS for the mean.  Every lane of a row evaluates the same expressions in the same order: identical statistics.
+template <int DW>
+__device__ __forceinline__ void ln_wave_moments(const f32x4 (&v)[DW], float s, float* red_s, float* red_m2, int lr, int lg) {
+    constexpr float n0 = 4.0f * DW;
+    const float c = s / n0;
+    float m2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < DW; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[t][e] - c; m2 = __builtin_fmaf(d, d, m2); }
+    {
+        const float so = __shfl_xor(s, 16), mo = __shfl_xor(m2, 16);
+        const float d = (s - so) / n0;
+        m2 = __builtin_fmaf(d * d, 0.5f * n0, m2 + mo); s += so;
+    }
+    {
+        const float so = __shfl_xor(s, 32), mo = __shfl_xor(m2, 32);
+        const float d = (s - so) / (2.0f * n0);
+        m2 = __builtin_fmaf(d * d, n0, m2 + mo); s += so;
+    }
+    if (lg == 0) { red_s[lr] = s; red_m2[lr] = m2; }
+}
+template <int NW, int D>
+__device__ __forceinline__ void ln_combine_moments(const float (&red_s)[NW][16], const float (&red_m2)[NW][16], int lr, float& mean, float& var) {
+    constexpr float nw = (float)(D / NW);
+    float sw[NW], tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { sw[w] = red_s[w][lr]; tot += sw[w]; }
+    mean = tot / (float)D;
+    float m2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { const float d = sw[w] / nw - mean; m2 += __builtin_fmaf(d * d, nw, red_m2[w][lr]); }
+    var = m2 / (float)D;
+}
+
 struct PF32 {                       // fp32 storage, v_mfma_f32_16x16x4_f32
     typedef float elem;
     static constexpr int E = 4;     // elements per 16-byte fragment
