@@ -162,7 +162,7 @@ __device__ __forceinline__ void inloc_body(const InLocArgs& g) {
         }
     }
     DSG_LDS_BARRIER();
-    local_attn_tail<P, HD, W>(a, rot, sc, b, w, h, keep, c2, s2);
+    local_attn_tail_valu<P, HD, W>(a, rot, sc, b, w, h, keep, c2, s2);
 }
 template <class P, int HD, int W>
 __global__ __launch_bounds__(256) void k_inloc(const InLocArgs g) { DSG_TL_SCOPE(); inloc_body<P, HD, W>(g); }

@@ -179,6 +179,7 @@ struct dsg_handle {
     double aql_ms = 0.0;
     // A/B switches of the batched sets, read ONCE at dsg_create (round-4 advisor: they used to be getenv calls in select_kernels /
     // run_step, i.e. in the hot path and outside the hipGraph key): -1 = not set
+    int env_loc64_from = 2048;           // DSG_LOC64_FROM=<workgroups>: k_loc as two waves per (head, window, clip) from that many of them (test hook / A/B)
     int env_ffn_rt4 = -1;                // DSG_FFN_RT4=<rows>: k_ffn on 64-row blocks from that many token rows at any lane count (0: never)
     int env_ffn_split = -1;              // DSG_FFN_SPLIT=0: linear1 + linear2 + LayerNorm-on-read instead of k_ffn_part + k_ffn_ln (BLOCK)
     int env_clip_attn = -1;              // DSG_CLIP_ATTN=0: QKV GEMM + k_attn_op instead of k_clip_attn + k_ffn_ln (BLOCK; differs in the last bits)
@@ -515,6 +516,7 @@ extern "C" int dsg_create(const dsg_config* c, dsg_handle** out) {
         }
     }
     if (const char* e = getenv("DSG_FFN_RT4")) h->env_ffn_rt4 = std::max(atoi(e), 0);
+    if (const char* e = getenv("DSG_LOC64_FROM")) h->env_loc64_from = std::max(atoi(e), 1);
     if (const char* e = getenv("DSG_FFN_SPLIT")) h->env_ffn_split = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("DSG_CLIP_ATTN")) h->env_clip_attn = atoi(e) != 0 ? 1 : 0;
     *out = h;
@@ -1369,6 +1371,19 @@ static int launch_attn(dsg_handle* h, const AttnArgs& a) {
                                                     std::to_string(h->hdl) + ", " + std::to_string(h->W) + ")");     \
     } while (0)
 
+// k_loc with TWO waves per (head, window, clip) instead of four (round 6): see the call site
+#define DSG_LOC1_DISPATCH(ARGS, GRID)                                                                                \
+    do {                                                                                                             \
+        const int key_ = h->hdl * 100 + h->W;                                                                        \
+        if (key_ == 32 * 100 + 11) CHK((step_launch<&k_loc<P, 32, 11, 128>>(h, GRID, dim3(128), ARGS)));               \
+        else if (key_ == 48 * 100 + 15) CHK((step_launch<&k_loc<P, 48, 15, 128>>(h, GRID, dim3(128), ARGS)));          \
+        else if (key_ == 64 * 100 + 15) CHK((step_launch<&k_loc<P, 64, 15, 128>>(h, GRID, dim3(128), ARGS)));          \
+        else if (key_ == 16 * 100 + 11) CHK((step_launch<&k_loc<P, 16, 11, 128>>(h, GRID, dim3(128), ARGS)));          \
+        else if (key_ == 8 * 100 + 15) CHK((step_launch<&k_loc<P, 8, 15, 128>>(h, GRID, dim3(128), ARGS)));            \
+        else return fail(DSG_E_NOT_IMPLEMENTED, "no local-attention instantiation for (head dim, window) = (" +      \
+                                                    std::to_string(h->hdl) + ", " + std::to_string(h->W) + ")");     \
+    } while (0)
+
 template <class P>
 static int launch_mid(dsg_handle* h, const MidArgs& a) {
     const dim3 grid(xcd_grid_x(a.ff / 64), a.MT);
@@ -1450,7 +1465,13 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
             }
             if (!done) CHK((launch_gemm<P, PRO_DIRECT, EPI_PARTIAL, 4, 1>(h, g)));
         }
-        DSG_LOC_DISPATCH(k_loc, la, dim3(h->Hl, T / h->W, B));
+        // Round 6: from 2048 (head, window, clip) items TWO waves each instead of a 256-thread workgroup: the kernel is one ~5 us chain of dependent
+        // phases per item, and 4096 workgroups of 4 waves (64 clips) need two rounds of the CUs' 8 workgroup slots where 4096 x 2 waves are all
+        // resident at once (32 per CU) -- 1 x 64 clips 249.1 -> 245.0 us per step (one wave each: 246.4), 4 x 64: 705 -> 692-702 (29.2-29.6 k frames/s);
+        // k_loc itself 13.3 -> 10.0 us at 5696 rows with one wave; below 2048 items the 4-wave form is ahead (16 clips: 184.1 vs 186.0).  Same arithmetic
+        // (the matrix-instruction tail is one wave's work in every form): bit-identical.  profiles/r06_cj_*, r06_cl_*
+        if (h->Hl * (T / h->W) * B >= h->env_loc64_from) DSG_LOC1_DISPATCH(la, dim3(h->Hl, T / h->W, B));
+        else DSG_LOC_DISPATCH(k_loc, la, dim3(h->Hl, T / h->W, B));
     }
     for (int l = 0; l < h->L; ++l) {
         const Layer& ly = h->layers[l];

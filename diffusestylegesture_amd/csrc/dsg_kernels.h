@@ -1120,11 +1120,11 @@ struct LocArgs {
     int x0a_frag;           // ... stored fragment-major (qk_off over [rows][D]): the STREAM set streams it into the layer-0 QKV; 2 (bf16w2, ROWS): as a hi + lo pair
 };
 
-// Shared tail of k_loc / k_inloc.  `rot` holds the rotary-embedded [2W][HD] tile (pad rows = -1).  Phase A: one thread
+// Tail of k_inloc (LATENCY set: one workgroup per CU, all four SIMDs on the tile).  `rot` holds the rotary-embedded [2W][HD] tile (pad rows = -1).  Phase A: one thread
 // per (query, key) pair forms the masked score, the 32 lanes of a query row reduce max / sum with shuffles; phase B:
 // one thread per (query, dim pair) forms the attention output and applies the second rotary (position + 1).
 template <class P, int HD, int W>
-__device__ __forceinline__ void local_attn_tail(const LocArgs& a, float (&rot)[2 * W][HD + 4], float (&sc)[W][2 * W + 2],
+__device__ __forceinline__ void local_attn_tail_valu(const LocArgs& a, float (&rot)[2 * W][HD + 4], float (&sc)[W][2 * W + 2],
                                                 int b, int w, int h, const bool (&keep)[(W * 32 + 255) / 256],
                                                 const float (&c2)[(W * (HD / 2) + 255) / 256],
                                                 const float (&s2)[(W * (HD / 2) + 255) / 256]) {
@@ -1210,11 +1210,125 @@ __device__ __forceinline__ void local_attn_tail(const LocArgs& a, float (&rot)[2
     }
 }
 
-template <class P, int HD, int W>
+// Tail of k_loc (every other set).  Round 6: the scores and the P V product of the (head, window) tile on fp32 MATRIX instructions (v_mfma_f32_16x16x4_f32),
+// by ONE wave of the workgroup -- which is what lets the kernel run as one wave per item at large batches (dsg_hip.cpp: DSG_LOC1_DISPATCH); k_inloc keeps the
+// VALU form above: alone on its CU at batch 1, four SIMDs on the tile beat 32 fp32 MFMAs on one (106.1 vs 106.8 us per step, profiles/r06_cm_*).
+// The VALU form read the rotary tile out of LDS once per (query, key) pair and per (query, dim pair) -- ~108 KB of LDS reads per workgroup against a 3 KB
+// tile: phase A alone was 1.8 of the kernel's 5.4 us at 16 clips and the kernel 13.3 us at 64 (4096 workgroups, two rounds of 8 per CU).  Here a lane reads
+// one float per operand and MFMA: S^T[key][query] = K . Q^T over the head dim (A = key rows, B = query rows of the tile), softmax as in k_attn (a lane owns a
+// query column: 8 keys in registers, two shuffle steps), O^T[dim][query] = V^T . P^T with the P values a lane already holds as its B operand (the k-slot of
+// step s is key 4 lg + s: V^T is gathered in that order), raw O rows -> LDS, then the (query, dim pair) threads apply the second rotary in place.  The worker
+// wave rotates with the block index (the workgroups of a CU do not all put it on the same SIMD).  Same masks, same pad / causal semantics; fp32 throughout.
+template <class P, int HD, int W, int NT = 256>
+__device__ __forceinline__ void local_attn_tail(const LocArgs& a, float (&rot)[2 * W][HD + 4], float (&sc)[W][2 * W + 2],
+                                                int b, int w, int h, const bool (&keyok)[2][4],
+                                                const float (&c2)[(W * (HD / 2) + NT - 1) / NT],
+                                                const float (&s2)[(W * (HD / 2) + NT - 1) / NT]) {
+    typedef typename P::elem elem;
+    constexpr int W2 = 2 * W, half = HD / 2, NP2 = W * half, NPO = (NP2 + NT - 1) / NT;
+    constexpr int NKT = 2, ND = (HD + 15) / 16, KS = HD / 4;
+    static_assert(W2 <= 32 && W <= 16 && HD % 4 == 0, "one query tile, two key tiles");
+    (void)sc;
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lg = lane >> 4;
+    const int f0 = (w - 1) * W;
+    const float scale = 1.0f / sqrtf((float)HD);
+    __shared__ __attribute__((aligned(16))) float ot[W][HD + 4];
+    if (NT == 64 || wave_id() == ((b + w + h) & (NT / 64 - 1))) {      // (NT = 64: the workgroup IS one wave)
+        const float* qrow = &rot[W + min(lr, W - 1)][0];
+        f32x4 s[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            const float* krow = &rot[min(16 * kt + lr, W2 - 1)][0];
+            s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(krow[4 * ks + lg], qrow[4 * ks + lg], s[kt], 0, 0, 0);   // D[key 4lg+r][query lr]
+        }
+        const int fq = w * W + lr;
+        float mx = -DSG_FLT_MAX;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int fk = f0 + 16 * kt + 4 * lg + r;
+                const bool masked = ((fk >= 0) && (fq < fk)) || !keyok[kt][r];   // causal | key mask (pads are masked keys)
+                const float v = masked ? -DSG_FLT_MAX : s[kt][r] * scale;
+                s[kt][r] = v;
+                mx = fmaxf(mx, (16 * kt + 4 * lg + r) < W2 ? v : -DSG_FLT_MAX);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = (16 * kt + 4 * lg + r) < W2 ? expf(s[kt][r] - mx) : 0.f;
+                s[kt][r] = pv;
+                sum += pv;
+            }
+        sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        DSG_TL_MARK(2);          // local attention: scores + softmax
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) {
+            f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int dim = min(16 * dt + lr, HD - 1);
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(rot[min(16 * kt + 4 * lg + st, W2 - 1)][dim], s[kt][st], o, 0, 0, 0);   // D[dim 4lg+r][query lr]
+            if (lr < W && 16 * dt + 4 * lg < HD) {
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = o[e] * inv;
+                *(f32x4*)&ot[lr][16 * dt + 4 * lg] = y;
+            }
+        }
+    }
+    DSG_LDS_BARRIER();
+    const int ntok = a.T + 1, col0 = h * HD;
+    // second rotary (position + 1) in place: thread (query, dim pair) owns both elements it touches
+#pragma unroll
+    for (int i = 0; i < NPO; ++i) {
+        const int p = tid + NT * i;
+        if (p < NP2) {
+            const int q = p / half, dd = p % half;
+            const float lo = ot[q][dd], hi = ot[q][dd + half];
+            ot[q][dd] = lo * c2[i] - hi * s2[i]; ot[q][dd + half] = hi * c2[i] + lo * s2[i];
+        }
+    }
+    DSG_LDS_BARRIER();
+    DSG_TL_MARK(3);          // P V + second rotary -> staged tile
+    constexpr int C4 = HD / 4, CE = HD / P::E;       // 16-byte chunks per row: fp32 rows / rows in the GEMM type
+    for (int p = tid; p < W * C4; p += NT) {
+        const int q = p / C4, c = p - q * C4;
+        *(f32x4*)(a.X0 + (imul24(b * ntok + 1 + w * W + q, a.D) + (unsigned)(col0 + 4 * c))) = *(const f32x4*)&ot[q][4 * c];
+    }
+    for (int p = tid; p < W * CE; p += NT) {
+        const int q = p / CE, c = p - q * CE, row = b * ntok + 1 + w * W + q;
+        elem* dst = (elem*)a.X0a + (a.x0a_frag ? (unsigned)qk_off<P>(row, col0 + P::E * c, a.D / P::KB) : imul24(row, a.D) + (unsigned)(col0 + P::E * c));
+        if constexpr (P::E == 4) {
+            *(f32x4*)dst = *(const f32x4*)&ot[q][4 * c];
+        } else {
+            if constexpr (P::W2) {
+                if (a.x0a_frag == 2) {       // bf16w2 in the ROWS set: hi + lo images, like every other A operand k_clip_attn reads
+                    const size_t off = (size_t)qk_off<P>(row, col0 + P::E * c, a.D / P::KB);
+                    P::store4_afrag((elem*)a.X0a, off, *(const f32x4*)&ot[q][8 * c]);
+                    P::store4_afrag((elem*)a.X0a, off + 4, *(const f32x4*)&ot[q][8 * c + 4]);
+                    continue;
+                }
+            }
+            P::store4(dst, *(const f32x4*)&ot[q][8 * c]);
+            P::store4(dst + 4, *(const f32x4*)&ot[q][8 * c + 4]);
+        }
+    }
+}
+
+template <class P, int HD, int W, int NT = 256>
 __device__ __forceinline__ void loc_body(const LocArgs& a, int h, int w, int b) {
     typedef typename P::elem elem;
-    constexpr int W2 = 2 * W, half = HD / 2, NP1 = W2 * half, NPI = (NP1 + 255) / 256;
-    constexpr int NSI = (W * 32 + 255) / 256, NP2 = W * half, NPO = (NP2 + 255) / 256, MAXKS = 9;
+    constexpr int W2 = 2 * W, half = HD / 2, NP1 = W2 * half, NPI = (NP1 + NT - 1) / NT;
+    constexpr int NP2 = W * half, NPO = (NP2 + NT - 1) / NT, MAXKS = 9;
     __shared__ __attribute__((aligned(16))) float rot[W2][HD + 4];
     __shared__ float sc[W][W2 + 2];
     const int tid = threadIdx.x;
@@ -1226,7 +1340,7 @@ __device__ __forceinline__ void loc_body(const LocArgs& a, int h, int w, int b) 
     float lo[NPI], hi[NPI], c1[NPI], s1[NPI];
 #pragma unroll
     for (int i = 0; i < NPI; ++i) {
-        const int p = min(tid + 256 * i, NP1 - 1);
+        const int p = min(tid + NT * i, NP1 - 1);
         const int r = p / half, dd = p % half, f = max(f0 + r, 0);
         const unsigned base = imul24(b * a.T + f, a.D) + (unsigned)(col0 + dd);      // (32-bit element offsets: imul24)
         lo[i] = a.Cf[base];
@@ -1247,25 +1361,27 @@ __device__ __forceinline__ void loc_body(const LocArgs& a, int h, int w, int b) 
     float c2[NPO], s2[NPO];
 #pragma unroll
     for (int i = 0; i < NPO; ++i) {
-        const int p = min(tid + 256 * i, NP2 - 1);
+        const int p = min(tid + NT * i, NP2 - 1);
         const int pos = w * W + p / half + 1;
         c2[i] = a.rcos[pos * half + p % half]; s2[i] = a.rsin[pos * half + p % half];
     }
     const int mrow = fdiv(b * a.Hl + h, a.inv_mask_div);
-    bool keep[NSI];
+    bool keyok[2][4];                                    // the 8 keys of this lane in the S^T layout of local_attn_tail: key j = 16 kt + 4 lg + r
 #pragma unroll
-    for (int i = 0; i < NSI; ++i) {
-        const int idx = tid + 256 * i, q = idx >> 5, j = idx & 31, fk = f0 + j;
-        const unsigned char mk = a.mask[(unsigned)(mrow * a.T + min(max(fk, 0), a.T - 1))];
-        keep[i] = ((int)(q < W) & (int)(j < W2) & ((int)(a.nomask != 0) | ((int)(fk >= 0) & (int)(mk != 0)))) != 0;   // bitwise: keeps the load unconditional
-    }
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 16 * kt + 4 * ((tid & 63) >> 4) + r, fk = f0 + j;
+            const unsigned char mk = a.mask[(unsigned)(mrow * a.T + min(max(fk, 0), a.T - 1))];
+            keyok[kt][r] = ((int)(j < W2) & ((int)(a.nomask != 0) | ((int)(fk >= 0) & (int)(mk != 0)))) != 0;   // bitwise: keeps the load unconditional
+        }
     const int tc = min(tid, HD - 1);
     float tokv = a.emb1[(unsigned)(b * a.D + col0 + tc)];
     // the loads that depend on the model timestep go out last (t itself was requested first)
     const float* te2 = a.TE2 + (size_t)t * a.D + col0;        // (t is wave-uniform: scalar arithmetic)
 #pragma unroll
     for (int i = 0; i < NPI; ++i) {
-        const int p = min(tid + 256 * i, NP1 - 1), dd = p % half;
+        const int p = min(tid + NT * i, NP1 - 1), dd = p % half;
         lo[i] += te2[dd];
         hi[i] += te2[dd + half];
     }
@@ -1279,7 +1395,7 @@ __device__ __forceinline__ void loc_body(const LocArgs& a, int h, int w, int b) 
     }
 #pragma unroll
     for (int i = 0; i < NPI; ++i) {
-        const int p = tid + 256 * i;
+        const int p = tid + NT * i;
         if (p < NP1) {
             const int r = p / half, dd = p % half, f = f0 + r;
             // rotary (rotary.py:20-27); rows before the sequence start are look_around's pad_value -1
@@ -1289,14 +1405,14 @@ __device__ __forceinline__ void loc_body(const LocArgs& a, int h, int w, int b) 
     }
     DSG_LDS_BARRIER();
     DSG_TL_MARK(1);          // rotary rows in LDS (the loads have landed)
-    local_attn_tail<P, HD, W>(a, rot, sc, b, w, h, keep, c2, s2);
+    local_attn_tail<P, HD, W, NT>(a, rot, sc, b, w, h, keyok, c2, s2);
 }
 
-template <class P, int HD, int W>
-__global__ __launch_bounds__(256) void k_loc(const LocArgs a) {
+template <class P, int HD, int W, int NT = 256>      // NT = 128 (round 6): two waves per (head, window, clip) at large batches -- see dsg_hip.cpp: DSG_LOC1_DISPATCH
+__global__ __launch_bounds__(NT) void k_loc(const LocArgs a) {
     DSG_TL_SCOPE();
     preload_kernargs(a);
-    loc_body<P, HD, W>(a, blockIdx.x, blockIdx.y, blockIdx.z);          // grid (local heads, windows, batch)
+    loc_body<P, HD, W, NT>(a, blockIdx.x, blockIdx.y, blockIdx.z);          // grid (local heads, windows, batch)
 }
 
 // ---------------------------------------------------------------------------------------------------------

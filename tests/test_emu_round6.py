@@ -135,3 +135,32 @@ def test_tile_gemm_xcd_balanced_mapping_from_16_row_tiles(emu_lib):
         small.load_state_dict(sd)
         ys = {k: (v[7:9] if v.shape[0] == B else v) for k, v in y.items()}
         assert np.array_equal(out[7:9], np.asarray(small(x[7:9], ts[7:9], ys))), (prec, kset)
+
+
+def test_local_attention_one_wave_form_is_bit_identical(emu_lib, monkeypatch):
+    """Round 6: k_loc's scores / P V on fp32 matrix instructions by one wave; from 2048 (head, window, clip) items the kernel runs as ONE wave per item
+    (DSG_LOC64_FROM is the test hook for the threshold; two waves per item in the shipped form).  Both forms against the oracle (incl. a key mask and mask_local=None), bit-identical to each other."""
+    from oracle.mdm import MDMOracle
+    cfg = C.TINY
+    sd = synth_state_dict(cfg, 20240)
+    ref = MDMOracle(sd, cfg)
+    B = 3
+    y = synth_window_inputs(cfg, B, window=1, seed_pose_scale=0.3)
+    ym = dict(y)
+    mask = np.ones_like(np.asarray(y["mask_local"]))
+    mask[..., 3:6] = 0
+    ym["mask_local"] = mask.astype(np.asarray(y["mask_local"]).dtype)
+    yn = dict(y)
+    yn["mask_local"] = None
+    x = np.random.RandomState(5).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+    ts = [10, 500, 999]
+    for prec, tol in (("fp32", 2e-5), ("bf16", 1.2e-2)):
+        outs = {}
+        for frm in ("1", "1000000"):
+            monkeypatch.setenv("DSG_LOC64_FROM", frm)
+            m = DSGDenoiser(cfg, precision=prec, max_batch=B, library=emu_lib).set_kernel_set("tile")
+            m.load_state_dict(sd)
+            outs[frm] = [np.asarray(m(x, ts, yy)) for yy in (y, ym, yn)]
+            for o, yy in zip(outs[frm], (y, ym, yn)):
+                assert rel_l2(o, ref(x, ts, yy)) < tol, (prec, frm)
+        assert all(np.array_equal(p, q) for p, q in zip(outs["1"], outs["1000000"])), prec

@@ -178,3 +178,31 @@ def test_rows_kernel_set_bf16w2_vs_oracle(gpu):
             w = sampler.ddim_sample_loop(OracleDiffusion(timestep_respacing="ddim50"), ref, (1,) + shape[1:],
                                          lambda k: sampler.philox.normal_bj1t(shape, 14, k, 2)[b:b + 1], {"y": yb})
             assert m.last_kernel_set() == "rows" and rel_l2(got[b:b + 1], w) < 1.5e-3
+
+
+def test_local_attention_one_wave_form_is_bit_identical(gpu, monkeypatch):
+    """Round 6: k_loc as ONE wave per (head, window, clip) (what 32+ clips per lane run: 2048 items; DSG_LOC64_FROM is the threshold's test hook) against
+    the 256-thread form at the ZEGGS and BEAT dims: the same bits, both within tolerance of the oracle -- with a key mask and with mask_local=None."""
+    from oracle.mdm import MDMOracle
+    for cfg in (C.ZEGGS, C.CONFIGS["beat"]):
+        sd = synth_state_dict(cfg, 20240)
+        ref = MDMOracle(sd, cfg)
+        B = 3
+        y = synth_window_inputs(cfg, B, window=1, seed_pose_scale=0.2)
+        ym = dict(y)
+        mask = np.ones_like(np.asarray(y["mask_local"]))
+        mask[..., 5:9] = 0
+        ym["mask_local"] = mask.astype(np.asarray(y["mask_local"]).dtype)
+        yn = dict(y)
+        yn["mask_local"] = None
+        x = np.random.RandomState(5).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+        ts = [10, 500, 999]
+        for prec in ("fp32", "bf16"):
+            outs = {}
+            for frm in ("1", "1000000"):
+                monkeypatch.setenv("DSG_LOC64_FROM", frm)
+                m = _model(cfg, prec, max_batch=B).set_kernel_set("tile")
+                outs[frm] = [np.asarray(m(x, ts, yy)) for yy in (y, ym, yn)]
+                for o, yy in zip(outs[frm], (y, ym, yn)):
+                    assert rel_l2(o, ref(x, ts, yy)) < TOL_FWD[prec], (cfg.name, prec, frm)
+            assert all(np.array_equal(p, q) for p, q in zip(outs["1"], outs["1000000"])), (cfg.name, prec)
