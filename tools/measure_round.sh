@@ -4,6 +4,7 @@
 TAG=${1:-r05_z}; WITH_TESTS=${2:-}
 O=gpurun_out; mkdir -p $O
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+python -c 'import __graft_entry__ as g; g.smoke()' > $O/${TAG}_smoke.log 2>&1; tail -3 $O/${TAG}_smoke.log
 if [ -n "$WITH_TESTS" ]; then
   timeout 900 python -m pytest tests -m gpu -q -s -p no:cacheprovider --durations=8 > $O/${TAG}_pytest_gpu.log 2>&1
   tail -12 $O/${TAG}_pytest_gpu.log
@@ -27,22 +28,28 @@ $B --config beat --precision bf16w2 --steps 1 --warmup 0 > $O/${TAG}_bench_beat_
 $B --config beat --clips-per-gpu 16 --steps 1 --warmup 1 > $O/${TAG}_bench_beat_16clips_l4_b4.log 2>&1
 $B --config twh --clips-per-gpu 16 --steps 1 --warmup 1 > $O/${TAG}_bench_twh_16clips_l4_b4.log 2>&1
 $B --sub-records off --precision bf16w2 --steps 2 --warmup 1 > $O/${TAG}_bench_bf16w2.log 2>&1
+$B --sub-records off --precision bf16w2 --clips-per-gpu 16 --lanes 1 --steps 1 --warmup 1 > $O/${TAG}_bench_bf16w2_16clips_lockstep.log 2>&1
+$B --sub-records off --precision bf16w2 --clips-per-gpu 16 --steps 1 --warmup 1 > $O/${TAG}_bench_bf16w2_16clips_l4_b4.log 2>&1
 $B --sub-records off --precision fp32 --steps 1 --warmup 1 > $O/${TAG}_bench_fp32.log 2>&1
 $B --precision fp32 --clips-per-gpu 16 --steps 1 --warmup 1 > $O/${TAG}_bench_fp32_16clips_l4_b4.log 2>&1
 timeout 600 python tools/e2e.py --reps 3 > $O/${TAG}_e2e_wav_to_bvh.log 2>&1
 python tools/aql_timeline.py --config beat --steps 300 --first 100 --n 16 --out $O/${TAG}_aql_step_timeline_beat.json > /dev/null 2>&1
 python tools/aql_timeline.py --config twh --steps 300 --first 100 --n 16 --out $O/${TAG}_aql_step_timeline_twh.json > /dev/null 2>&1
 # kernel sets side by side (one process, same inputs)
-timeout 900 python tools/sweep.py --steps 150 --reps 3 --spec latency:1x1,tile:1x1,latency:4x1,latency:1x2,tile:1x2,tile:4x2,latency:4x2,tile:1x4,block:1x4,block:4x4,tile:4x4,block:1x16,tile:1x16,stream:1x16,block:4x8,stream:4x8,block:4x10,stream:4x10,block:4x12,stream:4x12,block:1x20,stream:1x20,block:1x24,stream:1x24,block:4x16,stream:4x16,block:1x32,stream:1x32,block:4x32,stream:4x32,block:1x64,stream:1x64 2>&1 | grep -v amdgpu.ids > $O/${TAG}_sweep_kernel_sets.log
+timeout 900 python tools/sweep.py --steps 150 --reps 3 --spec latency:1x1,tile:1x1,latency:4x1,latency:1x2,tile:1x2,tile:4x2,tile:1x4,block:1x4,block:1x8,rows:1x8,rows:4x4,block:4x4,rows:1x16,block:1x16,tile:1x16,rows:4x8,stream:4x8,rows:4x12,stream:4x12,rows:1x24,stream:1x24,rows:1x46,stream:1x48,stream:4x16,stream:1x32,rows:1x32,stream:4x32,stream:1x64,stream:4x64 2>&1 | grep -v amdgpu.ids > $O/${TAG}_sweep_kernel_sets.log
 # the timed path's own timeline (in-kernel stamps; command-processor timestamps)
 python tools/aql_timeline.py --out $O/${TAG}_aql_step_timeline.json > $O/${TAG}_aql_step_timeline.log 2>&1
 python tools/aql_timeline.py --batch 16 --n 16 --out $O/${TAG}_aql_step_timeline_b16.json > /dev/null 2>&1
+python tools/aql_timeline.py --batch 16 --precision bf16w2 --n 16 --out $O/${TAG}_aql_step_timeline_b16_bf16w2.json > /dev/null 2>&1
 python tools/aql_timeline.py --lib product --out $O/${TAG}_aql_step_timeline_cp_timestamps.json > /dev/null 2>&1
 python tools/aql_timeline.py --batch 64 --kset stream --steps 120 --first 40 --n 16 --out $O/${TAG}_aql_step_timeline_b64_stream.json > /dev/null 2>&1
+# PMC traffic of the batched sets the sub-records of bench.py cite (round 6)
+bash tools/measure_traffic.sh $TAG 16 rows > $O/${TAG}_traffic_b16.txt 2>&1
+bash tools/measure_traffic.sh $TAG 4 rows > $O/${TAG}_traffic_b4.txt 2>&1
+bash tools/measure_traffic.sh $TAG 64 stream 20 > $O/${TAG}_traffic_b64.txt 2>&1
 # rocprofv3 (HIP-launch path): kernel stats at batch 1 / 16 / 64, PMC traffic (separate passes), MFMA / SQ counters
 bash tools/prof.sh ${TAG}_b1 latency:1x1:hip 100 > $O/${TAG}_prof_b1.txt 2>&1
-bash tools/prof.sh ${TAG}_b16 block:1x16:hip 50 > $O/${TAG}_prof_b16.txt 2>&1
-bash tools/prof.sh ${TAG}_b64_block block:1x64:hip 30 > $O/${TAG}_prof_b64_block.txt 2>&1
+bash tools/prof.sh ${TAG}_b16 rows:1x16:hip 50 > $O/${TAG}_prof_b16.txt 2>&1
 bash tools/prof.sh ${TAG}_b64_stream stream:1x64:hip 30 > $O/${TAG}_prof_b64_stream.txt 2>&1
 rm -rf $O/pmc_f_$TAG $O/pmc_w_$TAG
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f_$TAG -o z -- python tools/step_timing.py --steps 100 --reps 1 --spg=-1 > $O/${TAG}_pmc_f.log 2>&1
