@@ -1190,7 +1190,7 @@ struct FfnArgs {
     float* X1;              // OP on 64-row blocks (no LDS left to park them): the fp32 LayerNorm1 rows, written by the prologue and read back after phase 1
 };
 
-template <class P, int DT, int FT, int RT, int NW, int LA = 2, bool LATE_R = false, bool OP = false, int RING = 0>      // D = 64 DT, ff = 64 FT, RT row tiles per workgroup, NW waves, LA tiles / 2 LA k-blocks of look-ahead
+template <class P, int DT, int FT, int RT, int NW, int LA = 2, bool LATE_R = false, bool OP = false, int RING = 0, bool WO_RING = false>      // D = 64 DT, ff = 64 FT, RT row tiles per workgroup, NW waves, LA tiles / 2 LA k-blocks of look-ahead
 __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING > 0: the weights of both phases as ONE stream through a rolling ring of RING fragments (see below)
     DSG_TL_SCOPE();
     typedef typename P::elem elem;
@@ -1282,10 +1282,18 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
     // 17.96 k -> 18.98 k frames/s, 4 x 32: 23.86 k -> 24.30 k; 64-row form, 12 slots (16: 32 B of scratch): 4 x 64 clips 26.2-26.3 k -> 26.6-26.9 k.  A whole chunk of
     // look-ahead instead (hidden in 128-column chunks, the A operand in LDS: 33.0 vs 30.5 us per 64-row launch) and 4 waves of 512 registers (36.4) were slower:
     // the kernel is not waiting for bytes in flight alone -- what the ring removes is the drain at every group boundary.
+    // WO_RING (round 6, latent_dim 512): W_o joins the stream as its FIRST N0 fragments (k-block major: the order out_proj consumes them) instead of waiting whole
+    // in registers -- DW x KD = 64 two-... fragments per wave do not fit next to the attention rows at that width.  The ring is then filled at kernel start and
+    // stays full across LayerNorm1 (no quarter fills).
+    constexpr int N0 = WO_RING ? DW * KD : 0;
     constexpr int N1 = FW * KD, N2 = KF * DW, NRING = RING > 0 ? RING : 1;
     static_assert(RING == 0 || (OP && RING <= N1), "ring");
+    static_assert(!WO_RING || (RING > 0 && RING <= N0 && RT == 1), "W_o in the ring: the 16-row form");
     typename P::wfrag ring[NRING];
-    auto ring_load = [&](int i) -> typename P::wfrag {
+    const f32x4* wo_ring = (const f32x4*)g.Wo + lane;
+    auto ring_load = [&](int ig) -> typename P::wfrag {      // ig: index in the whole stream [W_o | W1 | W2]
+        if (ig < N0) return P::wload(wo_ring, (size_t)(wave * DW + ig % DW) * KD + ig / DW);
+        const int i = ig - N0;
         if (i < N1) return P::wload(w1, (size_t)(wave * FW + i / KD) * KD + i % KD);
         const int k = (i - N1) / DW, t = (i - N1) % DW;
         return P::wload(w2, (size_t)(wave * DW + t) * KF + k);
@@ -1315,11 +1323,16 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
         // ---- prologue: pre1 = attention rows . W_o^T + b_o + residual; x1 = LayerNorm1(pre1) -> LDS in the GEMM type (linear1's operand)
         //      and, in fp32, this lane's registers: phase 2 adds exactly these (row, column) values back (same wave -> column map)
         const f32x4* wo = (const f32x4*)g.Wo + lane;
-        typename P::wfrag wof[DW][KD];
+        typename P::wfrag wof[WO_RING ? 1 : DW][WO_RING ? 1 : KD];
+        if constexpr (WO_RING) {
 #pragma unroll
-        for (int t = 0; t < DW; ++t)
+            for (int i = 0; i < RING; ++i) ring[i] = ring_load(i);
+        } else {
 #pragma unroll
-            for (int kb = 0; kb < KD; ++kb) wof[t][kb] = P::wload(wo, (size_t)(wave * DW + t) * KD + kb);
+            for (int t = 0; t < DW; ++t)
+#pragma unroll
+                for (int kb = 0; kb < KD; ++kb) wof[t][kb] = P::wload(wo, (size_t)(wave * DW + t) * KD + kb);
+        }
         // (round 6, measured no: on 16-row tiles the register file has room for half of the weight ring next to W_o, but requesting it HERE puts
         //  W1 ahead of the attention rows and W_o in the CU's load path and delays out_proj: 1 x 16 clips 192.6 -> 195.4 us per step with 16 slots
         //  early, 198.2 with all 32 -- profiles/r06_z_*)
@@ -1344,7 +1357,15 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
 #pragma unroll
                 for (int rt = r0; rt < r0 + RH; ++rt)
 #pragma unroll
-                    for (int t = 0; t < DW; ++t) acc1[rt][t] = P::mma_w(wof[t][kb], af[rt][kb], acc1[rt][t]);      // D[n 4lg+r][row lr]
+                    for (int t = 0; t < DW; ++t) {
+                        if constexpr (WO_RING) {
+                            const int i = kb * DW + t;
+                            acc1[rt][t] = P::mma_w(ring[i % NRING], af[rt][kb], acc1[rt][t]);
+                            ring[i % NRING] = ring_load(i + RING);      // (RT == 1: the slot is consumed; what follows W_o in the stream is W1)
+                        } else {
+                            acc1[rt][t] = P::mma_w(wof[t][kb], af[rt][kb], acc1[rt][t]);      // D[n 4lg+r][row lr]
+                        }
+                    }
             if (r0 + RH < RT) {                               // (64-row blocks: the next two row tiles' attention rows and residual)
                 load_a(r0 + RH);
 #pragma unroll
@@ -1355,7 +1376,9 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
             }
         }
         DSG_TL_MARK(1);      // out_proj issued (attention rows shared through LDS, W_o landed)
-        if constexpr (RING > 0) {
+        if constexpr (WO_RING) {
+            // (the ring has been streaming since kernel start)
+        } else if constexpr (RING > 0) {
 #pragma unroll
             // Round 6: the ring's first fill goes out in FOUR quarters, one here and one behind each of LayerNorm1's next three stages.  A wave issues in
             // order: the 32 loads of a whole fill keep it in the issue stage while the CU's load path takes them (8 waves x 32 KB at 64 B / clk = 1.7 us) --
@@ -1381,7 +1404,7 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
             }
             ln_wave_moments<DW>(acc1[rt], sm, red[rt][0][wave], red[rt][1][wave], lr, lg);
         }
-        if constexpr (RING > 0) {
+        if constexpr (RING > 0 && !WO_RING) {
 #pragma unroll
             for (int i = RING / 4; i < RING / 2; ++i) ring[i] = ring_load(i);
             DSG_LOADS_ISSUED();
@@ -1391,7 +1414,7 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
         float var1[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) ln_combine_moments<NW, D>(red[rt][0], red[rt][1], lr, mean1[rt], var1[rt]);
-        if constexpr (RING > 0) {
+        if constexpr (RING > 0 && !WO_RING) {
 #pragma unroll
             for (int i = RING / 2; i < 3 * (RING / 4); ++i) ring[i] = ring_load(i);
             DSG_LOADS_ISSUED();
@@ -1413,7 +1436,7 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
                 else *(f32x4*)(x1f + (rt * 16 + lr) * X1P + n) = y;
             }
         }
-        if constexpr (RING > 0) {
+        if constexpr (RING > 0 && !WO_RING) {
 #pragma unroll
             for (int i = 3 * (RING / 4); i < RING; ++i) ring[i] = ring_load(i);
             DSG_LOADS_ISSUED();
@@ -1447,10 +1470,10 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
             for (int rt = 0; rt < RT; ++rt) c[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < KD; ++kb) {
-                const int i = j * KD + kb;
+                const int i = N0 + j * KD + kb;
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) c[rt] = P::mma_w(ring[i % NRING], af[rt][kb], c[rt]);      // D[n 4lg+r][row lr]
-                if (i + RING < N1 + N2) ring[i % NRING] = ring_load(i + RING);
+                if (i + RING < N0 + N1 + N2) ring[i % NRING] = ring_load(i + RING);
                 DSG_LOADS_ISSUED();
             }
 #pragma unroll
@@ -1490,10 +1513,10 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
             }
 #pragma unroll
             for (int t = 0; t < DW; ++t) {
-                const int i = N1 + k * DW + t;
+                const int i = N0 + N1 + k * DW + t;
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) acc[rt][t] = P::mma_w(ring[i % NRING], a[k % AB][rt], acc[rt][t]);
-                if (i + RING < N1 + N2) ring[i % NRING] = ring_load(i + RING);
+                if (i + RING < N0 + N1 + N2) ring[i % NRING] = ring_load(i + RING);
             }
             DSG_LOADS_ISSUED();
         }

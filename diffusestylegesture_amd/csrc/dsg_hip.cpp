@@ -963,6 +963,7 @@ struct KernelSel {
     bool stream = false;        // STREAM: BLOCK with the weight-stationary persistent GEMMs of dsg_stream.h (LayerNorm + QKV, linear1, linear2, pose head)
     bool ffn = false;           // STREAM (round 4): linear1 + GELU + linear2 + residual + LayerNorm2 in one kernel (k_ffn); QKV of the next layer
                                 // and the pose head then read normalised rows: direct streaming GEMMs, no k_ln_frag
+    bool ffn16_wide = false;    // ROWS at the DSG+ widths (round 6): direct QKV GEMM + k_attn + k_ffn<OP> on 16-row tiles
     bool ffn16 = false;         // ROWS (round 6): k_ffn on 16-row tiles (one workgroup per row tile), behind k_clip_attn; everything else as BLOCK
     bool ffn_rt4 = false;       // ... on 64-row blocks: 4 lanes x >= 4000 token rows (4 x 64 clips: 981 -> 903 us per step of the 4 lanes; 1 x 64: 376 -> 432,
                                 // 4 x 16: 334 -> 392, 4 x 32 even -- profiles/r04_y2_sweep_ffn_rt4_*.log).  Bit-identical to the 32-row form.
@@ -1006,6 +1007,11 @@ static bool ffn_split_wide(const dsg_handle* h) {
     return h->prec == DSG_PREC_BF16 && have_attn_op_wide(h) && h->ff == 1024 && (h->D == 384 || h->D == 512);
 }
 static bool ffn_split_ok(const dsg_handle* h) { return stream_set_ok(h) || ffn_split_wide(h); }
+// ROWS at the DSG+ widths (round 6, bf16): no k_clip_attn there (the clip's rows do not fit the LDS next to Q / K / V) -- the direct QKV GEMM + k_attn feed
+// k_ffn<OP> on one 16-row tile (out_proj + LayerNorm1 as its prologue): no k_attn_op_w, no ff-split, no slabs, no slab-sum pass
+static bool rows_wide_ok(const dsg_handle* h) {
+    return h->prec == DSG_PREC_BF16 && h->H == 4 && h->Tp == 160 && h->ff == 1024 && (h->D == 384 || h->D == 512);
+}
 // bf16w2 (round 6): the ROWS pair -- k_clip_attn + k_ffn on one 16-row tile -- exists with the two-register fragments at the ZEGGS / tiny widths
 // (not under fused guidance: its last layer runs the QKV GEMM + k_attn_op, which have no bf16w2 form)
 static bool rows_w2_ok(const dsg_handle* h) {
@@ -1029,12 +1035,19 @@ static int auto_kernel_set(const dsg_handle* h, int B, int lanes) {
         if (B <= 2 && latency_set_ok(h) && h->prec != DSG_PREC_FP32) return DSG_KSET_LATENCY;
         // (DSG+ widths, round 5: with k_ffn_part + k_ffn_ln behind k_attn_op_w BLOCK wins from 4 clips -- BEAT 283 vs 303 us, TWH 310 vs 365; 2 clips: 259 vs 198)
         // (only there: ffn_split_wide() is also true for fp32 at the ZEGGS widths, which has no such measurement -- round-5 advisor)
+        // (round 6, DSG+ widths: ROWS -- direct QKV + k_attn + k_ffn<OP> on 16-row tiles -- from 9 clips while the row tiles fit the CUs in one round: BEAT 1 x 16
+        //  526 -> 443 us per step, 1 x 24: 701 -> 556, 1 x 26: 806 -> 594, 1 x 8: 370 -> 346; TWH 1 x 16: 609 -> 524, 1 x 24: 835 -> 660, 1 x 8: 417 -> 410; below: BLOCK
+        //  (BEAT 1 x 6: 297 vs 305, TWH 1 x 6: 326 vs 366) -- profiles/r06_da_*, r06_db_*)
+        if (rows_wide_ok(h) && h->cfgB == 0 && rows >= 1300 && MT <= 256) return DSG_KSET_ROWS;
         if (ffn_split_wide(h) && h->prec == DSG_PREC_BF16 && (h->D == 384 || h->D == 512) && h->env_ffn_split != 0 && rows >= 600) return DSG_KSET_BLOCK;
         // (round 6, bf16 ZEGGS widths: BLOCK from 6 clips -- 1 x 6: 177.6 vs 190.1 TILE, 1 x 5: 176.4 vs 161.6, 1 x 4: 173.9 vs 157.4)
         return rows >= (s_ok ? 500 : 1000) ? DSG_KSET_BLOCK : DSG_KSET_TILE;
     }
     if (s_ok && rows >= 850 && lanes * MT > 300) return DSG_KSET_STREAM;
     if (s_ok && rows >= 250 && lanes * rows >= 1000 && lanes * MT <= 300) return DSG_KSET_ROWS;
+    // (DSG+ widths with several lanes: ROWS from 4 clips per lane and 16 over all lanes -- BEAT 4 x 4: 399 vs 405, 2 x 8: 412 vs 445, 4 x 8: 627 vs 699; TWH 4 x 4: 509 vs 518,
+    //  2 x 8: 514 vs 549, 4 x 8: 794 vs 949; below: BLOCK -- 4 x 3: 342 vs 363, 2 x 4: 297 vs 304, 4 x 2: 297 vs 319)
+    if (rows_wide_ok(h) && h->cfgB == 0 && rows >= 600 && lanes * rows >= 2400 && MT <= 256) return DSG_KSET_ROWS;
     if (B <= 1 && latency_set_ok(h) && h->prec != DSG_PREC_FP32) return DSG_KSET_LATENCY;
     // (2 x 4: BLOCK 178.1 vs ROWS 180.5; 4 x 2: TILE 179.4 vs BLOCK 183.3; 2 x 3: 175.1 = 173.8)
     return rows >= (s_ok ? 250 : 300) ? DSG_KSET_BLOCK : DSG_KSET_TILE;
@@ -1062,7 +1075,7 @@ static int select_kernels(const dsg_handle* h, int B, KernelSel& k) {
     int set = h->kset_req;
     if (set == DSG_KSET_AUTO) set = resolve_auto_set(h, B, 1);
     if (set == DSG_KSET_LATENCY && h->D > 512) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set LATENCY: latent_dim > 512");
-    if ((set == DSG_KSET_STREAM || set == DSG_KSET_ROWS) && !stream_set_ok(h) && !(set == DSG_KSET_ROWS && rows_w2_ok(h)))
+    if ((set == DSG_KSET_STREAM || set == DSG_KSET_ROWS) && !stream_set_ok(h) && !(set == DSG_KSET_ROWS && (rows_w2_ok(h) || rows_wide_ok(h))))
         return fail(DSG_E_NOT_IMPLEMENTED, "kernel sets STREAM / ROWS: bf16 (ROWS: bf16w2 as well), latent_dim 128 / 256, 4 heads, ff 128 / 1024 only");
     if (set < DSG_KSET_LATENCY || set > DSG_KSET_ROWS) return fail(DSG_E_INVALID, "unknown kernel set");
     if (h->prec == DSG_PREC_BF16W2 && ((set > DSG_KSET_TILE && !(set == DSG_KSET_ROWS && rows_w2_ok(h))) || (set == DSG_KSET_LATENCY && h->D > 256)))
@@ -1087,6 +1100,11 @@ static int select_kernels(const dsg_handle* h, int B, KernelSel& k) {
     // and at batch 1 its 10 workgroups per layer lose to k_attn + out_proj (BEAT: 200 vs 163 us/step; 16 clips: 3371 vs 2904 frames/s)
     if (k.ffn16 && h->prec == DSG_PREC_BF16W2 && h->cfgB > 0) return fail(DSG_E_NOT_IMPLEMENTED, "precision bf16w2, kernel set ROWS: no fused guidance (TILE has it)");
     k.attn_op = !k.lat && (have_attn_op_narrow(h) || (k.blk && have_attn_op_wide(h)) || (k.ffn16 && rows_w2_ok(h)));
+    k.ffn16_wide = k.ffn16 && rows_wide_ok(h);
+    if (k.ffn16_wide) {
+        if (h->cfgB > 0) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set ROWS at the DSG+ widths: no fused guidance (BLOCK has it)");
+        k.attn_op = false;      // k_attn writes the attention rows, k_ffn<OP> does out_proj + LayerNorm1
+    }
     k.xs_frag = k.blk && h->prec == DSG_PREC_BF16 && (h->Jp == 1152 || h->Jp == 128);
     if (set == DSG_KSET_BLOCK && ffn_split_ok(h)) k.ffn_split = h->env_ffn_split != 0;      // (A/B: DSG_FFN_SPLIT=0 = linear1 + linear2 + LayerNorm-on-read, round 3)
     k.clip_attn = (k.ffn_split || k.ffn) && have_attn_op_narrow(h) && h->env_clip_attn != 0;      // (A/B: DSG_CLIP_ATTN=0 = QKV GEMM + k_attn_op, round 4)
@@ -1112,7 +1130,7 @@ extern "C" int dsg_set_kernel_set(dsg_handle* h, int set) {
     if (!h) return fail(DSG_E_INVALID, "null handle");
     if (set < DSG_KSET_AUTO || set > DSG_KSET_ROWS) return fail(DSG_E_INVALID, "dsg_set_kernel_set: unknown kernel set");
     if (set == DSG_KSET_LATENCY && h->D > 512) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set LATENCY: latent_dim > 512");
-    if ((set == DSG_KSET_STREAM || set == DSG_KSET_ROWS) && !stream_set_ok(h) && !(set == DSG_KSET_ROWS && rows_w2_ok(h)))
+    if ((set == DSG_KSET_STREAM || set == DSG_KSET_ROWS) && !stream_set_ok(h) && !(set == DSG_KSET_ROWS && (rows_w2_ok(h) || rows_wide_ok(h))))
         return fail(DSG_E_NOT_IMPLEMENTED, "kernel sets STREAM / ROWS: bf16 (ROWS: bf16w2 as well), latent_dim 128 / 256, 4 heads, ff 128 / 1024 only");
     // (the same rule as select_kernels: round-5 advisor -- this entry point used to accept LATENCY at latent_dim 384 / 512, and every later call failed)
     if (h->prec == DSG_PREC_BF16W2 && ((set > DSG_KSET_TILE && !(set == DSG_KSET_ROWS && rows_w2_ok(h))) || (set == DSG_KSET_LATENCY && h->D > 256)))
@@ -1633,6 +1651,17 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                 CHK((launch_gemm_w<P, PRO_DIRECT, EPI_GELU>(h, g, ks)));
             }
           }
+        } else if (ks.ffn16_wide) {
+            if constexpr (sizeof(typename P::elem) == 2 && !P::W2) {
+                FfnArgs a;
+                memset(&a, 0, sizeof(a));
+                a.W1 = ly.W1; a.b1 = ly.b1; a.W2 = ly.W2; a.b2 = ly.b2; a.ln_g = ly.g2; a.ln_b = ly.be2; a.Xn = h->Xn; a.Xa = h->X0a; a.M = M; a.MT = MT;
+                a.A = h->attn; a.R = l == 0 ? h->X0 : h->Xn; a.Wo = ly.Wo; a.bo = ly.bo; a.ln1_g = ly.g1; a.ln1_b = ly.be1; a.X1 = h->X1;
+                // latent_dim 384: W_o (36 fragments per wave) waits in registers as at the ZEGGS widths; 512: 64 fragments do not fit -- W_o leads the weight ring
+                if (D == 384) CHK((step_launch<&k_ffn<P, 6, 16, 1, 8, 2, true, true, 24>>(h, dim3(MT), dim3(512), a)));
+                else CHK((step_launch<&k_ffn<P, 8, 16, 1, 8, 2, true, true, 24, true>>(h, dim3(MT), dim3(512), a)));
+                continue;
+            }
         } else {
             {   // out_proj + residual -> pre1
                 GemmArgs g = z;

@@ -164,3 +164,20 @@ def test_local_attention_one_wave_form_is_bit_identical(emu_lib, monkeypatch):
             for o, yy in zip(outs[frm], (y, ym, yn)):
                 assert rel_l2(o, ref(x, ts, yy)) < tol, (prec, frm)
         assert all(np.array_equal(p, q) for p, q in zip(outs["1"], outs["1000000"])), prec
+
+
+@pytest.mark.parametrize("name", ["beat", "twh"])
+def test_rows_kernel_set_at_dsgplus_widths(emu_lib, name):
+    """Round 6: ROWS at latent_dim 384 / 512 (direct QKV GEMM + k_attn + k_ffn<OP> on 16-row tiles; at 512 W_o leads the weight ring) -- one forward at batch 1 against
+    the oracle under the emulator (the GPU test has batch 16, batch independence and a chain)."""
+    from oracle.mdm import MDMOracle
+    cfg = C.CONFIGS[name]
+    sd = synth_state_dict(cfg, 20240)
+    ref = MDMOracle(sd, cfg)
+    y = synth_window_inputs(cfg, 1, window=1, seed_pose_scale=0.2)
+    x = np.random.RandomState(3).randn(1, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+    m = DSGDenoiser(cfg, precision="bf16", max_batch=1, library=emu_lib).set_kernel_set("rows")
+    m.load_state_dict(sd)
+    out = np.asarray(m(x, [417], y))
+    assert m.last_kernel_set() == "rows" and rel_l2(out, ref(x, [417], y)) < 1.2e-2
+    assert [m.recommend_kernel_set(b, 1) for b in (8, 9, 27, 28)] == ["block", "rows", "rows", "block"]

@@ -63,7 +63,7 @@ def test_every_kernel_set_at_dsgplus_dims_batch_1_8_32(gpu, cfg):
     from oracle.schedule import OracleDiffusion
     sd = synth_state_dict(cfg, 20240)
     ref = MDMOracle(sd, cfg)
-    for B, sets, precs in ((1, ("auto", "latency", "tile"), ("fp32", "bf16")), (8, ("tile", "block"), ("fp32", "bf16")), (32, ("tile", "block"), ("bf16",))):
+    for B, sets, precs in ((1, ("auto", "latency", "tile"), ("fp32", "bf16")), (8, ("tile", "block", "rows"), ("fp32", "bf16")), (32, ("tile", "block", "rows"), ("bf16",))):
         y = synth_window_inputs(cfg, B, window=2, clip0=5, seed_pose_scale=0.2)
         x = np.random.RandomState(B).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
         ts = (np.arange(B) * 31 + 7) % 1000
@@ -72,6 +72,8 @@ def test_every_kernel_set_at_dsgplus_dims_batch_1_8_32(gpu, cfg):
         for prec in precs:
             m = _model(cfg, prec, max_batch=B)
             for ks in sets:
+                if ks == "rows" and (prec != "bf16" or cfg.latent_dim not in (384, 512)):      # (round 6: ROWS at the DSG+ widths is a bf16 set; 32 clips: two rounds of row tiles)
+                    continue
                 m.set_kernel_set(ks)
                 out = np.asarray(m(x, ts, y))
                 if ks != "auto":
