@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void k_gemm_blk(const GemmArgs g) {
     __shared__ __attribute__((aligned(16))) char lds_a[BM * (DMAX * ES + 16)];
     preload_kernargs(g);
     const int NG = g.NT / (4 * TNW);
-    const int ng = xcd_ngroup<P>(), mb = blockIdx.y;
+    int ng = xcd_ngroup<P>(), mb = blockIdx.y;
     const int MB = (g.MT + RT - 1) / RT;
     if constexpr (EPI == EPI_OUT) {
         if (mb >= MB) {      // extra grid row: step bookkeeping (see gemm_body)
@@ -87,6 +87,8 @@ __global__ __launch_bounds__(256) void k_gemm_blk(const GemmArgs g) {
             return;
         }
     }
+    // (round 6: the QKV GEMM of the DSG+ widths is 18 column groups -- XCDs 0-1 held three, the others two: BEAT 16 clips 17.8 -> see profiles/r06_de_*)
+    if (!xcd_deal_groups(NG, MB, ng, mb)) return;
     if (ng >= NG || mb >= MB) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
     const int m0 = mb * BM;
@@ -245,7 +247,8 @@ __global__ __launch_bounds__(256) void k_gemm_blk_k(const GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float red[4][RT * CT][64][4];      // every wave's partial 32 x 32 block
     preload_kernargs(g);
     const int NG = g.NT / CT;
-    const int ng = xcd_ngroup<P>(), mb = blockIdx.y, ks = blockIdx.z;
+    int ng = xcd_ngroup<P>(), mb = blockIdx.y;
+    const int ks = blockIdx.z;
     const int MB = (g.MT + RT - 1) / RT;
     if constexpr (EPI == EPI_PARTIAL) {
         if (mb >= MB) {      // extra grid row: step bookkeeping (see gemm_body)
@@ -253,6 +256,7 @@ __global__ __launch_bounds__(256) void k_gemm_blk_k(const GemmArgs g) {
             return;
         }
     }
+    if (!xcd_deal_groups(NG, MB, ng, mb)) return;      // (round 6: the pose embedding of the DSG+ widths is 12 column groups: XCDs 0-3 held two, 4-7 one)
     if (ng >= NG || mb >= MB) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
     const int m0 = mb * 16 * RT, nt0 = ng * CT;

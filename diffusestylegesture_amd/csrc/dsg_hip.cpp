@@ -1273,6 +1273,14 @@ static int launch_ws(dsg_handle* h, GemmArgs g) {
         if (K == 256) return step_launch<&k_ws<EPI, 16, true>>(h, grid1, dim3(256), g);
         if (K == 128) return step_launch<&k_ws<EPI, 8, true>>(h, grid1, dim3(256), g);
     } else {
+        if constexpr (EPI == EPI_QKV) {      // (round 6: the DSG+ widths, one workgroup per CU)
+            if (K == 384 || K == 512) {
+                g.ws_G = ws_groups(P, MB, 1);
+                const dim3 gridw(ws_grid_x(P, g.ws_G));
+                if (K == 384) return step_launch<&k_ws<EPI, 24>>(h, gridw, dim3(256), g);
+                return step_launch<&k_ws<EPI, 32>>(h, gridw, dim3(256), g);
+            }
+        }
         const dim3 grid(ws_grid_x(P, g.ws_G));
         if (K == 256) return step_launch<&k_ws<EPI, 16>>(h, grid, dim3(256), g);
         if (K == 128) return step_launch<&k_ws<EPI, 8>>(h, grid, dim3(256), g);
@@ -1321,6 +1329,12 @@ static int launch_gemm_w(dsg_handle* h, const GemmArgs& g, const KernelSel& ks) 
     constexpr bool blk_wins = EPI == EPI_QKV || EPI == EPI_GELU;
     if constexpr (sizeof(typename P::elem) == 2 && !P::W2 && PRO == PRO_DIRECT && (EPI == EPI_GELU || EPI == EPI_QKV || EPI == EPI_OUT)) {
         if (ks.stream && g.a_frag) return launch_ws<EPI>(h, g);      // STREAM: linear1 on the fragment-major LayerNorm1 rows of k_attn_op
+        // (round 6, ROWS at the DSG+ widths: the weight-stationary QKV GEMM with a 192 / 256-register panel, one workgroup per CU -- bit-identical to the block form.
+        //  latent 384 from 1200 rows: BEAT 1 x 16 clips 417.9 -> 402.7 us per step, 4 x 8: 616 -> 591, 4 x 16: 1161 -> 1050, 4 x 4 even; latent 512 only with
+        //  several lanes: TWH 4 x 8: 799 -> 780, but 1 x 16: 526 -> 540, 1 x 24: 661 -> 682 -- profiles/r06_df_*)
+        if constexpr (EPI == EPI_QKV) {
+            if (ks.ffn16_wide && g.a_frag && g.M >= 1200 && (g.D == 384 || h->lanes_now >= 2)) return launch_ws<EPI>(h, g);
+        }
         // (the streaming pose head below the STREAM sizes loses: BLOCK 1 x 16 clips 207.5 -> 211.6 us per step, 4 x 4: 197.5 -> 205.4 -- profiles/r06_h_*, round 6)
     }
     if constexpr (sizeof(typename P::elem) == 2 && !P::W2 && PRO == PRO_LN && (EPI == EPI_QKV || EPI == EPI_OUT)) {
@@ -1458,7 +1472,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
     la.emb1 = h->emb1; la.ctl = c.use_ctr ? h->ctl : nullptr; la.t_arr = h->t_arr;
     la.rcos = h->rcos; la.rsin = h->rsin; la.mask = h->mask; la.mb = h->mb; la.inv_mask_div = fastdiv_inv((int)((long long)B * h->Hl / h->mb)); la.B = B; la.T = T; la.D = D; la.Hl = h->Hl;
     la.hd = h->hdl; la.W = h->W; la.X0 = h->X0; la.X0a = h->X0a; la.nomask = h->nomask;
-    la.x0a_frag = ((ks.stream || ks.clip_attn) && sizeof(typename P::elem) == 2) ? (P::W2 ? 2 : 1) : 0;      // (bf16w2: as a hi + lo pair)
+    la.x0a_frag = ((ks.stream || ks.clip_attn || ks.ffn16_wide) && sizeof(typename P::elem) == 2) ? (P::W2 ? 2 : 1) : 0;      // (bf16w2: as a hi + lo pair)
     h->fence_next = 1;         // the first packet of a step reads the state the previous step's last packet wrote (state_fences)
     if (ks.lat) {              // pose embedding + local attention in one launch (in the batched sets it loses: 1 x 16 clips 192.1 -> 198.5 us per
                                // step, 1 x 64: 258 -> 291, 4 x 4 even -- profiles/r06_ab_*, round 6)

@@ -569,6 +569,19 @@ struct GemmArgs {
 template <class P> __device__ __forceinline__ int xcd_ngroup() { const int x = (int)blockIdx.x; return (x & 7) + 8 * (x >> 3); }
 __host__ __device__ inline int xcd_grid_x(int NG) { return 8 * ((NG + 7) / 8); }
 
+// (gemm_body, k_gemm_blk, k_gemm_blk_k) column group ng runs on XCD ng % 8 -- grid x is padded to a multiple of 8 --, which leaves the XCDs with NG / 8 or NG / 8 + 1
+// groups each.  From 16 rows of the grid on, the NG % 8 groups past the last full round of 8 are dealt out by grid row over the 8 padded columns (item j = y * 8 + xcd),
+// so every XCD gets the same share of them; the dead slots are the last rows of the grid.  Returns false for a dead slot.
+__device__ __forceinline__ bool xcd_deal_groups(int NG, int n_rows, int& ng, int& row) {
+    const int NG8 = NG & ~7, rem = NG - NG8;
+    if (rem && ng >= NG8 && n_rows >= 16) {
+        const int j = row * 8 + (ng - NG8);
+        if (j >= rem * n_rows) return false;
+        row = (int)((unsigned)j / (unsigned)rem);
+        ng = NG8 + (j - row * rem);
+    }
+    return true;
+}
 // x / d for 0 <= x, x * d < 2^32, as one v_mul_hi_u32: inv = ceil(2^32 / d) (host: fastdiv_inv; d == 1 -> inv 0)
 __device__ __forceinline__ int fdiv(int x, unsigned inv) { return inv ? (int)__umulhi((unsigned)x, inv) : x; }
 __host__ __device__ inline unsigned fastdiv_inv(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1u) / (unsigned)d); }
@@ -911,15 +924,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g) {
     // From 16 row tiles only: with few row tiles every XCD finishes in one round of its CUs anyway, and the fixed group -> XCD map keeps a group's
     // weight columns resident in one L2 across the steps (batch 1 with the remap: 106.9 -> 108.7 us per step; 16 clips 187.7 -> 185.6, 4 x 8 clips
     // 202.0 -> 199.4, TILE at 4 clips 157.4 -> 153.6 -- profiles/r06_cd_ab_dev{A,B}.log).
-    {
-        const int NG8 = NG & ~7, rem = NG - NG8;
-        if (rem && ng >= NG8 && g.MT >= 16) {
-            const int j = mt_first * 8 + (ng - NG8);
-            if (j >= rem * g.MT) return;
-            mt_first = (int)((unsigned)j / (unsigned)rem);
-            ng = NG8 + (j - mt_first * rem);
-        }
-    }
+    if (!xcd_deal_groups(NG, g.MT, ng, mt_first)) return;
     if (ng >= NG || mt_first >= g.MT) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
     const int wn = wave % WN, wk = wave / WN;

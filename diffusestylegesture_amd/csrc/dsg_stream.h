@@ -298,11 +298,11 @@ __device__ __forceinline__ void ws_body(const GemmArgs& g, const WsId id, char* 
 }
 
 template <int EPI, int KD16, bool ONE = false>      // ONE (pose head): a workgroup per (panel, row block), one activation buffer, three workgroups per CU
-__global__ __launch_bounds__(256, ONE ? 3 : 2) void k_ws(const GemmArgs g) {
+__global__ __launch_bounds__(256, KD16 > 16 ? 1 : (ONE ? 3 : 2)) void k_ws(const GemmArgs g) {      // (round 6: K = 384 / 512 -- the DSG+ widths: a 192 / 256-register panel, one workgroup per CU)
     DSG_TL_SCOPE();
     typedef PBF16 P;
     constexpr int K = 16 * KD16, BM = 64;
-    static_assert(KD16 % 4 == 0 && KD16 <= 16, "K = 64, 128, 192 or 256");
+    static_assert(KD16 % 4 == 0 && KD16 <= 32, "K = 64 ... 512");
     static_assert(EPI == EPI_GELU || EPI == EPI_QKV || EPI == EPI_OUT, "GEMMs of the step with K = D");
     constexpr int ABYTES = BM * K * 2, STAGE = ws_stage_bytes(EPI, BM);
     static_assert(!ONE || EPI == EPI_OUT, "ONE belongs to the pose head");
