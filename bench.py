@@ -23,7 +23,8 @@ The default line (`python bench.py`, 1 GPU, config[1]) also carries time-bounded
 (`--sub-records off` drops them; each has its own value / us_per_denoise_step / kernel_set / roofline, about 25 s in all):
     config2   50-step DDIM, batch 16 in lock step                      (BASELINE config[2])
     config3   16 clips as 4 lanes x batch 4 = config[3]'s per-GPU share (with --gpus N: N x 16 clips gathered over RCCL)
-    config4   DiffuseStyleGesture+ BEAT and TWH denoisers, batch 1, 2 of the 16 windows of an 1830-frame clip (config[4])
+    config4   DiffuseStyleGesture+ BEAT and TWH denoisers, batch 1, 2 of the 16 windows of an 1830-frame clip (config[4]);
+              `beat_64clips`: 64 BEAT clips per GPU as 4 lanes x batch 16, 1 of the 16 windows
     stream    256 clips per GPU as 4 lanes x batch 64 (the STREAM kernel set), 1 pass
     precision config[1] in the two other arithmetic modes: fp32 (the reference's own arithmetic) and bf16w2 (hi + lo bf16), 1 pass each
 Top-level `value` / `config` stay config[1].  Sub-records with a committed PMC pass of their per-lane arrangement
@@ -406,6 +407,10 @@ def main():
             name: sub_record(f"config[4]: DiffuseStyleGesture+ {name.upper()} denoiser, batch 1, 2 of the 16 windows of an 1830-frame clip",
                              name, 1, 1, "ddpm", 1, n_windows=2, warm_skip=900)
             for name in ("beat", "twh")}
+        # ... and DSG+ with clips in flight (round 6: the ROWS kernel set at latent_dim 384 -- direct QKV + k_attn + k_ffn<OP> on 16-row tiles, streamed pose
+        # embedding): 64 BEAT clips as 4 lanes x batch 16, 1 of the 16 windows
+        subs["config4"]["beat_64clips"] = sub_record("DiffuseStyleGesture+ BEAT denoiser, 64 clips per GPU (4 lanes x batch 16), 1 of the 16 windows of an 1830-frame clip",
+                                                     "beat", 64, 4, "ddpm", 1, n_windows=1, warm_skip=960)
         subs["stream"] = sub_record("256 clips per GPU (4 lanes x batch 64, STREAM kernel set)", "zeggs", 256, 4, "ddpm", 1, warm_skip=960)
         # config[1] in the other two arithmetic modes (tolerances against the reference .bvh: README "which precision"): fp32 is the
         # reference's own arithmetic (main/train/training_loop.py:39), bf16w2 keeps weights and the step's own GEMM operands as hi + lo bf16

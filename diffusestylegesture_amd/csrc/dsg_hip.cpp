@@ -1017,6 +1017,13 @@ static bool rows_wide_ok(const dsg_handle* h) {
 static bool rows_w2_ok(const dsg_handle* h) {
     return h->prec == DSG_PREC_BF16W2 && h->H == 4 && ((h->D == 256 && h->Tp == 96 && h->ff == 1024) || (h->D == 128 && h->Tp == 32 && h->ff == 128));
 }
+// the streamed pose embedding at the DSG+ pose widths (round 6: k_ws2<EPI_PARTIAL, 17 / 18, 2>, K over two workgroups) -- in the ROWS set
+static bool xs_frag_wide(const dsg_handle* h, int set) {
+#ifdef DSG_X_NO_XS_WIDE      // (A/B: make dev DEVFLAGS=-DDSG_X_NO_XS_WIDE)
+    return false;
+#endif
+    return (set == DSG_KSET_ROWS || set == DSG_KSET_BLOCK) && (h->Jp == 2176 || h->Jp == 2304) && (h->D == 384 || h->D == 512);
+}
 static int auto_kernel_set(const dsg_handle* h, int B, int lanes) {
     const int rows = B * h->ntok, MT = cdiv(rows, 16);
     const bool s_ok = stream_set_ok(h);       // (bf16, the ZEGGS / tiny widths: STREAM and ROWS exist)
@@ -1105,7 +1112,7 @@ static int select_kernels(const dsg_handle* h, int B, KernelSel& k) {
         if (h->cfgB > 0) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set ROWS at the DSG+ widths: no fused guidance (BLOCK has it)");
         k.attn_op = false;      // k_attn writes the attention rows, k_ffn<OP> does out_proj + LayerNorm1
     }
-    k.xs_frag = k.blk && h->prec == DSG_PREC_BF16 && (h->Jp == 1152 || h->Jp == 128);
+    k.xs_frag = k.blk && h->prec == DSG_PREC_BF16 && (h->Jp == 1152 || h->Jp == 128 || xs_frag_wide(h, set));
     if (set == DSG_KSET_BLOCK && ffn_split_ok(h)) k.ffn_split = h->env_ffn_split != 0;      // (A/B: DSG_FFN_SPLIT=0 = linear1 + linear2 + LayerNorm-on-read, round 3)
     k.clip_attn = (k.ffn_split || k.ffn) && have_attn_op_narrow(h) && h->env_clip_attn != 0;      // (A/B: DSG_CLIP_ATTN=0 = QKV GEMM + k_attn_op, round 4)
     if (k.ffn16 && h->prec == DSG_PREC_BF16W2) k.clip_attn = true;
@@ -1308,18 +1315,22 @@ static int launch_ws2(dsg_handle* h, GemmArgs g) {
     g.KS = 1; g.kb_per_split = g.KBtot;
     g.inv_ntok = fastdiv_inv(g.ntok); g.inv_hd = fastdiv_inv(g.hd);
     if (g.NT % 4) return fail(DSG_E_INVALID, "k_ws2: N must be a multiple of 64");
-    const int P = g.NT / 4, MB = cdiv(g.M, 32);
-    g.ws_G = ws_groups(P, MB, 1);
-    const dim3 grid(ws_grid_x(P, g.ws_G) + (EPI == EPI_PARTIAL ? 8 : 0));      // EPI_PARTIAL: + the bookkeeping workgroup
     const int K = g.KBtot * 32;
+    const int ksplit = (EPI == EPI_PARTIAL && K > 1152) ? 2 : 1;      // (the DSG+ pose widths: K over two workgroups, two slabs for k_loc -- see k_ws2)
+    const int P = g.NT / 4 * ksplit, MB = cdiv(g.M, 32);
+    g.ws_G = ws_groups(P, MB, 1);
+    g.KS = ksplit;
+    const dim3 grid(ws_grid_x(P, g.ws_G) + (EPI == EPI_PARTIAL ? 8 : 0));      // EPI_PARTIAL: + the bookkeeping workgroup
     if constexpr (EPI == EPI_RESID) {
         if (K == 1024) return step_launch<&k_ws2<EPI, 16>>(h, grid, dim3(256), g);
         if (K == 128) return step_launch<&k_ws2<EPI, 2>>(h, grid, dim3(256), g);
     } else {
         if (K == 1152) return step_launch<&k_ws2<EPI, 18>>(h, grid, dim3(256), g);
         if (K == 128) return step_launch<&k_ws2<EPI, 2>>(h, grid, dim3(256), g);
+        if (K == 2176) return step_launch<&k_ws2<EPI, 17, 2>>(h, grid, dim3(256), g);      // BEAT (round 6)
+        if (K == 2304) return step_launch<&k_ws2<EPI, 18, 2>>(h, grid, dim3(256), g);      // TWH
     }
-    return fail(DSG_E_NOT_IMPLEMENTED, "k_ws2: K must be 128 / 1024 (linear2) or 128 / 1152 (pose embedding)");
+    return fail(DSG_E_NOT_IMPLEMENTED, "k_ws2: K must be 128 / 1024 (linear2) or 128 / 1152 / 2176 / 2304 (pose embedding)");
 }
 
 // a K = D GEMM of the un-fused sets: block kernel (BLOCK, the GEMMs it wins), else 16 x 16 tiles -- LayerNorm GEMMs from 512
@@ -1467,7 +1478,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
     // split-K of the pose-embedding GEMM across workgroups: one split per 256 pose features for the 16 x 16 tile kernel; the
     // block kernel splits K over its 4 waves already, so 2 workgroup splits keep a wave's share at <= 8 k-blocks (one batch of
     // loads) without fragmenting the work 5 ways
-    const int ks_in = ks.xs_frag ? 1 : ((ks.blk && !P::W2) ? std::min(h->KSin, 2) : h->KSin);      // (streamed embedding: K stays whole, see k_ws2; bf16w2: the 16 x 16 tiles)
+    const int ks_in = ks.xs_frag ? (h->Jp > 1152 ? 2 : 1) : ((ks.blk && !P::W2) ? std::min(h->KSin, 2) : h->KSin);      // (streamed embedding: K stays whole, see k_ws2; bf16w2: the 16 x 16 tiles)
     la.partial = h->partial; la.KS = ks_in; la.Min_pad = MTin * 16; la.Cf = h->Cf; la.TE2 = h->TE2; la.TE = h->TE;
     la.emb1 = h->emb1; la.ctl = c.use_ctr ? h->ctl : nullptr; la.t_arr = h->t_arr;
     la.rcos = h->rcos; la.rsin = h->rsin; la.mask = h->mask; la.mb = h->mb; la.inv_mask_div = fastdiv_inv((int)((long long)B * h->Hl / h->mb)); la.B = B; la.T = T; la.D = D; la.Hl = h->Hl;

@@ -333,19 +333,26 @@ __global__ __launch_bounds__(256, KD16 > 16 ? 1 : (ONE ? 3 : 2)) void k_ws(const
 //   EPI_PARTIAL  the pose embedding (K = Jp, the padded pose dimension) on the fragment-major state shadow: the plain product into
 //                `partial[0]` (k_loc adds the conditioning); 8 extra workgroups, the first one does the step bookkeeping (StepCtl)
 // ---------------------------------------------------------------------------------------------------------
-template <int EPI, int KW16>
+//   KSPLIT (round 6, EPI_PARTIAL at the DSG+ pose widths, Jp = 2176 / 2304): K is split over KSPLIT workgroups as well -- "panel" then counts (column panel,
+//                K part) pairs; a workgroup streams its K part of every row tile (two 32-row buffers of 68 / 72 KB in the LDS) and leaves partial[part], which k_loc sums
+//                in a fixed order like the slabs of the tile kernels.  KW16 = K / (64 KSPLIT)
+template <int EPI, int KW16, int KSPLIT = 1>
 __global__ __launch_bounds__(256, 1) void k_ws2(const GemmArgs g) {
     DSG_TL_SCOPE();
     typedef PBF16 P;
     static_assert(EPI == EPI_RESID || EPI == EPI_PARTIAL, "linear2 or the pose embedding");
-    constexpr int K = 64 * KW16, KB = K / 32, BM = 32;
+    static_assert(KSPLIT == 1 || EPI == EPI_PARTIAL, "split-K partials belong to the pose embedding");
+    constexpr int K = 64 * KW16, KB = K / 32, BM = 32;      // K, KB: this workgroup's part
+    constexpr int KBTOT = KB * KSPLIT;
     constexpr int ABYTES = BM * K * 2;
     constexpr int REDBYTES = 4 * 2 * 16 * 64 * 4;                 // 4 waves x 2 column tiles x 16 registers x 64 lanes, fp32
     constexpr bool RED_IN_A = ABYTES >= REDBYTES;                  // the partial sums go through the retired activation buffer
     __shared__ __attribute__((aligned(16))) char lds[2 * ABYTES + (RED_IN_A ? 0 : REDBYTES)];
     preload_kernargs(g);
-    const int n_panels = g.NT >> 2, G = g.ws_G;
-    const WsId id = ws_id(n_panels, G);
+    const int n_panels = (g.NT >> 2) * KSPLIT, G = g.ws_G;
+    WsId id = ws_id(n_panels, G);
+    const int kpart = KSPLIT > 1 ? id.panel % KSPLIT : 0;      // (the parts of a column panel are neighbours: same XCD, same group of row blocks)
+    if constexpr (KSPLIT > 1) id.panel /= KSPLIT;
     const int MB = (g.M + BM - 1) / BM;
     if constexpr (EPI == EPI_PARTIAL) {
         if (!id.work) {
@@ -364,8 +371,8 @@ __global__ __launch_bounds__(256, 1) void k_ws2(const GemmArgs g) {
         const int nt = id.panel * 4 + ct * 2 + (l31 >> 4);
 #pragma unroll
         for (int s = 0; s < KW16; ++s) {
-            const int ks = wave * KW16 + s;                        // k16 step of the whole K range
-            wf[ct][s] = wbase[((size_t)nt * KB + (ks >> 1)) * 64 + (2 * (ks & 1) + lhi) * 16 + (lane & 15)];
+            const int ks = kpart * 4 * KW16 + wave * KW16 + s;     // k16 step of the whole K range
+            wf[ct][s] = wbase[((size_t)nt * KBTOT + (ks >> 1)) * 64 + (2 * (ks & 1) + lhi) * 16 + (lane & 15)];
         }
     }
     // ---- the 2 output quads this wave finishes: column tile wave >> 1, registers 8 (wave & 1) .. + 7
@@ -375,12 +382,17 @@ __global__ __launch_bounds__(256, 1) void k_ws2(const GemmArgs g) {
     for (int j = 0; j < 2; ++j)
         pbias[j] = EPI == EPI_RESID ? *(const f32x4*)(g.bias + id.panel * 64 + ct_f * 32 + 8 * (q0 + j) + 4 * lhi) : (f32x4){0.f, 0.f, 0.f, 0.f};
     auto issue_a = [&](int mb, int buf) {
-        const char* src = (const char*)g.A + (size_t)mb * ABYTES;      // fragment-major: 2 row tiles x KB k-blocks, contiguous
+        const char* src = (const char*)g.A + (size_t)mb * (ABYTES * KSPLIT);      // fragment-major: 2 row tiles x KBTOT k-blocks, contiguous
         char* dst = lds + buf * ABYTES;
 #pragma unroll
         for (int c = 0; c < (ABYTES + 4095) / 4096; ++c) {
-            const int chunk = c * 4 + wave;
-            if (chunk * 1024 < ABYTES) glds16(src + chunk * 1024 + lane * 16, dst + chunk * 1024, lane);
+            const int chunk = c * 4 + wave;                        // one k-block (1 KB) of one row tile
+            if constexpr (KSPLIT == 1) {
+                if (chunk * 1024 < ABYTES) glds16(src + chunk * 1024 + lane * 16, dst + chunk * 1024, lane);
+            } else {                                               // this part's KB k-blocks of either row tile
+                const int rt = chunk / KB, kb = chunk - rt * KB;
+                if (chunk < 2 * KB) glds16(src + (size_t)((rt * KBTOT + kpart * KB + kb) * 1024 + lane * 16), dst + chunk * 1024, lane);
+            }
         }
     };
     int cur = 0;
@@ -430,7 +442,7 @@ __global__ __launch_bounds__(256, 1) void k_ws2(const GemmArgs g) {
                 v[e] = sum;
             }
             const int m = m0 + l31, n = id.panel * 64 + ct_f * 32 + 8 * (q0 + j) + 4 * lhi;
-            if (m < g.M) *(f32x4*)((float*)g.out + (size_t)m * g.ldo + n) = v + pbias[j] + pres[j];
+            if (m < g.M) *(f32x4*)((float*)g.out + ((size_t)kpart * g.MT * 16 + m) * g.ldo + n) = v + pbias[j] + pres[j];      // (EPI_PARTIAL: slab `kpart`)
         }
         if constexpr (!RED_IN_A) DSG_LDS_BARRIER();                // the separate partial-sum area is rewritten by the next block
         cur ^= 1;

@@ -245,6 +245,20 @@ def test_rows_kernel_set_at_dsgplus_widths(gpu, cfg):
     assert rel_l2(got[b:b + 1], w) < TOL_CHAIN["bf16"]
     with pytest.raises(NotImplementedError):
         _model(cfg, "fp32", max_batch=2).set_kernel_set("rows")
+    # batch 8 and 32 (round-5 verdict item 7: "oracle rows at batch 8 / 32"): the streamed pose embedding with K over two workgroups (k_ws2<PARTIAL, 17 / 18, 2>)
+    # on 8 / 38 full 32-row blocks and a partial one; at 32 clips the 302 row tiles need two rounds of the CUs
+    for Bn in (8, 32):
+        yn = synth_window_inputs(cfg, Bn, window=2, clip0=1, seed_pose_scale=0.2)
+        xn = np.random.RandomState(Bn).randn(Bn, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+        tn = (np.arange(Bn) * 31 + 5) % 1000
+        mn = _model(cfg, "bf16", max_batch=Bn).set_kernel_set("rows")
+        on = np.asarray(mn(xn, tn, yn))
+        assert mn.last_kernel_set() == "rows"
+        for b in (0, Bn - 1):
+            yb = {k: (v[b:b + 1] if v.shape[0] == Bn else v) for k, v in yn.items()}
+            e = rel_l2(on[b:b + 1], ref(xn[b:b + 1], [int(tn[b])], yb))
+            assert e < TOL_FWD["bf16"], (cfg.name, Bn, b, e)
+        del mn
     # two lanes x 8 clips: from 1200 rows the QKV projection is the weight-stationary streaming GEMM (k_ws at K = 384 / 512; at 512 only with several lanes) --
     # bit-identical to the block form a lane runs alone
     B2 = 8
