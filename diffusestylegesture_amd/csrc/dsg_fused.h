@@ -1209,13 +1209,14 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
     constexpr int XP = D * ES + 16;                  // OP: LDS pitch of a LayerNorm1 row
     constexpr bool BIG = OP && RT >= 4;              // 64-row blocks: `hidden` fills the LDS -- the LayerNorm1 rows alias its head (dead before phase 1
                                                      // writes: linear1's operand sits in registers by then) and the fp32 rows go through g.X1
+    constexpr bool X1MEM = BIG || (OP && RT == 2 && D >= 512);      // ... and (round 6) on 32-row blocks at latent_dim 512, where x1f (66 KB) does not fit next to `hidden` and the rows either: the fp32 rows through g.X1 only
     static_assert(!BIG || RT * 16 * XP <= RT * 16 * HP, "alias");
     constexpr int XA_LO = RT * 16 * XP;              // (bf16w2: ... and the LayerNorm1 rows)
     __shared__ __attribute__((aligned(16))) char xa_own[(OP && !BIG) ? P::AF * RT * 16 * XP : 16];
     char* const xa = BIG ? hid : xa_own;
     __shared__ __attribute__((aligned(16))) float vecs1[OP ? 3 : 1][OP ? D : 4];      // OP: b_o, LayerNorm1 scale / shift
     constexpr int X1P = D + 4;                       // OP: pitch (floats) of the fp32 LayerNorm1 rows parked in LDS across phase 1 (register budget)
-    __shared__ __attribute__((aligned(16))) float x1f[(OP && !BIG) ? RT * 16 * X1P : 4];
+    __shared__ __attribute__((aligned(16))) float x1f[(OP && !X1MEM) ? RT * 16 * X1P : 4];
     preload_kernargs(g);
     const int mb = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
@@ -1288,7 +1289,7 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
     constexpr int N0 = WO_RING ? DW * KD : 0;
     constexpr int N1 = FW * KD, N2 = KF * DW, NRING = RING > 0 ? RING : 1;
     static_assert(RING == 0 || (OP && RING <= N1), "ring");
-    static_assert(!WO_RING || (RING > 0 && RING <= N0 && RT == 1), "W_o in the ring: the 16-row form");
+    static_assert(!WO_RING || (RING > 0 && RING <= N0 && RT <= 2), "W_o in the ring: the 16- and 32-row forms");
     typename P::wfrag ring[NRING];
     const f32x4* wo_ring = (const f32x4*)g.Wo + lane;
     auto ring_load = [&](int ig) -> typename P::wfrag {      // ig: index in the whole stream [W_o | W1 | W2]
@@ -1353,19 +1354,22 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
             if (r0 > 0) DSG_LDS_BARRIER();                    // every wave has read the previous half out of the stage
             share_a(r0);
 #pragma unroll
-            for (int kb = 0; kb < KD; ++kb)
-#pragma unroll
-                for (int rt = r0; rt < r0 + RH; ++rt)
+            for (int kb = 0; kb < KD; ++kb) {
+                if constexpr (WO_RING) {      // (RH == RT <= 2: a slot is consumed by the row tiles side by side; what follows W_o in the stream is W1)
 #pragma unroll
                     for (int t = 0; t < DW; ++t) {
-                        if constexpr (WO_RING) {
-                            const int i = kb * DW + t;
-                            acc1[rt][t] = P::mma_w(ring[i % NRING], af[rt][kb], acc1[rt][t]);
-                            ring[i % NRING] = ring_load(i + RING);      // (RT == 1: the slot is consumed; what follows W_o in the stream is W1)
-                        } else {
-                            acc1[rt][t] = P::mma_w(wof[t][kb], af[rt][kb], acc1[rt][t]);      // D[n 4lg+r][row lr]
-                        }
+                        const int i = kb * DW + t;
+#pragma unroll
+                        for (int rt = r0; rt < r0 + RH; ++rt) acc1[rt][t] = P::mma_w(ring[i % NRING], af[rt][kb], acc1[rt][t]);
+                        ring[i % NRING] = ring_load(i + RING);
                     }
+                } else {
+#pragma unroll
+                    for (int rt = r0; rt < r0 + RH; ++rt)
+#pragma unroll
+                        for (int t = 0; t < DW; ++t) acc1[rt][t] = P::mma_w(wof[t][kb], af[rt][kb], acc1[rt][t]);      // D[n 4lg+r][row lr]
+                }
+            }
             if (r0 + RH < RT) {                               // (64-row blocks: the next two row tiles' attention rows and residual)
                 load_a(r0 + RH);
 #pragma unroll
@@ -1432,7 +1436,7 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
                 P::store4_a((elem*)(xa + (rt * 16 + lr) * XP) + n, XA_LO, y);
                 // linear2's residual: read back by the same lane after phase 2
                 // (64-row blocks: through g.X1, un-clamped and unconditional -- the row buffers are padded past the last 64-row block)
-                if constexpr (BIG) *(f32x4*)((char*)g.X1 + (size_t)(((unsigned)(m0 + rt * 16 + lr) * D + n) * 4u)) = y;
+                if constexpr (X1MEM) *(f32x4*)((char*)g.X1 + (size_t)(((unsigned)(m0 + rt * 16 + lr) * D + n) * 4u)) = y;
                 else *(f32x4*)(x1f + (rt * 16 + lr) * X1P + n) = y;
             }
         }
@@ -1484,7 +1488,7 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
                 P::store4_a((elem*)(hid + (rt * 16 + lr) * HP) + nt * 16 + 4 * lg, HID_LO, y);
             }
         }
-        if constexpr (BIG) {               // (64-row blocks: the fp32 LayerNorm1 rows come back from the padded X1 rows, as in the plain form)
+        if constexpr (X1MEM) {               // (64-row blocks: the fp32 LayerNorm1 rows come back from the padded X1 rows, as in the plain form)
             int lr_late = lr;
 #ifndef DSG_EMU
             asm volatile("" : "+v"(lr_late));
@@ -1549,18 +1553,18 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
                 for (int t = 0; t < DW; ++t) wb2[buf][k][t] = w2[((size_t)(wave * DW + t) * KF + c * KC + k) * 64];
         };
         load2(0, 0);
-        if constexpr ((LATE_R && !OP) || BIG) {      // (8 waves: the residual rows are requested only now -- the register budget of phase 1)
+        if constexpr ((LATE_R && !OP) || X1MEM) {      // (8 waves: the residual rows are requested only now -- the register budget of phase 1)
             int lr_late = lr;
-            if constexpr (BIG) {
+            if constexpr (X1MEM) {
     #ifndef DSG_EMU
                 asm volatile("" : "+v"(lr_late));      // opaque: the row offsets are RE-computed here -- kept live across phase 1 they were what spilled
     #endif
             }
     #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                const unsigned mr = BIG ? (unsigned)(m0 + rt * 16 + lr_late) : (unsigned)min(m0 + rt * 16 + lr_late, g.M - 1);
+                const unsigned mr = X1MEM ? (unsigned)(m0 + rt * 16 + lr_late) : (unsigned)min(m0 + rt * 16 + lr_late, g.M - 1);
     #pragma unroll
-                for (int t = 0; t < DW; ++t) pr[rt][t] = lda16<P>(BIG ? (const float*)g.X1 : g.R, (size_t)((mr * D + (wave * DW + t) * 16 + 4 * lg) * 4u));
+                for (int t = 0; t < DW; ++t) pr[rt][t] = lda16<P>(X1MEM ? (const float*)g.X1 : g.R, (size_t)((mr * D + (wave * DW + t) * 16 + 4 * lg) * 4u));
             }
         }
         DSG_LOADS_ISSUED();
@@ -1594,7 +1598,7 @@ __global__ __launch_bounds__(64 * NW) void k_ffn(const FfnArgs g) {      // RING
 #pragma unroll
         for (int t = 0; t < DW; ++t) {
             const f32x4 pb = *(const f32x4*)(&vecs[0][(wave * DW + t) * 16 + 4 * lg]);
-            if constexpr (OP && !BIG) pr[rt][t] = *(const f32x4*)(x1f + (rt * 16 + lr) * X1P + (wave * DW + t) * 16 + 4 * lg);
+            if constexpr (OP && !X1MEM) pr[rt][t] = *(const f32x4*)(x1f + (rt * 16 + lr) * X1P + (wave * DW + t) * 16 + 4 * lg);
             acc[rt][t] = acc[rt][t] + pb + pr[rt][t];
             sm += (acc[rt][t][0] + acc[rt][t][1]) + (acc[rt][t][2] + acc[rt][t][3]);
         }

@@ -964,6 +964,7 @@ struct KernelSel {
     bool ffn = false;           // STREAM (round 4): linear1 + GELU + linear2 + residual + LayerNorm2 in one kernel (k_ffn); QKV of the next layer
                                 // and the pose head then read normalised rows: direct streaming GEMMs, no k_ln_frag
     bool ffn16_wide = false;    // ROWS at the DSG+ widths (round 6): direct QKV GEMM + k_attn + k_ffn<OP> on 16-row tiles
+    bool ffn_rt2w = false;      // ... with k_ffn<OP> on 32-row blocks: >= 3 lanes whose row tiles together exceed one round of the CUs
     bool ffn16 = false;         // ROWS (round 6): k_ffn on 16-row tiles (one workgroup per row tile), behind k_clip_attn; everything else as BLOCK
     bool ffn_rt4 = false;       // ... on 64-row blocks: 4 lanes x >= 4000 token rows (4 x 64 clips: 981 -> 903 us per step of the 4 lanes; 1 x 64: 376 -> 432,
                                 // 4 x 16: 334 -> 392, 4 x 32 even -- profiles/r04_y2_sweep_ffn_rt4_*.log).  Bit-identical to the 32-row form.
@@ -1109,6 +1110,11 @@ static int select_kernels(const dsg_handle* h, int B, KernelSel& k) {
     k.attn_op = !k.lat && (have_attn_op_narrow(h) || (k.blk && have_attn_op_wide(h)) || (k.ffn16 && rows_w2_ok(h)));
     k.ffn16_wide = k.ffn16 && rows_wide_ok(h);
     if (k.ffn16_wide) {
+#if defined(DSG_X_FFN_RT2W)      // (A/B: 0 never, 1 always)
+        k.ffn_rt2w = DSG_X_FFN_RT2W != 0;
+#else
+        k.ffn_rt2w = h->lanes_now >= 3 && h->lanes_now * cdiv(B * h->ntok, 16) > 256;
+#endif
         if (h->cfgB > 0) return fail(DSG_E_NOT_IMPLEMENTED, "kernel set ROWS at the DSG+ widths: no fused guidance (BLOCK has it)");
         k.attn_op = false;      // k_attn writes the attention rows, k_ffn<OP> does out_proj + LayerNorm1
     }
@@ -1683,7 +1689,14 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                 a.W1 = ly.W1; a.b1 = ly.b1; a.W2 = ly.W2; a.b2 = ly.b2; a.ln_g = ly.g2; a.ln_b = ly.be2; a.Xn = h->Xn; a.Xa = h->X0a; a.M = M; a.MT = MT;
                 a.A = h->attn; a.R = l == 0 ? h->X0 : h->Xn; a.Wo = ly.Wo; a.bo = ly.bo; a.ln1_g = ly.g1; a.ln1_b = ly.be1; a.X1 = h->X1;
                 // latent_dim 384: W_o (36 fragments per wave) waits in registers as at the ZEGGS widths; 512: 64 fragments do not fit -- W_o leads the weight ring
-                if (D == 384) CHK((step_launch<&k_ffn<P, 6, 16, 1, 8, 2, true, true, 24>>(h, dim3(MT), dim3(512), a)));
+                // Round 6: with >= 3 lanes whose row tiles together need more than one round of the 256 CUs, 32-row blocks -- W_o | W1 | W2 (1.8 / 2.5 MB) streamed once
+                // per 32 rows; W_o leads the ring at both widths (20 / 12 slots: 250 VGPRs), at 512 the fp32 LayerNorm1 rows wait in X1 instead of the LDS.
+                // Bit-identical to the 16-row form.  BEAT 4 x 16 clips 946 -> 825 us per step, 4 x 8: 542 -> 516; 1 x 16: 375 -> 412, 4 x 4: 375 -> 398, 2 x 16 even
+                // (profiles/r06_dj_*)
+                if (ks.ffn_rt2w) {
+                    if (D == 384) CHK((step_launch<&k_ffn<P, 6, 16, 2, 8, 2, true, true, 20, true>>(h, dim3(cdiv(MT, 2)), dim3(512), a)));
+                    else CHK((step_launch<&k_ffn<P, 8, 16, 2, 8, 2, true, true, 12, true>>(h, dim3(cdiv(MT, 2)), dim3(512), a)));
+                } else if (D == 384) CHK((step_launch<&k_ffn<P, 6, 16, 1, 8, 2, true, true, 24>>(h, dim3(MT), dim3(512), a)));
                 else CHK((step_launch<&k_ffn<P, 8, 16, 1, 8, 2, true, true, 24, true>>(h, dim3(MT), dim3(512), a)));
                 continue;
             }

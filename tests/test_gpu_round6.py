@@ -259,14 +259,15 @@ def test_rows_kernel_set_at_dsgplus_widths(gpu, cfg):
             e = rel_l2(on[b:b + 1], ref(xn[b:b + 1], [int(tn[b])], yb))
             assert e < TOL_FWD["bf16"], (cfg.name, Bn, b, e)
         del mn
-    # two lanes x 8 clips: from 1200 rows the QKV projection is the weight-stationary streaming GEMM (k_ws at K = 384 / 512; at 512 only with several lanes) --
-    # bit-identical to the block form a lane runs alone
-    B2 = 8
+    # four lanes x 8 clips: from 1200 rows the QKV projection is the weight-stationary streaming GEMM (k_ws at K = 384 / 512; at 512 only with several lanes), and with
+    # >= 3 lanes whose row tiles together exceed one round of the CUs (4 x 76 = 304) k_ffn<OP> runs on 32-row blocks (W_o leading the weight ring at both widths, at 512
+    # the fp32 LayerNorm1 rows through X1) -- bit-identical to the forms a lane runs alone
+    B2, NL = 8, 4
     m8 = _model(cfg, "bf16", max_batch=B2).set_kernel_set("rows")
-    lanes = [m8, m8.clone()]
+    lanes = [m8] + [m8.clone() for _ in range(NL - 1)]
     shape2 = (B2, cfg.njoints, 1, cfg.n_poses)
-    ys = [{"y": synth_window_inputs(cfg, B2, window=w, clip0=B2 * w, seed_pose_scale=0.2)} for w in range(2)]
-    multi = d.manual_seed(9, 0).p_sample_loop_multi(lanes, shape2, ys, seeds=[9, 9], stream_ids=[0, 1], skip_timesteps=990)
-    for i in range(2):
+    ys = [{"y": synth_window_inputs(cfg, B2, window=w, clip0=B2 * w, seed_pose_scale=0.2)} for w in range(NL)]
+    multi = d.manual_seed(9, 0).p_sample_loop_multi(lanes, shape2, ys, seeds=[9] * NL, stream_ids=list(range(NL)), skip_timesteps=990)
+    for i in range(NL):
         alone = d.manual_seed(9, i).p_sample_loop(lanes[i], shape2, clip_denoised=False, model_kwargs=ys[i], skip_timesteps=990)
         assert lanes[i].last_kernel_set() == "rows" and np.array_equal(np.asarray(multi[i]), np.asarray(alone)), (cfg.name, i)
