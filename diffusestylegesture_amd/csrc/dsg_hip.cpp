@@ -1046,7 +1046,8 @@ static int auto_kernel_set(const dsg_handle* h, int B, int lanes) {
         // (round 6, DSG+ widths: ROWS -- direct QKV + k_attn + k_ffn<OP> on 16-row tiles -- from 9 clips while the row tiles fit the CUs in one round: BEAT 1 x 16
         //  526 -> 443 us per step, 1 x 24: 701 -> 556, 1 x 26: 806 -> 594, 1 x 8: 370 -> 346; TWH 1 x 16: 609 -> 524, 1 x 24: 835 -> 660, 1 x 8: 417 -> 410; below: BLOCK
         //  (BEAT 1 x 6: 297 vs 305, TWH 1 x 6: 326 vs 366) -- profiles/r06_da_*, r06_db_*)
-        if (rows_wide_ok(h) && h->cfgB == 0 && rows >= 1300 && MT <= 256) return DSG_KSET_ROWS;
+        //  (... and past one round of the CUs as well: BEAT 1 x 32 clips 702 vs 844 us BLOCK, 1 x 48: 822 vs 1179; TWH 1 x 32: 925 vs 1058 -- profiles/r06_dm_*)
+        if (rows_wide_ok(h) && h->cfgB == 0 && rows >= 1300) return DSG_KSET_ROWS;
         if (ffn_split_wide(h) && h->prec == DSG_PREC_BF16 && (h->D == 384 || h->D == 512) && h->env_ffn_split != 0 && rows >= 600) return DSG_KSET_BLOCK;
         // (round 6, bf16 ZEGGS widths: BLOCK from 6 clips -- 1 x 6: 177.6 vs 190.1 TILE, 1 x 5: 176.4 vs 161.6, 1 x 4: 173.9 vs 157.4)
         return rows >= (s_ok ? 500 : 1000) ? DSG_KSET_BLOCK : DSG_KSET_TILE;
@@ -1055,7 +1056,7 @@ static int auto_kernel_set(const dsg_handle* h, int B, int lanes) {
     if (s_ok && rows >= 250 && lanes * rows >= 1000 && lanes * MT <= 300) return DSG_KSET_ROWS;
     // (DSG+ widths with several lanes: ROWS from 4 clips per lane and 16 over all lanes -- BEAT 4 x 4: 399 vs 405, 2 x 8: 412 vs 445, 4 x 8: 627 vs 699; TWH 4 x 4: 509 vs 518,
     //  2 x 8: 514 vs 549, 4 x 8: 794 vs 949; below: BLOCK -- 4 x 3: 342 vs 363, 2 x 4: 297 vs 304, 4 x 2: 297 vs 319)
-    if (rows_wide_ok(h) && h->cfgB == 0 && rows >= 600 && lanes * rows >= 2400 && MT <= 256) return DSG_KSET_ROWS;
+    if (rows_wide_ok(h) && h->cfgB == 0 && rows >= 600 && lanes * rows >= 2400) return DSG_KSET_ROWS;
     if (B <= 1 && latency_set_ok(h) && h->prec != DSG_PREC_FP32) return DSG_KSET_LATENCY;
     // (2 x 4: BLOCK 178.1 vs ROWS 180.5; 4 x 2: TILE 179.4 vs BLOCK 183.3; 2 x 3: 175.1 = 173.8)
     return rows >= (s_ok ? 250 : 300) ? DSG_KSET_BLOCK : DSG_KSET_TILE;

@@ -27,6 +27,11 @@ $B --config twh --steps 1 > $O/${TAG}_bench_twh.log 2>&1
 $B --config beat --precision bf16w2 --steps 1 --warmup 0 > $O/${TAG}_bench_beat_bf16w2.log 2>&1
 $B --config beat --clips-per-gpu 16 --steps 1 --warmup 1 > $O/${TAG}_bench_beat_16clips_l4_b4.log 2>&1
 $B --config twh --clips-per-gpu 16 --steps 1 --warmup 1 > $O/${TAG}_bench_twh_16clips_l4_b4.log 2>&1
+for c in beat twh; do      # DSG+ with clips in flight (round 6: ROWS at latent_dim 384 / 512)
+  $B --config $c --clips-per-gpu 32 --lanes 4 --steps 1 --warmup 1 > $O/${TAG}_bench_${c}_32clips_l4_b8.log 2>&1
+  $B --config $c --clips-per-gpu 64 --lanes 4 --steps 1 --warmup 1 > $O/${TAG}_bench_${c}_64clips_l4_b16.log 2>&1
+  python tools/aql_timeline.py --config $c --batch 16 --kset rows --steps 300 --first 100 --n 16 --out $O/${TAG}_aql_step_timeline_${c}_b16_rows.json > /dev/null 2>&1
+done
 $B --sub-records off --precision bf16w2 --steps 2 --warmup 1 > $O/${TAG}_bench_bf16w2.log 2>&1
 $B --sub-records off --precision bf16w2 --clips-per-gpu 16 --lanes 1 --steps 1 --warmup 1 > $O/${TAG}_bench_bf16w2_16clips_lockstep.log 2>&1
 $B --sub-records off --precision bf16w2 --clips-per-gpu 16 --steps 1 --warmup 1 > $O/${TAG}_bench_bf16w2_16clips_l4_b4.log 2>&1
@@ -51,6 +56,8 @@ bash tools/measure_traffic.sh $TAG 64 stream 20 > $O/${TAG}_traffic_b64.txt 2>&1
 bash tools/prof.sh ${TAG}_b1 latency:1x1:hip 100 > $O/${TAG}_prof_b1.txt 2>&1
 bash tools/prof.sh ${TAG}_b16 rows:1x16:hip 50 > $O/${TAG}_prof_b16.txt 2>&1
 bash tools/prof.sh ${TAG}_b64_stream stream:1x64:hip 30 > $O/${TAG}_prof_b64_stream.txt 2>&1
+bash tools/prof.sh ${TAG}_beat_b16_rows rows:1x16:hip 30 --config beat > $O/${TAG}_prof_beat_b16_rows.txt 2>&1
+bash tools/prof.sh ${TAG}_twh_b16_rows rows:1x16:hip 30 --config twh > $O/${TAG}_prof_twh_b16_rows.txt 2>&1
 rm -rf $O/pmc_f_$TAG $O/pmc_w_$TAG
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f_$TAG -o z -- python tools/step_timing.py --steps 100 --reps 1 --spg=-1 > $O/${TAG}_pmc_f.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w_$TAG -o z -- python tools/step_timing.py --steps 100 --reps 1 --spg=-1 > $O/${TAG}_pmc_w.log 2>&1
