@@ -964,6 +964,7 @@ struct KernelSel {
     bool ffn = false;           // STREAM (round 4): linear1 + GELU + linear2 + residual + LayerNorm2 in one kernel (k_ffn); QKV of the next layer
                                 // and the pose head then read normalised rows: direct streaming GEMMs, no k_ln_frag
     bool ffn16_wide = false;    // ROWS at the DSG+ widths (round 6): direct QKV GEMM + k_attn + k_ffn<OP> on 16-row tiles
+    bool clip_w = false;        // ... with k_clip_attn_w instead of the QKV GEMM + k_attn
     bool ffn_rt2w = false;      // ... with k_ffn<OP> on 32-row blocks: >= 3 lanes whose row tiles together exceed one round of the CUs
     bool ffn16 = false;         // ROWS (round 6): k_ffn on 16-row tiles (one workgroup per row tile), behind k_clip_attn; everything else as BLOCK
     bool ffn_rt4 = false;       // ... on 64-row blocks: 4 lanes x >= 4000 token rows (4 x 64 clips: 981 -> 903 us per step of the 4 lanes; 1 x 64: 376 -> 432,
@@ -1111,6 +1112,9 @@ static int select_kernels(const dsg_handle* h, int B, KernelSel& k) {
     k.attn_op = !k.lat && (have_attn_op_narrow(h) || (k.blk && have_attn_op_wide(h)) || (k.ffn16 && rows_w2_ok(h)));
     k.ffn16_wide = k.ffn16 && rows_wide_ok(h);
     if (k.ffn16_wide) {
+#if !defined(DSG_X_NO_CLIP_W)      // (A/B: make dev DEVFLAGS=-DDSG_X_NO_CLIP_W)
+        k.clip_w = h->H == 4 && h->Tp == 160;
+#endif
 #if defined(DSG_X_FFN_RT2W)      // (A/B: 0 never, 1 always)
         k.ffn_rt2w = DSG_X_FFN_RT2W != 0;
 #else
@@ -1286,6 +1290,8 @@ static int launch_ws(dsg_handle* h, GemmArgs g) {
         const dim3 grid1(ws_grid_x(P, g.ws_G) + 8);
         if (K == 256) return step_launch<&k_ws<EPI, 16, true>>(h, grid1, dim3(256), g);
         if (K == 128) return step_launch<&k_ws<EPI, 8, true>>(h, grid1, dim3(256), g);
+        if (K == 384) return step_launch<&k_ws<EPI, 24, true>>(h, grid1, dim3(256), g);      // (round 6: the DSG+ widths, one workgroup per CU)
+        if (K == 512) return step_launch<&k_ws<EPI, 32, true>>(h, grid1, dim3(256), g);
     } else {
         if constexpr (EPI == EPI_QKV) {      // (round 6: the DSG+ widths, one workgroup per CU)
             if (K == 384 || K == 512) {
@@ -1354,6 +1360,11 @@ static int launch_gemm_w(dsg_handle* h, const GemmArgs& g, const KernelSel& ks) 
             if (ks.ffn16_wide && g.a_frag && g.M >= 1200 && (g.D == 384 || h->lanes_now >= 2)) return launch_ws<EPI>(h, g);
         }
         // (the streaming pose head below the STREAM sizes loses: BLOCK 1 x 16 clips 207.5 -> 211.6 us per step, 4 x 4: 197.5 -> 205.4 -- profiles/r06_h_*, round 6)
+#ifdef DSG_X_WS_OUT_WIDE      // (A/B: the streaming pose head at the DSG+ widths; 1: with >= 3 lanes past one round of the CUs, 2: always)
+        if constexpr (EPI == EPI_OUT) {
+            if (ks.ffn16_wide && g.a_frag && (DSG_X_WS_OUT_WIDE == 2 || ks.ffn_rt2w)) return launch_ws<EPI>(h, g);
+        }
+#endif
     }
     if constexpr (sizeof(typename P::elem) == 2 && !P::W2 && PRO == PRO_LN && (EPI == EPI_QKV || EPI == EPI_OUT)) {
         if (ks.stream) return launch_ln_ws<EPI>(h, g);                    // STREAM: LayerNorm once per row, then the same streaming GEMM
@@ -1527,7 +1538,20 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
         const Layer& ly = h->layers[l];
         // (guidance: the last layer leaves pre2 to the two-pass pose head, i.e. it runs the round-3 feed-forward kernels, which read k_attn_op's rows)
         const bool clip_l = ks.clip_attn && (l < h->L - 1 || h->cfgB == 0);
-        if (!clip_l) {   // QKV projection (LayerNorm2 of the previous layer applied on read)
+        bool clip_w_done = false;
+        if constexpr (sizeof(typename P::elem) == 2 && !P::W2) {
+            if (ks.clip_w) {      // ROWS at the DSG+ widths (round 6): QKV slices + attention per (clip, head) -- k_clip_attn_w (dsg_stream.h); X0a holds the embedding output /
+                                  // LayerNorm2 of the previous layer, fragment-major
+                ClipAttnArgs a;
+                a.X = h->X0a; a.Wqkv = ly.Wqkv; a.bqkv = ly.bqkv; a.out = h->attn; a.B = B; a.ntok = ntok;
+                // latent_dim 384: ONE pass over the rows, three column tiles on waves 0 - 1 (144 weight registers fit: 236 VGPRs); 512: two passes (Q / K, then V in pairs)
+                // (384 in the two-pass form: 1 x 16 clips 371.3 vs 360.0 us per step, 4 x 16: 614 vs 604 -- profiles/r06_dq_*)
+                if (D == 384) CHK((step_launch<&k_clip_attn_w<6, 10, 4, true>>(h, dim3(4, B), dim3(512), a)));
+                else CHK((step_launch<&k_clip_attn_w<8, 10, 2, false>>(h, dim3(4, B), dim3(512), a)));
+                clip_w_done = true;
+            }
+        }
+        if (!clip_l && !clip_w_done) {   // QKV projection (LayerNorm2 of the previous layer applied on read)
             GemmArgs g = z;
             g.M = M; g.MT = MT; g.NT = 3 * D / 16; g.KBtot = D / KB; g.Wp = ly.Wqkv; g.bias = ly.bqkv;
             g.q = h->q; g.k = h->k; g.vt = h->vt;
@@ -1542,7 +1566,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                 CHK((launch_gemm_w<P, PRO_LN, EPI_QKV>(h, g, ks)));
             }
         }
-        if (!ks.attn_in_mid && !ks.attn_op) {   // attention
+        if (!ks.attn_in_mid && !ks.attn_op && !clip_w_done) {   // attention
             AttnArgs a;
             memset(&a, 0, sizeof(a));
             a.q = h->q; a.k = h->k; a.vt = h->vt; a.out = h->attn; a.B = B; a.H = h->H; a.ntok = ntok; a.Tp = h->Tp;

@@ -449,4 +449,289 @@ __global__ __launch_bounds__(256, 1) void k_ws2(const GemmArgs g) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// k_clip_attn_w (round 6, ROWS at the DSG+ widths): k_clip_attn (dsg_fused.h) at latent_dim 384 / 512 -- the attention half of an encoder layer per
+// (clip, head): the workgroup projects its head's Q / K / V from the clip's rows and runs the self-attention of all NKT query tiles on them; the QKV GEMM
+// and k_attn disappear as dispatches, Q / K / V^T never reach memory.  What differs from the narrow kernel, because nothing fits as laid out there:
+//   * the clip's rows (10 row tiles x 12 / 16 KB) pass through the LDS in chunks of XR row tiles, double-buffered with global -> LDS loads (no registers):
+//     the next chunk is in flight while a chunk is projected;
+//   * 8 waves, column tile t of the head's [Q | K | V] order by wave t % 8.  latent_dim 384 (ONEP): ONE pass over the rows, 18 tiles = three on waves 0 - 1, two
+//     on the others (144 weight registers: 236 VGPRs).  latent_dim 512: 24 tiles x 16 fragments would be 192 weight registers next to the A fragments, so TWO
+//     passes with two tiles per wave (128 registers): pass A the 16 Q / K tiles, pass B the 8 V tiles in pairs on waves 0 - 3 (one A fragment from the LDS per
+//     two MFMAs, as in pass A; one tile per wave would make the pass LDS-bound) with the chunk's two row tiles side by side (four accumulation chains: the pass
+//     runs one wave per SIMD).  Every active wave reads ALL of the rows from the LDS once per pass -- 8 x 120 / 160 KB at 128 B / clk is what bounds a pass;
+//   * EVERY tile is computed as W . X^T (a lane holds 4 consecutive dims of one token) -- one operand order -- and a V tile is transposed when it moves
+//     into V^T (four 2-byte LDS stores per row tile instead of one 8-byte store); the V tiles wait in registers, rounded, until every wave is done with the
+//     rows: V^T takes their place;
+//   * query tiles qt = wave, wave + 8 (10 query tiles on 8 waves); the K / V^T fragment reads of the attention are fenced per two key / dim tiles (hoisted
+//     above their MFMAs they were 120 - 160 registers: 228 / 552 bytes of scratch in the first build).
+// Bit-identical to the QKV GEMM + k_attn path.  Measured (profiles/r06_dn_*, r06_dq_*): the kernel is 17 / 24 us at 16 clips -- what the QKV GEMM + k_attn + their
+// boundary took -- on 64 CUs instead of 192 + 256: BEAT 1 x 16 clips 374.7 -> 360.0 us per step, 4 x 16: 827 -> 604; TWH 1 x 16: 492 -> 475, 4 x 16: 1194 -> 871.
+// Same rounding points as k_attn on the QKV GEMM's output (Q / K / V and P in bf16, softmax in fp32, 1 / sum applied to the fp32 P V).
+// Reference arithmetic: nn.MultiheadAttention of torch's TransformerEncoderLayer (BEAT-TWH-main/model/mdm.py:134-146), in_proj + softmax(QK^T/sqrt(hd))V.
+// ---------------------------------------------------------------------------------------------------------
+template <int NJ, int CW, int KD>      // NJ column tiles against one row tile: the A fragments four k-blocks at a time, the next four in flight
+__device__ __forceinline__ void clip_w_proj(const f32x4 (&wf)[CW][KD], const f32x4 (*xrow)[64], int lane, f32x4 (&acc)[CW]) {
+    static_assert(KD % 4 == 0, "k-blocks in groups of 4");
+    f32x4 a[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[0][i] = xrow[i][lane];
+#pragma unroll
+    for (int kg = 0; kg < KD / 4; ++kg) {
+        if (kg + 1 < KD / 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[(kg + 1) & 1][i] = xrow[4 * (kg + 1) + i][lane];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] = PBF16::mma(wf[j][4 * kg + i], a[kg & 1][i], acc[j]);      // D[dim = 4 lg + r][token = lr]
+        DSG_LOADS_ISSUED();
+    }
+}
+// ... two column tiles against TWO row tiles side by side: four independent accumulation chains (pass B of the two-pass form: one wave per SIMD)
+template <int KD>
+__device__ __forceinline__ void clip_w_proj2(const f32x4 (&wf)[2][KD], const f32x4 (*xrow0)[64], const f32x4 (*xrow1)[64], int lane, f32x4 (&acc0)[2], f32x4 (&acc1)[2]) {
+    f32x4 a[2][2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { a[0][0][i] = xrow0[i][lane]; a[0][1][i] = xrow1[i][lane]; }
+#pragma unroll
+    for (int kg = 0; kg < KD / 2; ++kg) {
+        if (kg + 1 < KD / 2) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { a[(kg + 1) & 1][0][i] = xrow0[2 * (kg + 1) + i][lane]; a[(kg + 1) & 1][1][i] = xrow1[2 * (kg + 1) + i][lane]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc0[j] = PBF16::mma(wf[j][2 * kg + i], a[kg & 1][0][i], acc0[j]);
+                acc1[j] = PBF16::mma(wf[j][2 * kg + i], a[kg & 1][1][i], acc1[j]);
+            }
+        DSG_LOADS_ISSUED();
+    }
+}
+
+template <int DT, int NKT, int XR, bool ONEP>      // D = 64 DT, H = 4, hd = 16 DT, Tp = 16 NKT; XR row tiles per LDS chunk; ONEP: one pass over the rows (three column tiles per wave fit)
+__global__ __launch_bounds__(512, 1) void k_clip_attn_w(const ClipAttnArgs g) {
+    DSG_TL_SCOPE();
+    typedef PBF16 P;
+    typedef P::elem elem;
+    constexpr int NW = 8;
+    constexpr int D = DT * 64, HD = DT * 16;
+    constexpr int KD = D / P::KB, KDH = HD / P::KB, ND = HD / 16, NVF = NKT / 2;
+    constexpr int CT = 3 * ND, NP = ND / 2;          // column tiles of the head; V tile pairs (pass B)
+    constexpr int CW = ONEP ? 3 : 2;
+    constexpr int NCH = (NKT + XR - 1) / XR, CF = XR * KD, CFW = (CF + NW - 1) / NW;
+    static_assert(NKT % 2 == 0 && HD % P::KB == 0 && ND % 2 == 0 && 2 * ND <= 2 * NW && NP <= NW && CT <= 3 * NW && CT > 2 * NW, "shape");
+    static_assert(ONEP || XR == 2, "two passes: pass B takes the row tiles in pairs");
+    __shared__ __attribute__((aligned(16))) f32x4 xs[2][CF][64];
+    __shared__ __attribute__((aligned(16))) f32x4 qs[NKT * KDH][64];
+    __shared__ __attribute__((aligned(16))) f32x4 ks[NKT * KDH][64];
+    f32x4 (* const vs)[64] = &xs[0][0];
+    static_assert(ND * NVF <= 2 * CF, "V^T fits in the retired rows");
+    typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+    preload_kernargs(g);
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = wave_id(), lr = lane & 15, lg = lane >> 4;
+    // ---- step i of the row stream (chunk i % NCH) -> LDS buffer i & 1: fragment f = (row tile, k-block) by wave f % 8; a lane fetches the 16 bytes
+    //      of ITS row (the clip's rows start anywhere in the flattened row tiles); rows past the clip: its last row (masked / dropped later)
+    auto issue_x = [&](int i) {
+        const int c = i % NCH;
+#pragma unroll
+        for (int k = 0; k < CFW; ++k) {
+            const int f = wave + NW * k, rl = f / KD, kb = f - rl * KD, rt = c * XR + rl;
+            if (f < CF && rt < NKT) {
+                const int m = b * g.ntok + min(rt * 16 + lr, g.ntok - 1);
+                glds16((const char*)g.X + (size_t)qk_off<P>(m, kb * P::KB + P::E * lg, KD) * sizeof(elem), &xs[i & 1][f][0], lane);
+            }
+        }
+    };
+    issue_x(0);
+    const f32x4* wq = (const f32x4*)g.Wqkv + lane;
+    f32x4 wf[CW][KD];
+    f32x4 pb[CW];
+    bf16x4v vkeep[NKT][ONEP ? 1 : 2];                // the wave's V tile(s), 4 dims of one token per row tile
+    // the wave's column tiles in the head's [Q | K | V] order (ND tiles each): packed in_proj column tile, weights, bias
+    auto load_tiles = [&](const int (&t)[CW]) {
+#pragma unroll
+        for (int j = 0; j < CW; ++j) {
+            const int which = t[j] / ND, d0 = (t[j] - which * ND) * 16;
+            const int nt = which * (D / 16) + h * ND + d0 / 16;
+#pragma unroll
+            for (int kb = 0; kb < KD; ++kb) wf[j][kb] = P::wload(wq, (size_t)nt * KD + kb);
+            pb[j] = *(const f32x4*)(g.bqkv + nt * 16 + 4 * lg);
+        }
+        DSG_LOADS_ISSUED();
+    };
+    int dv[2] = {0, 0};                              // first dim of the parked V tile(s) inside the head
+    bool vb = false;                                 // this wave holds V tiles
+    if constexpr (ONEP) {
+        // ---- one pass: tiles wave, wave + 8, wave + 16 (18 tiles: waves 0 - 1 three, the others two; at most one of them a V tile)
+        int t[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) t[j] = min(wave + NW * j, CT - 1);
+        const bool three = wave + 2 * NW < CT;
+        load_tiles(t);
+        DSG_TL_MARK(0);      // first chunk of rows + the wave's columns requested
+        const int jv = t[1] >= 2 * ND ? 1 : 2;       // slot of the V tile, if any
+        vb = t[1] >= 2 * ND || three;
+        dv[0] = (t[jv] - 2 * ND) * 16;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            glds_wait();
+            DSG_LDS_BARRIER();            // chunk c has landed for every wave; every wave is done with the other buffer
+            if (c + 1 < NCH) issue_x(c + 1);
+#pragma unroll
+            for (int rl = 0; rl < XR; ++rl) {
+                const int rt = c * XR + rl;
+                if (rt < NKT) {
+                    f32x4 acc[3] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+                    if (three) clip_w_proj<3, 3, KD>(wf, &xs[c & 1][rl * KD], lane, acc);
+                    else clip_w_proj<2, 3, KD>(wf, &xs[c & 1][rl * KD], lane, acc);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        if (j < 2 || three) {
+                            const int which = t[j] / ND, d0 = (t[j] - which * ND) * 16;
+                            const f32x4 y = acc[j] + pb[j];
+                            if (which < 2) P::store4((elem*)(which == 0 ? &qs[0][0] : &ks[0][0]) + qk_off<P>(rt * 16 + lr, d0 + 4 * lg, KDH), y);
+                            else vkeep[rt][0] = __builtin_convertvector(y, bf16x4v);      // (P::store4's rounding)
+                        }
+                    }
+                }
+            }
+        }
+        DSG_TL_MARK(1);      // projection done
+    } else {
+        // ---- pass A: Q / K tiles wave, wave + 8
+        const int ta[2] = {wave, min(wave + NW, 2 * ND - 1)};
+        const int nja = wave + NW < 2 * ND ? 2 : 1;
+        load_tiles(ta);
+        DSG_TL_MARK(0);      // first chunk of rows + the Q / K columns requested
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            glds_wait();
+            DSG_LDS_BARRIER();            // chunk c has landed for every wave; every wave is done with the other buffer
+            issue_x(c + 1);               // (the last one: chunk 0 again, for pass B)
+#pragma unroll
+            for (int rl = 0; rl < XR; ++rl) {
+                const int rt = c * XR + rl;
+                if (rt < NKT) {
+                    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+                    if (nja == 2) clip_w_proj<2, 2, KD>(wf, &xs[c & 1][rl * KD], lane, acc);
+                    else clip_w_proj<1, 2, KD>(wf, &xs[c & 1][rl * KD], lane, acc);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if (j < nja) {
+                            const int which = ta[j] / ND, d0 = (ta[j] - which * ND) * 16;
+                            P::store4((elem*)(which == 0 ? &qs[0][0] : &ks[0][0]) + qk_off<P>(rt * 16 + lr, d0 + 4 * lg, KDH), acc[j] + pb[j]);
+                        }
+                    }
+                }
+            }
+        }
+        DSG_TL_MARK(1);      // pass A done: Q / K of the head in LDS
+        // ---- pass B: V tiles in pairs (waves 0 .. NP - 1), the chunk's two row tiles side by side (four accumulation chains: one wave per SIMD)
+        vb = wave < NP;
+        const int tb[2] = {2 * ND + min(wave, NP - 1), 2 * ND + min(wave, NP - 1) + NP};
+        dv[0] = (tb[0] - 2 * ND) * 16; dv[1] = (tb[1] - 2 * ND) * 16;
+        if (vb) load_tiles(tb);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int i = NCH + c;
+            glds_wait();
+            DSG_LDS_BARRIER();
+            if (c + 1 < NCH) issue_x(i + 1);
+            if (vb) {
+                f32x4 acc0[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}}, acc1[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+                static_assert(NKT % 2 == 0, "pairs");
+                clip_w_proj2<KD>(wf, &xs[i & 1][0], &xs[i & 1][KD], lane, acc0, acc1);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    vkeep[2 * c][j] = __builtin_convertvector(acc0[j] + pb[j], bf16x4v);      // (P::store4's rounding)
+                    vkeep[2 * c + 1][j] = __builtin_convertvector(acc1[j] + pb[j], bf16x4v);
+                }
+            }
+        }
+    }
+    DSG_LDS_BARRIER();                                            // every wave is done with the rows: V^T moves in
+    if (vb) {
+#pragma unroll
+        for (int j = 0; j < (ONEP ? 1 : 2); ++j) {
+#pragma unroll
+            for (int rt = 0; rt < NKT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) *((__bf16*)&vs[0][0] + vt_off<P>(dv[j] + 4 * lg + r, rt * 16 + lr, NVF)) = vkeep[rt][j][r];
+        }
+    }
+    DSG_LDS_BARRIER();
+    DSG_TL_MARK(2);      // Q / K / V^T of the head in LDS
+    // ---- attention of query tiles wave, wave + 8 (k_attn on LDS operands)
+    const float scale = 1.0f / sqrtf((float)HD);
+#pragma unroll 1
+    for (int qt = wave; qt < NKT; qt += NW) {
+        f32x4 s[NKT], qf[KDH];
+#pragma unroll
+        for (int kb = 0; kb < KDH; ++kb) qf[kb] = qs[qt * KDH + kb][lane];
+#pragma unroll
+        for (int nt = 0; nt < NKT; ++nt) {
+            s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < KDH; ++kb) s[nt] = P::mma(ks[nt * KDH + kb][lane], qf[kb], s[nt]);   // D[key = 4 lg + r][query = lr]
+            if (nt & 1) DSG_LOADS_ISSUED();      // (two key tiles' fragments in flight: all NKT x KDH of them hoisted were 120 - 160 registers -- scratch)
+        }
+        float mx = -DSG_FLT_MAX;
+#pragma unroll
+        for (int nt = 0; nt < NKT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = nt * 16 + 4 * lg + r;
+                const float v = key < g.ntok ? s[nt][r] * scale : -DSG_FLT_MAX;
+                s[nt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NKT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = nt * 16 + 4 * lg + r;
+                const float pv = key < g.ntok ? P::exp_sm(s[nt][r] - mx) : 0.f;
+                s[nt][r] = pv;
+                sum += pv;
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        DSG_LOADS_ISSUED();
+        f32x4 pfr[NVF];
+#pragma unroll
+        for (int kb = 0; kb < NVF; ++kb) {
+            typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+            u16x8 pp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pp[e] = f2bf(s[2 * kb][e]); pp[4 + e] = f2bf(s[2 * kb + 1][e]); }
+            pfr[kb] = __builtin_bit_cast(f32x4, pp);
+        }
+        const int q = qt * 16 + lr;
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) {
+            f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < NVF; ++kb) o = P::mma(vs[dt * NVF + kb][lane], pfr[kb], o);     // D[dim = 4 lg + r][query = lr]
+            if (q < g.ntok) {
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = o[e] * inv;
+                P::store4_afrag((elem*)g.out, (size_t)qk_off<P>(b * g.ntok + q, h * HD + dt * 16 + 4 * lg, KD), y);      // the rounding point of the attention rows
+            }
+            if (dt & 1) DSG_LOADS_ISSUED();      // (two dim tiles' V^T fragments in flight)
+        }
+    }
+    DSG_TL_MARK(3);      // attention + stores issued
+}
+
 }  // namespace dsg

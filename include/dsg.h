@@ -89,8 +89,9 @@ enum {
                                streams a layer's W_o + W1 + W2 for its 16 rows: it pays while the row tiles of all lanes fit the 256 CUs in one
                                round -- 1000 .. 4000 token rows in one lane (12 .. 45 ZEGGS clips), fewer per lane with several lanes.  Same shapes
                                as STREAM, in bf16 and (without fused guidance) bf16w2.  At the DSG+ widths (bf16, latent_dim 384 / 512, 4 heads, ff 1024;
-                               no fused guidance): streamed pose embedding, then per layer the QKV GEMM + attention per (clip, head, query tile) + the same
-                               feed-forward kernel -- on 32-row blocks when >= 3 lanes together exceed one round of the CUs -- = 3 + 3L dispatches; from
+                               no fused guidance): streamed pose embedding, then per layer the attention half per (clip, head) (k_clip_attn_w: the rows pass
+                               through the LDS in chunks) + the same feed-forward kernel -- on 32-row blocks when >= 3 lanes together exceed one round of the
+                               CUs -- = 3 + 2L dispatches; from
                                9 BEAT / TWH clips in one lane, 4 per lane and 16 in all with several lanes.  DSG_E_NOT_IMPLEMENTED elsewhere */
 };
 enum { DSG_MODE_DDPM = 0, DSG_MODE_DDIM = 1 };
