@@ -1360,9 +1360,12 @@ static int launch_gemm_w(dsg_handle* h, const GemmArgs& g, const KernelSel& ks) 
             if (ks.ffn16_wide && g.a_frag && g.M >= 1200 && (g.D == 384 || h->lanes_now >= 2)) return launch_ws<EPI>(h, g);
         }
         // (the streaming pose head below the STREAM sizes loses: BLOCK 1 x 16 clips 207.5 -> 211.6 us per step, 4 x 4: 197.5 -> 205.4 -- profiles/r06_h_*, round 6)
-#ifdef DSG_X_WS_OUT_WIDE      // (A/B: the streaming pose head at the DSG+ widths; 1: with >= 3 lanes past one round of the CUs, 2: always)
+        // (... at the DSG+ widths it wins or is even everywhere in ROWS -- k_ws<OUT, 24 / 32, ONE>: 112 VGPRs + 32 AGPRs, the panel re-read per block: BEAT 1 x 16 clips
+        //  358.3 -> 353.8 us per step, 4 x 8: 440.9 -> 423.3, 4 x 16: 615.6 -> 568.3; TWH 1 x 16 even, 4 x 16: 878 -> 844 -- profiles/r06_ds_*; 32 x 32 x 16 MFMAs: the
+        //  pose head's last bits differ from the 16 x 16 tiles', so it belongs to the set, not to the lane count)
+#ifndef DSG_X_NO_WS_OUT_WIDE
         if constexpr (EPI == EPI_OUT) {
-            if (ks.ffn16_wide && g.a_frag && (DSG_X_WS_OUT_WIDE == 2 || ks.ffn_rt2w)) return launch_ws<EPI>(h, g);
+            if (ks.ffn16_wide && g.a_frag) return launch_ws<EPI>(h, g);
         }
 #endif
     }
