@@ -963,7 +963,7 @@ struct KernelSel {
     bool stream = false;        // STREAM: BLOCK with the weight-stationary persistent GEMMs of dsg_stream.h (LayerNorm + QKV, linear1, linear2, pose head)
     bool ffn = false;           // STREAM (round 4): linear1 + GELU + linear2 + residual + LayerNorm2 in one kernel (k_ffn); QKV of the next layer
                                 // and the pose head then read normalised rows: direct streaming GEMMs, no k_ln_frag
-    bool ffn16_wide = false;    // ROWS at the DSG+ widths (round 6): direct QKV GEMM + k_attn + k_ffn<OP> on 16-row tiles
+    bool ffn16_wide = false;    // ROWS at the DSG+ widths (round 6): k_clip_attn_w (or the direct QKV GEMM + k_attn) + k_ffn<OP> on 16-row tiles
     bool clip_w = false;        // ... with k_clip_attn_w instead of the QKV GEMM + k_attn
     bool ffn_rt2w = false;      // ... with k_ffn<OP> on 32-row blocks: >= 3 lanes whose row tiles together exceed one round of the CUs
     bool ffn16 = false;         // ROWS (round 6): k_ffn on 16-row tiles (one workgroup per row tile), behind k_clip_attn; everything else as BLOCK
@@ -1009,8 +1009,9 @@ static bool ffn_split_wide(const dsg_handle* h) {
     return h->prec == DSG_PREC_BF16 && have_attn_op_wide(h) && h->ff == 1024 && (h->D == 384 || h->D == 512);
 }
 static bool ffn_split_ok(const dsg_handle* h) { return stream_set_ok(h) || ffn_split_wide(h); }
-// ROWS at the DSG+ widths (round 6, bf16): no k_clip_attn there (the clip's rows do not fit the LDS next to Q / K / V) -- the direct QKV GEMM + k_attn feed
-// k_ffn<OP> on one 16-row tile (out_proj + LayerNorm1 as its prologue): no k_attn_op_w, no ff-split, no slabs, no slab-sum pass
+// ROWS at the DSG+ widths (round 6, bf16): k_clip_attn_w (dsg_stream.h: the clip's rows do not fit the LDS next to Q / K / V -- they pass through it in chunks; first
+// version: the direct QKV GEMM + k_attn) feeds k_ffn<OP> on one 16-row tile (out_proj + LayerNorm1 as its prologue): no k_attn_op_w, no ff-split, no slabs, no slab-sum
+// pass; streamed pose embedding (K over two workgroups) and pose head
 static bool rows_wide_ok(const dsg_handle* h) {
     return h->prec == DSG_PREC_BF16 && h->H == 4 && h->Tp == 160 && h->ff == 1024 && (h->D == 384 || h->D == 512);
 }
@@ -1048,7 +1049,9 @@ static int auto_kernel_set(const dsg_handle* h, int B, int lanes) {
         //  526 -> 443 us per step, 1 x 24: 701 -> 556, 1 x 26: 806 -> 594, 1 x 8: 370 -> 346; TWH 1 x 16: 609 -> 524, 1 x 24: 835 -> 660, 1 x 8: 417 -> 410; below: BLOCK
         //  (BEAT 1 x 6: 297 vs 305, TWH 1 x 6: 326 vs 366) -- profiles/r06_da_*, r06_db_*)
         //  (... and past one round of the CUs as well: BEAT 1 x 32 clips 702 vs 844 us BLOCK, 1 x 48: 822 vs 1179; TWH 1 x 32: 925 vs 1058 -- profiles/r06_dm_*)
-        if (rows_wide_ok(h) && h->cfgB == 0 && rows >= 1300) return DSG_KSET_ROWS;
+        //  (with k_clip_attn_w -- 24 us at latent_dim 512 whatever the batch -- BLOCK keeps 9 .. 12 TWH clips: 1 x 9: 417 vs 452 us, 1 x 12: 457 vs 466, 1 x 14: 551 vs 472;
+        //   BEAT 1 x 9: 356 vs 339 ROWS -- profiles/r06_dv_*)
+        if (rows_wide_ok(h) && h->cfgB == 0 && rows >= (h->D == 512 ? 1960 : 1300)) return DSG_KSET_ROWS;
         if (ffn_split_wide(h) && h->prec == DSG_PREC_BF16 && (h->D == 384 || h->D == 512) && h->env_ffn_split != 0 && rows >= 600) return DSG_KSET_BLOCK;
         // (round 6, bf16 ZEGGS widths: BLOCK from 6 clips -- 1 x 6: 177.6 vs 190.1 TILE, 1 x 5: 176.4 vs 161.6, 1 x 4: 173.9 vs 157.4)
         return rows >= (s_ok ? 500 : 1000) ? DSG_KSET_BLOCK : DSG_KSET_TILE;

@@ -92,7 +92,7 @@ enum {
                                no fused guidance): streamed pose embedding, then per layer the attention half per (clip, head) (k_clip_attn_w: the rows pass
                                through the LDS in chunks) + the same feed-forward kernel -- on 32-row blocks when >= 3 lanes together exceed one round of the
                                CUs -- = 3 + 2L dispatches; from
-                               9 BEAT / TWH clips in one lane, 4 per lane and 16 in all with several lanes.  DSG_E_NOT_IMPLEMENTED elsewhere */
+                               9 BEAT / 13 TWH clips in one lane, 4 per lane and 16 in all with several lanes.  DSG_E_NOT_IMPLEMENTED elsewhere */
 };
 enum { DSG_MODE_DDPM = 0, DSG_MODE_DDIM = 1 };
 

@@ -168,7 +168,8 @@ def test_local_attention_one_wave_form_is_bit_identical(emu_lib, monkeypatch):
 
 @pytest.mark.parametrize("name", ["beat", "twh"])
 def test_rows_kernel_set_at_dsgplus_widths(emu_lib, name):
-    """Round 6: ROWS at latent_dim 384 / 512 (direct QKV GEMM + k_attn + k_ffn<OP> on 16-row tiles; at 512 W_o leads the weight ring) -- one forward at batch 1 against
+    """Round 6: ROWS at latent_dim 384 / 512 (streamed pose embedding with K over two workgroups, k_clip_attn_w -- one pass over the rows at 384, two at 512 --, k_ffn<OP> on 16-row
+    tiles -- at 512 W_o leads the weight ring --, the streaming pose head k_ws<OUT, 24 / 32>) -- one forward at batch 1 against
     the oracle under the emulator (the GPU test has batch 16, batch independence and a chain)."""
     from oracle.mdm import MDMOracle
     cfg = C.CONFIGS[name]
@@ -180,4 +181,4 @@ def test_rows_kernel_set_at_dsgplus_widths(emu_lib, name):
     m.load_state_dict(sd)
     out = np.asarray(m(x, [417], y))
     assert m.last_kernel_set() == "rows" and rel_l2(out, ref(x, [417], y)) < 1.2e-2
-    assert [m.recommend_kernel_set(b, 1) for b in (8, 9, 27, 28, 48)] == ["block", "rows", "rows", "rows", "rows"]      # (past one round of the CUs too: 1 x 32 clips 702 vs 844 us BLOCK)
+    assert [m.recommend_kernel_set(b, 1) for b in (8, 9, 13, 27, 28, 48)] == ["block", "rows" if cfg.latent_dim == 384 else "block", "rows", "rows", "rows", "rows"]      # (past one round of the CUs too: 1 x 32 clips 702 vs 844 us BLOCK)

@@ -210,8 +210,9 @@ def test_local_attention_one_wave_form_is_bit_identical(gpu, monkeypatch):
 
 @pytest.mark.parametrize("cfg", [C.BEAT, C.TWH], ids=lambda c: c.name)
 def test_rows_kernel_set_at_dsgplus_widths(gpu, cfg):
-    """Round 6 (round-5 verdict item 7, first step): ROWS at latent_dim 384 / 512 -- the direct QKV GEMM + k_attn + k_ffn<OP> on one 16-row tile per workgroup (at 512
-    W_o leads the weight ring instead of waiting in registers): no k_attn_op_w, no ff-split, no slabs.  Forward rows at batch 16 (what `auto` picks from 9 clips)
+    """Round 6 (round-5 verdict item 7): ROWS at latent_dim 384 / 512 -- the streamed pose embedding (K over two workgroups), k_clip_attn_w (the attention half per (clip, head), the
+    clip's rows through the LDS in chunks) + k_ffn<OP> on one 16-row tile per workgroup (at 512 W_o leads the weight ring instead of waiting in registers), the streaming pose head:
+    no QKV GEMM, no k_attn_op_w, no ff-split, no slabs.  Forward rows at batch 16 (what `auto` picks from 9 clips)
     against the oracle, a clip's rows the same bits at batch 2, a 20-step DDPM chain; BLOCK stays the choice at 8 clips and under fused guidance."""
     from diffusestylegesture_amd.diffusion import create_gaussian_diffusion
     from oracle import sampler
@@ -224,7 +225,7 @@ def test_rows_kernel_set_at_dsgplus_widths(gpu, cfg):
     x = np.random.RandomState(7).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
     ts = (np.arange(B) * 53 + 11) % 1000
     m = _model(cfg, "bf16", max_batch=B)
-    assert [m.recommend_kernel_set(b, 1) for b in (4, 8, 9, 16)] == ["block", "block", "rows", "rows"]
+    assert [m.recommend_kernel_set(b, 1) for b in (4, 8, 9, 13, 16)] == ["block", "block", "rows" if cfg.latent_dim == 384 else "block", "rows", "rows"]
     assert [m.recommend_kernel_set(b, 4) for b in (2, 3, 4, 8)] == ["block", "block", "rows", "rows"]
     out = np.asarray(m(x, ts, y))
     assert m.last_kernel_set() == "rows"
