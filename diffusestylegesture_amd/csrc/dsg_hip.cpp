@@ -1550,10 +1550,17 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                                   // LayerNorm2 of the previous layer, fragment-major
                 ClipAttnArgs a;
                 a.X = h->X0a; a.Wqkv = ly.Wqkv; a.bqkv = ly.bqkv; a.out = h->attn; a.B = B; a.ntok = ntok;
-                // latent_dim 384: ONE pass over the rows, three column tiles on waves 0 - 1 (144 weight registers fit: 236 VGPRs); 512: two passes (Q / K, then V in pairs)
+                // latent_dim 384: ONE pass over the rows, three column tiles on waves 0 - 1 (144 weight registers fit: 236 VGPRs)
                 // (384 in the two-pass form: 1 x 16 clips 371.3 vs 360.0 us per step, 4 x 16: 614 vs 604 -- profiles/r06_dq_*)
                 if (D == 384) CHK((step_launch<&k_clip_attn_w<6, 10, 4, true>>(h, dim3(4, B), dim3(512), a)));
+                // 512: one pass as well -- 192 weight registers, so the bias waits in the LDS and the A fragments have no look-ahead (254 VGPRs); the two-pass form
+                // (Q / K, then V in pairs on waves 0 - 3) reads the rows from the LDS 1.5 times and reloads weights in between: TWH 1 x 16 clips 475.1 vs 472.9 us per
+                // step, 4 x 8: 601 vs 585, 4 x 16: 836.7 vs 830.1, bit-identical -- profiles/r06_dw_*
+#ifdef DSG_X_TWH_TWOPASS
                 else CHK((step_launch<&k_clip_attn_w<8, 10, 2, false>>(h, dim3(4, B), dim3(512), a)));
+#else
+                else CHK((step_launch<&k_clip_attn_w<8, 10, 2, true>>(h, dim3(4, B), dim3(512), a)));
+#endif
                 clip_w_done = true;
             }
         }

@@ -456,11 +456,12 @@ __global__ __launch_bounds__(256, 1) void k_ws2(const GemmArgs g) {
 // and k_attn disappear as dispatches, Q / K / V^T never reach memory.  What differs from the narrow kernel, because nothing fits as laid out there:
 //   * the clip's rows (10 row tiles x 12 / 16 KB) pass through the LDS in chunks of XR row tiles, double-buffered with global -> LDS loads (no registers):
 //     the next chunk is in flight while a chunk is projected;
-//   * 8 waves, column tile t of the head's [Q | K | V] order by wave t % 8.  latent_dim 384 (ONEP): ONE pass over the rows, 18 tiles = three on waves 0 - 1, two
-//     on the others (144 weight registers: 236 VGPRs).  latent_dim 512: 24 tiles x 16 fragments would be 192 weight registers next to the A fragments, so TWO
-//     passes with two tiles per wave (128 registers): pass A the 16 Q / K tiles, pass B the 8 V tiles in pairs on waves 0 - 3 (one A fragment from the LDS per
-//     two MFMAs, as in pass A; one tile per wave would make the pass LDS-bound) with the chunk's two row tiles side by side (four accumulation chains: the pass
-//     runs one wave per SIMD).  Every active wave reads ALL of the rows from the LDS once per pass -- 8 x 120 / 160 KB at 128 B / clk is what bounds a pass;
+//   * 8 waves, column tile t of the head's [Q | K | V] order by wave t % 8, ONE pass over the rows (ONEP): at latent_dim 384 18 tiles = three on waves 0 - 1, two
+//     on the others (144 weight registers: 236 VGPRs); at 512 24 tiles = three on every wave (192 weight registers: the bias waits in the LDS and the A fragments
+//     have no look-ahead -- 254 VGPRs).  Every wave reads ALL of the rows from the LDS once -- 8 x 120 / 160 KB at 128 B / clk is what bounds the pass.  The
+//     TWO-pass form (!ONEP; kept as the A/B reference, -DDSG_X_TWH_TWOPASS): two tiles per wave (128 registers), pass A the 16 Q / K tiles, pass B the 8 V tiles
+//     in pairs on waves 0 - 3 with the chunk's two row tiles side by side (four accumulation chains: one wave per SIMD) -- 1.5 x the LDS reads and a weight
+//     reload in between: 475.1 vs 472.9 us per TWH step at 16 clips, 4 x 8 clips 601 vs 585;
 //   * EVERY tile is computed as W . X^T (a lane holds 4 consecutive dims of one token) -- one operand order -- and a V tile is transposed when it moves
 //     into V^T (four 2-byte LDS stores per row tile instead of one 8-byte store); the V tiles wait in registers, rounded, until every wave is done with the
 //     rows: V^T takes their place;
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(256, 1) void k_ws2(const GemmArgs g) {
 // Same rounding points as k_attn on the QKV GEMM's output (Q / K / V and P in bf16, softmax in fp32, 1 / sum applied to the fp32 P V).
 // Reference arithmetic: nn.MultiheadAttention of torch's TransformerEncoderLayer (BEAT-TWH-main/model/mdm.py:134-146), in_proj + softmax(QK^T/sqrt(hd))V.
 // ---------------------------------------------------------------------------------------------------------
-template <int NJ, int CW, int KD>      // NJ column tiles against one row tile: the A fragments four k-blocks at a time, the next four in flight
+template <int NJ, int CW, int KD, bool PF = true>      // NJ column tiles against one row tile: the A fragments four k-blocks at a time, the next four in flight (PF)
 __device__ __forceinline__ void clip_w_proj(const f32x4 (&wf)[CW][KD], const f32x4 (*xrow)[64], int lane, f32x4 (&acc)[CW]) {
     static_assert(KD % 4 == 0, "k-blocks in groups of 4");
     f32x4 a[2][4];
@@ -479,15 +480,19 @@ __device__ __forceinline__ void clip_w_proj(const f32x4 (&wf)[CW][KD], const f32
     for (int i = 0; i < 4; ++i) a[0][i] = xrow[i][lane];
 #pragma unroll
     for (int kg = 0; kg < KD / 4; ++kg) {
-        if (kg + 1 < KD / 4) {
+        if (PF && kg + 1 < KD / 4) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) a[(kg + 1) & 1][i] = xrow[4 * (kg + 1) + i][lane];
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[j] = PBF16::mma(wf[j][4 * kg + i], a[kg & 1][i], acc[j]);      // D[dim = 4 lg + r][token = lr]
+            for (int j = 0; j < NJ; ++j) acc[j] = PBF16::mma(wf[j][4 * kg + i], a[PF ? (kg & 1) : 0][i], acc[j]);      // D[dim = 4 lg + r][token = lr]
         DSG_LOADS_ISSUED();
+        if (!PF && kg + 1 < KD / 4) {      // (no room for the look-ahead: the other wave of the SIMD covers the LDS latency)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[0][i] = xrow[4 * (kg + 1) + i][lane];
+        }
     }
 }
 // ... two column tiles against TWO row tiles side by side: four independent accumulation chains (pass B of the two-pass form: one wave per SIMD)
@@ -551,7 +556,13 @@ __global__ __launch_bounds__(512, 1) void k_clip_attn_w(const ClipAttnArgs g) {
     issue_x(0);
     const f32x4* wq = (const f32x4*)g.Wqkv + lane;
     f32x4 wf[CW][KD];
-    f32x4 pb[CW];
+    constexpr bool LB = ONEP && KD > 12;             // (one pass at latent_dim 512: 192 weight registers -- the bias waits in the LDS, no look-ahead for the A fragments)
+    f32x4 pb[LB ? 1 : CW];
+    __shared__ __attribute__((aligned(16))) float bs[LB ? CT * 16 : 4];
+    if constexpr (LB) {
+        const int c4 = threadIdx.x;                  // four bias values of the head's [Q | K | V] columns
+        if (c4 < CT * 4) { const int which = (4 * c4) / HD, within = 4 * c4 - which * HD; *(f32x4*)&bs[4 * c4] = *(const f32x4*)(g.bqkv + which * D + h * HD + within); }
+    }
     bf16x4v vkeep[NKT][ONEP ? 1 : 2];                // the wave's V tile(s), 4 dims of one token per row tile
     // the wave's column tiles in the head's [Q | K | V] order (ND tiles each): packed in_proj column tile, weights, bias
     auto load_tiles = [&](const int (&t)[CW]) {
@@ -561,7 +572,7 @@ __global__ __launch_bounds__(512, 1) void k_clip_attn_w(const ClipAttnArgs g) {
             const int nt = which * (D / 16) + h * ND + d0 / 16;
 #pragma unroll
             for (int kb = 0; kb < KD; ++kb) wf[j][kb] = P::wload(wq, (size_t)nt * KD + kb);
-            pb[j] = *(const f32x4*)(g.bqkv + nt * 16 + 4 * lg);
+            if constexpr (!LB) pb[j] = *(const f32x4*)(g.bqkv + nt * 16 + 4 * lg);
         }
         DSG_LOADS_ISSUED();
     };
@@ -588,13 +599,15 @@ __global__ __launch_bounds__(512, 1) void k_clip_attn_w(const ClipAttnArgs g) {
                 const int rt = c * XR + rl;
                 if (rt < NKT) {
                     f32x4 acc[3] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-                    if (three) clip_w_proj<3, 3, KD>(wf, &xs[c & 1][rl * KD], lane, acc);
-                    else clip_w_proj<2, 3, KD>(wf, &xs[c & 1][rl * KD], lane, acc);
+                    if (three) clip_w_proj<3, 3, KD, !LB>(wf, &xs[c & 1][rl * KD], lane, acc);
+                    else clip_w_proj<2, 3, KD, !LB>(wf, &xs[c & 1][rl * KD], lane, acc);
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
                         if (j < 2 || three) {
                             const int which = t[j] / ND, d0 = (t[j] - which * ND) * 16;
-                            const f32x4 y = acc[j] + pb[j];
+                            f32x4 pbj;
+                            if constexpr (LB) pbj = *(const f32x4*)&bs[t[j] * 16 + 4 * lg]; else pbj = pb[j];
+                            const f32x4 y = acc[j] + pbj;
                             if (which < 2) P::store4((elem*)(which == 0 ? &qs[0][0] : &ks[0][0]) + qk_off<P>(rt * 16 + lr, d0 + 4 * lg, KDH), y);
                             else vkeep[rt][0] = __builtin_convertvector(y, bf16x4v);      // (P::store4's rounding)
                         }
