@@ -272,3 +272,24 @@ def test_rows_kernel_set_at_dsgplus_widths(gpu, cfg):
     for i in range(NL):
         alone = d.manual_seed(9, i).p_sample_loop(lanes[i], shape2, clip_denoised=False, model_kwargs=ys[i], skip_timesteps=990)
         assert lanes[i].last_kernel_set() == "rows" and np.array_equal(np.asarray(multi[i]), np.asarray(alone)), (cfg.name, i)
+
+
+def test_rows_kernel_set_at_beat_v2_pose_width(gpu):
+    """BEAT "v2" (motion_dim 1141 -> 1152 padded pose features at latent_dim 384): the ROWS set with the pose embedding streamed WHOLE (k_ws2<PARTIAL, 18>: K = 1152 fits one
+    workgroup, no K split) and a 9-panel streaming pose head next to k_clip_attn_w / k_ffn<OP> -- forward rows at batch 16 against the oracle."""
+    from oracle.mdm import MDMOracle
+    cfg = C.BEATV2
+    sd = synth_state_dict(cfg, 20240)
+    ref = MDMOracle(sd, cfg)
+    B = 16
+    y = synth_window_inputs(cfg, B, window=1, clip0=3, seed_pose_scale=0.2)
+    x = np.random.RandomState(11).randn(B, cfg.njoints, 1, cfg.n_poses).astype(np.float32)
+    ts = (np.arange(B) * 61 + 3) % 1000
+    m = _model(cfg, "bf16", max_batch=B)
+    assert m.recommend_kernel_set(B, 1) == "rows"
+    out = np.asarray(m(x, ts, y))
+    assert m.last_kernel_set() == "rows"
+    for b in (0, 9, B - 1):
+        yb = {k: (v[b:b + 1] if v.shape[0] == B else v) for k, v in y.items()}
+        e = rel_l2(out[b:b + 1], ref(x[b:b + 1], [int(ts[b])], yb))
+        assert e < TOL_FWD["bf16"], (b, e)
