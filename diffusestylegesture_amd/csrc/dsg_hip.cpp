@@ -1734,7 +1734,7 @@ static int run_step(dsg_handle* h, const StepCtx& c) {
                 if (ks.ffn_rt2w) {
                     if (D == 384) CHK((step_launch<&k_ffn<P, 6, 16, 2, 8, 2, true, true, 20, true>>(h, dim3(cdiv(MT, 2)), dim3(512), a)));
                     else CHK((step_launch<&k_ffn<P, 8, 16, 2, 8, 2, true, true, 12, true>>(h, dim3(cdiv(MT, 2)), dim3(512), a)));
-                } else if (D == 384) CHK((step_launch<&k_ffn<P, 6, 16, 1, 8, 2, true, true, 24>>(h, dim3(MT), dim3(512), a)));
+                } else if (D == 384) CHK((step_launch<&k_ffn<P, 6, 16, 1, 8, 2, true, true, 24>>(h, dim3(MT), dim3(512), a)));      // (W_o leading the ring here too: 353.1 -> 357.8 us per step at 16 clips, r06_ea)
                 else CHK((step_launch<&k_ffn<P, 8, 16, 1, 8, 2, true, true, 24, true>>(h, dim3(MT), dim3(512), a)));
                 continue;
             }
