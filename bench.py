@@ -28,7 +28,7 @@ The default line (`python bench.py`, 1 GPU, config[1]) also carries time-bounded
     stream    256 clips per GPU as 4 lanes x batch 64 (the STREAM kernel set), 1 pass
     precision config[1] in the two other arithmetic modes: fp32 (the reference's own arithmetic) and bf16w2 (hi + lo bf16), 1 pass each
 Top-level `value` / `config` stay config[1].  Sub-records with a committed PMC pass of their per-lane arrangement
-(profiles/r*_traffic_zeggs_b<B>_<set>_bf16.json, tools/measure_traffic.sh) carry it as `roofline.traffic`.
+(profiles/r*_traffic_<config>_b<B>_<set>_bf16.json, tools/measure_traffic.sh) carry it as `roofline.traffic`.
 """
 import argparse
 import json
@@ -183,9 +183,9 @@ def pmc_traffic(config, precision, B, kset):
     (tools/measure_traffic.sh -> tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in separate runs, FETCH doubled as the MI355X guide
     prescribes for wide coalesced reads; HIP-launch path, the profiler cannot see AQL packets).  (corrected, raw, file) or None."""
     import glob
-    if config != "zeggs" or precision != "bf16":
+    if precision != "bf16":
         return None
-    name = f"r*_traffic_zeggs_b{B}_bf16.json" if B == 1 else f"r*_traffic_zeggs_b{B}_{kset}_bf16.json"
+    name = f"r*_traffic_{config}_b{B}_bf16.json" if B == 1 else f"r*_traffic_{config}_b{B}_{kset}_bf16.json"
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", name)))       # newest round last
     if not cands:
         return None
